@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the real reference.  DEV CONTAINER ONLY.
+
+TEST INFRASTRUCTURE: imports the read-only Python reference from
+/root/reference (with the stand-in modules in oracle/shims for the two absent
+third-party packages), runs the reference's own functions at the seams of the
+hot path and stores inputs + outputs as small .npz files
+under tests/golden/.  Only data is written - no reference source.
+
+    cd /tmp && python /root/repo/oracle/gen_golden.py [seams|tdvp|dmrg|mpo|all]
+
+The GPU box never runs this (no /root/reference there); tests read the .npz.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+os.environ.setdefault("RENO_NUM_THREADS", "4")
+os.environ.setdefault("RENO_LOG_LEVEL", "40")
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "shims"))
+
+import numpy as np  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+
+
+def _rand(rng, shape, cplx):
+    a = rng.standard_normal(shape)
+    if cplx:
+        a = a + 1j * rng.standard_normal(shape)
+    return a
+
+
+def gen_seams():
+    from renormalizer.mps.lib import contract_one_site, select_basis
+    from renormalizer.mps.hop_expr import hop_expr
+    from renormalizer.lib.krylov.krylov import expm_krylov
+    from renormalizer.mps import svd_qn as ref_svd
+    from renormalizer.utils.configs import CompressConfig, CompressCriteria
+
+    rng = np.random.default_rng(20260928)
+    out = {}
+
+    # ---- a1: contract_one_site  (lib.py:169-250)
+    cases = []
+    k = 0
+    for cplx in (False, True):
+        for anc in (False, True):
+            for dom in ("L", "R"):
+                Dl, Dr, d, da, wl, wr = 5, 7, 3, 2, 4, 3
+                shp = (Dl, d, da, Dr) if anc else (Dl, d, Dr)
+                ms = _rand(rng, shp, cplx)
+                bra = _rand(rng, shp, cplx)          # independent bra (transition amplitude use)
+                mo = _rand(rng, (wl, d, d, wr), False)
+                if dom == "L":
+                    env = _rand(rng, (Dl, wl, Dl), cplx)
+                else:
+                    env = _rand(rng, (Dr, wr, Dr), cplx)
+                res = contract_one_site(env, ms, mo, dom, ms_conj=bra.conj())
+                res2 = contract_one_site(env, ms, mo, dom)
+                for nm, v in (("env", env), ("ms", ms), ("bra", bra), ("mo", mo), ("out", res), ("out_self", res2)):
+                    out[f"c1s_{k}_{nm}"] = np.asarray(v)
+                out[f"c1s_{k}_dom"] = np.array(dom)
+                cases.append(k)
+                k += 1
+    out["c1s_n"] = np.array(k)
+
+    # ---- a4: hop_expr  (hop_expr.py:57-115)
+    k = 0
+    for cplx in (False, True):
+        for nsite in (0, 1, 2):
+            for anc in ((False,) if nsite == 0 else (False, True)):
+                Dl, Dr, d1, d2, da, wl, wm, wr = 6, 5, 3, 4, 2, 3, 4, 2
+                if nsite == 0:
+                    l = _rand(rng, (Dl, wl, Dl), cplx)
+                    r = _rand(rng, (Dr, wl, Dr), cplx)
+                    cmo, cshape = [], (Dl, Dr)
+                elif nsite == 1:
+                    l = _rand(rng, (Dl, wl, Dl), cplx)
+                    r = _rand(rng, (Dr, wr, Dr), cplx)
+                    cmo = [_rand(rng, (wl, d1, d1, wr), False)]
+                    cshape = (Dl, d1, da, Dr) if anc else (Dl, d1, Dr)
+                else:
+                    l = _rand(rng, (Dl, wl, Dl), cplx)
+                    r = _rand(rng, (Dr, wr, Dr), cplx)
+                    cmo = [_rand(rng, (wl, d1, d1, wm), False), _rand(rng, (wm, d2, d2, wr), False)]
+                    cshape = (Dl, d1, da, d2, da, Dr) if anc else (Dl, d1, d2, Dr)
+                c = _rand(rng, cshape, cplx)
+                expr = hop_expr(l, r, list(cmo), list(cshape))
+                hc = expr(c)
+                out[f"hop_{k}_l"], out[f"hop_{k}_r"], out[f"hop_{k}_c"], out[f"hop_{k}_out"] = l, r, c, np.asarray(hc)
+                out[f"hop_{k}_nsite"] = np.array(nsite)
+                for j, w in enumerate(cmo):
+                    out[f"hop_{k}_w{j}"] = w
+                k += 1
+    out["hop_n"] = np.array(k)
+
+    # ---- a5: expm_krylov  (krylov.py:27-82)
+    k = 0
+    for n, dt in ((1, -0.3j), (2, 0.2j), (7, -0.5j), (60, -0.4j), (150, -0.05j), (150, -0.3)):
+        a = _rand(rng, (n, n), True)
+        a = (a + a.conj().T) / 2 / max(1.0, np.sqrt(n))
+        v = _rand(rng, (n,), True)
+        res, nv = expm_krylov(lambda x: a @ x, dt, v)
+        out[f"kry_{k}_a"], out[f"kry_{k}_v"], out[f"kry_{k}_dt"] = a, v, np.array(dt)
+        out[f"kry_{k}_out"], out[f"kry_{k}_nvec"] = np.asarray(res), np.array(nv)
+        k += 1
+    out["kry_n"] = np.array(k)
+    # large structured case: A = diag(x) + u u^H  (stored as x, u only)
+    n = 800
+    x = rng.standard_normal(n)
+    u = _rand(rng, (n,), True) / np.sqrt(n)
+    v = _rand(rng, (n,), True)
+    res, nv = expm_krylov(lambda y: x * y + u * np.vdot(u, y), -0.2j, v)
+    out["kryL_x"], out["kryL_u"], out["kryL_v"], out["kryL_dt"] = x, u, v, np.array(-0.2j)
+    out["kryL_out"], out["kryL_nvec"] = np.asarray(res), np.array(nv)
+
+    # ---- a6: svd_qn  (svd_qn.py:99-240)
+    k = 0
+    for cplx in (False, True):
+        for (QR, system, full) in ((True, "L", False), (True, "R", False), (False, None, False), (False, None, True)):
+            for qn_size in (1, 2):
+                Dl, d, Dr = 9, 3, 8
+                to_right = system != "R"
+                while True:
+                    hi = 3 if qn_size == 1 else 2
+                    qnl = rng.integers(0, hi, size=(Dl, qn_size))
+                    sig = rng.integers(0, 2, size=(d, qn_size))
+                    qnr = rng.integers(0, hi, size=(Dr, qn_size))
+                    qntot = np.full(qn_size, 3 if qn_size == 1 else 2)
+                    if to_right:
+                        qnbigl = ref_svd.add_outer(qnl, sig)
+                        qnbigr = qnr
+                    else:
+                        qnbigl = qnl
+                        qnbigr = ref_svd.add_outer(sig, qnr)
+                    mask = ref_svd.get_qn_mask(ref_svd.add_outer(qnbigl, qnbigr), qntot)
+                    if mask.sum() >= 20:
+                        break
+                c = _rand(rng, (Dl, d, Dr), cplx) * mask
+                np.random.seed(7)
+                res = ref_svd.svd_qn(c, qnbigl, qnbigr, qntot, QR=QR, system=system, full_matrices=full)
+                pre = f"svd_{k}_"
+                out[pre + "c"], out[pre + "qnbigl"], out[pre + "qnbigr"], out[pre + "qntot"] = c, qnbigl, qnbigr, qntot
+                out[pre + "QR"], out[pre + "system"], out[pre + "full"] = np.array(QR), np.array(str(system)), np.array(full)
+                if QR:
+                    u, ql, v, qr_ = res
+                    out[pre + "u"], out[pre + "v"] = u, v
+                else:
+                    u, su, ql, v, sv, qr_ = res
+                    out[pre + "u"], out[pre + "v"], out[pre + "su"], out[pre + "sv"] = u, v, su, sv
+                out[pre + "qnl"] = np.array(ql).reshape(len(ql), qn_size)
+                out[pre + "qnr"] = np.array(qr_).reshape(len(qr_), qn_size)
+                k += 1
+    out["svd_n"] = np.array(k)
+
+    # ---- a7: select_basis + compute_m_trunc  (lib.py:253-322, configs.py:196-219)
+    k = 0
+    for percent in (0, 0.1, 0.4):
+        for mmax in (5, 12, 40):
+            nrow, ncol = 14, 20
+            u = _rand(rng, (nrow, ncol), True)
+            vv = _rand(rng, (11, ncol - 3), True)        # compset may have fewer columns
+            s = np.sort(rng.random(ncol))[::-1].copy()
+            s[5] = s[4]                                   # a tie
+            qn = [list(x) for x in rng.integers(0, 3, size=(ncol, 1))]
+            ms, dim, mqn, comp = select_basis(u, s, qn, vv, mmax, percent=percent)
+            pre = f"sel_{k}_"
+            out[pre + "u"], out[pre + "s"], out[pre + "qn"], out[pre + "v"] = u, s, np.array(qn), vv
+            out[pre + "mmax"], out[pre + "percent"] = np.array(mmax), np.array(percent)
+            out[pre + "ms"], out[pre + "dim"], out[pre + "mqn"], out[pre + "comp"] = np.asarray(ms), np.array(dim), np.asarray(mqn), np.asarray(comp)
+            k += 1
+    out["sel_n"] = np.array(k)
+    k = 0
+    for crit, nm in ((CompressCriteria.threshold, "threshold"), (CompressCriteria.fixed, "fixed"), (CompressCriteria.both, "both")):
+        for thr in (1e-3, 0.2):
+            s = np.sort(rng.random(17) ** 4)[::-1].copy()
+            cfg = CompressConfig(criteria=crit, threshold=thr, max_bonddim=9)
+            cfg.set_bonddim(6)
+            m = cfg.compute_m_trunc(s, 2, True)
+            pre = f"mtr_{k}_"
+            out[pre + "s"], out[pre + "crit"], out[pre + "thr"], out[pre + "maxdim"], out[pre + "m"] = s, np.array(nm), np.array(thr), np.array(9), np.array(m)
+            k += 1
+    out["mtr_n"] = np.array(k)
+    np.savez_compressed(os.path.join(GOLD, "seams.npz"), **out)
+    print("seams.npz written:", len(out), "arrays")
+
+
+def _dump_mps(out, pre, mps):
+    out[pre + "nsite"] = np.array(len(mps))
+    for i in range(len(mps)):
+        out[pre + f"site_{i}"] = np.asarray(mps[i].array)
+    for i in range(len(mps) + 1):
+        out[pre + f"qn_{i}"] = np.asarray(mps.qn[i]).reshape(len(mps.qn[i]), -1).astype(np.int64)
+    out[pre + "qnidx"] = np.array(mps.qnidx)
+    out[pre + "qntot"] = np.asarray(mps.qntot).astype(np.int64)
+    out[pre + "to_right"] = np.array(bool(mps.to_right))
+    out[pre + "coeff"] = np.array(complex(mps.coeff))
+
+
+def _dump_mpo(out, pre, mpo):
+    out[pre + "nsite"] = np.array(len(mpo))
+    for i in range(len(mpo)):
+        out[pre + f"w_{i}"] = np.asarray(mpo[i].array)
+
+
+def _tdvp_run(model, mpo, init, obs_mpos, nsteps, dt, fname, extra=None):
+    out = dict(extra or {})
+    _dump_mpo(out, "mpo_", mpo)
+    for j, o in enumerate(obs_mpos):
+        _dump_mpo(out, f"obs{j}_", o)
+    out["nobs"] = np.array(len(obs_mpos))
+    for i, b in enumerate(model.basis):
+        out[f"sigmaqn_{i}"] = np.asarray(b.sigmaqn).reshape(b.nbas, -1).astype(np.int64)
+    _dump_mps(out, "init_", init)
+    mps = init
+    vals, energies, kdims, bdims, norms = [], [], [], [], []
+    vals.append([mps.expectation(o) for o in obs_mpos])
+    energies.append(mps.expectation(mpo))
+    for step in range(nsteps):
+        mps = mps.evolve(mpo, dt)
+        vals.append([mps.expectation(o) for o in obs_mpos])
+        energies.append(mps.expectation(mpo))
+        bdims.append(mps.bond_dims)
+        norms.append(mps.mp_norm)
+        st = mps.evolve_config.stat
+        kdims.append([st.nobs, st.minmax[0], st.minmax[1], st.mean])
+        if step == 0:
+            _dump_mps(out, "step1_", mps)
+    out["dt"] = np.array(dt)
+    out["obs_values"] = np.array(vals, dtype=complex).real
+    out["energies"] = np.array(energies, dtype=complex).real
+    out["krylov_stat"] = np.array(kdims)
+    out["bond_dims"] = np.array(bdims)
+    out["norms"] = np.array(norms)
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
+    print(fname, "obs[-1] =", out["obs_values"][-1], "krylov", kdims[-1])
+
+
+def gen_tdvp():
+    from renormalizer.model import Phonon, Mol, HolsteinModel, SpinBosonModel, Op
+    from renormalizer.mps import Mps, Mpo
+    from renormalizer.utils import Quantity, CompressConfig, EvolveConfig, EvolveMethod, CompressCriteria
+
+    # --- Holstein chain, reduced headline config: std.yaml parameters
+    nmol, pdim, D = 4, 4, 8
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), pdim)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
+    gs = Mps.ground_state(model, max_entangled=False)
+    init = Mpo.onsite(model, r"a^\dagger", dof_set={nmol // 2}).apply(gs)
+    e0 = Quantity(init.expectation(Mpo(model)))
+    mpo = Mpo(model, offset=e0)
+    init.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=D)
+    init.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    np.random.seed(9012)
+    init = init.expand_bond_dimension(mpo)
+    init.canonicalise()
+    occ = [Mpo(model, Op(r"a^\dagger a", dof)) for dof in model.e_dofs]
+    _tdvp_run(model, mpo, init, occ, 4, 10.0, "tdvp_holstein_small.npz",
+              {"e0": np.array(e0.as_au())})
+
+    # --- spin-boson, reduced config 2
+    nmode, pdim, D = 5, 5, 10
+    omegas = np.linspace(0.5, 4.0, nmode)
+    cs = 0.3 / np.sqrt(np.arange(1, nmode + 1))
+    ph_list = [Phonon.simple_phonon(Quantity(w), Quantity(c / w ** 2), pdim) for w, c in zip(omegas, cs)]
+    model = SpinBosonModel(Quantity(0.0), Quantity(0.8), ph_list)
+    mpo = Mpo(model)
+    init = Mps.ground_state(model, False)
+    init.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=D)
+    init.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    np.random.seed(9012)
+    init = init.expand_bond_dimension(mpo, coef=1e-16, include_ex=False)
+    sz = [Mpo(model, Op("sigma_z", "spin")), Mpo(model, Op("sigma_x", "spin"))]
+    _tdvp_run(model, mpo, init, sz, 5, 0.1, "tdvp_sbm_small.npz")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("seams", "all"):
+        gen_seams()
+    if what in ("tdvp", "all"):
+        gen_tdvp()

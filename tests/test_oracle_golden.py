@@ -1,0 +1,168 @@
+"""Pins the CPU oracle (oracle/mps_oracle.py) to vectors captured from the real
+reference at its own seams (oracle/gen_golden.py -> tests/golden/*.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mps_oracle as orc
+
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def seams(golden_dir):
+    return np.load(os.path.join(golden_dir, "seams.npz"))
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    assert np.abs(a - b).max() <= tol * scale if b.size else True
+
+
+def test_contract_one_site(seams):
+    for k in range(int(seams["c1s_n"])):
+        g = lambda n: seams[f"c1s_{k}_{n}"]
+        dom = str(g("dom"))
+        out = orc.contract_one_site(g("env"), g("ms"), g("mo"), dom, ms_conj=g("bra").conj())
+        _close(out, g("out"))
+        _close(orc.contract_one_site(g("env"), g("ms"), g("mo"), dom), g("out_self"))
+
+
+def test_hop_apply(seams):
+    for k in range(int(seams["hop_n"])):
+        g = lambda n: seams[f"hop_{k}_{n}"]
+        ns = int(g("nsite"))
+        cmo = [g(f"w{j}") for j in range(ns)]
+        _close(orc.hop_apply(g("l"), g("r"), cmo, g("c")), g("out"))
+        if ns >= 1 and g("c").ndim == ns + 2:
+            h = orc.hop_dense(g("l"), g("r"), cmo)
+            _close((h @ g("c").ravel()).reshape(g("out").shape), g("out"))
+
+
+def test_expm_krylov(seams):
+    for k in range(int(seams["kry_n"])):
+        g = lambda n: seams[f"kry_{k}_{n}"]
+        a = g("a")
+        res, nv = orc.expm_krylov(lambda x: a @ x, complex(g("dt")), g("v"))
+        assert nv == int(g("nvec"))
+        _close(res, g("out"))
+    x, u = seams["kryL_x"], seams["kryL_u"]
+    res, nv = orc.expm_krylov(lambda y: x * y + u * np.vdot(u, y), complex(seams["kryL_dt"]), seams["kryL_v"])
+    assert nv == int(seams["kryL_nvec"])
+    _close(res, seams["kryL_out"])
+
+
+def _sorted_rows(a):
+    a = np.asarray(a)
+    a = a.reshape(len(a), -1)
+    return a[np.lexsort(a.T[::-1])]
+
+
+def test_svd_qn(seams):
+    for k in range(int(seams["svd_n"])):
+        g = lambda n: seams[f"svd_{k}_{n}"]
+        QR, full = bool(g("QR")), bool(g("full"))
+        system = str(g("system"))
+        system = None if system == "None" else system
+        c = g("c")
+        res = orc.svd_qn(c, g("qnbigl"), g("qnbigr"), g("qntot"), QR=QR, system=system, full_matrices=full)
+        mat = c.reshape(res[0].shape[0], -1)
+        if QR:
+            u, ql, v, qr_ = res
+            _close(u @ v.T, mat)
+            iso = u if system == "L" else v
+            _close(iso.conj().T @ iso, np.eye(iso.shape[1]))
+        else:
+            u, su, ql, v, sv, qr_ = res
+            rec = _recon_full(u, su, v, sv) if full else (u * su) @ v.T
+            _close(rec, mat)
+            _close(np.sort(su)[::-1], np.sort(g("su"))[::-1])
+            _close(np.sort(sv)[::-1], np.sort(g("sv"))[::-1])
+            _close(u.conj().T @ u, np.eye(u.shape[1]))
+            _close(v.conj().T @ v, np.eye(v.shape[1]))
+        assert u.shape == g("u").shape and v.shape == g("v").shape
+        # integer bookkeeping: multiset of qn rows is exact
+        assert np.array_equal(_sorted_rows(ql), _sorted_rows(g("qnl")))
+        assert np.array_equal(_sorted_rows(qr_), _sorted_rows(g("qnr")))
+        # every kept column lives entirely inside its own qn sector
+        lq = g("qnbigl").reshape(-1, len(g("qntot")))
+        for col, qn in zip(u.T, ql):
+            rows = np.nonzero(np.abs(col) > 1e-13)[0]
+            assert np.all(lq[rows] == np.array(qn))
+
+
+def _recon_full(u, su, v, sv):
+    # full_matrices=True: the sigma>0 columns come first and pair up one-to-one in u and v;
+    # the trailing null-space columns carry sigma == 0 and contribute nothing
+    n_nz = 0
+    for a, b in zip(su, sv):
+        if a != b or a == 0:
+            break
+        n_nz += 1
+    return (u[:, :n_nz] * su[:n_nz]) @ v[:, :n_nz].T
+
+
+def test_select_basis(seams):
+    for k in range(int(seams["sel_n"])):
+        g = lambda n: seams[f"sel_{k}_{n}"]
+        qn = [list(x) for x in g("qn")]
+        ms, dim, mqn, comp = orc.select_basis(g("u"), g("s"), qn, g("v"), int(g("mmax")), float(g("percent")))
+        assert dim == int(g("dim"))
+        assert np.array_equal(_sorted_rows(mqn), _sorted_rows(g("mqn")))
+        # same set of kept columns (column order is a gauge when percent != 0)
+        def colset(a):
+            a = np.asarray(a)
+            return a[:, np.lexsort((a.imag.sum(0), a.real.sum(0)))]
+        _close(colset(ms), colset(g("ms")))
+        _close(colset(comp), colset(g("comp")))
+
+
+def test_compute_m_trunc(seams):
+    for k in range(int(seams["mtr_n"])):
+        g = lambda n: seams[f"mtr_{k}_{n}"]
+        m = orc.compute_m_trunc(g("s"), str(g("crit")), float(g("thr")), int(g("maxdim")))
+        assert m == int(g("m"))
+
+
+def _load_state(z, pre, sigmaqn):
+    n = int(z[pre + "nsite"])
+    return orc.MpsState(
+        sites=[z[pre + f"site_{i}"] for i in range(n)],
+        qn=[z[pre + f"qn_{i}"] for i in range(n + 1)],
+        qnidx=int(z[pre + "qnidx"]), qntot=z[pre + "qntot"], to_right=bool(z[pre + "to_right"]),
+        sigmaqn=sigmaqn, coeff=complex(z[pre + "coeff"]))
+
+
+@pytest.mark.parametrize("fname", ["tdvp_holstein_small.npz", "tdvp_sbm_small.npz"])
+def test_tdvp_ps_end_to_end(golden_dir, fname):
+    z = np.load(os.path.join(golden_dir, fname))
+    n = int(z["mpo_nsite"])
+    mpo = [z[f"mpo_w_{i}"] for i in range(n)]
+    obs = [[z[f"obs{j}_w_{i}"] for i in range(n)] for j in range(int(z["nobs"]))]
+    sigmaqn = [z[f"sigmaqn_{i}"] for i in range(n)]
+    st = _load_state(z, "init_", sigmaqn)
+    dt = float(z["dt"])
+    ref_obs, ref_e = z["obs_values"], z["energies"]
+    _close([orc.expectation(st.sites, o) for o in obs], ref_obs[0], 1e-9)
+    nsteps = len(ref_obs) - 1
+    for step in range(nsteps):
+        st = orc.tdvp_ps_step(st, mpo, dt)
+        vals = [orc.expectation(st.sites, o) for o in obs]
+        assert np.abs(np.array(vals) - ref_obs[step + 1]).max() < 1e-8
+        e = orc.expectation(st.sites, mpo)
+        assert abs(e - ref_e[step + 1]) < 1e-8 * max(1.0, abs(ref_e[step + 1])) + 1e-10
+        assert list(st.bond_dims) == list(z["bond_dims"][step])
+        ks = z["krylov_stat"][step]
+        assert len(st.krylov_dims) == int(ks[0])
+        assert abs(np.mean(st.krylov_dims) - ks[3]) < 0.35   # Krylov dims may differ by gauge-level rounding
+        if step == 0:
+            ref1 = _load_state(z, "step1_", sigmaqn)
+            ov = orc.mps_dot([s.conj() for s in ref1.sites], st.sites)
+            assert abs(abs(ov) - 1.0) < 1e-9
+            for a, b in zip(st.qn, ref1.qn):
+                assert np.array_equal(_sorted_rows(a), _sorted_rows(b))
+            assert st.qnidx == ref1.qnidx and st.to_right == ref1.to_right
