@@ -1,0 +1,202 @@
+/*
+ * mpsengine.h - C ABI of the MI355X (gfx950) matrix-product-state sweep engine.
+ *
+ * This is the drop-in boundary for the per-site hot path of Renormalizer's
+ * DMRG (optimize_mps) and TDVP (Mps.evolve) loops.  Each entry point names the
+ * reference call site(s) it replaces (paths relative to renormalizer/ in
+ * shuaigroup/Renormalizer v0.0.11).  The reference reaches all of this
+ * arithmetic through `xp.tensordot`, `opt_einsum` and SciPy LAPACK; here it is
+ * hand-written HIP (FP64 MFMA contraction kernel, wavefront reductions,
+ * Householder / one-sided Jacobi factorizations), device resident.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (MPSE_OK == 0)
+ *     and never throws; mpse_last_error(ctx) gives a message for the last failure;
+ *   - `void*` tensor arguments are DEVICE pointers obtained from mpse_malloc
+ *     unless the name ends in `_host`;
+ *   - tensors are dense, C-order (last index fastest), dtype MPSE_F64 (8 B) or
+ *     MPSE_C128 (interleaved re,im; 16 B);
+ *   - index roles follow the reference: environment (bra bond, mpo bond, ket bond),
+ *     mps site (D_l, d[, d_anc], D_r), mpo site (w_l, d_up, d_down, w_r);
+ *   - all work is enqueued on the context's HIP stream; only the functions
+ *     documented as synchronous (downloads, scalar results) wait for it;
+ *   - one context per GPU per process (mirrors mps/backend.py:129-132).
+ */
+#ifndef MPSENGINE_H
+#define MPSENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpse_ctx mpse_ctx;
+
+enum {
+  MPSE_OK = 0,
+  MPSE_ERR_OOM = 1,      /* device allocation failed (reference: MEMORY_ERRORS, mps/backend.py:89-94) */
+  MPSE_ERR_SHAPE = 2,    /* inconsistent extents / "Invalid quantum number" (mps/svd_qn.py:219-220) */
+  MPSE_ERR_NOCONV = 3,   /* iterative routine hit its iteration limit */
+  MPSE_ERR_HIP = 4,      /* a HIP runtime call failed */
+  MPSE_ERR_ARG = 5       /* bad argument (null pointer, unknown dtype, ...) */
+};
+
+enum { MPSE_F64 = 0, MPSE_C128 = 1 };
+enum { MPSE_DOMAIN_L = 0, MPSE_DOMAIN_R = 1 };
+
+/* ---------------------------------------------------------------- context */
+
+/* Replaces backend selection / device binding, mps/backend.py:29-62 (RENO_GPU). */
+int mpse_ctx_create(int device, mpse_ctx** out);
+int mpse_ctx_destroy(mpse_ctx* ctx);
+/* mps/backend.py:129-132 Backend.sync() */
+int mpse_sync(mpse_ctx* ctx);
+const char* mpse_last_error(const mpse_ctx* ctx);
+const char* mpse_version(void);
+/* device name, compute-unit count and the HIP stream handle (as void*) for callers that time with HIP events */
+int mpse_device_info(mpse_ctx* ctx, char* name, size_t name_len, int* n_cu, void** stream);
+
+/* --------------------------------------------------------- device memory */
+
+/* Pooled device allocator (mps/backend.py:116-127 free_all_blocks/log_memory_usage). */
+int mpse_malloc(mpse_ctx* ctx, size_t bytes, void** dptr);
+int mpse_free(mpse_ctx* ctx, void* dptr);
+int mpse_pool_trim(mpse_ctx* ctx);
+int mpse_mem_info(mpse_ctx* ctx, size_t* pool_bytes, size_t* in_use_bytes, size_t* device_free, size_t* device_total);
+/* mps/matrix.py:298-322 asnumpy/asxp. h2d/d2h are synchronous with respect to the host buffer. */
+int mpse_memcpy_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes);
+int mpse_memcpy_d2h(mpse_ctx* ctx, void* dst_host, const void* src, size_t bytes);
+int mpse_memcpy_d2d(mpse_ctx* ctx, void* dst, const void* src, size_t bytes);
+int mpse_memset_zero(mpse_ctx* ctx, void* dst, size_t bytes);
+
+/* ------------------------------------------------------ vector primitives */
+/* The Lanczos / Davidson vector algebra of lib/krylov/krylov.py:54-82 and
+ * lib/davidson/davidson.py.  n counts elements of the given dtype.          */
+int mpse_cast_f64_to_c128(mpse_ctx* ctx, void* dst, const void* src, int64_t n);
+int mpse_conj_inplace(mpse_ctx* ctx, void* x, int64_t n);                       /* C128 only */
+int mpse_scal(mpse_ctx* ctx, int dtype, void* x, int64_t n, double a_re, double a_im);
+int mpse_axpy(mpse_ctx* ctx, int dtype, void* y, const void* x, int64_t n, double a_re, double a_im);
+/* out_host[0..1] = sum conj(x_i) y_i  (xp.vdot); synchronous */
+int mpse_dotc(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n, double* out_host);
+/* out_host[0] = ||x||_2 (xp.linalg.norm); synchronous */
+int mpse_nrm2(mpse_ctx* ctx, int dtype, const void* x, int64_t n, double* out_host);
+
+/* ------------------------------------------- general tensor contraction */
+
+/* A logical matrix index that addresses memory through up to two levels:
+ *   offset(i) = (i / lo_ext) * s_hi + (i % lo_ext) * s_lo      (strides in elements)
+ * Single-level indices use lo_ext >= ext (s_hi ignored). */
+typedef struct {
+  int64_t ext;
+  int64_t lo_ext;
+  int64_t s_hi;
+  int64_t s_lo;
+} mpse_index;
+
+/* C[b](i,j) = alpha * sum_k opA(A[b](i,k)) * opB(B[b](k,j)) + beta * C[b](i,j)
+ * Replaces mps/matrix.py:210-211 tensordot and :283-295 pair_tensor_contract
+ * (transpose-copy + ?gemm in the reference) with one FP64-MFMA kernel that reads
+ * the operands through their strides.  C is C128 if either operand is.       */
+typedef struct {
+  int dtype_a, dtype_b;
+  int conj_a, conj_b;
+  mpse_index m_a, k_a;      /* A(i,k) */
+  mpse_index k_b, n_b;      /* B(k,j) */
+  mpse_index m_c, n_c;      /* C(i,j) */
+  int64_t batch;
+  int64_t sb_a, sb_b, sb_c; /* batch strides, elements */
+  double alpha_re, alpha_im;
+  double beta_re, beta_im;
+} mpse_gemm_desc;
+
+int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* desc, const void* A, const void* B, void* C);
+
+/* out = transpose of `in` viewed as (d0,d1,d2) -> (d0,d2,d1); optional conjugation. */
+int mpse_transpose_inner(mpse_ctx* ctx, int dtype, void* out, const void* in,
+                         int64_t d0, int64_t d1, int64_t d2, int conj);
+
+/* --------------------------------------------------- hot-path contractions */
+
+/* Extents of a (one- or two-site) centre and its surroundings. */
+typedef struct {
+  int64_t Dl_bra, Dl_ket;   /* left bond of bra / ket (equal for an effective Hamiltonian) */
+  int64_t Dr_bra, Dr_ket;
+  int64_t d0, d1;           /* physical dims of the centre site(s); d1 unused for 0/1-site */
+  int64_t danc;             /* ancilla dim of an MPDM site, 1 for an MPS */
+  int64_t wl, wm, wr;       /* mpo bonds: left, middle (2-site only), right */
+} mpse_dims;
+
+/* Environment update, replaces mps/lib.py:169-250 contract_one_site
+ * (L: abc,adf->bcdf; bcdf,bdeg->cfeg; cfeg,ceh->fgh   R: fda,abc->fdbc; fdbc,gdeb->fcge; fcge,hec->fgh,
+ * ancilla variants lib.py:207-211/239-243).
+ *   env : (Dl_bra,wl,Dl_ket) for L, (Dr_bra,wr,Dr_ket) for R;  ket : (Dl_ket,d0[,danc],Dr_ket)
+ *   bra : same layout with the bra extents, or NULL to use ket; bra_conj!=0 -> conjugate it here
+ *         (pass 0 when the buffer already holds the conjugated tensor, like the reference's ms_conj)
+ *   W   : (wl,d0,d0,wr), dtype w_dtype
+ *   out : (Dr_bra,wr,Dr_ket) for L, (Dl_bra,wl,Dl_ket) for R; dtype `dtype`
+ * env_dtype may be MPSE_F64 for the all-ones sentinel (lib.py:25). */
+int mpse_env_update(mpse_ctx* ctx, int dtype, int domain, const mpse_dims* dims,
+                    const void* env, int env_dtype, const void* ket, const void* bra, int bra_conj,
+                    const void* W, int w_dtype, void* out);
+
+/* Effective Hamiltonian applied to the centre, replaces the closures built by
+ * mps/hop_expr.py:57-115 (0-site abc,lbk,ck->al ; 1-site abc,bdef,lfk,cek->adl ;
+ * 2-site abc,bdef,fghj,ljk,cehk->adgl ; ancilla variants), order (L.C).W.R.
+ *   L (Dl,wl,Dl)  R (Dr,wr,Dr)  W0 (wl,d0,d0,wm|wr)  W1 (wm,d1,d1,wr)  C/out (Dl,d0[,danc][,d1[,danc]],Dr)
+ * nsite in {0,1,2}; for nsite==0 wl==wr is the shared mpo bond. */
+typedef struct {
+  int nsite;
+  mpse_dims dims;
+  const void* L; int l_dtype;
+  const void* R; int r_dtype;
+  const void* W0; const void* W1; int w_dtype;
+} mpse_heff;
+
+int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, void* out);
+
+/* Lanczos exponential out = expm(dt*Heff) C, replaces lib/krylov/krylov.py:27-82
+ * expm_krylov as called at mps/mps.py:1300-1303, 1343-1346, 1377-1380 (same
+ * recurrence without re-orthogonalisation, same stopping rule: successive
+ * approximations allclose(rtol,atol) on even j > 3, breakdown at beta < 100 n eps).
+ * Synchronous; *nvec receives the Krylov dimension. */
+int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re, double dt_im,
+                      const void* C, void* out, double rtol, double atol, int max_dim, int* nvec);
+
+/* ------------------------------------------------ block decompositions */
+
+/* Quantum-number blocked QR (system 'L') / RQ (system 'R') of the centre matrix
+ * coef (nrow x ncol), replaces mps/svd_qn.py:99-227 with QR=True, full_matrices=False
+ * (scipy.linalg.qr / rq per block + blockrecover).  The integer bookkeeping stays
+ * with the caller: block b owns rows row_idx_host[row_off_host[b]..row_off_host[b+1])
+ * and columns col_idx_host[col_off_host[b]..col_off_host[b+1]); it contributes
+ * min(rows,cols) columns.  Outputs (device, zero outside the blocks):
+ *   U  (nrow x K)  and  Vt (K x ncol),  K = sum_b min(m_b,n_b),  coef == U @ Vt on the blocks;
+ *   system 'L': U has orthonormal columns;  system 'R': Vt has orthonormal rows. */
+int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int64_t ncol,
+                  int nblocks, const int64_t* row_idx_host, const int64_t* row_off_host,
+                  const int64_t* col_idx_host, const int64_t* col_off_host,
+                  int system_is_R, void* U, void* Vt, int64_t K);
+
+/* Quantum-number blocked economic SVD by one-sided Jacobi, replaces mps/svd_qn.py:99-240
+ * with QR=False, full_matrices=False (scipy.linalg.svd gesdd per block).  Same block
+ * description; outputs U (nrow x K), Vt (K x ncol) (block order, NOT globally sorted) and
+ * the singular values S_host[K] (descending inside each block).  Synchronous. */
+int mpse_block_svd(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int64_t ncol,
+                   int nblocks, const int64_t* row_idx_host, const int64_t* row_off_host,
+                   const int64_t* col_idx_host, const int64_t* col_off_host,
+                   void* U, void* Vt, double* S_host, int64_t K);
+
+/* out[:, j] = in[:, cols_host[j]] * scale_host[j]  (column gather of a row-major matrix,
+ * replaces the per-column copies of mps/lib.py:303-316 select_basis; scale_host may be NULL). */
+int mpse_gather_cols(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t nrow, int64_t ncol_in,
+                     const int64_t* cols_host, const double* scale_host, int64_t ncol_out);
+/* out[i, :] = in[rows_host[i], :] * scale_host[i] */
+int mpse_gather_rows(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t ncol,
+                     const int64_t* rows_host, const double* scale_host, int64_t nrow_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPSENGINE_H */

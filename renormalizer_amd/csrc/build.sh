@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds libmpsengine.so (gfx950) in-tree.  Usage: renormalizer_amd/csrc/build.sh [extra hipcc flags]
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+SRCS="mpse_core.hip mpse_gemm.hip mpse_contract.hip mpse_vec.hip mpse_qr.hip mpse_svd.hip"
+OBJS=""
+for s in $SRCS; do
+  [ -f "$s" ] || continue
+  o="build/${s%.hip}.o"
+  mkdir -p build
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer "$o" 2>/dev/null)" ] || [ ../../include/mpsengine.h -nt "$o" ]; then
+    $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" "$@" &
+  fi
+  OBJS="$OBJS $o"
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o libmpsengine.so
+echo "built $(pwd)/libmpsengine.so"

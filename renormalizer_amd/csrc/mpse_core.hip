@@ -1,0 +1,177 @@
+// Context, pooled device memory and host<->device transfers of libmpsengine.so.
+#include "mpse_internal.h"
+
+int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+extern "C" {
+
+const char* mpse_version(void) { return "mpsengine 0.1 (gfx950)"; }
+
+const char* mpse_last_error(const mpse_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int mpse_ctx_create(int device, mpse_ctx** out) {
+  if (!out) return MPSE_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MPSE_ERR_HIP;
+  if (device < 0 || device >= ndev) return MPSE_ERR_ARG;
+  mpse_ctx* ctx = new mpse_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete ctx;
+    return MPSE_ERR_HIP;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+    ctx->n_cu = prop.multiProcessorCount;
+    snprintf(ctx->dev_name, sizeof(ctx->dev_name), "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc((void**)&ctx->pinned, 4096 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&ctx->dscratch, (size_t(1) << 16) * sizeof(double)) != hipSuccess) {
+    delete ctx;
+    return MPSE_ERR_HIP;
+  }
+  *out = ctx;
+  return MPSE_OK;
+}
+
+int mpse_pool_trim(mpse_ctx* ctx) {
+  if (!ctx) return MPSE_ERR_ARG;
+  MPSE_HIP(ctx, hipSetDevice(ctx->device));
+  MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& kv : ctx->free_blocks) {
+    (void)hipFree(kv.second);
+    ctx->pool_bytes -= kv.first;
+  }
+  ctx->free_blocks.clear();
+  return MPSE_OK;
+}
+
+int mpse_ctx_destroy(mpse_ctx* ctx) {
+  if (!ctx) return MPSE_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
+  for (auto& kv : ctx->live) (void)hipFree(kv.first);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->dscratch) (void)hipFree(ctx->dscratch);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return MPSE_OK;
+}
+
+int mpse_sync(mpse_ctx* ctx) {
+  if (!ctx) return MPSE_ERR_ARG;
+  MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MPSE_OK;
+}
+
+int mpse_device_info(mpse_ctx* ctx, char* name, size_t name_len, int* n_cu, void** stream) {
+  if (!ctx) return MPSE_ERR_ARG;
+  if (name && name_len) snprintf(name, name_len, "%s", ctx->dev_name);
+  if (n_cu) *n_cu = ctx->n_cu;
+  if (stream) *stream = (void*)ctx->stream;
+  return MPSE_OK;
+}
+
+static size_t bucket_of(size_t bytes) {
+  // 256 B granularity below 1 MiB, then 1/8-octave size classes (<= 12.5 % slack)
+  if (bytes < 256) return 256;
+  if (bytes <= (size_t(1) << 20)) return (bytes + 255) & ~size_t(255);
+  size_t p = size_t(1) << 20;
+  while ((p << 1) <= bytes) p <<= 1;
+  size_t step = p >> 3;
+  return ((bytes + step - 1) / step) * step;
+}
+
+int mpse_malloc(mpse_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return MPSE_ERR_ARG;
+  size_t b = bucket_of(bytes);
+  auto it = ctx->free_blocks.find(b);
+  void* p = nullptr;
+  if (it != ctx->free_blocks.end()) {
+    p = it->second;
+    ctx->free_blocks.erase(it);
+  } else {
+    hipError_t e = hipMalloc(&p, b);
+    if (e != hipSuccess) {
+      // give cached blocks back to the driver and retry once
+      mpse_pool_trim(ctx);
+      e = hipMalloc(&p, b);
+      if (e != hipSuccess) {
+        *dptr = nullptr;
+        return mpse_fail(ctx, MPSE_ERR_OOM, "hipMalloc(%zu) failed: %s (pool %zu B, in use %zu B)", b,
+                         hipGetErrorString(e), ctx->pool_bytes, ctx->in_use_bytes);
+      }
+    }
+    ctx->pool_bytes += b;
+  }
+  ctx->live[p] = b;
+  ctx->in_use_bytes += b;
+  *dptr = p;
+  return MPSE_OK;
+}
+
+int mpse_free(mpse_ctx* ctx, void* dptr) {
+  if (!ctx) return MPSE_ERR_ARG;
+  if (!dptr) return MPSE_OK;
+  auto it = ctx->live.find(dptr);
+  if (it == ctx->live.end()) return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_free: unknown pointer %p", dptr);
+  ctx->free_blocks.emplace(it->second, dptr);
+  ctx->in_use_bytes -= it->second;
+  ctx->live.erase(it);
+  return MPSE_OK;
+}
+
+int mpse_mem_info(mpse_ctx* ctx, size_t* pool_bytes, size_t* in_use_bytes, size_t* device_free,
+                  size_t* device_total) {
+  if (!ctx) return MPSE_ERR_ARG;
+  if (pool_bytes) *pool_bytes = ctx->pool_bytes;
+  if (in_use_bytes) *in_use_bytes = ctx->in_use_bytes;
+  size_t f = 0, t = 0;
+  MPSE_HIP(ctx, hipMemGetInfo(&f, &t));
+  if (device_free) *device_free = f;
+  if (device_total) *device_total = t;
+  return MPSE_OK;
+}
+
+int mpse_memcpy_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src_host))) return MPSE_ERR_ARG;
+  if (!bytes) return MPSE_OK;
+  MPSE_HIP(ctx, hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MPSE_OK;
+}
+
+int mpse_memcpy_d2h(mpse_ctx* ctx, void* dst_host, const void* src, size_t bytes) {
+  if (!ctx || (bytes && (!dst_host || !src))) return MPSE_ERR_ARG;
+  if (!bytes) return MPSE_OK;
+  MPSE_HIP(ctx, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MPSE_OK;
+}
+
+int mpse_memcpy_d2d(mpse_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return MPSE_ERR_ARG;
+  if (!bytes) return MPSE_OK;
+  MPSE_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return MPSE_OK;
+}
+
+int mpse_memset_zero(mpse_ctx* ctx, void* dst, size_t bytes) {
+  if (!ctx || (bytes && !dst)) return MPSE_ERR_ARG;
+  if (!bytes) return MPSE_OK;
+  MPSE_HIP(ctx, hipMemsetAsync(dst, 0, bytes, ctx->stream));
+  return MPSE_OK;
+}
+
+}  // extern "C"

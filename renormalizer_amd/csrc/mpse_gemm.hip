@@ -1,0 +1,369 @@
+// FP64-MFMA strided tensor-contraction kernel (the one dense kernel every hot-path
+// contraction is built from) and its launcher mpse_gemm.
+//
+//   C[b](i,j) = alpha * sum_k opA(A[b](i,k)) opB(B[b](k,j)) + beta * C[b](i,j)
+//
+// Design for gfx950 (MI355X):
+//   * v_mfma_f64_16x16x4_f64 (64 cycles/SIMD): a wave owns a 32x32 output tile = 2x2
+//     MFMA tiles; complex x complex = 4 real MFMAs per tile pair on planar (re / im)
+//     operand fragments, complex x real = 2, real x real = 1.
+//   * a 256-thread workgroup (4 waves, 2x2) owns a 64x64 tile; K advances 16 at a
+//     time: global -> registers (issued one tile ahead, so HBM/L2 latency hides behind
+//     the 16..64 MFMAs of the current tile) -> LDS as planar [k][i] panels padded to
+//     80 doubles so the two k-rows a half-wave reads land on disjoint banks.
+//   * operands are read straight through two-level strides (no transpose copies: the
+//     reference's tensordot materialises a transposed copy before every ?gemm);
+//     complex128 elements are 16-byte loads; the thread->element map follows whichever
+//     logical index is contiguous in memory so wave loads coalesce.
+//   * accumulation order over k is fixed => bitwise reproducible results.
+#include "mpse_internal.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct IdxMap {
+  long long s_hi, s_lo;
+  int ext, lo;
+};
+
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  IdxMap mA, kA, kB, nB, mC, nC;
+  long long sbA, sbB, sbC;  // batch strides in elements
+  int M, N, K;
+  int tiles_m, tiles_n;
+  int a_kfast, b_kfast;
+  int conjA, conjB;
+  int use_beta;
+  double alpha_re, alpha_im, beta_re, beta_im;
+};
+
+__device__ __forceinline__ long long idx_off(const IdxMap& m, int i) {
+  if (m.lo >= m.ext) return (long long)i * m.s_lo;
+  int hi = i / m.lo;
+  int l = i - hi * m.lo;
+  return (long long)hi * m.s_hi + (long long)l * m.s_lo;
+}
+
+constexpr int BM = 64, BN = 64, BK = 16, LD = 80;
+
+template <bool CA, bool CB>
+__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
+  constexpr bool CC = CA || CB;
+  constexpr int EA = CA ? 2 : 1, EB = CB ? 2 : 1, EC = CC ? 2 : 1;
+  // one LDS object: [Are | Aim? | Bre | Bim?], each BK x LD doubles
+  __shared__ double smem[(2 + (CA ? 1 : 0) + (CB ? 1 : 0)) * BK * LD];
+  double* sAr = smem;
+  double* sAi = sAr + BK * LD;  // only meaningful if CA
+  double* sBr = smem + (CA ? 2 : 1) * BK * LD;
+  double* sBi = sBr + BK * LD;  // only meaningful if CB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntile = g.tiles_m * g.tiles_n;
+  const int bid = blockIdx.x;
+  const int b = bid / ntile;
+  const int t = bid - b * ntile;
+  const int tm = t / g.tiles_n;
+  const int tn = t - tm * g.tiles_n;
+
+  const double* A = g.A + (long long)b * g.sbA * EA;
+  const double* B = g.B + (long long)b * g.sbB * EB;
+  double* C = g.C + (long long)b * g.sbC * EC;
+
+  // ---- per-thread staging coordinates (4 elements of each operand tile)
+  int ai[4], ak[4], bj[4], bk[4];
+  long long aoff[4], boff[4];
+  bool aval[4], bval[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (g.a_kfast) {
+      ak[r] = tid & 15;
+      ai[r] = (tid >> 4) + 16 * r;
+    } else {
+      ai[r] = tid & 63;
+      ak[r] = (tid >> 6) + 4 * r;
+    }
+    if (g.b_kfast) {
+      bk[r] = tid & 15;
+      bj[r] = (tid >> 4) + 16 * r;
+    } else {
+      bj[r] = tid & 63;
+      bk[r] = (tid >> 6) + 4 * r;
+    }
+    int gi = tm * BM + ai[r];
+    int gj = tn * BN + bj[r];
+    aval[r] = gi < g.M;
+    bval[r] = gj < g.N;
+    aoff[r] = aval[r] ? idx_off(g.mA, gi) : 0;
+    boff[r] = bval[r] ? idx_off(g.nB, gj) : 0;
+  }
+
+  double2 ra[4], rb[4];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int k = kt * BK + ak[r];
+      double2 v = make_double2(0.0, 0.0);
+      if (aval[r] && k < g.K) {
+        const double* p = A + (aoff[r] + idx_off(g.kA, k)) * EA;
+        if constexpr (CA) {
+          v = *reinterpret_cast<const double2*>(p);
+          if (g.conjA) v.y = -v.y;
+        } else {
+          v.x = *p;
+        }
+      }
+      ra[r] = v;
+      k = kt * BK + bk[r];
+      v = make_double2(0.0, 0.0);
+      if (bval[r] && k < g.K) {
+        const double* p = B + (boff[r] + idx_off(g.kB, k)) * EB;
+        if constexpr (CB) {
+          v = *reinterpret_cast<const double2*>(p);
+          if (g.conjB) v.y = -v.y;
+        } else {
+          v.x = *p;
+        }
+      }
+      rb[r] = v;
+    }
+  };
+
+  v4d acc_re[2][2], acc_im[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc_re[i][j] = v4d{0, 0, 0, 0};
+      acc_im[i][j] = v4d{0, 0, 0, 0};
+    }
+
+  const int nkt = (g.K + BK - 1) / BK;
+  if (nkt > 0) load_tile(0);
+  const int frow = lane & 15, fk = lane >> 4;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sAr[ak[r] * LD + ai[r]] = ra[r].x;
+      if constexpr (CA) sAi[ak[r] * LD + ai[r]] = ra[r].y;
+      sBr[bk[r] * LD + bj[r]] = rb[r].x;
+      if constexpr (CB) sBi[bk[r] * LD + bj[r]] = rb[r].y;
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) load_tile(kt + 1);
+
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int k = kk * 4 + fk;
+      double ar[2], aim[2], br[2], bim[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ar[i] = sAr[k * LD + wm * 32 + i * 16 + frow];
+        if constexpr (CA) aim[i] = sAi[k * LD + wm * 32 + i * 16 + frow];
+        br[i] = sBr[k * LD + wn * 32 + i * 16 + frow];
+        if constexpr (CB) bim[i] = sBi[k * LD + wn * 32 + i * 16 + frow];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], br[j], acc_re[i][j], 0, 0, 0);
+          if constexpr (CA && CB) {
+            acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim[i], bim[j], acc_re[i][j], 0, 0, 0);
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], bim[j], acc_im[i][j], 0, 0, 0);
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[i], br[j], acc_im[i][j], 0, 0, 0);
+          } else if constexpr (CA) {
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[i], br[j], acc_im[i][j], 0, 0, 0);
+          } else if constexpr (CB) {
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], bim[j], acc_im[i][j], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 tile
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int gj = tn * BN + wn * 32 + j * 16 + (lane & 15);
+    if (gj >= g.N) continue;
+    const long long coffn = idx_off(g.nC, gj);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = tm * BM + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        if (gi >= g.M) continue;
+        double* p = C + (idx_off(g.mC, gi) + coffn) * EC;
+        const double xr = acc_re[i][j][r];
+        if constexpr (CC) {
+          const double xi = acc_im[i][j][r];
+          double2 o;
+          o.x = g.alpha_re * xr - g.alpha_im * xi;
+          o.y = g.alpha_re * xi + g.alpha_im * xr;
+          if (g.use_beta) {
+            const double2 c0 = *reinterpret_cast<const double2*>(p);
+            o.x += g.beta_re * c0.x - g.beta_im * c0.y;
+            o.y += g.beta_re * c0.y + g.beta_im * c0.x;
+          }
+          *reinterpret_cast<double2*>(p) = o;
+        } else {
+          double o = g.alpha_re * xr;
+          if (g.use_beta) o += g.beta_re * (*p);
+          *p = o;
+        }
+      }
+    }
+  }
+}
+
+bool to_map(const mpse_index& s, IdxMap* m) {
+  if (s.ext < 0 || s.ext > 0x7fffffffLL) return false;
+  m->ext = (int)s.ext;
+  long long lo = s.lo_ext <= 0 ? 1 : s.lo_ext;
+  if (lo > 0x7fffffffLL) lo = 0x7fffffffLL;
+  m->lo = (int)lo;
+  m->s_hi = s.s_hi;
+  m->s_lo = s.s_lo;
+  return true;
+}
+
+long long fast_stride(const mpse_index& s) {
+  long long a = s.s_lo < 0 ? -s.s_lo : s.s_lo;
+  return s.ext <= 1 ? (long long)1 << 60 : a;
+}
+
+// ---- (d0,d1,d2) -> (d0,d2,d1) copy through a 32x32 LDS tile
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_transpose_inner(double* out, const double* in, long long d0, int d1,
+                                                         int d2, int conj) {
+  constexpr int E = CPLX ? 2 : 1;
+  __shared__ double tile[32][33 * E];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int t1 = (d1 + 31) / 32, t2 = (d2 + 31) / 32;
+  long long bid = blockIdx.x;
+  const long long b0 = bid / ((long long)t1 * t2);
+  const int rem = (int)(bid - b0 * t1 * t2);
+  const int by = rem / t2, bx = rem - by * t2;
+  const double* src = in + b0 * (long long)d1 * d2 * E;
+  double* dst = out + b0 * (long long)d1 * d2 * E;
+  for (int yy = ty; yy < 32; yy += 8) {
+    int y = by * 32 + yy, x = bx * 32 + tx;
+    if (y < d1 && x < d2) {
+      const double* p = src + ((long long)y * d2 + x) * E;
+      tile[yy][tx * E] = p[0];
+      if (CPLX) tile[yy][tx * E + 1] = conj ? -p[1] : p[1];
+    }
+  }
+  __syncthreads();
+  for (int yy = ty; yy < 32; yy += 8) {
+    int x = bx * 32 + yy, y = by * 32 + tx;  // output row = old column
+    if (y < d1 && x < d2) {
+      double* p = dst + ((long long)x * d1 + y) * E;
+      p[0] = tile[tx][yy * E];
+      if (CPLX) p[1] = tile[tx][yy * E + 1];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C) {
+  if (!ctx || !d) return MPSE_ERR_ARG;
+  if ((d->dtype_a != MPSE_F64 && d->dtype_a != MPSE_C128) || (d->dtype_b != MPSE_F64 && d->dtype_b != MPSE_C128))
+    return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_gemm: unknown dtype");
+  if (d->m_a.ext != d->m_c.ext || d->n_b.ext != d->n_c.ext || d->k_a.ext != d->k_b.ext)
+    return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpse_gemm: extents disagree (M %lld/%lld N %lld/%lld K %lld/%lld)",
+                     (long long)d->m_a.ext, (long long)d->m_c.ext, (long long)d->n_b.ext, (long long)d->n_c.ext,
+                     (long long)d->k_a.ext, (long long)d->k_b.ext);
+  if (d->m_a.ext == 0 || d->n_b.ext == 0 || d->batch <= 0) return MPSE_OK;
+  if (!A || !B || !C) return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_gemm: null operand");
+  GemmArgs g;
+  g.A = (const double*)A;
+  g.B = (const double*)B;
+  g.C = (double*)C;
+  if (!to_map(d->m_a, &g.mA) || !to_map(d->k_a, &g.kA) || !to_map(d->k_b, &g.kB) || !to_map(d->n_b, &g.nB) ||
+      !to_map(d->m_c, &g.mC) || !to_map(d->n_c, &g.nC))
+    return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpse_gemm: extent out of range");
+  g.sbA = d->sb_a;
+  g.sbB = d->sb_b;
+  g.sbC = d->sb_c;
+  g.M = g.mA.ext;
+  g.N = g.nB.ext;
+  g.K = g.kA.ext;
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  g.a_kfast = fast_stride(d->k_a) <= fast_stride(d->m_a);
+  g.b_kfast = fast_stride(d->k_b) <= fast_stride(d->n_b);
+  g.conjA = d->conj_a && d->dtype_a == MPSE_C128;
+  g.conjB = d->conj_b && d->dtype_b == MPSE_C128;
+  g.alpha_re = d->alpha_re;
+  g.alpha_im = d->alpha_im;
+  g.beta_re = d->beta_re;
+  g.beta_im = d->beta_im;
+  g.use_beta = (d->beta_re != 0.0 || d->beta_im != 0.0);
+  long long nblk = (long long)g.tiles_m * g.tiles_n * d->batch;
+  if (nblk > 0x7fffffffLL) return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpse_gemm: grid too large");
+  dim3 grid((unsigned)nblk), block(256);
+  const bool ca = d->dtype_a == MPSE_C128, cb = d->dtype_b == MPSE_C128;
+  if (ca && cb)
+    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, g);
+  else if (ca)
+    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, g);
+  else if (cb)
+    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, g);
+  else
+    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, g);
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
+int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index ma, mpse_index ka, mpse_index kb,
+              mpse_index nb, mpse_index mc, mpse_index nc, int64_t batch, int64_t sba, int64_t sbb, int64_t sbc,
+              const void* A, const void* B, void* C, double alpha, double beta) {
+  mpse_gemm_desc d;
+  d.dtype_a = dta;
+  d.dtype_b = dtb;
+  d.conj_a = conja;
+  d.conj_b = conjb;
+  d.m_a = ma;
+  d.k_a = ka;
+  d.k_b = kb;
+  d.n_b = nb;
+  d.m_c = mc;
+  d.n_c = nc;
+  d.batch = batch;
+  d.sb_a = sba;
+  d.sb_b = sbb;
+  d.sb_c = sbc;
+  d.alpha_re = alpha;
+  d.alpha_im = 0.0;
+  d.beta_re = beta;
+  d.beta_im = 0.0;
+  return mpse_gemm(ctx, &d, A, B, C);
+}
+
+extern "C" int mpse_transpose_inner(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t d0, int64_t d1,
+                                    int64_t d2, int conj) {
+  if (!ctx) return MPSE_ERR_ARG;
+  if (d0 <= 0 || d1 <= 0 || d2 <= 0) return MPSE_OK;
+  if (!out || !in) return MPSE_ERR_ARG;
+  long long nblk = d0 * ((d1 + 31) / 32) * ((d2 + 31) / 32);
+  if (nblk > 0x7fffffffLL) return mpse_fail(ctx, MPSE_ERR_SHAPE, "transpose grid too large");
+  if (dtype == MPSE_C128)
+    hipLaunchKernelGGL((k_transpose_inner<true>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, (double*)out,
+                       (const double*)in, (long long)d0, (int)d1, (int)d2, conj);
+  else
+    hipLaunchKernelGGL((k_transpose_inner<false>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, (double*)out,
+                       (const double*)in, (long long)d0, (int)d1, (int)d2, 0);
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}

@@ -1,0 +1,86 @@
+// Internal declarations shared by the translation units of libmpsengine.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mpsengine.h"
+
+struct mpse_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_cu = 0;
+  char err[512] = {0};
+  char dev_name[128] = {0};
+
+  // size-bucketed caching allocator: hipMalloc/hipFree synchronise the device, the
+  // sweep allocates per site.  Single in-order stream => a freed block may be handed
+  // out again immediately.
+  std::multimap<size_t, void*> free_blocks;
+  std::unordered_map<void*, size_t> live;   // ptr -> bucket size
+  size_t pool_bytes = 0;
+  size_t in_use_bytes = 0;
+
+  // small pinned staging buffer for scalar read-backs
+  double* pinned = nullptr;     // 4096 doubles
+  double* dscratch = nullptr;   // device scratch for reductions (1<<16 doubles)
+};
+
+int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...);
+
+#define MPSE_HIP(ctx, call)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (call);                                                              \
+    if (_e != hipSuccess)                                                                \
+      return mpse_fail((ctx), (_e == hipErrorOutOfMemory) ? MPSE_ERR_OOM : MPSE_ERR_HIP, \
+                       "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+  } while (0)
+
+#define MPSE_TRY(call)            \
+  do {                            \
+    int _s = (call);              \
+    if (_s != MPSE_OK) return _s; \
+  } while (0)
+
+// RAII temporary from the pool
+struct TmpBuf {
+  mpse_ctx* ctx;
+  void* p = nullptr;
+  TmpBuf(mpse_ctx* c) : ctx(c) {}
+  int alloc(size_t bytes) { return mpse_malloc(ctx, bytes ? bytes : 16, &p); }
+  ~TmpBuf() {
+    if (p) mpse_free(ctx, p);
+  }
+  template <class T>
+  T* as() { return reinterpret_cast<T*>(p); }
+};
+
+static inline size_t dtype_size(int dt) { return dt == MPSE_C128 ? 16 : 8; }
+static inline mpse_index idx1(int64_t ext, int64_t stride) { return mpse_index{ext, ext > 0 ? ext : 1, 0, stride}; }
+static inline mpse_index idx2(int64_t hi_ext, int64_t lo_ext, int64_t s_hi, int64_t s_lo) {
+  return mpse_index{hi_ext * lo_ext, lo_ext > 0 ? lo_ext : 1, s_hi, s_lo};
+}
+
+// convenience wrapper over mpse_gemm used by the contraction entry points
+int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index ma, mpse_index ka,
+              mpse_index kb, mpse_index nb, mpse_index mc, mpse_index nc, int64_t batch, int64_t sba,
+              int64_t sbb, int64_t sbc, const void* A, const void* B, void* C, double alpha = 1.0,
+              double beta = 0.0);
+
+// reductions (mpse_vec.hip): results land in ctx->pinned after a stream sync
+int dotc_sync(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n, double* re, double* im);
+
+// Householder building blocks on column-major workspaces (mpse_qr.hip), shared with the SVD
+struct HhParam {  // per reflector: H = I - tau v v^H, v = (1, scale * tail)
+  double tau_re, tau_im;
+  double scale_re, scale_im;
+};
+int hh_factor_colmajor(mpse_ctx* ctx, bool cplx, double* ws, int mm, int nn, int k, HhParam* prm);
+int hh_formq_colmajor(mpse_ctx* ctx, bool cplx, double* q, const double* ws, int mm, int k, const HhParam* prm);

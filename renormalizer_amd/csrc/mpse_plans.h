@@ -1,0 +1,170 @@
+// Contraction plans for the hot path: each environment update / effective-Hamiltonian
+// matvec is a short list of strided-GEMM steps (see mpse_gemm.hip) over named buffers.
+// Pure host C++ with no HIP dependency, so the index algebra can be exercised on a CPU
+// (tests/host_emu) with a naive loop executor; the product executes the same plans
+// with the FP64-MFMA kernel (mpse_contract.hip).
+//
+// Contraction order is (env . site) . W . (other side) - the order opt_einsum's
+// optimal path picks for D >> w, d (mps/hop_expr.py via mps/oe_contract_wrap.py:24-35) -
+// i.e. two large GEMMs around a small batched contraction with the MPO site tensor.
+// All index permutations are absorbed in operand strides; nothing is transposed in memory.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/mpsengine.h"
+
+namespace mpse_plan {
+
+enum Buf { B_L = 0, B_R, B_W0, B_W1, B_C, B_BRA, B_OUT, B_T1, B_T2, B_T3, B_COUNT };
+
+struct Step {
+  int a, b, c;                 // buffer ids
+  int64_t a_off, b_off, c_off; // element offsets into the buffers
+  int dta, dtb;
+  int conja, conjb;
+  mpse_index ma, ka, kb, nb, mc, nc;
+  int64_t batch, sba, sbb, sbc;
+};
+
+struct Plan {
+  std::vector<Step> steps;
+  int64_t tmp_elems[3] = {0, 0, 0};  // T1, T2, T3 sizes (elements of the working dtype)
+  const char* error = nullptr;
+};
+
+inline mpse_index i1(int64_t ext, int64_t stride) { return mpse_index{ext, ext > 0 ? ext : 1, 0, stride}; }
+inline mpse_index i2(int64_t hi, int64_t lo, int64_t s_hi, int64_t s_lo) {
+  return mpse_index{hi * lo, lo > 0 ? lo : 1, s_hi, s_lo};
+}
+
+inline void push(Plan& p, int a, int64_t ao, int dta, int conja, int b, int64_t bo, int dtb, int conjb, int c,
+                 int64_t co, mpse_index ma, mpse_index ka, mpse_index kb, mpse_index nb, mpse_index mc,
+                 mpse_index nc, int64_t batch = 1, int64_t sba = 0, int64_t sbb = 0, int64_t sbc = 0) {
+  p.steps.push_back(Step{a, b, c, ao, bo, co, dta, dtb, conja, conjb, ma, ka, kb, nb, mc, nc, batch, sba, sbb, sbc});
+}
+
+// T_out[a, d, f, n] = sum_{b,e} W[b,d,e,f] T_in[a, b, e, n]   (W (wl,d,d,wr) row-major; batch over a)
+inline void push_w(Plan& p, int wbuf, int w_dtype, int tin, int tout, int t_dtype, int64_t na, int64_t wl, int64_t d,
+                   int64_t wr, int64_t N) {
+  push(p, wbuf, 0, w_dtype, 0, tin, 0, t_dtype, 0, tout, 0,
+       /*A=W: i=(d | f), k=(b | e)*/ i2(d, wr, d * wr, 1), i2(wl, d, d * d * wr, wr),
+       /*B=T_in[a]: k=(b,e), n*/ i1(wl * d, N), i1(N, 1),
+       /*C=T_out[a]: (d,f), n*/ i1(d * wr, N), i1(N, 1), na, 0, wl * d * N, d * wr * N);
+}
+
+// Effective Hamiltonian matvec, mps/hop_expr.py:57-115.
+inline Plan plan_heff(int dtype, const mpse_heff& h) {
+  Plan p;
+  const mpse_dims& s = h.dims;
+  const int64_t Dl = s.Dl_ket, Dr = s.Dr_ket, wl = s.wl, wr = s.wr;
+  const int64_t anc = s.danc > 0 ? s.danc : 1;
+  if (s.Dl_bra != s.Dl_ket || s.Dr_bra != s.Dr_ket) {
+    p.error = "heff: bra/ket bonds must agree";
+    return p;
+  }
+  if (h.nsite == 0) {
+    // abc,lbk,ck->al (hop_expr.py:63-67): T[a,b,k] = L[(a,b),c] S[c,k] ; out[a,l] = T[a,(b,k)] R[l,(b,k)]
+    if (wl != wr) {
+      p.error = "heff(0-site): wl != wr";
+      return p;
+    }
+    p.tmp_elems[0] = Dl * wl * Dr;
+    push(p, B_L, 0, h.l_dtype, 0, B_C, 0, dtype, 0, B_T1, 0, i1(Dl * wl, Dl), i1(Dl, 1), i1(Dl, Dr), i1(Dr, 1),
+         i1(Dl * wl, Dr), i1(Dr, 1));
+    push(p, B_T1, 0, dtype, 0, B_R, 0, h.r_dtype, 0, B_OUT, 0, i1(Dl, wl * Dr), i1(wl * Dr, 1), i1(wr * Dr, 1),
+         i1(Dr, wr * Dr), i1(Dl, Dr), i1(Dr, 1));
+    return p;
+  }
+  if (h.nsite == 1) {
+    // abc,bdef,lfk,cek->adl (hop_expr.py:75-79); ancilla cegk->adgl (87-91)
+    const int64_t d = s.d0, N = d * anc * Dr, Nb = anc * Dr;
+    p.tmp_elems[0] = Dl * wl * N;
+    p.tmp_elems[1] = Dl * d * wr * Nb;
+    // T1[a,b,(e,g,k)] = sum_c L[(a,b),c] C[c,(e,g,k)]
+    push(p, B_L, 0, h.l_dtype, 0, B_C, 0, dtype, 0, B_T1, 0, i1(Dl * wl, Dl), i1(Dl, 1), i1(Dl, N), i1(N, 1),
+         i1(Dl * wl, N), i1(N, 1));
+    // T2[a,d,f,(g,k)] = sum_{b,e} W[b,d,e,f] T1[a,b,e,(g,k)]
+    push_w(p, B_W0, h.w_dtype, B_T1, B_T2, dtype, Dl, wl, d, wr, Nb);
+    // out[(a,d,g),l] = sum_{f,k} T2[a,d,f,g,k] R[l,f,k]
+    push(p, B_T2, 0, dtype, 0, B_R, 0, h.r_dtype, 0, B_OUT, 0,
+         /*A: m=((a,d) | g)*/ i2(Dl * d, anc, wr * anc * Dr, Dr), /*k=(f | k)*/ i2(wr, Dr, anc * Dr, 1),
+         /*B=R: k=(f,k), n=l*/ i1(wr * Dr, 1), i1(Dr, wr * Dr), i1(Dl * d * anc, Dr), i1(Dr, 1));
+    return p;
+  }
+  if (h.nsite == 2) {
+    // abc,bdef,fghj,ljk,cehk->adgl (hop_expr.py:99-103); ancilla cemhnk->admgnl (111-115)
+    const int64_t d0 = s.d0, d1 = s.d1, wm = s.wm;
+    const int64_t n2 = anc * Dr;            // (n,k): trailing block after h
+    const int64_t n1 = anc * d1 * n2;       // (m,h,n,k): trailing block after e
+    const int64_t N = d0 * n1;
+    p.tmp_elems[0] = Dl * wl * N;
+    p.tmp_elems[1] = Dl * d0 * wm * n1;
+    p.tmp_elems[2] = Dl * d0 * anc * d1 * wr * n2;
+    // T1[a,b,(e,m,h,n,k)]
+    push(p, B_L, 0, h.l_dtype, 0, B_C, 0, dtype, 0, B_T1, 0, i1(Dl * wl, Dl), i1(Dl, 1), i1(Dl, N), i1(N, 1),
+         i1(Dl * wl, N), i1(N, 1));
+    // T2[a,d,f,(m,h,n,k)]
+    push_w(p, B_W0, h.w_dtype, B_T1, B_T2, dtype, Dl, wl, d0, wm, n1);
+    // T3[(a,d),m,g,j,(n,k)] = sum_{f,h} W1[f,g,h,j] T2[(a,d),f,m,h,(n,k)]   batch (a,d); one step per m
+    for (int64_t m = 0; m < anc; ++m)
+      push(p, B_W1, 0, h.w_dtype, 0, B_T2, m * d1 * n2, dtype, 0, B_T3, m * d1 * wr * n2,
+           i2(d1, wr, d1 * wr, 1), i2(wm, d1, d1 * d1 * wr, wr),
+           /*B: k=(f | h)*/ i2(wm, d1, anc * d1 * n2, n2), i1(n2, 1),
+           /*C: (g,j),(n,k)*/ i1(d1 * wr, n2), i1(n2, 1), Dl * d0, 0, wm * anc * d1 * n2, anc * d1 * wr * n2);
+    // out[(a,d,m,g,n),l] = sum_{j,k} T3[a,d,m,g,j,n,k] R[l,j,k]
+    push(p, B_T3, 0, dtype, 0, B_R, 0, h.r_dtype, 0, B_OUT, 0, i2(Dl * d0 * anc * d1, anc, wr * anc * Dr, Dr),
+         i2(wr, Dr, anc * Dr, 1), i1(wr * Dr, 1), i1(Dr, wr * Dr), i1(Dl * d0 * anc * d1 * anc, Dr), i1(Dr, 1));
+    return p;
+  }
+  p.error = "heff: nsite must be 0, 1 or 2";
+  return p;
+}
+
+// Environment update, mps/lib.py:169-250.  Buffers: B_L = incoming environment (either
+// domain), B_C = ket site, B_BRA = bra site, B_W0 = mpo site, B_OUT = new environment.
+inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, int w_dtype, int bra_conj) {
+  Plan p;
+  const int64_t d = s.d0, wl = s.wl, wr = s.wr;
+  const int64_t anc = s.danc > 0 ? s.danc : 1;
+  const int64_t Dlb = s.Dl_bra, Dlk = s.Dl_ket, Drb = s.Dr_bra, Drk = s.Dr_ket;
+  if (domain == MPSE_DOMAIN_L) {
+    // env L[a,b,c] ; ket A[c,e,g,h] ; W[b,d,e,f] ; bra Ab[a,d,g,p] -> out[p,f,h]  (g = traced ancilla)
+    const int64_t N = d * anc * Drk;
+    p.tmp_elems[0] = Dlb * wl * N;
+    p.tmp_elems[1] = Dlb * d * wr * anc * Drk;
+    // X[a,b,(e,g,h)] = sum_c L[(a,b),c] A[c,(e,g,h)]
+    push(p, B_L, 0, env_dtype, 0, B_C, 0, dtype, 0, B_T1, 0, i1(Dlb * wl, Dlk), i1(Dlk, 1), i1(Dlk, N), i1(N, 1),
+         i1(Dlb * wl, N), i1(N, 1));
+    // Y[a,d,f,(g,h)] = sum_{b,e} W[b,d,e,f] X[a,b,e,(g,h)]
+    push_w(p, B_W0, w_dtype, B_T1, B_T2, dtype, Dlb, wl, d, wr, anc * Drk);
+    // out[p,(f,h)] = sum_{a,d,g} bra*[(a,d,g),p] Y[a,d,f,g,h]
+    //   A = bra^T: m = p (stride 1), k = (a,d,g) (stride Drb)
+    //   B = Y: k = ((a,d) | g): s_hi = wr*anc*Drk, s_lo = Drk ; n = (f | h): s_hi = anc*Drk, s_lo = 1
+    push(p, B_BRA, 0, dtype, bra_conj, B_T2, 0, dtype, 0, B_OUT, 0, i1(Drb, 1), i1(Dlb * d * anc, Drb),
+         i2(Dlb * d, anc, wr * anc * Drk, Drk), i2(wr, Drk, anc * Drk, 1), i1(Drb, wr * Drk), i1(wr * Drk, 1));
+    return p;
+  }
+  if (domain == MPSE_DOMAIN_R) {
+    // env R[a,b,c] ; ket A[h,e,g,c] ; W[q,d,e,b] ; bra Ab[p,d,g,a] -> out[p,q,h]
+    p.tmp_elems[0] = Dlk * d * anc * wr * Drb;
+    p.tmp_elems[1] = Dlk * wl * d * anc * Drb;
+    // X[(h,e,g),(b,a)] = sum_c A[(h,e,g),c] R[a,b,c]   (n ordered (b | a) through the strides of R)
+    push(p, B_C, 0, dtype, 0, B_L, 0, env_dtype, 0, B_T1, 0, i1(Dlk * d * anc, Drk), i1(Drk, 1), i1(Drk, 1),
+         i2(wr, Drb, Drk, wr * Drk), i1(Dlk * d * anc, wr * Drb), i1(wr * Drb, 1));
+    // Y[h,q,d,g,a] = sum_{e,b} W[q,d,e,b] X[h,e,g,b,a] ; batch h ; one step per ancilla value g
+    for (int64_t g = 0; g < anc; ++g)
+      push(p, B_W0, 0, w_dtype, 0, B_T1, g * wr * Drb, dtype, 0, B_T2, g * Drb,
+           /*A=W: m=(q,d), k=(e,b)*/ i1(wl * d, d * wr), i1(d * wr, 1),
+           /*B: k=(e | b), n=a*/ i2(d, wr, anc * wr * Drb, Drb), i1(Drb, 1),
+           /*C: m=(q,d), n=a*/ i1(wl * d, anc * Drb), i1(Drb, 1), Dlk, 0, d * anc * wr * Drb, wl * d * anc * Drb);
+    // out[p,(q,h)] = sum_{d,g,a} bra*[p,(d,g,a)] Y[h,q,(d,g,a)]
+    push(p, B_BRA, 0, dtype, bra_conj, B_T2, 0, dtype, 0, B_OUT, 0, i1(Dlb, d * anc * Drb), i1(d * anc * Drb, 1),
+         i1(d * anc * Drb, 1), i2(wl, Dlk, d * anc * Drb, wl * d * anc * Drb), i1(Dlb, wl * Dlk), i1(wl * Dlk, 1));
+    return p;
+  }
+  p.error = "env: bad domain";
+  return p;
+}
+
+}  // namespace mpse_plan

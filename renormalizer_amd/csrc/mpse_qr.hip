@@ -1,0 +1,420 @@
+// Quantum-number blocked QR / RQ on the device (replaces scipy.linalg.qr / rq per block in
+// mps/svd_qn.py:177-213 plus the blockrecover scatter, :89-96).
+//
+// Householder reflections (LAPACK ?geqr2/?ung2r conventions), because the centre matrices of
+// a fixed-bond TDVP sweep are numerically rank deficient most of the time: Gram-matrix
+// (Cholesky) schemes break down there, Householder always returns an exact isometry.
+// Layout: each block is gathered into a column-major workspace so that the column-wise
+// reductions are coalesced; one workgroup owns one column.
+//   factorisation : one launch per reflector j - workgroup c applies H_j^H to column c > j
+//                   (dot + update, column stays in L2) and the owner of column j+1 then
+//                   derives the next reflector's parameters in the same launch;
+//   Q formation   : ONE launch - column c of Q = H_0 ... H_c e_c is independent of all other
+//                   columns, so workgroup c applies its reflectors back to back.
+#include "mpse_device.h"
+#include "mpse_internal.h"
+
+namespace {
+
+template <bool CPLX>
+struct Cx;
+template <>
+struct Cx<true> {
+  static constexpr int E = 2;
+  __device__ static double2 ld(const double* p, long long i) { return reinterpret_cast<const double2*>(p)[i]; }
+  __device__ static void st(double* p, long long i, double2 v) { reinterpret_cast<double2*>(p)[i] = v; }
+};
+template <>
+struct Cx<false> {
+  static constexpr int E = 1;
+  __device__ static double2 ld(const double* p, long long i) { return make_double2(p[i], 0.0); }
+  __device__ static void st(double* p, long long i, double2 v) { p[i] = v.x; }
+};
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cmulc(double2 a, double2 b) {  // conj(a) * b
+  return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+}
+
+// gather a block into the column-major workspace: ws[r + c*mm]
+//   !herm: ws[r,c] = coef[rows[r], cols[c]]          (mm = #rows)
+//    herm: ws[r,c] = conj(coef[rows[c], cols[r]])    (mm = #cols)  -> QR of the adjoint gives RQ
+template <bool CPLX>
+__global__ void k_gather_block(double* ws, const double* __restrict__ coef, long long ncol,
+                               const long long* __restrict__ rows, const long long* __restrict__ cols, int mm, int nn,
+                               int herm) {
+  const long long total = (long long)mm * nn;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    // make the SOURCE access coalesced: consecutive threads walk along a coef row
+    int r, c;
+    if (!herm) {
+      c = (int)(t % nn);
+      r = (int)(t / nn);
+      double2 v = Cx<CPLX>::ld(coef, rows[r] * ncol + cols[c]);
+      Cx<CPLX>::st(ws, r + (long long)c * mm, v);
+    } else {
+      r = (int)(t % mm);
+      c = (int)(t / mm);
+      double2 v = Cx<CPLX>::ld(coef, rows[c] * ncol + cols[r]);
+      v.y = -v.y;
+      Cx<CPLX>::st(ws, r + (long long)c * mm, v);
+    }
+  }
+}
+
+// reflector parameters for column j from its current content (rows >= j); one workgroup.
+template <bool CPLX>
+__device__ void hh_make_params(double* a, int mm, int j, HhParam* prm) {
+  double* col = a + (long long)j * mm * Cx<CPLX>::E;
+  double s = 0, z = 0;
+  for (int r = j + 1 + threadIdx.x; r < mm; r += RED_THREADS) {
+    const double2 v = Cx<CPLX>::ld(col, r);
+    s += v.x * v.x + v.y * v.y;
+  }
+  block_allsum2(s, z);
+  if (threadIdx.x == 0) {
+    const double2 alpha = Cx<CPLX>::ld(col, j);
+    HhParam p;
+    if (s == 0.0 && alpha.y == 0.0) {
+      p.tau_re = p.tau_im = p.scale_re = p.scale_im = 0.0;  // H = I
+    } else {
+      const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + s);
+      const double beta = alpha.x >= 0.0 ? -nrm : nrm;
+      p.tau_re = (beta - alpha.x) / beta;
+      p.tau_im = -alpha.y / beta;
+      const double dr = alpha.x - beta, di = alpha.y;  // scale = 1 / (alpha - beta)
+      const double den = dr * dr + di * di;
+      p.scale_re = dr / den;
+      p.scale_im = -di / den;
+      Cx<CPLX>::st(col, j, make_double2(beta, 0.0));
+    }
+    prm[j] = p;
+  }
+}
+
+template <bool CPLX>
+__global__ __launch_bounds__(RED_THREADS) void k_hh_first(double* a, int mm, HhParam* prm) {
+  hh_make_params<CPLX>(a, mm, 0, prm);
+}
+
+// apply H_j^H to column c = j + 1 + blockIdx.x ; then (c == j+1) derive reflector j+1
+template <bool CPLX>
+__global__ __launch_bounds__(RED_THREADS) void k_hh_apply(double* a, int mm, int kref, int j, HhParam* prm) {
+  constexpr int E = Cx<CPLX>::E;
+  const int c = j + 1 + blockIdx.x;
+  const double* vj = a + (long long)j * mm * E;
+  double* col = a + (long long)c * mm * E;
+  const HhParam p = prm[j];
+  const double2 tau = make_double2(p.tau_re, p.tau_im), scale = make_double2(p.scale_re, p.scale_im);
+  if (tau.x != 0.0 || tau.y != 0.0) {
+    double dr = 0, di = 0;
+    for (int r = j + 1 + threadIdx.x; r < mm; r += RED_THREADS) {
+      const double2 t = cmulc(Cx<CPLX>::ld(vj, r), Cx<CPLX>::ld(col, r));
+      dr += t.x;
+      di += t.y;
+    }
+    block_allsum2(dr, di);
+    // dot = v^H col = col[j] + conj(scale) * sum conj(tail) col
+    const double2 head = Cx<CPLX>::ld(col, j);
+    const double2 sc = cmulc(scale, make_double2(dr, di));
+    const double2 dot = make_double2(head.x + sc.x, head.y + sc.y);
+    const double2 f = cmulc(tau, dot);          // conj(tau) * dot
+    const double2 fs = cmul(f, scale);
+    __syncthreads();  // everyone has read col[j] before thread 0 overwrites it
+    for (int r = j + 1 + threadIdx.x; r < mm; r += RED_THREADS) {
+      const double2 t = cmul(fs, Cx<CPLX>::ld(vj, r));
+      double2 x = Cx<CPLX>::ld(col, r);
+      x.x -= t.x;
+      x.y -= t.y;
+      Cx<CPLX>::st(col, r, x);
+    }
+    if (threadIdx.x == 0) Cx<CPLX>::st(col, j, make_double2(head.x - f.x, head.y - f.y));
+  }
+  if (blockIdx.x == 0 && j + 1 < kref) {
+    __syncthreads();
+    hh_make_params<CPLX>(a, mm, j + 1, prm);
+  }
+}
+
+// column c of Q (mm x k, column-major) = H_0 H_1 ... H_c e_c
+template <bool CPLX>
+__global__ __launch_bounds__(RED_THREADS) void k_hh_formq(double* q, const double* __restrict__ a, int mm, int kref,
+                                                          const HhParam* __restrict__ prm) {
+  constexpr int E = Cx<CPLX>::E;
+  const int c = blockIdx.x;
+  double* col = q + (long long)c * mm * E;
+  for (int r = threadIdx.x; r < mm; r += RED_THREADS) Cx<CPLX>::st(col, r, make_double2(r == c ? 1.0 : 0.0, 0.0));
+  __syncthreads();
+  for (int j = c; j >= 0; --j) {
+    const HhParam p = prm[j];
+    const double2 tau = make_double2(p.tau_re, p.tau_im), scale = make_double2(p.scale_re, p.scale_im);
+    if (tau.x == 0.0 && tau.y == 0.0) continue;
+    const double* vj = a + (long long)j * mm * E;
+    double dr = 0, di = 0;
+    for (int r = j + 1 + threadIdx.x; r < mm; r += RED_THREADS) {
+      const double2 t = cmulc(Cx<CPLX>::ld(vj, r), Cx<CPLX>::ld(col, r));
+      dr += t.x;
+      di += t.y;
+    }
+    block_allsum2(dr, di);
+    const double2 head = Cx<CPLX>::ld(col, j);
+    const double2 sc = cmulc(scale, make_double2(dr, di));
+    const double2 dot = make_double2(head.x + sc.x, head.y + sc.y);
+    const double2 f = cmul(tau, dot);  // H (not H^H)
+    const double2 fs = cmul(f, scale);
+    __syncthreads();  // everyone has read col[j]
+    for (int r = j + 1 + threadIdx.x; r < mm; r += RED_THREADS) {
+      const double2 t = cmul(fs, Cx<CPLX>::ld(vj, r));
+      double2 x = Cx<CPLX>::ld(col, r);
+      x.x -= t.x;
+      x.y -= t.y;
+      Cx<CPLX>::st(col, r, x);
+    }
+    if (threadIdx.x == 0) Cx<CPLX>::st(col, j, make_double2(head.x - f.x, head.y - f.y));
+    __syncthreads();
+  }
+}
+
+// scatter Q (mm x k col-major) and R (upper triangle of a, k x nn) to U (nrow x K) / Vt (K x ncol)
+//   !herm: U[rows[r], koff+c] = Q[r,c] ; Vt[koff+i, cols[c]] = R[i,c]
+//    herm: Vt[koff+c, cols[r]] = conj(Q[r,c]) ; U[rows[c], koff+i] = conj(R[i,c])
+template <bool CPLX>
+__global__ void k_scatter_q(double* U, double* Vt, const double* __restrict__ q, long long K, long long ncol,
+                            const long long* __restrict__ rows, const long long* __restrict__ cols, int mm, int k,
+                            long long koff, int herm) {
+  const long long total = (long long)mm * k;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    if (!herm) {
+      const int c = (int)(t % k), r = (int)(t / k);  // consecutive threads along a U row
+      Cx<CPLX>::st(U, rows[r] * K + koff + c, Cx<CPLX>::ld(q, r + (long long)c * mm));
+    } else {
+      const int r = (int)(t % mm), c = (int)(t / mm);
+      double2 v = Cx<CPLX>::ld(q, r + (long long)c * mm);
+      v.y = -v.y;
+      Cx<CPLX>::st(Vt, (koff + c) * ncol + cols[r], v);
+    }
+  }
+}
+
+template <bool CPLX>
+__global__ void k_scatter_r(double* U, double* Vt, const double* __restrict__ a, long long K, long long ncol,
+                            const long long* __restrict__ rows, const long long* __restrict__ cols, int mm, int nn,
+                            int k, long long koff, int herm) {
+  const long long total = (long long)k * nn;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int c = (int)(t % nn), i = (int)(t / nn);
+    double2 v = (i <= c) ? Cx<CPLX>::ld(a, i + (long long)c * mm) : make_double2(0.0, 0.0);
+    if (!herm) {
+      Cx<CPLX>::st(Vt, (koff + i) * ncol + cols[c], v);
+    } else {
+      v.y = -v.y;
+      Cx<CPLX>::st(U, rows[c] * K + koff + i, v);
+    }
+  }
+}
+
+inline int ew_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+// Householder factorisation of a column-major mm x nn workspace in place (k = min(mm,nn)
+// reflectors; R ends up in the upper triangle, reflector tails below the diagonal).
+int hh_factor_colmajor(mpse_ctx* ctx, bool cplx, double* ws, int mm, int nn, int k, HhParam* prm) {
+  if (k <= 0) return MPSE_OK;
+  if (cplx)
+    hipLaunchKernelGGL((k_hh_first<true>), dim3(1), dim3(RED_THREADS), 0, ctx->stream, ws, mm, prm);
+  else
+    hipLaunchKernelGGL((k_hh_first<false>), dim3(1), dim3(RED_THREADS), 0, ctx->stream, ws, mm, prm);
+  for (int j = 0; j < k; ++j) {
+    const int ncols_right = nn - j - 1;
+    if (ncols_right <= 0) break;
+    if (cplx)
+      hipLaunchKernelGGL((k_hh_apply<true>), dim3(ncols_right), dim3(RED_THREADS), 0, ctx->stream, ws, mm, k, j, prm);
+    else
+      hipLaunchKernelGGL((k_hh_apply<false>), dim3(ncols_right), dim3(RED_THREADS), 0, ctx->stream, ws, mm, k, j, prm);
+  }
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
+// explicit Q (mm x k, column-major) from a factored workspace
+int hh_formq_colmajor(mpse_ctx* ctx, bool cplx, double* q, const double* ws, int mm, int k, const HhParam* prm) {
+  if (k <= 0) return MPSE_OK;
+  if (cplx)
+    hipLaunchKernelGGL((k_hh_formq<true>), dim3(k), dim3(RED_THREADS), 0, ctx->stream, q, ws, mm, k, prm);
+  else
+    hipLaunchKernelGGL((k_hh_formq<false>), dim3(k), dim3(RED_THREADS), 0, ctx->stream, q, ws, mm, k, prm);
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
+namespace {
+
+template <bool CPLX>
+int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, int nblocks, const int64_t* row_idx,
+                  const int64_t* row_off, const int64_t* col_idx, const int64_t* col_off, int herm, void* U, void* Vt,
+                  int64_t K) {
+  constexpr size_t es = CPLX ? 16 : 8;
+  int64_t ktot = 0, maxws = 0, maxq = 0, maxk = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    const int64_t m = row_off[b + 1] - row_off[b], n = col_off[b + 1] - col_off[b];
+    if (m < 0 || n < 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_qr: negative block extent");
+    const int64_t k = m < n ? m : n;
+    ktot += k;
+    if (m * n > maxws) maxws = m * n;
+    const int64_t mm = herm ? n : m;
+    if (mm * k > maxq) maxq = mm * k;
+    if (k > maxk) maxk = k;
+  }
+  if (ktot != K) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_qr: K=%lld but blocks give %lld", (long long)K, (long long)ktot);
+  if (ktot == 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
+  MPSE_TRY(mpse_memset_zero(ctx, U, size_t(nrow * K) * es));
+  MPSE_TRY(mpse_memset_zero(ctx, Vt, size_t(K * ncol) * es));
+  const int64_t nri = row_off[nblocks], nci = col_off[nblocks];
+  TmpBuf IDX(ctx), WS(ctx), Q(ctx), PRM(ctx);
+  MPSE_TRY(IDX.alloc(size_t(nri + nci) * sizeof(int64_t)));
+  MPSE_TRY(WS.alloc(size_t(maxws) * es));
+  MPSE_TRY(Q.alloc(size_t(maxq) * es));
+  MPSE_TRY(PRM.alloc(size_t(maxk + 1) * sizeof(HhParam)));
+  // index lists -> device (host arrays are caller owned: copy synchronously)
+  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.p, row_idx, size_t(nri) * sizeof(int64_t)));
+  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.as<char>() + size_t(nri) * sizeof(int64_t), col_idx, size_t(nci) * sizeof(int64_t)));
+  const long long* drows = IDX.as<long long>();
+  const long long* dcols = IDX.as<long long>() + nri;
+  int64_t koff = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    const int m = (int)(row_off[b + 1] - row_off[b]), n = (int)(col_off[b + 1] - col_off[b]);
+    const int k = m < n ? m : n;
+    if (k == 0) continue;
+    const int mm = herm ? n : m, nn = herm ? m : n;
+    const long long* rows = drows + row_off[b];
+    const long long* cols = dcols + col_off[b];
+    double* ws = WS.as<double>();
+    double* q = Q.as<double>();
+    HhParam* prm = PRM.as<HhParam>();
+    hipLaunchKernelGGL((k_gather_block<CPLX>), dim3(ew_blocks((int64_t)mm * nn)), dim3(256), 0, ctx->stream, ws,
+                       (const double*)coef, (long long)ncol, rows, cols, mm, nn, herm);
+    MPSE_TRY(hh_factor_colmajor(ctx, CPLX, ws, mm, nn, k, prm));
+    MPSE_TRY(hh_formq_colmajor(ctx, CPLX, q, ws, mm, k, prm));
+    hipLaunchKernelGGL((k_scatter_q<CPLX>), dim3(ew_blocks((int64_t)mm * k)), dim3(256), 0, ctx->stream, (double*)U,
+                       (double*)Vt, (const double*)q, (long long)K, (long long)ncol, rows, cols, mm, k,
+                       (long long)koff, herm);
+    hipLaunchKernelGGL((k_scatter_r<CPLX>), dim3(ew_blocks((int64_t)k * nn)), dim3(256), 0, ctx->stream, (double*)U,
+                       (double*)Vt, (const double*)ws, (long long)K, (long long)ncol, rows, cols, mm, nn, k,
+                       (long long)koff, herm);
+    MPSE_HIP(ctx, hipGetLastError());
+    koff += k;
+  }
+  return MPSE_OK;
+}
+
+template <bool CPLX>
+__global__ void k_gather_cols(double* out, const double* __restrict__ in, long long nrow, long long ncol_in,
+                              const long long* __restrict__ cols, const double* __restrict__ scale, long long ncol_out) {
+  const long long total = nrow * ncol_out;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const long long j = t % ncol_out, r = t / ncol_out;
+    double2 v = Cx<CPLX>::ld(in, r * ncol_in + cols[j]);
+    if (scale) {
+      v.x *= scale[j];
+      v.y *= scale[j];
+    }
+    Cx<CPLX>::st(out, t, v);
+  }
+}
+
+template <bool CPLX>
+__global__ void k_gather_rows(double* out, const double* __restrict__ in, long long ncol,
+                              const long long* __restrict__ rows, const double* __restrict__ scale, long long nrow_out) {
+  const long long total = nrow_out * ncol;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const long long j = t % ncol, r = t / ncol;
+    double2 v = Cx<CPLX>::ld(in, rows[r] * ncol + j);
+    if (scale) {
+      v.x *= scale[r];
+      v.y *= scale[r];
+    }
+    Cx<CPLX>::st(out, t, v);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int64_t ncol, int nblocks,
+                  const int64_t* row_idx_host, const int64_t* row_off_host, const int64_t* col_idx_host,
+                  const int64_t* col_off_host, int system_is_R, void* U, void* Vt, int64_t K) {
+  if (!ctx || !coef || !U || !Vt || !row_idx_host || !row_off_host || !col_idx_host || !col_off_host)
+    return MPSE_ERR_ARG;
+  if (nblocks <= 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
+  if (dtype == MPSE_C128)
+    return block_qr_impl<true>(ctx, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host, col_off_host,
+                               system_is_R ? 1 : 0, U, Vt, K);
+  if (dtype == MPSE_F64)
+    return block_qr_impl<false>(ctx, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host,
+                                col_off_host, system_is_R ? 1 : 0, U, Vt, K);
+  return mpse_fail(ctx, MPSE_ERR_ARG, "block_qr: unknown dtype");
+}
+
+int mpse_gather_cols(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t nrow, int64_t ncol_in,
+                     const int64_t* cols_host, const double* scale_host, int64_t ncol_out) {
+  if (!ctx || !cols_host || (nrow * ncol_out && (!out || !in))) return MPSE_ERR_ARG;
+  if (nrow * ncol_out <= 0) return MPSE_OK;
+  TmpBuf IDX(ctx);
+  MPSE_TRY(IDX.alloc(size_t(ncol_out) * 16));
+  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.p, cols_host, size_t(ncol_out) * 8));
+  double* dscale = nullptr;
+  if (scale_host) {
+    dscale = IDX.as<double>() + ncol_out;
+    MPSE_TRY(mpse_memcpy_h2d(ctx, dscale, scale_host, size_t(ncol_out) * 8));
+  }
+  const int nb = ew_blocks(nrow * ncol_out);
+  if (dtype == MPSE_C128)
+    hipLaunchKernelGGL((k_gather_cols<true>), dim3(nb), dim3(256), 0, ctx->stream, (double*)out, (const double*)in,
+                       (long long)nrow, (long long)ncol_in, IDX.as<const long long>(), (const double*)dscale,
+                       (long long)ncol_out);
+  else
+    hipLaunchKernelGGL((k_gather_cols<false>), dim3(nb), dim3(256), 0, ctx->stream, (double*)out, (const double*)in,
+                       (long long)nrow, (long long)ncol_in, IDX.as<const long long>(), (const double*)dscale,
+                       (long long)ncol_out);
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
+int mpse_gather_rows(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t ncol, const int64_t* rows_host,
+                     const double* scale_host, int64_t nrow_out) {
+  if (!ctx || !rows_host || (nrow_out * ncol && (!out || !in))) return MPSE_ERR_ARG;
+  if (nrow_out * ncol <= 0) return MPSE_OK;
+  TmpBuf IDX(ctx);
+  MPSE_TRY(IDX.alloc(size_t(nrow_out) * 16));
+  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.p, rows_host, size_t(nrow_out) * 8));
+  double* dscale = nullptr;
+  if (scale_host) {
+    dscale = IDX.as<double>() + nrow_out;
+    MPSE_TRY(mpse_memcpy_h2d(ctx, dscale, scale_host, size_t(nrow_out) * 8));
+  }
+  const int nb = ew_blocks(nrow_out * ncol);
+  if (dtype == MPSE_C128)
+    hipLaunchKernelGGL((k_gather_rows<true>), dim3(nb), dim3(256), 0, ctx->stream, (double*)out, (const double*)in,
+                       (long long)ncol, IDX.as<const long long>(), (const double*)dscale, (long long)nrow_out);
+  else
+    hipLaunchKernelGGL((k_gather_rows<false>), dim3(nb), dim3(256), 0, ctx->stream, (double*)out, (const double*)in,
+                       (long long)ncol, IDX.as<const long long>(), (const double*)dscale, (long long)nrow_out);
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,325 @@
+// Quantum-number blocked economic SVD by one-sided (Hestenes) Jacobi on the device.
+// Replaces scipy.linalg.svd(gesdd) per block in mps/svd_qn.py:12-49,177-213.
+//
+// Per block (mm >= nn; wide blocks are processed as their adjoint):
+//   * the block is gathered column-major, V = I;
+//   * round-robin sweeps: every launch orthogonalises nn/2 disjoint column pairs, one
+//     workgroup per pair (Gram entries by wavefront-shuffle reductions, then the plane
+//     rotation on the A and V columns); a sweep without rotations ends the iteration;
+//   * sigma_j = |a_j| are read back, sorted on the host (descending, like LAPACK);
+//   * columns are normalised; numerically null columns are zeroed and the left basis is
+//     completed to an exact isometry by a Householder QR of the normalised matrix
+//     (Q R with |R_jj| = 1 on the non-null columns), which is what LAPACK's economic U
+//     guarantees and what the sweep algorithms above this layer rely on.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "mpse_device.h"
+#include "mpse_internal.h"
+
+namespace {
+
+template <bool CPLX>
+struct Cx;
+template <>
+struct Cx<true> {
+  static constexpr int E = 2;
+  __device__ static double2 ld(const double* p, long long i) { return reinterpret_cast<const double2*>(p)[i]; }
+  __device__ static void st(double* p, long long i, double2 v) { reinterpret_cast<double2*>(p)[i] = v; }
+};
+template <>
+struct Cx<false> {
+  static constexpr int E = 1;
+  __device__ static double2 ld(const double* p, long long i) { return make_double2(p[i], 0.0); }
+  __device__ static void st(double* p, long long i, double2 v) { p[i] = v.x; }
+};
+
+inline int ew_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <bool CPLX>
+__global__ void k_gather_block(double* ws, const double* __restrict__ coef, long long ncol,
+                               const long long* __restrict__ rows, const long long* __restrict__ cols, int mm, int nn,
+                               int herm) {
+  const long long total = (long long)mm * nn;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    if (!herm) {
+      const int c = (int)(t % nn), r = (int)(t / nn);
+      Cx<CPLX>::st(ws, r + (long long)c * mm, Cx<CPLX>::ld(coef, rows[r] * ncol + cols[c]));
+    } else {
+      const int r = (int)(t % mm), c = (int)(t / mm);
+      double2 v = Cx<CPLX>::ld(coef, rows[c] * ncol + cols[r]);
+      v.y = -v.y;
+      Cx<CPLX>::st(ws, r + (long long)c * mm, v);
+    }
+  }
+}
+
+template <bool CPLX>
+__global__ void k_set_identity(double* v, int n) {
+  const long long total = (long long)n * n;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride)
+    Cx<CPLX>::st(v, t, make_double2((t % n) == (t / n) ? 1.0 : 0.0, 0.0));
+}
+
+// one round-robin step: workgroup b handles the pair (p,q) of step `step` (circle method on N = even(nn))
+template <bool CPLX>
+__global__ __launch_bounds__(RED_THREADS) void k_jacobi_step(double* a, double* v, int mm, int nn, int N, int step,
+                                                             double tol, int* nrot) {
+  constexpr int E = Cx<CPLX>::E;
+  const int kk = blockIdx.x;
+  int p, q;
+  if (kk == 0) {
+    p = step % (N - 1);
+    q = N - 1;
+  } else {
+    p = (step + kk) % (N - 1);
+    q = (step - kk + (N - 1)) % (N - 1);
+  }
+  if (p > q) {
+    const int t = p;
+    p = q;
+    q = t;
+  }
+  if (q >= nn) return;  // padding column of an odd nn
+  double* ap = a + (long long)p * mm * E;
+  double* aq = a + (long long)q * mm * E;
+  double alpha = 0, beta = 0, gr = 0, gi = 0;
+  for (int r = threadIdx.x; r < mm; r += RED_THREADS) {
+    const double2 x = Cx<CPLX>::ld(ap, r), y = Cx<CPLX>::ld(aq, r);
+    alpha += x.x * x.x + x.y * x.y;
+    beta += y.x * y.x + y.y * y.y;
+    gr += x.x * y.x + x.y * y.y;  // conj(x) * y
+    gi += x.x * y.y - x.y * y.x;
+  }
+  block_allsum2(alpha, beta);
+  block_allsum2(gr, gi);
+  const double g = sqrt(gr * gr + gi * gi);
+  if (g == 0.0 || !(g > tol * sqrt(alpha * beta))) return;  // already orthogonal (block-uniform decision)
+  // phase of gamma and the real Jacobi rotation for [[alpha, g], [g, beta]]
+  const double pr = gr / g, pi = gi / g;
+  const double zeta = (beta - alpha) / (2.0 * g);
+  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+  // a_p' = c a_p - s e^{-i phi} a_q ; a_q' = s a_p + c e^{-i phi} a_q     (e^{-i phi} = (pr, -pi))
+  for (int r = threadIdx.x; r < mm; r += RED_THREADS) {
+    const double2 x = Cx<CPLX>::ld(ap, r), y0 = Cx<CPLX>::ld(aq, r);
+    const double2 y = make_double2(y0.x * pr + y0.y * pi, y0.y * pr - y0.x * pi);
+    Cx<CPLX>::st(ap, r, make_double2(c * x.x - s * y.x, c * x.y - s * y.y));
+    Cx<CPLX>::st(aq, r, make_double2(s * x.x + c * y.x, s * x.y + c * y.y));
+  }
+  double* vp = v + (long long)p * nn * E;
+  double* vq = v + (long long)q * nn * E;
+  for (int r = threadIdx.x; r < nn; r += RED_THREADS) {
+    const double2 x = Cx<CPLX>::ld(vp, r), y0 = Cx<CPLX>::ld(vq, r);
+    const double2 y = make_double2(y0.x * pr + y0.y * pi, y0.y * pr - y0.x * pi);
+    Cx<CPLX>::st(vp, r, make_double2(c * x.x - s * y.x, c * x.y - s * y.y));
+    Cx<CPLX>::st(vq, r, make_double2(s * x.x + c * y.x, s * x.y + c * y.y));
+  }
+  if (threadIdx.x == 0) atomicAdd(nrot, 1);
+}
+
+// sig[c] = |a_c|
+template <bool CPLX>
+__global__ __launch_bounds__(RED_THREADS) void k_col_norms(const double* __restrict__ a, int mm, double* sig) {
+  const double* col = a + (long long)blockIdx.x * mm * Cx<CPLX>::E;
+  double s = 0, z = 0;
+  for (int r = threadIdx.x; r < mm; r += RED_THREADS) {
+    const double2 x = Cx<CPLX>::ld(col, r);
+    s += x.x * x.x + x.y * x.y;
+  }
+  block_allsum2(s, z);
+  if (threadIdx.x == 0) sig[blockIdx.x] = sqrt(s);
+}
+
+// dst[:, j] = src[:, perm[j]] / sig[perm[j]]  (zero when sig <= thresh): columns in descending-sigma
+// order, so that numerically null columns come last and the completing QR has a diagonal R on the rest
+template <bool CPLX>
+__global__ void k_normalise_perm(double* dst, const double* __restrict__ src, int mm, int nn,
+                                 const double* __restrict__ sig, const long long* __restrict__ perm, double thresh) {
+  const long long total = (long long)mm * nn;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int j = (int)(t / mm), r = (int)(t % mm);
+    const int pj = (int)perm[j];
+    const double sg = sig[pj];
+    double2 x = Cx<CPLX>::ld(src, r + (long long)pj * mm);
+    if (sg > thresh) {
+      x.x /= sg;
+      x.y /= sg;
+    } else {
+      x = make_double2(0.0, 0.0);
+    }
+    Cx<CPLX>::st(dst, t, x);
+  }
+}
+
+// scatter the factors of one block.  un: normalised, sigma-ordered and factored workspace (R_jj on its
+// diagonal), q: completed isometry (mm x nn col-major, sigma-ordered), vm: V (nn x nn col-major, Jacobi order),
+// perm: column order (descending sigma).
+//   !herm: U[rows[r], koff+j] = q[r,j] * d_j ; Vt[koff+j, cols[c]] = conj(vm[c,pj])
+//    herm: Vt[koff+j, cols[r]] = conj(q[r,j] * d_j) ; U[rows[c], koff+j] = vm[c,pj]
+//   d_j = R_jj (unit modulus) for a regular column, 1 for a completed null column
+template <bool CPLX>
+__global__ void k_scatter_svd(double* U, double* Vt, const double* __restrict__ un, const double* __restrict__ q,
+                              const double* __restrict__ vm, const long long* __restrict__ perm, long long K,
+                              long long ncol, const long long* __restrict__ rows, const long long* __restrict__ cols,
+                              int mm, int nn, long long koff, int herm) {
+  const long long totq = (long long)mm * nn, totv = (long long)nn * nn;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < totq + totv; t += stride) {
+    if (t < totq) {
+      int j, r;
+      if (!herm) {
+        j = (int)(t % nn);
+        r = (int)(t / nn);
+      } else {
+        r = (int)(t % mm);
+        j = (int)(t / mm);
+      }
+      double2 d = Cx<CPLX>::ld(un, j + (long long)j * mm);
+      if (d.x == 0.0 && d.y == 0.0) d = make_double2(1.0, 0.0);
+      const double2 x = Cx<CPLX>::ld(q, r + (long long)j * mm);
+      double2 y = make_double2(x.x * d.x - x.y * d.y, x.x * d.y + x.y * d.x);
+      if (!herm) {
+        Cx<CPLX>::st(U, rows[r] * K + koff + j, y);
+      } else {
+        y.y = -y.y;
+        Cx<CPLX>::st(Vt, (koff + j) * ncol + cols[r], y);
+      }
+    } else {
+      const long long t2 = t - totq;
+      int j, c;
+      if (!herm) {
+        c = (int)(t2 % nn);
+        j = (int)(t2 / nn);
+      } else {
+        j = (int)(t2 % nn);
+        c = (int)(t2 / nn);
+      }
+      const int pj = (int)perm[j];
+      double2 x = Cx<CPLX>::ld(vm, c + (long long)pj * nn);
+      if (!herm) {
+        x.y = -x.y;
+        Cx<CPLX>::st(Vt, (koff + j) * ncol + cols[c], x);
+      } else {
+        Cx<CPLX>::st(U, rows[c] * K + koff + j, x);
+      }
+    }
+  }
+}
+
+template <bool CPLX>
+int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, int nblocks, const int64_t* row_idx,
+                   const int64_t* row_off, const int64_t* col_idx, const int64_t* col_off, void* U, void* Vt,
+                   double* S_host, int64_t K) {
+  constexpr size_t es = CPLX ? 16 : 8;
+  int64_t ktot = 0, maxws = 0, maxk = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    const int64_t m = row_off[b + 1] - row_off[b], n = col_off[b + 1] - col_off[b];
+    if (m < 0 || n < 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_svd: negative block extent");
+    const int64_t k = std::min(m, n);
+    ktot += k;
+    maxws = std::max(maxws, m * n);
+    maxk = std::max(maxk, k);
+  }
+  if (ktot != K) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_svd: K=%lld but blocks give %lld", (long long)K, (long long)ktot);
+  if (ktot == 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
+  MPSE_TRY(mpse_memset_zero(ctx, U, size_t(nrow * K) * es));
+  MPSE_TRY(mpse_memset_zero(ctx, Vt, size_t(K * ncol) * es));
+  const int64_t nri = row_off[nblocks], nci = col_off[nblocks];
+  TmpBuf IDX(ctx), WS(ctx), Q(ctx), VM(ctx), PRM(ctx), SIG(ctx), PERM(ctx), CNT(ctx);
+  MPSE_TRY(IDX.alloc(size_t(nri + nci) * 8));
+  MPSE_TRY(WS.alloc(size_t(maxws) * es));
+  MPSE_TRY(Q.alloc(size_t(maxws) * es));
+  MPSE_TRY(VM.alloc(size_t(maxk * maxk) * es));
+  MPSE_TRY(PRM.alloc(size_t(maxk + 1) * sizeof(HhParam)));
+  MPSE_TRY(SIG.alloc(size_t(maxk) * 8));
+  MPSE_TRY(PERM.alloc(size_t(maxk) * 8));
+  MPSE_TRY(CNT.alloc(64));
+  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.p, row_idx, size_t(nri) * 8));
+  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.as<char>() + size_t(nri) * 8, col_idx, size_t(nci) * 8));
+  const long long* drows = IDX.as<long long>();
+  const long long* dcols = IDX.as<long long>() + nri;
+  std::vector<double> sig;
+  std::vector<long long> perm;
+  int64_t koff = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    const int m = (int)(row_off[b + 1] - row_off[b]), n = (int)(col_off[b + 1] - col_off[b]);
+    const int k = std::min(m, n);
+    if (k == 0) continue;
+    const int herm = m < n ? 1 : 0;
+    const int mm = herm ? n : m, nn = herm ? m : n;  // mm >= nn == k
+    const long long* rows = drows + row_off[b];
+    const long long* cols = dcols + col_off[b];
+    double* ws = WS.as<double>();
+    double* vm = VM.as<double>();
+    hipLaunchKernelGGL((k_gather_block<CPLX>), dim3(ew_blocks((int64_t)mm * nn)), dim3(256), 0, ctx->stream, ws,
+                       (const double*)coef, (long long)ncol, rows, cols, mm, nn, herm);
+    hipLaunchKernelGGL((k_set_identity<CPLX>), dim3(ew_blocks((int64_t)nn * nn)), dim3(256), 0, ctx->stream, vm, nn);
+    if (nn > 1) {
+      const int N = (nn + 1) & ~1;
+      const double tol = 2.220446049250313e-16 * sqrt((double)mm);
+      bool converged = false;
+      for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
+        MPSE_HIP(ctx, hipMemsetAsync(CNT.p, 0, sizeof(int), ctx->stream));
+        for (int step = 0; step < N - 1; ++step)
+          hipLaunchKernelGGL((k_jacobi_step<CPLX>), dim3(N / 2), dim3(RED_THREADS), 0, ctx->stream, ws, vm, mm, nn, N,
+                             step, tol, CNT.as<int>());
+        MPSE_HIP(ctx, hipGetLastError());
+        MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + 8, CNT.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        converged = (*reinterpret_cast<int*>(ctx->pinned + 8) == 0);
+      }
+      if (!converged) return mpse_fail(ctx, MPSE_ERR_NOCONV, "block_svd: Jacobi did not converge (block %d, %dx%d)", b, m, n);
+    }
+    hipLaunchKernelGGL((k_col_norms<CPLX>), dim3(nn), dim3(RED_THREADS), 0, ctx->stream, (const double*)ws, mm,
+                       SIG.as<double>());
+    sig.resize(nn);
+    MPSE_TRY(mpse_memcpy_d2h(ctx, sig.data(), SIG.p, size_t(nn) * 8));
+    perm.resize(nn);
+    std::iota(perm.begin(), perm.end(), 0LL);
+    std::stable_sort(perm.begin(), perm.end(), [&](long long x, long long y) { return sig[x] > sig[y]; });
+    for (int j = 0; j < nn; ++j) S_host[koff + j] = sig[perm[j]];
+    MPSE_TRY(mpse_memcpy_h2d(ctx, PERM.p, perm.data(), size_t(nn) * 8));
+    const double smax = sig[perm[0]];
+    const double thresh = smax * 2.220446049250313e-16 * (double)mm;
+    double* un = Q.as<double>();
+    hipLaunchKernelGGL((k_normalise_perm<CPLX>), dim3(ew_blocks((int64_t)mm * nn)), dim3(256), 0, ctx->stream, un,
+                       (const double*)ws, mm, nn, SIG.as<const double>(), PERM.as<const long long>(), thresh);
+    MPSE_TRY(hh_factor_colmajor(ctx, CPLX, un, mm, nn, nn, PRM.as<HhParam>()));
+    MPSE_TRY(hh_formq_colmajor(ctx, CPLX, ws, un, mm, nn, PRM.as<HhParam>()));
+    hipLaunchKernelGGL((k_scatter_svd<CPLX>), dim3(ew_blocks((int64_t)mm * nn + (int64_t)nn * nn)), dim3(256), 0,
+                       ctx->stream, (double*)U, (double*)Vt, (const double*)un, (const double*)ws,
+                       (const double*)vm, PERM.as<const long long>(), (long long)K, (long long)ncol, rows, cols, mm, nn,
+                       (long long)koff, herm);
+    MPSE_HIP(ctx, hipGetLastError());
+    // PERM / SIG are rewritten for the next block only after this block's scatter: same stream, in order
+    koff += k;
+  }
+  return MPSE_OK;
+}
+
+}  // namespace
+
+extern "C" int mpse_block_svd(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int64_t ncol, int nblocks,
+                              const int64_t* row_idx_host, const int64_t* row_off_host, const int64_t* col_idx_host,
+                              const int64_t* col_off_host, void* U, void* Vt, double* S_host, int64_t K) {
+  if (!ctx || !coef || !U || !Vt || !S_host || !row_idx_host || !row_off_host || !col_idx_host || !col_off_host)
+    return MPSE_ERR_ARG;
+  if (nblocks <= 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
+  if (dtype == MPSE_C128)
+    return block_svd_impl<true>(ctx, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host,
+                                col_off_host, U, Vt, S_host, K);
+  if (dtype == MPSE_F64)
+    return block_svd_impl<false>(ctx, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host,
+                                 col_off_host, U, Vt, S_host, K);
+  return mpse_fail(ctx, MPSE_ERR_ARG, "block_svd: unknown dtype");
+}

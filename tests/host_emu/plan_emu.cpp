@@ -1,0 +1,88 @@
+// TEST INFRASTRUCTURE: executes the product's contraction plans (renormalizer_amd/csrc/
+// mpse_plans.h) on HOST memory with a naive loop implementation of the strided-GEMM
+// contract, so the index algebra of the hot-path contractions is checked on a CPU-only
+// machine against numpy (tests/test_plans_host.py).  Never linked into libmpsengine.so.
+#include <complex>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../renormalizer_amd/csrc/mpse_plans.h"
+
+using namespace mpse_plan;
+typedef std::complex<double> cd;
+
+static inline int64_t off(const mpse_index& m, int64_t i) {
+  if (m.lo_ext >= m.ext) return i * m.s_lo;
+  return (i / m.lo_ext) * m.s_hi + (i % m.lo_ext) * m.s_lo;
+}
+
+static inline cd ld(const void* p, int dt, int64_t o, int conj) {
+  if (dt == MPSE_C128) {
+    cd v = ((const cd*)p)[o];
+    return conj ? std::conj(v) : v;
+  }
+  return cd(((const double*)p)[o], 0.0);
+}
+
+static void naive_gemm(const Step& s, const void* A, const void* B, void* C) {
+  const int dtc = (s.dta == MPSE_C128 || s.dtb == MPSE_C128) ? MPSE_C128 : MPSE_F64;
+  for (int64_t b = 0; b < s.batch; ++b)
+    for (int64_t i = 0; i < s.ma.ext; ++i)
+      for (int64_t j = 0; j < s.nb.ext; ++j) {
+        cd acc = 0;
+        for (int64_t k = 0; k < s.ka.ext; ++k)
+          acc += ld(A, s.dta, b * s.sba + off(s.ma, i) + off(s.ka, k), s.conja) *
+                 ld(B, s.dtb, b * s.sbb + off(s.kb, k) + off(s.nb, j), s.conjb);
+        int64_t o = b * s.sbc + off(s.mc, i) + off(s.nc, j);
+        if (dtc == MPSE_C128)
+          ((cd*)C)[o] = acc;
+        else
+          ((double*)C)[o] = acc.real();
+      }
+}
+
+static int run(int dtype, const Plan& p, const void* bufs_in[B_COUNT]) {
+  if (p.error) return MPSE_ERR_SHAPE;
+  const void* bufs[B_COUNT];
+  for (int i = 0; i < B_COUNT; ++i) bufs[i] = bufs_in[i];
+  const size_t es = dtype == MPSE_C128 ? 16 : 8;
+  std::vector<char> t[3];
+  for (int i = 0; i < 3; ++i) {
+    t[i].assign(size_t(p.tmp_elems[i]) * es + 16, 0x7f);  // poison: every element must be written before use
+    bufs[B_T1 + i] = t[i].data();
+  }
+  for (const Step& s : p.steps) {
+    const size_t ea = s.dta == MPSE_C128 ? 16 : 8, eb = s.dtb == MPSE_C128 ? 16 : 8;
+    const int dtc = (s.dta == MPSE_C128 || s.dtb == MPSE_C128) ? MPSE_C128 : MPSE_F64;
+    if (dtc != dtype) return MPSE_ERR_ARG;
+    naive_gemm(s, (const char*)bufs[s.a] + s.a_off * ea, (const char*)bufs[s.b] + s.b_off * eb,
+               (char*)const_cast<void*>(bufs[s.c]) + s.c_off * es);
+  }
+  return MPSE_OK;
+}
+
+extern "C" int emu_heff_apply(int dtype, const mpse_heff* h, const void* C, void* out) {
+  Plan p = plan_heff(dtype, *h);
+  const void* bufs[B_COUNT] = {nullptr};
+  bufs[B_L] = h->L;
+  bufs[B_R] = h->R;
+  bufs[B_W0] = h->W0;
+  bufs[B_W1] = h->W1;
+  bufs[B_C] = C;
+  bufs[B_OUT] = out;
+  return run(dtype, p, bufs);
+}
+
+extern "C" int emu_env_update(int dtype, int domain, const mpse_dims* dims, const void* env, int env_dtype,
+                              const void* ket, const void* bra, int bra_conj, const void* W, int w_dtype, void* out) {
+  if (!bra) bra = ket;
+  Plan p = plan_env(dtype, domain, *dims, env_dtype, w_dtype, bra_conj);
+  const void* bufs[B_COUNT] = {nullptr};
+  bufs[B_L] = env;
+  bufs[B_W0] = W;
+  bufs[B_C] = ket;
+  bufs[B_BRA] = bra;
+  bufs[B_OUT] = out;
+  return run(dtype, p, bufs);
+}

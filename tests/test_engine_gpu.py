@@ -1,0 +1,381 @@
+"""GPU parity tests of the C-ABI primitives (libmpsengine.so through ctypes) against the
+reference-pinned oracle and the golden vectors.  Run on the MI355X box: pytest -m gpu."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mps_oracle as orc
+from renormalizer_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return E.get_engine()
+
+
+def _rand(rng, shape, cplx):
+    a = rng.standard_normal(shape)
+    return a + 1j * rng.standard_normal(shape) if cplx else a
+
+
+def _relerr(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, np.abs(b).max()))
+
+
+# ------------------------------------------------------------------ gemm
+
+@pytest.mark.parametrize("ca,cb", [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm_dtypes_and_edges(eng, ca, cb):
+    rng = np.random.default_rng(1)
+    for (M, N, K) in [(1, 1, 1), (3, 5, 2), (16, 16, 4), (64, 64, 16), (65, 63, 17), (130, 70, 33), (200, 31, 129)]:
+        a = _rand(rng, (M, K), ca)
+        b = _rand(rng, (K, N), cb)
+        A, B = eng.asdevice(a), eng.asdevice(b)
+        out = eng.matmul(A, B).to_host()
+        assert _relerr(out, a @ b) < 1e-13, (M, N, K)
+        # transposed / conjugated operand views through strides
+        At, Bt = eng.asdevice(np.ascontiguousarray(a.T)), eng.asdevice(np.ascontiguousarray(b.T))
+        out = eng.matmul(At, Bt, trans_a=True, trans_b=True, conj_a=True, conj_b=True).to_host()
+        assert _relerr(out, a.conj() @ b.conj()) < 1e-13, (M, N, K)
+
+
+def test_gemm_is_asymmetric_safe(eng):
+    """A = I against an asymmetric B catches transposed operand / output maps."""
+    n = 48
+    b = np.arange(n * n, dtype=float).reshape(n, n) + 1j * np.arange(n * n)[::-1].reshape(n, n)
+    out = eng.matmul(eng.asdevice(np.eye(n)), eng.asdevice(b)).to_host()
+    assert np.array_equal(out, b)
+    out = eng.matmul(eng.asdevice(b), eng.asdevice(np.eye(n))).to_host()
+    assert np.array_equal(out, b)
+
+
+def test_gemm_composite_batch_alpha_beta(eng):
+    rng = np.random.default_rng(2)
+    nb, d0, d1, K, N = 3, 4, 5, 7, 6
+    # A[b, i0, k, i1] (composite row index (i0 | i1) around k), B[b, k, n]
+    a = _rand(rng, (nb, d0, K, d1), True)
+    b = _rand(rng, (nb, K, N), False)
+    c0 = _rand(rng, (nb, d0 * d1, N), True)
+    A, B, Cd = eng.asdevice(a), eng.asdevice(b), eng.asdevice(c0)
+    eng.gemm(A, B, Cd, E.idx2(d0, d1, K * d1, 1), E.idx1(K, d1), E.idx1(K, N), E.idx1(N, 1),
+             E.idx1(d0 * d1, N), E.idx1(N, 1), batch=nb, sb_a=d0 * K * d1, sb_b=K * N, sb_c=d0 * d1 * N,
+             alpha=0.5 - 2j, beta=1.5 + 0.25j)
+    ref = (0.5 - 2j) * np.einsum("bikj,bkn->bijn", a, b).reshape(nb, d0 * d1, N) + (1.5 + 0.25j) * c0
+    assert _relerr(Cd.to_host(), ref) < 1e-13
+
+
+def test_gemm_bitwise_reproducible(eng):
+    rng = np.random.default_rng(3)
+    a, b = _rand(rng, (150, 300), True), _rand(rng, (300, 90), True)
+    A, B = eng.asdevice(a), eng.asdevice(b)
+    r1 = eng.matmul(A, B).to_host()
+    r2 = eng.matmul(A, B).to_host()
+    assert np.array_equal(r1, r2)
+
+
+def test_transpose_inner(eng):
+    rng = np.random.default_rng(4)
+    for cplx in (False, True):
+        a = _rand(rng, (3, 37, 45), cplx)
+        A = eng.asdevice(a)
+        out = eng.empty((3, 45, 37), a.dtype)
+        eng._check(eng.lib.mpse_transpose_inner(eng.ctx, A.code, out.ptr, A.ptr, 3, 37, 45, 1))
+        assert np.array_equal(out.to_host(), a.transpose(0, 2, 1).conj())
+
+
+# ---------------------------------------------------------- vector algebra
+
+def test_vector_ops(eng):
+    rng = np.random.default_rng(5)
+    for cplx in (False, True):
+        for n in (1, 63, 1000, 300001):
+            x, y = _rand(rng, n, cplx), _rand(rng, n, cplx)
+            X, Y = eng.asdevice(x), eng.asdevice(y)
+            assert abs(X.vdot(Y) - np.vdot(x, y)) < 1e-12 * n
+            assert abs(X.norm() - np.linalg.norm(x)) < 1e-13 * np.sqrt(n) * 10
+            a = (0.3 - 1.2j) if cplx else -0.7
+            a_ = complex(a)
+            eng._check(eng.lib.mpse_axpy(eng.ctx, X.code, Y.ptr, X.ptr, n, a_.real, a_.imag))
+            assert _relerr(Y.to_host(), y + a * x) < 1e-14
+            X.scale_(a)
+            assert _relerr(X.to_host(), a * x) < 1e-14
+    r = rng.standard_normal(1000)
+    assert np.array_equal(eng.asdevice(r).to_complex().to_host(), r.astype(complex))
+    z = _rand(rng, 1000, True)
+    assert np.array_equal(eng.asdevice(z).conj().to_host(), z.conj())
+
+
+# ------------------------------------------------- hot-path contractions
+
+def _dims(ket, mo, bra=None):
+    d = E.mpse_dims()
+    bra = ket if bra is None else bra
+    d.Dl_ket, d.Dr_ket = ket.shape[0], ket.shape[-1]
+    d.Dl_bra, d.Dr_bra = bra.shape[0], bra.shape[-1]
+    d.d0 = ket.shape[1]
+    d.d1 = 1
+    d.danc = ket.shape[2] if ket.ndim == 4 else 1
+    d.wl, d.wr, d.wm = mo.shape[0], mo.shape[3], 1
+    return d
+
+
+def dev_env_update(eng, env, ket, mo, dom, bra=None, bra_conj=True):
+    cplx = np.iscomplexobj(ket) or np.iscomplexobj(env) or (bra is not None and np.iscomplexobj(bra))
+    wdt = np.complex128 if cplx else np.float64
+    K = eng.asdevice(ket, wdt)
+    Bt = None if bra is None else eng.asdevice(bra, wdt)
+    Ev, W = eng.asdevice(env), eng.asdevice(mo)
+    d = _dims(ket, mo, bra)
+    oshape = (d.Dr_bra, d.wr, d.Dr_ket) if dom == "L" else (d.Dl_bra, d.wl, d.Dl_ket)
+    out = eng.empty(oshape, wdt)
+    eng._check(eng.lib.mpse_env_update(eng.ctx, out.code, 0 if dom == "L" else 1, C.byref(d), Ev.ptr, Ev.code, K.ptr,
+                                       None if Bt is None else Bt.ptr, int(bra_conj), W.ptr, W.code, out.ptr))
+    return out.to_host()
+
+
+def make_heff(eng, l, r, cmo, cshape):
+    """returns (mpse_heff, keepalive)"""
+    ns = len(cmo)
+    h = E.mpse_heff()
+    h.nsite = ns
+    d = h.dims
+    d.Dl_bra = d.Dl_ket = cshape[0]
+    d.Dr_bra = d.Dr_ket = cshape[-1]
+    d.danc = cshape[2] if (ns >= 1 and len(cshape) == 2 * ns + 2) else 1
+    d.wl, d.wr = l.shape[1], r.shape[1]
+    d.d0 = cmo[0].shape[1] if ns >= 1 else 1
+    d.d1 = cmo[1].shape[1] if ns == 2 else 1
+    d.wm = cmo[0].shape[3] if ns == 2 else 1
+    keep = [eng.asdevice(l), eng.asdevice(r)] + [eng.asdevice(w) for w in cmo]
+    h.L, h.l_dtype, h.R, h.r_dtype = keep[0].ptr, keep[0].code, keep[1].ptr, keep[1].code
+    if ns >= 1:
+        h.W0, h.w_dtype = keep[2].ptr, keep[2].code
+    if ns == 2:
+        h.W1 = keep[3].ptr
+    return h, keep
+
+
+def dev_heff_apply(eng, l, r, cmo, c):
+    h, keep = make_heff(eng, l, r, cmo, c.shape)
+    Cd = eng.asdevice(c)
+    out = eng.empty(c.shape, c.dtype)
+    eng._check(eng.lib.mpse_heff_apply(eng.ctx, Cd.code, C.byref(h), Cd.ptr, out.ptr))
+    return out.to_host()
+
+
+def test_env_update_golden(eng, golden_dir):
+    z = np.load(os.path.join(golden_dir, "seams.npz"))
+    for k in range(int(z["c1s_n"])):
+        g = lambda n: z[f"c1s_{k}_{n}"]
+        dom = str(g("dom"))
+        assert _relerr(dev_env_update(eng, g("env"), g("ms"), g("mo"), dom, bra=g("bra")), g("out")) < 1e-12
+        assert _relerr(dev_env_update(eng, g("env"), g("ms"), g("mo"), dom), g("out_self")) < 1e-12
+
+
+def test_heff_apply_golden(eng, golden_dir):
+    z = np.load(os.path.join(golden_dir, "seams.npz"))
+    for k in range(int(z["hop_n"])):
+        g = lambda n: z[f"hop_{k}_{n}"]
+        cmo = [g(f"w{j}") for j in range(int(g("nsite")))]
+        assert _relerr(dev_heff_apply(eng, g("l"), g("r"), cmo, g("c")), g("out")) < 1e-12
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_contractions_midsize_vs_oracle(eng, cplx):
+    """Shapes that cross tile boundaries (not multiples of 64/16) against the oracle."""
+    rng = np.random.default_rng(7)
+    Dl, Dr, d, wl, wr = 70, 45, 6, 5, 4
+    l, r = _rand(rng, (Dl, wl, Dl), cplx), _rand(rng, (Dr, wr, Dr), cplx)
+    w = _rand(rng, (wl, d, d, wr), False)
+    c = _rand(rng, (Dl, d, Dr), cplx)
+    assert _relerr(dev_heff_apply(eng, l, r, [w], c), orc.hop_apply(l, r, [w], c)) < 1e-12
+    r0 = _rand(rng, (Dr, wl, Dr), cplx)
+    s = _rand(rng, (Dl, Dr), cplx)
+    assert _relerr(dev_heff_apply(eng, l, r0, [], s), orc.hop_apply(l, r0, [], s)) < 1e-12
+    w2 = _rand(rng, (wr, 3, 3, 2), False)
+    r2 = _rand(rng, (Dr, 2, Dr), cplx)
+    c2 = _rand(rng, (Dl, d, 3, Dr), cplx)
+    assert _relerr(dev_heff_apply(eng, l, r2, [w, w2], c2), orc.hop_apply(l, r2, [w, w2], c2)) < 1e-12
+    ket = _rand(rng, (Dl, d, Dr), cplx)
+    assert _relerr(dev_env_update(eng, l, ket, w, "L"), orc.contract_one_site(l, ket, w, "L")) < 1e-12
+    assert _relerr(dev_env_update(eng, r, ket, w, "R"), orc.contract_one_site(r, ket, w, "R")) < 1e-12
+    # hermiticity of the effective Hamiltonian built from Hermitian parts: <x|H y> == <H x|y>
+    lh = l + l.transpose(2, 1, 0).conj()
+    rh = r + r.transpose(2, 1, 0).conj()
+    wh = w + w.transpose(0, 2, 1, 3)
+    x, y = _rand(rng, (Dl, d, Dr), cplx), _rand(rng, (Dl, d, Dr), cplx)
+    hx, hy = dev_heff_apply(eng, lh, rh, [wh], x), dev_heff_apply(eng, lh, rh, [wh], y)
+    assert abs(np.vdot(x, hy) - np.vdot(hx, y)) < 1e-9 * abs(np.vdot(x, hy))
+
+
+# ---------------------------------------------------------------- Lanczos
+
+def dev_expm(eng, l, r, cmo, c, dt, rtol=1e-5, atol=1e-8):
+    h, keep = make_heff(eng, l, r, cmo, c.shape)
+    Cd = eng.asdevice(c)
+    out = eng.empty(c.shape, c.dtype)
+    nv = C.c_int()
+    dt = complex(dt)
+    eng._check(eng.lib.mpse_expm_lanczos(eng.ctx, Cd.code, C.byref(h), dt.real, dt.imag, Cd.ptr, out.ptr, rtol, atol,
+                                         0, C.byref(nv)))
+    return out.to_host(), nv.value
+
+
+def test_expm_lanczos_vs_oracle(eng):
+    rng = np.random.default_rng(8)
+    Dl, Dr, d, wl, wr = 12, 9, 4, 3, 3
+    l = _rand(rng, (Dl, wl, Dl), True)
+    r = _rand(rng, (Dr, wr, Dr), True)
+    l = (l + l.transpose(2, 1, 0).conj()) / 8
+    r = (r + r.transpose(2, 1, 0).conj()) / 8
+    w = _rand(rng, (wl, d, d, wr), False)
+    w = (w + w.transpose(0, 2, 1, 3)) / 2
+    c = _rand(rng, (Dl, d, Dr), True)
+    for dt in (-0.05j, 0.2j, -0.5j):
+        ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(l, r, [w], y.reshape(c.shape)).ravel(), dt, c.ravel())
+        out, nv = dev_expm(eng, l, r, [w], c, dt)
+        assert nv == nref
+        assert _relerr(out.ravel(), ref) < 1e-10
+        # against the exact exponential too
+        hd = orc.hop_dense(l, r, [w])
+        ev, U = np.linalg.eigh(hd)
+        exact = U @ (np.exp(dt * ev) * (U.conj().T @ c.ravel()))
+        assert _relerr(out.ravel(), exact) < 1e-6
+    # 0-site (bond) solve, real dtype with a real step (imaginary-time), tiny full-space case
+    r0 = _rand(rng, (Dr, wl, Dr), True)
+    r0 = (r0 + r0.transpose(2, 1, 0).conj()) / 8
+    s = _rand(rng, (Dl, Dr), True)
+    ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(l, r0, [], y.reshape(s.shape)).ravel(), 0.3j, s.ravel())
+    out, nv = dev_expm(eng, l, r0, [], s, 0.3j)
+    assert nv == nref and _relerr(out.ravel(), ref) < 1e-10
+    lr, rr = l.real.copy(), r.real.copy()
+    lr = lr + lr.transpose(2, 1, 0)
+    rr = rr + rr.transpose(2, 1, 0)
+    cr = c.real.copy()
+    ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(lr, rr, [w], y.reshape(cr.shape)).ravel(), -0.1, cr.ravel())
+    out, nv = dev_expm(eng, lr, rr, [w], cr, -0.1)
+    assert nv == nref and _relerr(out.ravel(), ref) < 1e-10
+    one = np.ones((1, 1, 1))
+    wt = _rand(rng, (1, 2, 2, 1), False)
+    wt = wt + wt.transpose(0, 2, 1, 3)
+    ct = _rand(rng, (1, 2, 1), True)
+    ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(one, one, [wt], y.reshape(ct.shape)).ravel(), -0.4j, ct.ravel())
+    out, nv = dev_expm(eng, one, one, [wt], ct, -0.4j)
+    assert nv == nref == 2 and _relerr(out.ravel(), ref) < 1e-12
+
+
+# --------------------------------------------------------------- block QR
+
+def dev_block_qr(eng, c, qnbigl, qnbigr, qntot, system):
+    blocks = orc.qn_blocks(qnbigl, qnbigr, qntot)
+    nrow = int(np.prod(np.asarray(qnbigl).shape[:-1]))
+    ncol = int(np.prod(np.asarray(qnbigr).shape[:-1]))
+    rows = np.concatenate([b[2] for b in blocks]).astype(np.int64)
+    cols = np.concatenate([b[3] for b in blocks]).astype(np.int64)
+    roff = np.cumsum([0] + [len(b[2]) for b in blocks]).astype(np.int64)
+    coff = np.cumsum([0] + [len(b[3]) for b in blocks]).astype(np.int64)
+    K = int(sum(min(len(b[2]), len(b[3])) for b in blocks))
+    Cd = eng.asdevice(np.ascontiguousarray(c).reshape(nrow, ncol))
+    U, Vt = eng.empty((nrow, K), c.dtype), eng.empty((K, ncol), c.dtype)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    eng._check(eng.lib.mpse_block_qr(eng.ctx, Cd.code, Cd.ptr, nrow, ncol, len(blocks), p(rows), p(roff), p(cols),
+                                     p(coff), int(system == "R"), U.ptr, Vt.ptr, K))
+    return U.to_host(), Vt.to_host(), blocks
+
+
+def test_block_qr_golden_inputs(eng, golden_dir):
+    z = np.load(os.path.join(golden_dir, "seams.npz"))
+    for k in range(int(z["svd_n"])):
+        g = lambda n: z[f"svd_{k}_{n}"]
+        if not bool(g("QR")):
+            continue
+        system = str(g("system"))
+        c = g("c")
+        u, vt, blocks = dev_block_qr(eng, c, g("qnbigl"), g("qnbigr"), g("qntot"), system)
+        mat = c.reshape(u.shape[0], -1)
+        assert _relerr(u @ vt, mat) < 1e-13
+        iso = u if system == "L" else vt.conj().T
+        assert np.abs(iso.conj().T @ iso - np.eye(iso.shape[1])).max() < 1e-13
+        assert u.shape == g("u").shape and vt.T.shape == g("v").shape
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_block_qr_rank_deficient_and_shapes(eng, cplx):
+    rng = np.random.default_rng(9)
+    # single block (no symmetry), tall / wide / square, with exactly dependent and zero columns
+    for (m, n) in [(300, 40), (40, 300), (64, 64), (1, 7), (7, 1), (513, 130)]:
+        a = _rand(rng, (m, n), cplx)
+        if n > 3:
+            a[:, 2] = a[:, 0] * (2.0 - 0.5j if cplx else 2.0)   # dependent column
+            a[:, 3] = 0                                           # zero column
+        if min(m, n) > 10:
+            a[:, 5:8] *= 1e-14                                    # numerically negligible columns
+        qnl = np.zeros((m, 1), dtype=int)
+        qnr = np.zeros((n, 1), dtype=int)
+        for system in ("L", "R"):
+            u, vt, _ = dev_block_qr(eng, a, qnl, qnr, np.array([0]), system)
+            assert _relerr(u @ vt, a) < 1e-13
+            iso = u if system == "L" else vt.conj().T
+            assert np.abs(iso.conj().T @ iso - np.eye(iso.shape[1])).max() < 1e-13
+
+
+# -------------------------------------------------------------- block SVD
+
+def dev_block_svd(eng, c, qnbigl, qnbigr, qntot):
+    blocks = orc.qn_blocks(qnbigl, qnbigr, qntot)
+    nrow = int(np.prod(np.asarray(qnbigl).shape[:-1]))
+    ncol = int(np.prod(np.asarray(qnbigr).shape[:-1]))
+    rows = np.concatenate([b[2] for b in blocks]).astype(np.int64)
+    cols = np.concatenate([b[3] for b in blocks]).astype(np.int64)
+    roff = np.cumsum([0] + [len(b[2]) for b in blocks]).astype(np.int64)
+    coff = np.cumsum([0] + [len(b[3]) for b in blocks]).astype(np.int64)
+    K = int(sum(min(len(b[2]), len(b[3])) for b in blocks))
+    Cd = eng.asdevice(np.ascontiguousarray(c).reshape(nrow, ncol))
+    U, Vt = eng.empty((nrow, K), c.dtype), eng.empty((K, ncol), c.dtype)
+    S = np.zeros(K)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    eng._check(eng.lib.mpse_block_svd(eng.ctx, Cd.code, Cd.ptr, nrow, ncol, len(blocks), p(rows), p(roff), p(cols),
+                                      p(coff), U.ptr, Vt.ptr, S.ctypes.data_as(C.POINTER(C.c_double)), K))
+    return U.to_host(), S, Vt.to_host(), blocks
+
+
+def test_block_svd_golden_inputs(eng, golden_dir):
+    z = np.load(os.path.join(golden_dir, "seams.npz"))
+    for k in range(int(z["svd_n"])):
+        g = lambda n: z[f"svd_{k}_{n}"]
+        if bool(g("QR")) or bool(g("full")):
+            continue
+        c = g("c")
+        u, s, vt, blocks = dev_block_svd(eng, c, g("qnbigl"), g("qnbigr"), g("qntot"))
+        mat = c.reshape(u.shape[0], -1)
+        assert _relerr((u * s) @ vt, mat) < 1e-13
+        assert np.abs(u.conj().T @ u - np.eye(u.shape[1])).max() < 1e-13
+        assert np.abs(vt @ vt.conj().T - np.eye(vt.shape[0])).max() < 1e-13
+        # singular values: same multiset as the reference's LAPACK result
+        assert np.abs(np.sort(s)[::-1] - g("su")).max() < 1e-13 * g("su").max()
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_block_svd_shapes_and_rank(eng, cplx):
+    rng = np.random.default_rng(10)
+    for (m, n) in [(120, 40), (40, 120), (64, 64), (1, 7), (7, 1), (33, 1), (257, 90)]:
+        a = _rand(rng, (m, n), cplx)
+        k = min(m, n)
+        if k > 6:
+            # rank deficient: kill some singular directions exactly, scale one tiny
+            uu, ss, vv = np.linalg.svd(a, full_matrices=False)
+            ss[-3:] = 0
+            ss[-4] *= 1e-12
+            a = (uu * ss) @ vv
+        qnl, qnr = np.zeros((m, 1), dtype=int), np.zeros((n, 1), dtype=int)
+        u, s, vt, _ = dev_block_svd(eng, a, qnl, qnr, np.array([0]))
+        sref = np.linalg.svd(a, compute_uv=False)
+        assert np.abs(s - sref).max() < 1e-13 * sref.max()
+        assert np.all(np.diff(s) <= 0)
+        assert _relerr((u * s) @ vt, a) < 1e-13
+        assert np.abs(u.conj().T @ u - np.eye(k)).max() < 1e-12
+        assert np.abs(vt @ vt.conj().T - np.eye(k)).max() < 1e-12

@@ -1,0 +1,158 @@
+"""CPU check of the product's contraction plans (renormalizer_amd/csrc/mpse_plans.h):
+the plans are executed on host memory by a naive strided-GEMM loop (tests/host_emu) and
+compared with the reference-pinned oracle and with golden vectors.  No GPU needed."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import mps_oracle as orc
+from renormalizer_amd import engine as E
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("emu") / "libplan_emu.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC",
+                           os.path.join(REPO, "tests", "host_emu", "plan_emu.cpp"), "-o", out])
+    lib = C.CDLL(out)
+    lib.emu_heff_apply.argtypes = [C.c_int, C.POINTER(E.mpse_heff), C.c_void_p, C.c_void_p]
+    lib.emu_env_update.argtypes = [C.c_int, C.c_int, C.POINTER(E.mpse_dims), C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    return lib
+
+
+def _rand(rng, shape, cplx):
+    a = rng.standard_normal(shape)
+    return a + 1j * rng.standard_normal(shape) if cplx else a
+
+
+def _c(a):
+    return np.ascontiguousarray(a)
+
+
+def emu_heff(lib, l, r, cmo, c):
+    cplx = np.iscomplexobj(c)
+    dt = E.C128 if cplx else E.F64
+    ns = len(cmo)
+    h = E.mpse_heff()
+    h.nsite = ns
+    anc = 1
+    if ns >= 1 and c.ndim == 2 * ns + 2:
+        anc = c.shape[2]
+    d = h.dims
+    d.Dl_bra = d.Dl_ket = c.shape[0]
+    d.Dr_bra = d.Dr_ket = c.shape[-1]
+    d.danc = anc
+    d.wl, d.wr = l.shape[1], r.shape[1]
+    d.d0 = cmo[0].shape[1] if ns >= 1 else 1
+    d.d1 = cmo[1].shape[1] if ns == 2 else 1
+    d.wm = cmo[0].shape[3] if ns == 2 else 1
+    keep = [_c(l), _c(r)] + [_c(w) for w in cmo] + [_c(c)]
+    h.L, h.l_dtype = keep[0].ctypes.data, E.dtype_code(keep[0].dtype)
+    h.R, h.r_dtype = keep[1].ctypes.data, E.dtype_code(keep[1].dtype)
+    if ns >= 1:
+        h.W0 = keep[2].ctypes.data
+        h.w_dtype = E.dtype_code(keep[2].dtype)
+    if ns == 2:
+        h.W1 = keep[3].ctypes.data
+    out = np.full(c.shape, np.nan, dtype=c.dtype)
+    st = lib.emu_heff_apply(dt, C.byref(h), keep[-1].ctypes.data, out.ctypes.data)
+    assert st == 0
+    return out
+
+
+def emu_env(lib, env, ket, mo, dom, bra=None, bra_conj=True):
+    cplx = np.iscomplexobj(ket) or np.iscomplexobj(env)
+    wdt = complex if cplx else float
+    ket = _c(ket.astype(wdt))
+    brab = ket if bra is None else _c(bra.astype(wdt))
+    env = _c(env)
+    mo = _c(mo)
+    d = E.mpse_dims()
+    d.Dl_ket, d.Dr_ket = ket.shape[0], ket.shape[-1]
+    d.Dl_bra, d.Dr_bra = brab.shape[0], brab.shape[-1]
+    d.d0 = ket.shape[1]
+    d.danc = ket.shape[2] if ket.ndim == 4 else 1
+    d.wl, d.wr = mo.shape[0], mo.shape[3]
+    if dom == "L":
+        oshape = (d.Dr_bra, d.wr, d.Dr_ket)
+    else:
+        oshape = (d.Dl_bra, d.wl, d.Dl_ket)
+    out = np.full(oshape, np.nan, dtype=wdt)
+    st = lib.emu_env_update(E.C128 if cplx else E.F64, 0 if dom == "L" else 1, C.byref(d), env.ctypes.data,
+                            E.dtype_code(env.dtype), ket.ctypes.data, brab.ctypes.data, int(bra_conj),
+                            mo.ctypes.data, E.dtype_code(mo.dtype), out.ctypes.data)
+    assert st == 0
+    return out
+
+
+def test_heff_plans_vs_golden(emu, golden_dir):
+    z = np.load(os.path.join(golden_dir, "seams.npz"))
+    for k in range(int(z["hop_n"])):
+        g = lambda n: z[f"hop_{k}_{n}"]
+        ns = int(g("nsite"))
+        cmo = [g(f"w{j}") for j in range(ns)]
+        out = emu_heff(emu, g("l"), g("r"), cmo, g("c"))
+        assert np.abs(out - g("out")).max() < 1e-11 * max(1, np.abs(g("out")).max())
+
+
+def test_env_plans_vs_golden(emu, golden_dir):
+    z = np.load(os.path.join(golden_dir, "seams.npz"))
+    for k in range(int(z["c1s_n"])):
+        g = lambda n: z[f"c1s_{k}_{n}"]
+        dom = str(g("dom"))
+        out = emu_env(emu, g("env"), g("ms"), g("mo"), dom, bra=g("bra"), bra_conj=True)
+        assert np.abs(out - g("out")).max() < 1e-11 * max(1, np.abs(g("out")).max())
+        out = emu_env(emu, g("env"), g("ms"), g("mo"), dom)
+        assert np.abs(out - g("out_self")).max() < 1e-11 * max(1, np.abs(g("out_self")).max())
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_env_plans_rectangular_and_sentinel(emu, cplx):
+    """bra and ket with different bond dims (transition amplitudes) and the real all-ones sentinel."""
+    rng = np.random.default_rng(5)
+    for anc in (False, True):
+        for dom in ("L", "R"):
+            Dlk, Drk, Dlb, Drb, d, da, wl, wr = 4, 6, 3, 5, 3, 2, 2, 4
+            ks = (Dlk, d, da, Drk) if anc else (Dlk, d, Drk)
+            bs = (Dlb, d, da, Drb) if anc else (Dlb, d, Drb)
+            ket, bra = _rand(rng, ks, cplx), _rand(rng, bs, cplx)
+            mo = _rand(rng, (wl, d, d, wr), False)
+            env = _rand(rng, (Dlb, wl, Dlk) if dom == "L" else (Drb, wr, Drk), cplx)
+            ref = orc.contract_one_site(env, ket, mo, dom, ms_conj=bra.conj())
+            out = emu_env(emu, env, ket, mo, dom, bra=bra)
+            assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max()
+            # pre-conjugated bra buffer with bra_conj=0 (the reference's ms_conj convention)
+            out = emu_env(emu, env, ket, mo, dom, bra=bra.conj(), bra_conj=False)
+            assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max()
+    # sentinel: edge site, env = ones((1,1,1)) real while the sites are complex
+    ket = _rand(rng, (1, 3, 5), cplx)
+    mo = _rand(rng, (1, 3, 3, 4), False)
+    ref = orc.contract_one_site(np.ones((1, 1, 1)), ket, mo, "L")
+    assert np.abs(emu_env(emu, np.ones((1, 1, 1)), ket, mo, "L") - ref).max() < 1e-12
+
+
+def test_heff_plans_odd_shapes(emu):
+    rng = np.random.default_rng(11)
+    for cplx in (False, True):
+        for (Dl, Dr, d0, d1, wl, wm, wr) in ((1, 3, 2, 3, 1, 2, 3), (7, 1, 4, 2, 3, 1, 1), (5, 5, 2, 2, 4, 5, 4)):
+            l = _rand(rng, (Dl, wl, Dl), cplx)
+            r = _rand(rng, (Dr, wr, Dr), cplx)
+            w0 = _rand(rng, (wl, d0, d0, wr), False)
+            c = _rand(rng, (Dl, d0, Dr), cplx)
+            ref = orc.hop_apply(l, r, [w0], c)
+            assert np.abs(emu_heff(emu, l, r, [w0], c) - ref).max() < 1e-11 * np.abs(ref).max()
+            w0 = _rand(rng, (wl, d0, d0, wm), False)
+            w1 = _rand(rng, (wm, d1, d1, wr), False)
+            c = _rand(rng, (Dl, d0, d1, Dr), cplx)
+            ref = orc.hop_apply(l, r, [w0, w1], c)
+            assert np.abs(emu_heff(emu, l, r, [w0, w1], c) - ref).max() < 1e-11 * np.abs(ref).max()
+            r0 = _rand(rng, (Dr, wl, Dr), cplx)
+            c = _rand(rng, (Dl, Dr), cplx)
+            ref = orc.hop_apply(l, r0, [], c)
+            assert np.abs(emu_heff(emu, l, r0, [], c) - ref).max() < 1e-11 * np.abs(ref).max()
