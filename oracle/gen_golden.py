@@ -284,3 +284,60 @@ if __name__ == "__main__":
         gen_seams()
     if what in ("tdvp", "all"):
         gen_tdvp()
+
+
+def gen_mpo():
+    """Dense matrices + bond dimensions of reference MPOs for small models (pins the build's own
+    MPO construction)."""
+    from renormalizer.model import Phonon, Mol, HolsteinModel, SpinBosonModel, Op, Model, BasisHalfSpin
+    from renormalizer.mps import Mpo
+    from renormalizer.utils import Quantity
+    out = {}
+    # (1) Holstein 3 molecules x 2 modes (tests/parameter.py values, reduced phonon levels), scheme 3
+    omega = [Quantity(106.51, "cm^{-1}"), Quantity(1555.55, "cm^{-1}")]
+    dis = [Quantity(30.1370), Quantity(8.7729)]
+    ph_list = [Phonon.simple_phonon(o, d, 3) for o, d in zip(omega, dis)]
+    ph_list = [Phonon.simple_phonon(o, d, n) for o, d, n in zip(omega, dis, (3, 2))]
+    j = np.array([[0.0, -0.1, -0.2], [-0.1, 0.0, -0.3], [-0.2, -0.3, 0.0]]) / 27.211386245988
+    model = HolsteinModel([Mol(Quantity(2.67, "eV"), ph_list)] * 3, j, 3)
+    mpo = Mpo(model)
+    out["hol_dense"], out["hol_bond"] = mpo.todense(), np.array(mpo.bond_dims)
+    mpo = Mpo(model, offset=Quantity(0.05))
+    out["hol_off_dense"] = mpo.todense()
+    mpo = Mpo.onsite(model, r"a^\dagger", dof_set={1})
+    out["hol_adag_dense"], out["hol_adag_bond"] = mpo.todense(), np.array(mpo.bond_dims)
+    mpo = Mpo(model, Op(r"a^\dagger a", 2))
+    out["hol_occ_dense"] = mpo.todense()
+    # (2) chain used by the headline config, 3 molecules
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), 4)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * 3, Quantity(3.0e-2), 3)
+    mpo = Mpo(model)
+    out["chain_dense"], out["chain_bond"] = mpo.todense(), np.array(mpo.bond_dims)
+    # (3) spin-boson, 3 modes
+    ph_list = [Phonon.simple_phonon(Quantity(w), Quantity(c / w ** 2), 3) for w, c in zip((0.5, 1.5, 3.0), (0.3, 0.2, 0.1))]
+    model = SpinBosonModel(Quantity(0.1), Quantity(0.8), ph_list)
+    mpo = Mpo(model)
+    out["sbm_dense"], out["sbm_bond"] = mpo.todense(), np.array(mpo.bond_dims)
+    # (4) README quick start
+    model = Model([BasisHalfSpin(0), BasisHalfSpin(1)], Op("sigma_+ sigma_-", [0, 1]) + Op("sigma_+ sigma_-", [1, 0]))
+    mpo = Mpo(model)
+    out["qs_dense"], out["qs_bond"] = mpo.todense(), np.array(mpo.bond_dims)
+    # (5) a longer-range spin model with a complex coefficient
+    basis = [BasisHalfSpin(i) for i in range(5)]
+    terms = []
+    for i in range(5):
+        terms.append(Op("Z", i, 0.3 + 0.1 * i))
+        for k in range(i + 1, 5):
+            terms.append(Op("X X", [i, k], 1.0 / (k - i) ** 2))
+            terms.append(Op("sigma_+ sigma_-", [i, k], 0.2j / (k - i)))
+            terms.append(Op("sigma_- sigma_+", [i, k], -0.2j / (k - i)))
+    terms.append(Op("Z Z Z", [0, 2, 4], 0.7))
+    model = Model(basis, terms)
+    mpo = Mpo(model)
+    out["lr_dense"], out["lr_bond"] = mpo.todense(), np.array(mpo.bond_dims)
+    np.savez_compressed(os.path.join(GOLD, "mpo_dense.npz"), **out)
+    print("mpo_dense.npz written; bond dims:", {k: v.tolist() for k, v in out.items() if k.endswith("bond")})
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("mpo",)):
+    gen_mpo()

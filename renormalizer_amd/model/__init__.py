@@ -1,0 +1,5 @@
+from .op import Op, OpSum
+from .basis import (BasisSet, BasisSHO, BasisSimpleElectron, BasisHalfSpin, BasisMultiElectron,
+                    BasisMultiElectronVac)
+from .phonon import Phonon, Mol
+from .model import Model, HolsteinModel, SpinBosonModel, construct_j_matrix

@@ -1,0 +1,94 @@
+"""Host-side model / MPO construction against dense matrices and bond dimensions produced by
+the reference (tests/golden/mpo_dense.npz, oracle/gen_golden.py gen_mpo).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from renormalizer_amd.model import (Op, Model, BasisHalfSpin, BasisSHO, BasisSimpleElectron, Phonon, Mol,
+                                    HolsteinModel, SpinBosonModel)
+from renormalizer_amd.mps.mpo import Mpo
+from renormalizer_amd.utils import Quantity
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "mpo_dense.npz"))
+
+
+def _check(mpo, dense, bond=None):
+    got = mpo.todense()
+    assert got.shape == dense.shape
+    assert np.abs(got - dense).max() <= 1e-12 * max(1.0, np.abs(dense).max())
+    if bond is not None:
+        assert list(mpo.bond_dims) == list(bond)      # same (optimal) bond dimensions as the reference
+
+
+def test_holstein_mpo(gold):
+    omega = [Quantity(106.51, "cm^{-1}"), Quantity(1555.55, "cm^{-1}")]
+    dis = [Quantity(30.1370), Quantity(8.7729)]
+    ph_list = [Phonon.simple_phonon(o, d, n) for o, d, n in zip(omega, dis, (3, 2))]
+    j = np.array([[0.0, -0.1, -0.2], [-0.1, 0.0, -0.3], [-0.2, -0.3, 0.0]]) / 27.211386245988
+    model = HolsteinModel([Mol(Quantity(2.67, "eV"), ph_list)] * 3, j, 3)
+    _check(Mpo(model), gold["hol_dense"], gold["hol_bond"])
+    _check(Mpo(model, offset=Quantity(0.05)), gold["hol_off_dense"])
+    _check(Mpo.onsite(model, r"a^\dagger", dof_set={1}), gold["hol_adag_dense"], gold["hol_adag_bond"])
+    _check(Mpo(model, Op(r"a^\dagger a", 2)), gold["hol_occ_dense"])
+    m = Mpo.onsite(model, r"a^\dagger", dof_set={1})
+    assert m.qntot.tolist() == [1]
+    assert Mpo(model).qntot.tolist() == [0]
+
+
+def test_chain_and_sbm_mpo(gold):
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), 4)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * 3, Quantity(3.0e-2), 3)
+    _check(Mpo(model), gold["chain_dense"], gold["chain_bond"])
+    ph_list = [Phonon.simple_phonon(Quantity(w), Quantity(c / w ** 2), 3) for w, c in zip((0.5, 1.5, 3.0), (0.3, 0.2, 0.1))]
+    model = SpinBosonModel(Quantity(0.1), Quantity(0.8), ph_list)
+    _check(Mpo(model), gold["sbm_dense"], gold["sbm_bond"])
+
+
+def test_spin_mpos(gold):
+    model = Model([BasisHalfSpin(0), BasisHalfSpin(1)], Op("sigma_+ sigma_-", [0, 1]) + Op("sigma_+ sigma_-", [1, 0]))
+    _check(Mpo(model), gold["qs_dense"], gold["qs_bond"])
+    basis = [BasisHalfSpin(i) for i in range(5)]
+    terms = []
+    for i in range(5):
+        terms.append(Op("Z", i, 0.3 + 0.1 * i))
+        for k in range(i + 1, 5):
+            terms.append(Op("X X", [i, k], 1.0 / (k - i) ** 2))
+            terms.append(Op("sigma_+ sigma_-", [i, k], 0.2j / (k - i)))
+            terms.append(Op("sigma_- sigma_+", [i, k], -0.2j / (k - i)))
+    terms.append(Op("Z Z Z", [0, 2, 4], 0.7))
+    _check(Mpo(Model(basis, terms)), gold["lr_dense"], gold["lr_bond"])
+
+
+def test_mpo_is_hermitian_and_sparse():
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), 3)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * 4, Quantity(3.0e-2), 3)
+    mpo = Mpo(model)
+    h = mpo.todense()
+    assert np.abs(h - h.conj().T).max() < 1e-13
+    assert mpo.bond_dims[0] == mpo.bond_dims[-1] == 1
+    assert max(mpo.bond_dims) <= 5
+    # operator algebra
+    x, y = Op("X", 0, 0.5), Op("Y", 1, 0.2)
+    s = (y + x) * (x + y)
+    assert [o.symbol for o in s] == ["Y X", "Y Y", "X X", "X Y"]
+    assert np.isclose(s[1].factor, 0.04)
+
+
+def test_basis_matrices():
+    b = BasisSHO(0, 2.0, 5)
+    x, p = b.op_mat("x"), b.op_mat("p")
+    comm = x @ p - p @ x
+    assert np.allclose(comm[:4, :4], 1j * np.eye(4))                 # [x,p] = i away from the truncation edge
+    assert np.allclose(b.op_mat("x^2")[:3, :3], (x @ x)[:3, :3])
+    assert not np.allclose(b.op_mat("x^2"), x @ x)                   # exact second-quantised form at the edge
+    h = 0.5 * b.op_mat("p^2") + 0.5 * 4.0 * b.op_mat("x^2")
+    assert np.allclose(np.diag(h).real, 2.0 * (np.arange(5) + 0.5))
+    e = BasisSimpleElectron("e")
+    assert np.allclose(e.op_mat(r"a^\dagger") @ e.op_mat("a"), e.op_mat(r"a^\dagger a"))
+    s = BasisHalfSpin("s")
+    assert np.allclose(s.op_mat("X") @ s.op_mat("Y"), 1j * s.op_mat("Z"))
+    assert np.allclose(s.op_mat(Op("sigma_+ sigma_-", "s", 2.0)), 2.0 * np.diag([1.0, 0.0]))
