@@ -1,1 +1,3 @@
+from .backend import backend
 from .mpo import Mpo
+from .mps import Mps

@@ -1,0 +1,107 @@
+"""Environment tensors of the sweep algorithms, device resident.
+
+Counterpart of renormalizer/mps/lib.py: ``contract_one_site`` (:169-250) is one C-ABI call
+(mpse_env_update: two large FP64-MFMA GEMMs around the small MPO contraction) and ``Environ``
+(:12-118) is a table of HBM-resident handles - the reference's CuPy path copies every
+environment to the host on write and back on read (lib.py:114-118)."""
+import ctypes as C
+
+import numpy as np
+
+from ..engine import DOMAIN_L, DOMAIN_R, DeviceTensor, get_engine, mpse_dims
+
+
+def _as_w(eng, mo):
+    if isinstance(mo, DeviceTensor):
+        return mo
+    return eng.asdevice(np.asarray(mo))
+
+
+def contract_one_site(environ, ms, mo, domain, ms_conj=None):
+    """One environment update.  ``ms_conj`` follows the reference convention: it holds the
+    already-conjugated bra tensor; ``None`` means conj(ms) (no copy is made)."""
+    assert domain in ["L", "R"]
+    eng = ms.eng
+    mo = _as_w(eng, mo)
+    bra = ms if ms_conj is None else ms_conj
+    if ms.ndim not in (3, 4):
+        raise ValueError(f"MPS ndim is not 3 or 4, got {ms.ndim}")
+    cplx = ms.is_complex or environ.is_complex or bra.is_complex or mo.is_complex
+    dt = np.complex128 if cplx else np.float64
+    ket = ms.to_complex() if cplx else ms
+    bra = bra.to_complex() if cplx else bra
+    d = mpse_dims()
+    d.Dl_ket, d.Dr_ket = ket.shape[0], ket.shape[-1]
+    d.Dl_bra, d.Dr_bra = bra.shape[0], bra.shape[-1]
+    d.d0, d.d1 = ket.shape[1], 1
+    d.danc = ket.shape[2] if ket.ndim == 4 else 1
+    d.wl, d.wr, d.wm = mo.shape[0], mo.shape[3], 1
+    if domain == "L":
+        assert environ.shape == (d.Dl_bra, d.wl, d.Dl_ket), (environ.shape, bra.shape, mo.shape, ket.shape)
+        oshape = (d.Dr_bra, d.wr, d.Dr_ket)
+    else:
+        assert environ.shape == (d.Dr_bra, d.wr, d.Dr_ket), (environ.shape, bra.shape, mo.shape, ket.shape)
+        oshape = (d.Dl_bra, d.wl, d.Dl_ket)
+    out = eng.empty(oshape, dt)
+    eng._check(eng.lib.mpse_env_update(
+        eng.ctx, out.code, DOMAIN_L if domain == "L" else DOMAIN_R, C.byref(d), environ.ptr, environ.code,
+        ket.ptr, bra.ptr, 1 if ms_conj is None else 0, mo.ptr, mo.code, out.ptr))
+    return out
+
+
+class Environ:
+    """Cache {("L"|"R", idx): environment}; idx is the site the tensor reaches up to
+    (L(idx-1) - mpo(idx) - R(idx+1)).  ``domain=None`` builds both directions like the
+    reference; pass "L" or "R" to build only what a sweep needs."""
+
+    def __init__(self, mps, mpo, domain=None, mps_conj=None):
+        self.eng = get_engine()
+        self._virtual_disk = {}
+        self.sentinel = self.eng.ones((1, 1, 1), np.float64)
+        self._construct(mps, mpo, domain, mps_conj)
+
+    def _mo(self, mpo, idx):
+        return mpo.device(idx, self.eng) if hasattr(mpo, "device") else _as_w(self.eng, mpo[idx])
+
+    def _construct(self, mps, mpo, domain=None, mps_conj=None):
+        assert domain in ["L", "R", None]
+        if domain is None:
+            self._construct(mps, mpo, "L", mps_conj)
+            self._construct(mps, mpo, "R", mps_conj)
+            return
+        n = len(mps)
+        rng = range(0, n - 1) if domain == "L" else range(n - 1, 0, -1)
+        self.write("L", -1, self.sentinel)
+        self.write("R", n, self.sentinel)
+        tensor = self.sentinel
+        for idx in rng:
+            cj = None if mps_conj is None else mps_conj[idx]
+            tensor = contract_one_site(tensor, mps[idx], self._mo(mpo, idx), domain, ms_conj=cj)
+            self.write(domain, idx, tensor)
+
+    def GetLR(self, domain, siteidx, mps, mpo, itensor=None, method="Scratch", mps_conj=None):
+        assert domain in ["L", "R"]
+        assert method in ["Enviro", "System", "Scratch"]
+        if mps_conj is None:
+            mps_conj = [None] * len(mps)
+        if siteidx not in range(len(mps)):
+            return self.sentinel
+        if method == "Scratch":
+            itensor = self.sentinel
+            sites = range(siteidx + 1) if domain == "L" else range(len(mps) - 1, siteidx - 1, -1)
+            for i in sites:
+                itensor = contract_one_site(itensor, mps[i], self._mo(mpo, i), domain, ms_conj=mps_conj[i])
+        elif method == "Enviro":
+            itensor = self.read(domain, siteidx)
+        else:
+            if itensor is None:
+                itensor = self.read(domain, siteidx + (-1 if domain == "L" else 1))
+            itensor = contract_one_site(itensor, mps[siteidx], self._mo(mpo, siteidx), domain, mps_conj[siteidx])
+            self.write(domain, siteidx, itensor)
+        return itensor
+
+    def write(self, domain, siteidx, tensor):
+        self._virtual_disk[(domain, siteidx)] = tensor
+
+    def read(self, domain, siteidx):
+        return self._virtual_disk[(domain, siteidx)]

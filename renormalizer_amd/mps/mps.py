@@ -1,0 +1,479 @@
+"""Matrix product states resident in HBM and their sweep algorithms.
+
+Kept API surface of renormalizer/mps/mp.py (MatrixProduct) and renormalizer/mps/mps.py (Mps):
+constructors, qn bookkeeping, ``expectation(s)``, ``evolve`` (TDVP-PS), ``canonicalise`` /
+``compress``.  The Python here is sweep *control* only (order of operations copied from the
+reference drivers, cited per method); every tensor is a ``DeviceTensor`` and every flop runs in
+libmpsengine.so.  Integer quantum-number bookkeeping stays on the host in NumPy int arrays."""
+import ctypes
+import logging
+from typing import Dict, List
+
+import numpy as np
+
+from ..engine import DeviceTensor, get_engine
+from ..lib.krylov import expm_krylov
+from ..model import Model, Op, OpSum
+from ..utils import CompressConfig, EvolveConfig, EvolveMethod, OptimizeConfig
+from . import svd_qn
+from .hop_expr import hop_expr
+from .lib import Environ, contract_one_site
+from .mpo import Mpo
+from .svd_qn import add_outer, get_qn_mask
+
+logger = logging.getLogger("renormalizer_amd")
+
+
+class Mps:
+    def __init__(self):
+        self._mp: List[DeviceTensor] = []
+        self.dtype = np.dtype(np.float64)
+        self.model: Model = None
+        self.compress_config: CompressConfig = CompressConfig()
+        self.evolve_config: EvolveConfig = EvolveConfig()
+        self.optimize_config: OptimizeConfig = OptimizeConfig()
+        self.qn: List[np.ndarray] = []
+        self.qnidx: int = None
+        self.qntot: np.ndarray = None
+        self.to_right: bool = None
+        self.coeff = 1.0
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_arrays(cls, model, arrays, qn, qnidx, qntot, to_right, coeff=1.0):
+        """Upload host site tensors (D_l, d, D_r) and their quantum numbers."""
+        eng = get_engine()
+        mps = cls()
+        mps.model = model
+        cplx = any(np.iscomplexobj(a) for a in arrays)
+        mps.dtype = np.dtype(np.complex128 if cplx else np.float64)
+        mps._mp = [eng.asdevice(np.asarray(a), mps.dtype) for a in arrays]
+        q = len(np.atleast_1d(qntot))
+        mps.qn = [np.asarray(x, dtype=int).reshape(-1, q) for x in qn]
+        mps.qnidx = int(qnidx)
+        mps.qntot = np.asarray(qntot, dtype=int).reshape(q)
+        mps.to_right = bool(to_right)
+        mps.coeff = coeff
+        return mps
+
+    @classmethod
+    def hartree_product_state(cls, model, condition: Dict = None, qn_idx: int = None):
+        """mps/mps.py:187-262"""
+        condition = dict(condition or {})
+        idx = [model.dof_to_siteidx[k] for k in condition]
+        assert len(idx) == len(set(idx))
+        condition = {model.dof_to_siteidx[k]: v for k, v in condition.items()}
+        q = model.qn_size
+        arrays, qn = [], [np.zeros((1, q), dtype=int)]
+        for isite, b in enumerate(model.basis):
+            ms = np.zeros((1, b.nbas, 1))
+            st = condition.pop(isite, 0)
+            if isinstance(st, (int, np.integer)):
+                ms[0, st, 0] = 1.0
+                sq = b.sigmaqn[st]
+            else:
+                ms[0, :, 0] = st
+                allq = np.array(b.sigmaqn)[np.nonzero(st)]
+                if not np.allclose(allq.std(axis=0), 0):
+                    raise ValueError("Quantum numbers are mixed in the condition.")
+                sq = allq[0]
+            arrays.append(ms)
+            qn.append(qn[-1] + np.asarray(sq).reshape(1, q))
+        if condition:
+            raise ValueError(f"Condition not completely used: {condition}")
+        mps = cls.from_arrays(model, arrays, qn, model.nsite, qn[-1][0], False)
+        mps.move_qnidx(model.nsite - 1 if qn_idx is None else qn_idx)
+        return mps
+
+    @classmethod
+    def ground_state(cls, model, max_entangled: bool, normalize: bool = True, condition: Dict = None):
+        """mps/mps.py:264-350 (phonons in |0> or maximally entangled, electrons empty)."""
+        q = model.qn_size
+        arrays = []
+        for b in model.basis:
+            ms = np.zeros((1, b.nbas, 1))
+            if (b.is_phonon or b.is_spin) and max_entangled:
+                ms[0, :, 0] = 1.0 / np.sqrt(b.nbas) if normalize else 1.0
+            else:
+                ms[0, 0, 0] = 1.0
+            arrays.append(ms)
+        qn = [np.zeros((1, q), dtype=int)] * (model.nsite + 1)
+        return cls.from_arrays(model, arrays, qn, model.nsite - 1, np.zeros(q, dtype=int), False)
+
+    # ------------------------------------------------------------------ container protocol
+    def __len__(self):
+        return len(self._mp)
+
+    def __getitem__(self, i):
+        return self._mp[i]
+
+    def __setitem__(self, i, t):
+        assert isinstance(t, DeviceTensor)
+        self._mp[i] = t
+
+    def __iter__(self):
+        return iter(self._mp)
+
+    @property
+    def site_num(self):
+        return len(self._mp)
+
+    @property
+    def is_complex(self):
+        return self.dtype == np.complex128
+
+    @property
+    def bond_dims(self):
+        return [t.shape[0] for t in self._mp] + [self._mp[-1].shape[-1]]
+
+    bond_list = vbond_dims = bond_dims
+
+    @property
+    def bond_dims_mean(self):
+        return int(round(np.mean(self.bond_dims)))
+
+    @property
+    def pbond_dims(self):
+        return self.model.pbond_list
+
+    pbond_list = pbond_dims
+
+    @property
+    def bond_dims_exact(self):
+        p = np.array(self.pbond_dims, dtype=float)
+        with np.errstate(over="ignore"):
+            d1 = [1] + list(np.cumprod(p))
+            d2 = ([1] + list(np.cumprod(p[::-1])))[::-1]
+        return np.minimum(d1, d2)
+
+    @property
+    def nexciton(self):
+        return self.qntot
+
+    def to_arrays(self):
+        """Download all site tensors (debugging / checkpointing)."""
+        return [t.to_host() for t in self._mp]
+
+    def _get_sigmaqn(self, idx):
+        return np.array(self.model.basis[idx].sigmaqn)
+
+    # ------------------------------------------------------------------ copies
+    def metacopy(self):
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__ = self.__dict__.copy()
+        new._mp = [None] * len(self._mp)
+        new.qn = [q.copy() for q in self.qn]
+        new.qntot = self.qntot.copy()
+        new.compress_config = self.compress_config.copy()
+        new.evolve_config = self.evolve_config.copy()
+        new.optimize_config = self.optimize_config.copy()
+        return new
+
+    def copy(self):
+        """Site buffers are immutable by convention, so a copy shares them (copy-on-write)."""
+        new = self.metacopy()
+        new._mp = list(self._mp)
+        return new
+
+    def conj(self):
+        new = self.metacopy()
+        new._mp = [t.conj() if t.is_complex else t for t in self._mp]
+        return new
+
+    def to_complex(self, inplace=False):
+        """mps/mp.py:996-1007.  Site buffers are immutable by convention (every update installs a
+        new handle), so an already complex MPS shares its tensors with the result."""
+        new = self if inplace else self.metacopy()
+        new.dtype = np.dtype(np.complex128)
+        new._mp = [t.to_complex() for t in self._mp]
+        return new
+
+    # ------------------------------------------------------------------ qn bookkeeping (integer, host)
+    def move_qnidx(self, dstidx: int):
+        """mps/mp.py:159-172"""
+        for idx in range(self.qnidx + 1, self.site_num + 1):
+            self.qn[idx] = self.qntot - self.qn[idx]
+        for idx in range(self.site_num, dstidx, -1):
+            self.qn[idx] = self.qntot - self.qn[idx]
+        self.qnidx = dstidx
+
+    def iter_idx_list(self, full: bool, stop_idx: int = None):
+        """mps/mp.py:230-243"""
+        if self.to_right:
+            last = stop_idx if stop_idx is not None else (self.site_num if full else self.site_num - 1)
+            return range(self.qnidx, last)
+        last = stop_idx if stop_idx is not None else (-1 if full else 0)
+        return range(self.qnidx, last, -1)
+
+    def _switch_direction(self):
+        """mps/mp.py:297-306"""
+        assert self.to_right is not None
+        if self.to_right:
+            self.qnidx, self.to_right = self.site_num - 1, False
+        else:
+            self.qnidx, self.to_right = 0, True
+
+    def _get_big_qn(self, cidx: List[int], swap=False):
+        """mps/mp.py:308-352"""
+        cidx = sorted(cidx)
+        assert len(cidx) in (1, 2) and self.qnidx in cidx
+        sigmaqn = [self._get_sigmaqn(i) for i in cidx]
+        if swap:
+            sigmaqn = sigmaqn[::-1]
+        qnl = np.array(self.qn[cidx[0]])
+        qnr = np.array(self.qn[cidx[-1] + 1])
+        if len(cidx) == 1:
+            if self.to_right:
+                qnbigl, qnbigr = add_outer(qnl, sigmaqn[0]), qnr
+            else:
+                qnbigl, qnbigr = qnl, add_outer(sigmaqn[0], qnr)
+        else:
+            qnbigl, qnbigr = add_outer(qnl, sigmaqn[0]), add_outer(sigmaqn[1], qnr)
+        return qnbigl, qnbigr, add_outer(qnbigl, qnbigr)
+
+    # ------------------------------------------------------------------ scalar products and norms
+    def dot(self, other: "Mps", self_is_conj=True) -> complex:
+        """<self|other> with ``self`` holding the already-conjugated bra (mps/mp.py:933-956);
+        ``self_is_conj=False`` conjugates on the fly inside the contraction instead."""
+        eng = get_engine()
+        assert len(self) == len(other)
+        e = eng.ones((1, 1), np.float64)
+        for b, k in zip(self._mp, other._mp):
+            t = eng.matmul(e, k.reshape(k.shape[0], -1))                      # (Db, d*Dr_k)
+            t = t.reshape(-1, k.shape[-1])                                     # (Db*d, Dr_k)
+            e = eng.matmul(b.reshape(-1, b.shape[-1]), t, trans_a=True, conj_a=not self_is_conj)
+        return complex(e.to_host()[0, 0])
+
+    @property
+    def mp_norm(self) -> float:
+        """mps/mp.py:354-372"""
+        res = self.dot(self, self_is_conj=False).real
+        if res < 0:
+            assert abs(res) < 1e-8
+            res = 0.0
+        return float(np.sqrt(res))
+
+    @property
+    def norm(self):
+        return float(np.linalg.norm(self.coeff) * self.mp_norm)
+
+    def scale(self, val, inplace=False):
+        """mps/mp.py:984-994: multiplies the qn-centre site."""
+        new = self if inplace else self.copy()
+        val = complex(val)
+        if val.imag != 0:
+            new.to_complex(inplace=True)
+        else:
+            val = val.real
+        new._mp[new.qnidx] = new._mp[new.qnidx].copy().scale_(val)
+        return new
+
+    def normalize(self, kind):
+        """mps/mps.py:2025-2059"""
+        nrm = self.mp_norm
+        if kind == "mps_only":
+            new_coeff = self.coeff
+        elif kind == "mps_and_coeff":
+            new_coeff = self.coeff / np.linalg.norm(self.coeff)
+        elif kind == "mps_norm_to_coeff":
+            new_coeff = self.coeff * nrm
+        else:
+            raise ValueError(f"kind={kind} is not valid.")
+        self.scale(1.0 / nrm, inplace=True)
+        self.coeff = new_coeff
+        return self
+
+    # ------------------------------------------------------------------ observables
+    def expectation(self, mpo, self_conj: "Mps" = None):
+        """<psi|O|psi> (mps/mps.py:471-525): R-environment sweep and a closing contraction at site 0."""
+        if isinstance(mpo, (Op, OpSum)):
+            mpo = Mpo(self.model, mpo)
+        conj_sites = None if self_conj is None else self_conj._mp
+        environ = Environ(self, mpo, "R", mps_conj=conj_sites)
+        r = environ.read("R", 1) if len(self) > 1 else environ.sentinel
+        val = contract_one_site(r, self[0], environ._mo(mpo, 0), "R",
+                                ms_conj=None if conj_sites is None else conj_sites[0]).to_host().reshape(-1)[0]
+        val = complex(val)
+        return float(val.real) if np.isclose(val.imag, 0) else val
+
+    def expectations(self, mpos, self_conj: "Mps" = None, opt=True) -> np.ndarray:
+        """mps/mps.py:527-575 (shared-prefix caching is left to a later round: observables are
+        outside the timed sweep)."""
+        return np.array([self.expectation(m, self_conj) for m in mpos])
+
+    @property
+    def e_occupations(self):
+        """mps/mps.py:600-609"""
+        key = "e_occupations"
+        if key not in self.model.mpos:
+            self.model.mpos[key] = [Mpo(self.model, Op(r"a^\dagger a", dof)) for dof in self.model.e_dofs]
+        return self.expectations(self.model.mpos[key])
+
+    # ------------------------------------------------------------------ canonical form / compression
+    def _update_ms(self, idx, u, vt, sigma=None, qnlset=None, qnrset=None, m_trunc=None):
+        """mps/mp.py:245-295 for an MPS: keep the first m_trunc columns, push sigma/R to the neighbour."""
+        eng = get_engine()
+        K = u.shape[1]
+        if m_trunc is None:
+            m_trunc = K
+        m_trunc = int(m_trunc)
+        q = len(self.qntot)
+        if m_trunc < K or sigma is not None:
+            keep = np.arange(m_trunc, dtype=np.int64)
+            p = svd_qn._p64(keep)
+            su = sv = None
+            if sigma is not None:
+                sg = np.ascontiguousarray(np.asarray(sigma, dtype=float)[:m_trunc])
+                sp = sg.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+                su, sv = (None, sp) if self.to_right else (sp, None)
+            u2 = eng.empty((u.shape[0], m_trunc), u.dtype)
+            vt2 = eng.empty((m_trunc, vt.shape[1]), vt.dtype)
+            eng._check(eng.lib.mpse_gather_cols(eng.ctx, u.code, u2.ptr, u.ptr, u.shape[0], K, p, su, m_trunc))
+            eng._check(eng.lib.mpse_gather_rows(eng.ctx, vt.code, vt2.ptr, vt.ptr, vt.shape[1], p, sv, m_trunc))
+            u, vt = u2, vt2
+        pdim = self[idx].shape[1:-1]
+        if self.to_right:
+            nxt = self[idx + 1]
+            self[idx + 1] = eng.matmul(vt, nxt.reshape(nxt.shape[0], -1)).reshape((m_trunc,) + nxt.shape[1:])
+            self[idx] = u.reshape((-1,) + tuple(pdim) + (m_trunc,))
+            if qnlset is not None:
+                self.qn[idx + 1] = np.array(qnlset[:m_trunc], dtype=int).reshape(m_trunc, q)
+                self.qnidx = idx + 1
+        else:
+            prv = self[idx - 1]
+            self[idx - 1] = eng.matmul(prv.reshape(-1, prv.shape[-1]), u).reshape(prv.shape[:-1] + (m_trunc,))
+            self[idx] = vt.reshape((m_trunc,) + tuple(pdim) + (-1,))
+            if qnrset is not None:
+                self.qn[idx] = np.array(qnrset[:m_trunc], dtype=int).reshape(m_trunc, q)
+                self.qnidx = idx - 1
+
+    def _push_cano(self, idx):
+        """mps/mp.py:890-908"""
+        qnbigl, qnbigr, _ = self._get_big_qn([idx])
+        system = "L" if self.to_right else "R"
+        u, qnlset, v, qnrset = svd_qn.svd_qn(self[idx], qnbigl, qnbigr, self.qntot, QR=True, system=system,
+                                             full_matrices=False)
+        self._update_ms(idx, u, v.T, sigma=None, qnlset=qnlset, qnrset=qnrset)
+
+    def canonicalise(self, stop_idx: int = None):
+        """mps/mp.py:910-922"""
+        if self.to_right:
+            assert self.qnidx == 0
+        else:
+            assert self.qnidx == self.site_num - 1
+        idx = None
+        for idx in self.iter_idx_list(full=False, stop_idx=stop_idx):
+            self._push_cano(idx)
+        if idx is not None and ((not self.to_right and idx == 1) or (self.to_right and idx == self.site_num - 2)):
+            self._switch_direction()
+        return self
+
+    def compress(self, temp_m_trunc=None, ret_s=False):
+        """SVD sweep, mps/mp.py:437-511 (the caller canonicalises first, as in the reference)."""
+        if self.to_right:
+            assert self.qnidx == 0
+        else:
+            assert self.qnidx == self.site_num - 1
+        if self.compress_config.bonddim_should_set:
+            self.compress_config.set_bonddim(len(self) + 1)
+        system = "L" if self.to_right else "R"
+        s_list = []
+        for idx in self.iter_idx_list(full=False):
+            qnbigl, qnbigr, _ = self._get_big_qn([idx])
+            u, sigma, qnlset, v, sigma, qnrset = svd_qn.svd_qn(self[idx], qnbigl, qnbigr, self.qntot, system=system,
+                                                               full_matrices=False)
+            s_list.append(sigma)
+            if temp_m_trunc is None:
+                m_trunc = self.compress_config.compute_m_trunc(sigma, idx, self.to_right)
+            else:
+                if isinstance(temp_m_trunc, (list, tuple, np.ndarray)):
+                    m_trunc = temp_m_trunc[idx + 1 if self.to_right else idx]
+                else:
+                    m_trunc = temp_m_trunc
+                m_trunc = min(int(m_trunc), len(sigma))
+            self._update_ms(idx, u, v.T, sigma, qnlset, qnrset, m_trunc)
+        self._switch_direction()
+        if not ret_s:
+            return self
+        width = max(len(s) for s in s_list)
+        return self, np.array([np.pad(s, (0, width - len(s))) for s in s_list])
+
+    # ------------------------------------------------------------------ time evolution
+    def evolve(self, mpo, evolve_dt, normalize=True) -> "Mps":
+        """mps/mps.py:644-662"""
+        method = self.evolve_config.method
+        if method is EvolveMethod.tdvp_ps:
+            new_mps = self._evolve_tdvp_ps(mpo, evolve_dt)
+        else:
+            raise NotImplementedError(f"{method} is not implemented in the MI355X engine yet (TDVP-PS is)")
+        if normalize:
+            if np.iscomplex(evolve_dt):
+                new_mps.normalize("mps_and_coeff")
+            else:
+                new_mps.normalize("mps_only")
+        return new_mps
+
+    def _evolve_tdvp_ps(self, mpo, evolve_dt) -> "Mps":
+        """One-site TDVP with projector splitting, PhysRevB 94, 165116; order of operations of
+        mps/mps.py:1267-1404: two half sweeps; per site a forward step -i dt/2 of the centre
+        tensor (Lanczos), QR/RQ by quantum-number block, one environment update, a backward
+        step +i dt/2 of the bond factor (0-site Lanczos), absorbed into the next site; the last
+        site of each half sweep is not split."""
+        if self.evolve_config.ivp_solver != "krylov":
+            raise NotImplementedError("only the Krylov (Lanczos) local propagator is implemented")
+        eng = get_engine()
+        if np.iscomplex(evolve_dt):
+            mps = self.copy()
+        else:
+            mps = self.to_complex()
+        evolve_dt = complex(evolve_dt)
+        n = len(mps)
+        # Only the environments ahead of the sweep are needed: the reference builds both
+        # directions and discards half (mps.py:1281-1283).
+        environ = Environ(mps, mpo, "R" if mps.to_right else "L")
+        local_steps = []
+        q = len(mps.qntot)
+        for _ in range(2):
+            for imps in mps.iter_idx_list(full=True):
+                system = "L" if mps.to_right else "R"
+                l_array = environ.read("L", imps - 1)
+                r_array = environ.read("R", imps + 1)
+                shape = list(mps[imps].shape)
+                w = mpo.device(imps, eng)
+                hop = hop_expr(l_array, r_array, [w], shape)
+                mps_t, j = expm_krylov(hop, -1j * evolve_dt / 2, mps[imps])
+                local_steps.append(j)
+                qnbigl, qnbigr, _ = mps._get_big_qn([imps])
+                if (not mps.to_right and imps != 0) or (mps.to_right and imps != n - 1):
+                    u, qnlset, v, qnrset = svd_qn.svd_qn(mps_t, qnbigl, qnbigr, mps.qntot, QR=True, system=system,
+                                                         full_matrices=False)
+                    vt = v.T
+                if not mps.to_right and imps != 0:
+                    mps[imps] = vt.reshape([-1] + shape[1:])
+                    mps.qn[imps] = np.array(qnrset, dtype=int).reshape(-1, q)
+                    mps.qnidx = imps - 1
+                    r_array = environ.GetLR("R", imps, mps, mpo, itensor=r_array, method="System")
+                    hop_u = hop_expr(l_array, r_array, [], u.shape)
+                    b_t, j = expm_krylov(hop_u, 1j * evolve_dt / 2, u)
+                    local_steps.append(j)
+                    prv = mps[imps - 1]
+                    mps[imps - 1] = eng.matmul(prv.reshape(-1, prv.shape[-1]), b_t.reshape(u.shape)) \
+                        .reshape(prv.shape[:-1] + (u.shape[1],))
+                elif mps.to_right and imps != n - 1:
+                    mps[imps] = u.reshape(shape[:-1] + [-1])
+                    mps.qn[imps + 1] = np.array(qnlset, dtype=int).reshape(-1, q)
+                    mps.qnidx = imps + 1
+                    l_array = environ.GetLR("L", imps, mps, mpo, itensor=l_array, method="System")
+                    hop_svt = hop_expr(l_array, r_array, [], vt.shape)
+                    b_t, j = expm_krylov(hop_svt, 1j * evolve_dt / 2, vt)
+                    local_steps.append(j)
+                    nxt = mps[imps + 1]
+                    mps[imps + 1] = eng.matmul(b_t.reshape(vt.shape), nxt.reshape(nxt.shape[0], -1)) \
+                        .reshape((vt.shape[0],) + nxt.shape[1:])
+                else:
+                    mps[imps] = mps_t.reshape(shape)
+            mps._switch_direction()
+        mps.evolve_config.stat = dict(nobs=len(local_steps), min=int(np.min(local_steps)),
+                                      max=int(np.max(local_steps)), mean=float(np.mean(local_steps)),
+                                      steps=list(local_steps))
+        return mps

@@ -1,0 +1,109 @@
+"""Quantum-number blocked decompositions on the device (counterpart of renormalizer/mps/svd_qn.py).
+
+The integer bookkeeping (which rows / columns form a symmetry block, the qn lists of the new
+bond) is done here on the host exactly like the reference (:99-240, 305-317); the floating
+point work per block runs in the engine (Householder QR/RQ, one-sided Jacobi SVD)."""
+import ctypes as C
+
+import numpy as np
+
+from ..engine import DeviceTensor, get_engine
+
+
+def add_outer(a, b):
+    """svd_qn.py:305-313"""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape[-1] == b.shape[-1]
+    return a.reshape(a.shape[:-1] + (1,) * (b.ndim - 1) + a.shape[-1:]) + b
+
+
+def get_qn_mask(qnmat, qntot):
+    """svd_qn.py:316-317"""
+    return np.all(np.asarray(qnmat) == np.asarray(qntot), axis=-1)
+
+
+def qn_blocks(qnbigl, qnbigr, qntot):
+    """[(nl, nr, row indices, column indices)] for every left qn ``nl`` that has partner columns
+    with ``qntot - nl`` (svd_qn.py:177-182); blocks in lexicographic order of nl."""
+    qntot = np.asarray(qntot)
+    q = len(qntot)
+    lq = np.ascontiguousarray(np.asarray(qnbigl).reshape(-1, q))
+    rq = np.ascontiguousarray(np.asarray(qnbigr).reshape(-1, q))
+    out = []
+    uniq, inv = np.unique(lq, axis=0, return_inverse=True)
+    inv = np.asarray(inv).reshape(-1)
+    for k, nl in enumerate(uniq):
+        nr = qntot - nl
+        rset = np.nonzero(np.all(rq == nr, axis=1))[0]
+        if len(rset) == 0:
+            continue
+        lset = np.nonzero(inv == k)[0]
+        out.append((nl.astype(int), nr.astype(int), lset.astype(np.int64), rset.astype(np.int64)))
+    return out
+
+
+class TransposedView:
+    """What the reference returns as ``v`` (ncol x K); the engine produces v.T directly."""
+
+    def __init__(self, vt: DeviceTensor):
+        self.T = vt
+        self.shape = (vt.shape[1], vt.shape[0])
+
+    def to_host(self):
+        return self.T.to_host().T
+
+
+def _p64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def svd_qn(coef_array, qnbigl, qnbigr, qntot, QR=False, system=None, full_matrices=True, opt_full_matrices=True):
+    """Block decomposition of the centre tensor.  Returns ``(u, new_qnl, v, new_qnr)`` for QR and
+    ``(u, su, new_qnl, v, sv, new_qnr)`` for SVD with ``coef == u @ diag(s) @ v.T`` (``v.T`` is
+    available as ``v.T``, a device tensor)."""
+    eng = get_engine()
+    coef = eng.asdevice(coef_array)
+    qntot = np.asarray(qntot)
+    nrow = int(np.prod(np.asarray(qnbigl).shape[:-1]))
+    ncol = int(np.prod(np.asarray(qnbigr).shape[:-1]))
+    if coef.size != nrow * ncol:
+        raise ValueError(f"coefficient array {coef.shape} does not match quantum numbers ({nrow}x{ncol})")
+    blocks = qn_blocks(qnbigl, qnbigr, qntot)
+    if len(blocks) == 0:
+        raise ValueError("Invalid quantum number")
+    rows = np.concatenate([b[2] for b in blocks])
+    cols = np.concatenate([b[3] for b in blocks])
+    roff = np.cumsum([0] + [len(b[2]) for b in blocks]).astype(np.int64)
+    coff = np.cumsum([0] + [len(b[3]) for b in blocks]).astype(np.int64)
+    dims = [min(len(b[2]), len(b[3])) for b in blocks]
+    K = int(sum(dims))
+    new_qnl, new_qnr = [], []
+    for b, k in zip(blocks, dims):
+        new_qnl += [b[0].tolist()] * k
+        new_qnr += [b[1].tolist()] * k
+    if full_matrices:
+        raise NotImplementedError("full_matrices=True is handled by the DMRG update path")
+    u = eng.empty((nrow, K), coef.dtype)
+    vt = eng.empty((K, ncol), coef.dtype)
+    if QR:
+        if system not in ("L", "R"):
+            raise ValueError("system must be 'L' or 'R' for QR")
+        eng._check(eng.lib.mpse_block_qr(eng.ctx, coef.code, coef.ptr, nrow, ncol, len(blocks), _p64(rows), _p64(roff),
+                                         _p64(cols), _p64(coff), int(system == "R"), u.ptr, vt.ptr, K))
+        return u, new_qnl, TransposedView(vt), new_qnr
+    s = np.zeros(K)
+    eng._check(eng.lib.mpse_block_svd(eng.ctx, coef.code, coef.ptr, nrow, ncol, len(blocks), _p64(rows), _p64(roff),
+                                      _p64(cols), _p64(coff), u.ptr, vt.ptr, s.ctypes.data_as(C.POINTER(C.c_double)), K))
+    # economic SVD: globally sort by singular value, descending (svd_qn.py:231-239)
+    order = np.argsort(s)[::-1].astype(np.int64)
+    if not np.array_equal(order, np.arange(K)):
+        u2 = eng.empty((nrow, K), coef.dtype)
+        vt2 = eng.empty((K, ncol), coef.dtype)
+        eng._check(eng.lib.mpse_gather_cols(eng.ctx, u.code, u2.ptr, u.ptr, nrow, K, _p64(order), None, K))
+        eng._check(eng.lib.mpse_gather_rows(eng.ctx, vt.code, vt2.ptr, vt.ptr, ncol, _p64(order), None, K))
+        u, vt = u2, vt2
+        s = s[order]
+        new_qnl = np.array(new_qnl)[order].tolist()
+        new_qnr = np.array(new_qnr)[order].tolist()
+    return u, s, new_qnl, TransposedView(vt), s, new_qnr
