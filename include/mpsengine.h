@@ -58,6 +58,16 @@ const char* mpse_version(void);
 /* device name, compute-unit count and the HIP stream handle (as void*) for callers that time with HIP events */
 int mpse_device_info(mpse_ctx* ctx, char* name, size_t name_len, int* n_cu, void** stream);
 
+/* ------------------------------------------------------------- profiling */
+/* Optional per-launch timing of the contraction kernel with HIP events on the context stream
+ * (no reference counterpart; used by bench.py for the roofline figures).  variant indexes the
+ * operand types of mpse_gemm: 0 = f64 x f64, 1 = c128 x f64, 2 = f64 x c128, 3 = c128 x c128.
+ * Totals cover the launches since the last reset; algorithmic flops use 2/4/4/8 per MAC. */
+int mpse_prof_enable(mpse_ctx* ctx, int on);
+int mpse_prof_reset(mpse_ctx* ctx);
+int mpse_prof_get(mpse_ctx* ctx, int variant, double* total_ms, double* total_flops, double* total_bytes,
+                  int64_t* launches);
+
 /* --------------------------------------------------------- device memory */
 
 /* Pooled device allocator (mps/backend.py:116-127 free_all_blocks/log_memory_usage). */

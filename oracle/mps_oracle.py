@@ -497,18 +497,30 @@ def normalize(state: MpsState, kind):
     return state
 
 
-def tdvp_ps_step(state: MpsState, mpo, dt, normalize_after=True) -> MpsState:
+def tdvp_ps_step(state: MpsState, mpo, dt, normalize_after=True, max_updates=None, timings=None,
+                 env_domain=None) -> MpsState:
     """One ``Mps.evolve`` with EvolveMethod.tdvp_ps and the Krylov solver:
-    mps/mps.py:1267-1404 followed by normalize (mps.py:644-662)."""
+    mps/mps.py:1267-1404 followed by normalize (mps.py:644-662).
+
+    ``max_updates`` / ``timings`` serve the bounded CPU-baseline sample of bench.py: stop after that
+    many site updates and append (site, shape, seconds) per update.  ``env_domain`` restricts the
+    initial environment construction to the direction the first half sweep needs."""
+    import time as _time
     imag_time = (complex(dt).imag != 0)
     st = state.copy()
     if not imag_time:
         st.sites = [s.astype(complex) for s in st.sites]
     n = st.nsite
-    env = build_environ(st.sites, mpo, None)
+    env = build_environ(st.sites, mpo, env_domain)
     dims = []
+    done = 0
     for _ in range(2):
         for i in st.iter_idx_list(full=True):
+            if max_updates is not None and done >= max_updates:
+                st.krylov_dims = dims
+                return st
+            done += 1
+            _t0 = _time.perf_counter()
             system = "L" if st.to_right else "R"
             l = env[("L", i - 1)]
             r = env[("R", i + 1)]
@@ -544,6 +556,8 @@ def tdvp_ps_step(state: MpsState, mpo, dt, normalize_after=True) -> MpsState:
                 st.sites[i + 1] = np.tensordot(b.reshape(vt.shape), st.sites[i + 1], axes=(1, 0))
             else:
                 st.sites[i] = c
+            if timings is not None:
+                timings.append((i, tuple(shape), _time.perf_counter() - _t0))
         st.switch_direction()
     st.krylov_dims = dims
     if normalize_after:

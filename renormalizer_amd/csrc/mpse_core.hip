@@ -11,7 +11,53 @@ int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
+void prof_drain(mpse_ctx* ctx) {
+  for (auto& r : ctx->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      ctx->prof_ms[r.variant] += ms;
+      ctx->prof_flops[r.variant] += r.flops;
+      ctx->prof_bytes[r.variant] += r.bytes;
+      ctx->prof_launches[r.variant] += 1;
+    }
+    ctx->prof_free_events.push_back(r.e0);
+    ctx->prof_free_events.push_back(r.e1);
+  }
+  ctx->prof_pending.clear();
+}
+
 extern "C" {
+
+int mpse_prof_enable(mpse_ctx* ctx, int on) {
+  if (!ctx) return MPSE_ERR_ARG;
+  MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  prof_drain(ctx);
+  ctx->prof_on = on != 0;
+  return MPSE_OK;
+}
+
+int mpse_prof_reset(mpse_ctx* ctx) {
+  if (!ctx) return MPSE_ERR_ARG;
+  MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  prof_drain(ctx);
+  for (int i = 0; i < 4; ++i) {
+    ctx->prof_ms[i] = ctx->prof_flops[i] = ctx->prof_bytes[i] = 0;
+    ctx->prof_launches[i] = 0;
+  }
+  return MPSE_OK;
+}
+
+int mpse_prof_get(mpse_ctx* ctx, int variant, double* total_ms, double* total_flops, double* total_bytes,
+                  int64_t* launches) {
+  if (!ctx || variant < 0 || variant > 3) return MPSE_ERR_ARG;
+  MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  prof_drain(ctx);
+  if (total_ms) *total_ms = ctx->prof_ms[variant];
+  if (total_flops) *total_flops = ctx->prof_flops[variant];
+  if (total_bytes) *total_bytes = ctx->prof_bytes[variant];
+  if (launches) *launches = ctx->prof_launches[variant];
+  return MPSE_OK;
+}
 
 const char* mpse_version(void) { return "mpsengine 0.1 (gfx950)"; }
 
@@ -60,6 +106,8 @@ int mpse_ctx_destroy(mpse_ctx* ctx) {
   if (!ctx) return MPSE_ERR_ARG;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  prof_drain(ctx);
+  for (auto e : ctx->prof_free_events) (void)hipEventDestroy(e);
   for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -72,6 +120,7 @@ int mpse_ctx_destroy(mpse_ctx* ctx) {
 int mpse_sync(mpse_ctx* ctx) {
   if (!ctx) return MPSE_ERR_ARG;
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!ctx->prof_pending.empty()) prof_drain(ctx);
   return MPSE_OK;
 }
 

@@ -314,6 +314,26 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
   if (nblk > 0x7fffffffLL) return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpse_gemm: grid too large");
   dim3 grid((unsigned)nblk), block(256);
   const bool ca = d->dtype_a == MPSE_C128, cb = d->dtype_b == MPSE_C128;
+  mpse_ctx::ProfRec rec;
+  if (ctx->prof_on) {
+    auto get_event = [&](hipEvent_t* e) {
+      if (!ctx->prof_free_events.empty()) {
+        *e = ctx->prof_free_events.back();
+        ctx->prof_free_events.pop_back();
+        return hipSuccess;
+      }
+      return hipEventCreate(e);
+    };
+    MPSE_HIP(ctx, get_event(&rec.e0));
+    MPSE_HIP(ctx, get_event(&rec.e1));
+    rec.variant = (ca ? 1 : 0) + (cb ? 2 : 0);
+    const double mnk = double(g.M) * double(g.N) * double(g.K) * double(d->batch);
+    rec.flops = mnk * ((ca && cb) ? 8.0 : (ca || cb) ? 4.0 : 2.0);
+    // compulsory traffic: read A and B once, write C once (+ read C when beta != 0)
+    rec.bytes = double(d->batch) * (double(g.M) * g.K * (ca ? 16 : 8) + double(g.K) * g.N * (cb ? 16 : 8) +
+                                    double(g.M) * g.N * ((ca || cb) ? 16 : 8) * (g.use_beta ? 2 : 1));
+    MPSE_HIP(ctx, hipEventRecord(rec.e0, ctx->stream));
+  }
   if (ca && cb)
     hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, g);
   else if (ca)
@@ -322,6 +342,10 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
     hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, g);
   else
     hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, g);
+  if (ctx->prof_on) {
+    MPSE_HIP(ctx, hipEventRecord(rec.e1, ctx->stream));
+    ctx->prof_pending.push_back(rec);
+  }
   MPSE_HIP(ctx, hipGetLastError());
   return MPSE_OK;
 }

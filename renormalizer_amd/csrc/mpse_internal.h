@@ -28,12 +28,28 @@ struct mpse_ctx {
   size_t pool_bytes = 0;
   size_t in_use_bytes = 0;
 
+  // optional HIP-event profiling of the contraction kernel (mpse_prof_*)
+  struct ProfRec {
+    hipEvent_t e0, e1;
+    int variant;
+    double flops, bytes;
+  };
+  bool prof_on = false;
+  std::vector<ProfRec> prof_pending;
+  std::vector<hipEvent_t> prof_free_events;
+  double prof_ms[4] = {0, 0, 0, 0};
+  double prof_flops[4] = {0, 0, 0, 0};
+  double prof_bytes[4] = {0, 0, 0, 0};
+  int64_t prof_launches[4] = {0, 0, 0, 0};
+
   // small pinned staging buffer for scalar read-backs
   double* pinned = nullptr;     // 4096 doubles
   double* dscratch = nullptr;   // device scratch for reductions (1<<16 doubles)
 };
 
 int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...);
+// fold finished profiling records into the totals; call only when the stream is idle
+void prof_drain(mpse_ctx* ctx);
 
 #define MPSE_HIP(ctx, call)                                                              \
   do {                                                                                   \

@@ -229,6 +229,7 @@ void expm_coefs(int m, const std::vector<double>& alpha, const std::vector<doubl
 int read_scalar2(mpse_ctx* ctx, const double* dsrc, double* a, double* b) {
   MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned, dsrc, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->prof_pending.size() > 2048) prof_drain(ctx);
   if (a) *a = ctx->pinned[0];
   if (b) *b = ctx->pinned[1];
   return MPSE_OK;

@@ -79,6 +79,9 @@ _SIGNATURES = {
     "mpse_ctx_destroy": [C.c_void_p],
     "mpse_sync": [C.c_void_p],
     "mpse_device_info": [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_void_p)],
+    "mpse_prof_enable": [C.c_void_p, C.c_int],
+    "mpse_prof_reset": [C.c_void_p],
+    "mpse_prof_get": [C.c_void_p, C.c_int, _dblp, _dblp, _dblp, C.POINTER(C.c_int64)],
     "mpse_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
     "mpse_free": [C.c_void_p, C.c_void_p],
     "mpse_pool_trim": [C.c_void_p],
@@ -313,6 +316,23 @@ class Engine:
 
     def free_all_blocks(self):
         self._check(self.lib.mpse_pool_trim(self.ctx))
+
+    # -- kernel profiling (HIP events on the engine stream)
+    def prof_enable(self, on=True):
+        self._check(self.lib.mpse_prof_enable(self.ctx, int(on)))
+
+    def prof_reset(self):
+        self._check(self.lib.mpse_prof_reset(self.ctx))
+
+    def prof_get(self):
+        """{variant: dict(ms, flops, bytes, launches)} for the contraction kernel variants."""
+        names = {0: "f64xf64", 1: "c128xf64", 2: "f64xc128", 3: "c128xc128"}
+        out = {}
+        for v, nm in names.items():
+            ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+            self._check(self.lib.mpse_prof_get(self.ctx, v, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
+            out[nm] = dict(ms=ms.value, flops=fl.value, bytes=by.value, launches=n.value)
+        return out
 
     # -- tensor factories
     def empty(self, shape, dtype=np.float64):

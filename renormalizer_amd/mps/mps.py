@@ -57,6 +57,54 @@ class Mps:
         return mps
 
     @classmethod
+    def random(cls, model, qntot, m_max, percent=1.0, rng=None) -> "Mps":
+        """Random quantum-number-conserving MPS, construction of mps/mps.py:119-185: per site a
+        random orthogonal basis inside every symmetry block of the (left bond x physical) space,
+        ``m_max`` of them kept (``percent`` of the slots shared equally between blocks), the
+        last site filled with masked random numbers and normalised.  Host-side state
+        preparation (runs once, outside the sweep); the result is uploaded to the device."""
+        from .basis_select import select_basis_indices
+        if rng is None:
+            rng = np.random.default_rng()
+        if isinstance(qntot, (int, np.integer)):
+            qntot = np.array([qntot])
+        qntot = np.asarray(qntot, dtype=int)
+        q = len(qntot)
+        assert q == model.qn_size
+        qn = [np.zeros((1, q), dtype=int)]
+        dims = [1]
+        arrays = []
+        for imps in range(model.nsite - 1):
+            sig = np.array(model.basis[imps].sigmaqn)
+            qnbig = add_outer(qn[imps], sig).reshape(-1, q)
+            u_set, s_set, qnset = [], [], []
+            for blk in sorted(set(map(tuple, qnbig.tolist()))):
+                if np.all(qntot < np.array(blk)):
+                    continue
+                idx = np.nonzero(np.all(qnbig == np.array(blk), axis=1))[0]
+                a = rng.random((len(idx), len(idx))) - 0.5
+                s, u = np.linalg.eigh(a + a.T)
+                full = np.zeros((len(qnbig), len(idx)))
+                full[idx, :] = u
+                u_set.append(full)
+                s_set.append(s)
+                qnset += [blk] * len(idx)
+            u_set = np.concatenate(u_set, axis=1)
+            s_set = np.concatenate(s_set)
+            mmax = m_max[imps + 1] if isinstance(m_max, (list, tuple, np.ndarray)) else m_max
+            keep = select_basis_indices(s_set, qnset, mmax, percent)
+            dims.append(len(keep))
+            arrays.append(u_set[:, keep].reshape(dims[imps], -1, dims[imps + 1]))
+            qn.append(np.array([qnset[i] for i in keep], dtype=int).reshape(len(keep), q))
+        qn.append(np.zeros((1, q), dtype=int))
+        last = rng.random((dims[-1], model.pbond_list[-1], 1)) - 0.5
+        mask = get_qn_mask(add_outer(qn[-2], np.array(model.basis[-1].sigmaqn)), qntot)
+        last[~mask.reshape(last.shape[:2])] = 0
+        last /= np.linalg.norm(last)
+        arrays.append(last)
+        return cls.from_arrays(model, arrays, qn, model.nsite - 1, qntot, False)
+
+    @classmethod
     def hartree_product_state(cls, model, condition: Dict = None, qn_idx: int = None):
         """mps/mps.py:187-262"""
         condition = dict(condition or {})
