@@ -9,8 +9,11 @@
 //     operand fragments, complex x real = 2, real x real = 1.
 //   * a 256-thread workgroup (4 waves, 2x2) owns a 64x64 tile; K advances 16 at a
 //     time: global -> registers (issued one tile ahead, so HBM/L2 latency hides behind
-//     the 16..64 MFMAs of the current tile) -> LDS as planar [k][i] panels padded to
-//     80 doubles so the two k-rows a half-wave reads land on disjoint banks.
+//     the 16..64 MFMAs of the current tile) -> LDS as planar (re / im) panels whose
+//     layout follows the operand's memory order: [i][k] rows of 17 doubles when k is the
+//     contiguous index, [k][i] rows of 80 doubles otherwise, so that both the staging
+//     ds_write_b64 (consecutive lanes -> consecutive addresses) and the fragment
+//     ds_read_b64 (16 rows x 2 k per half-wave on distinct bank pairs) are conflict free.
 //   * operands are read straight through two-level strides (no transpose copies: the
 //     reference's tensordot materialises a transposed copy before every ?gemm);
 //     complex128 elements are 16-byte loads; the thread->element map follows whichever
@@ -39,18 +42,22 @@ struct GemmArgs {
   int conjA, conjB;
   int use_beta;
   double alpha_re, alpha_im, beta_re, beta_im;
+  int ksplit;          // number of K slices (1 = none)
+  int kt_per_split;    // k-tiles per slice
+  double* ws;          // split-K partial sums: [batch][ksplit][M][N] compact, dtype of C
 };
 
 __device__ __forceinline__ long long idx_off(const IdxMap& m, int i) {
-  if (m.lo >= m.ext) return (long long)i * m.s_lo;
-  int hi = i / m.lo;
-  int l = i - hi * m.lo;
+  // branch-free: single-level maps are canonicalised on the host to lo >= ext (hi == 0)
+  const int hi = i / m.lo;
+  const int l = i - hi * m.lo;
   return (long long)hi * m.s_hi + (long long)l * m.s_lo;
 }
 
-constexpr int BM = 64, BN = 64, BK = 16, LD = 80;
+constexpr int BM = 64, BN = 64, BK = 16, LD = 80, LDK = 17;  // panel = BK*LD >= BM*LDK doubles
 
-template <bool CA, bool CB>
+// KS: both K maps are single level -> no integer division in the K loop
+template <bool CA, bool CB, bool KS>
 __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
   constexpr bool CC = CA || CB;
   constexpr int EA = CA ? 2 : 1, EB = CB ? 2 : 1, EC = CC ? 2 : 1;
@@ -68,8 +75,10 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
 
   const int ntile = g.tiles_m * g.tiles_n;
   const int bid = blockIdx.x;
-  const int b = bid / ntile;
-  const int t = bid - b * ntile;
+  const int bs = bid / ntile;            // (batch, k-slice)
+  const int b = bs / g.ksplit;
+  const int ks_id = bs - b * g.ksplit;
+  const int t = bid - bs * ntile;
   const int tm = t / g.tiles_n;
   const int tn = t - tm * g.tiles_n;
 
@@ -80,7 +89,6 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
   // ---- per-thread staging coordinates (4 elements of each operand tile)
   int ai[4], ak[4], bj[4], bk[4];
   long long aoff[4], boff[4];
-  bool aval[4], bval[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (g.a_kfast) {
@@ -97,44 +105,54 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
       bj[r] = tid & 63;
       bk[r] = (tid >> 6) + 4 * r;
     }
-    int gi = tm * BM + ai[r];
-    int gj = tn * BN + bj[r];
-    aval[r] = gi < g.M;
-    bval[r] = gj < g.N;
-    aoff[r] = aval[r] ? idx_off(g.mA, gi) : 0;
-    boff[r] = bval[r] ? idx_off(g.nB, gj) : 0;
+    // rows / columns past the edge read a clamped (valid) address: they only feed outputs that
+    // are never stored, so no predication is needed and every load below is unconditional
+    int gi = min(tm * BM + ai[r], g.M - 1);
+    int gj = min(tn * BN + bj[r], g.N - 1);
+    aoff[r] = idx_off(g.mA, gi);
+    boff[r] = idx_off(g.nB, gj);
   }
 
   double2 ra[4], rb[4];
+  bool ka_in[4], kb_in[4];
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int k = kt * BK + ak[r];
-      double2 v = make_double2(0.0, 0.0);
-      if (aval[r] && k < g.K) {
-        const double* p = A + (aoff[r] + idx_off(g.kA, k)) * EA;
+      {
+        const int k = kt * BK + ak[r];
+        const bool kin = k < g.K;
+        const int kc = kin ? k : g.K - 1;
+        const long long ko = KS ? (long long)kc * g.kA.s_lo : idx_off(g.kA, kc);
+        const double* p = A + (aoff[r] + ko) * EA;
+        double2 v;
         if constexpr (CA) {
           v = *reinterpret_cast<const double2*>(p);
-          if (g.conjA) v.y = -v.y;
         } else {
           v.x = *p;
+          v.y = 0.0;
         }
+        ra[r] = v;       // zeroing of k >= K happens at LDS-write time: nothing here consumes the load,
+        ka_in[r] = kin;  // so the waitcnt for it lands after the MFMA block of the current tile
       }
-      ra[r] = v;
-      k = kt * BK + bk[r];
-      v = make_double2(0.0, 0.0);
-      if (bval[r] && k < g.K) {
-        const double* p = B + (boff[r] + idx_off(g.kB, k)) * EB;
+      {
+        const int k = kt * BK + bk[r];
+        const bool kin = k < g.K;
+        const int kc = kin ? k : g.K - 1;
+        const long long ko = KS ? (long long)kc * g.kB.s_lo : idx_off(g.kB, kc);
+        const double* p = B + (boff[r] + ko) * EB;
+        double2 v;
         if constexpr (CB) {
           v = *reinterpret_cast<const double2*>(p);
-          if (g.conjB) v.y = -v.y;
         } else {
           v.x = *p;
+          v.y = 0.0;
         }
+        rb[r] = v;
+        kb_in[r] = kin;
       }
-      rb[r] = v;
     }
   };
+  const double sgn_a = g.conjA ? -1.0 : 1.0, sgn_b = g.conjB ? -1.0 : 1.0;
 
   v4d acc_re[2][2], acc_im[2][2];
 #pragma unroll
@@ -145,32 +163,47 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
       acc_im[i][j] = v4d{0, 0, 0, 0};
     }
 
-  const int nkt = (g.K + BK - 1) / BK;
-  if (nkt > 0) load_tile(0);
+  const int nkt_all = (g.K + BK - 1) / BK;
+  const int kt_begin = ks_id * g.kt_per_split;
+  const int kt_end = min(nkt_all, kt_begin + g.kt_per_split);
+  if (kt_begin < kt_end) load_tile(kt_begin);
   const int frow = lane & 15, fk = lane >> 4;
+  // LDS strides (in doubles) of element (i, k) of each panel
+  const int sai = g.a_kfast ? LDK : 1, sak = g.a_kfast ? 1 : LD;
+  const int sbj = g.b_kfast ? LDK : 1, sbk = g.b_kfast ? 1 : LD;
+  int wofa[4], wofb[4], rofa[2], rofb[2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    wofa[r] = ai[r] * sai + ak[r] * sak;
+    wofb[r] = bj[r] * sbj + bk[r] * sbk;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    rofa[i] = (wm * 32 + i * 16 + frow) * sai + fk * sak;
+    rofb[i] = (wn * 32 + i * 16 + frow) * sbj + fk * sbk;
+  }
 
-  for (int kt = 0; kt < nkt; ++kt) {
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      sAr[ak[r] * LD + ai[r]] = ra[r].x;
-      if constexpr (CA) sAi[ak[r] * LD + ai[r]] = ra[r].y;
-      sBr[bk[r] * LD + bj[r]] = rb[r].x;
-      if constexpr (CB) sBi[bk[r] * LD + bj[r]] = rb[r].y;
+      sAr[wofa[r]] = ka_in[r] ? ra[r].x : 0.0;
+      if constexpr (CA) sAi[wofa[r]] = ka_in[r] ? sgn_a * ra[r].y : 0.0;
+      sBr[wofb[r]] = kb_in[r] ? rb[r].x : 0.0;
+      if constexpr (CB) sBi[wofb[r]] = kb_in[r] ? sgn_b * rb[r].y : 0.0;
     }
     __syncthreads();
-    if (kt + 1 < nkt) load_tile(kt + 1);
+    if (kt + 1 < kt_end) load_tile(kt + 1);
 
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      const int k = kk * 4 + fk;
       double ar[2], aim[2], br[2], bim[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ar[i] = sAr[k * LD + wm * 32 + i * 16 + frow];
-        if constexpr (CA) aim[i] = sAi[k * LD + wm * 32 + i * 16 + frow];
-        br[i] = sBr[k * LD + wn * 32 + i * 16 + frow];
-        if constexpr (CB) bim[i] = sBi[k * LD + wn * 32 + i * 16 + frow];
+        ar[i] = sAr[rofa[i] + kk * 4 * sak];
+        if constexpr (CA) aim[i] = sAi[rofa[i] + kk * 4 * sak];
+        br[i] = sBr[rofb[i] + kk * 4 * sbk];
+        if constexpr (CB) bim[i] = sBi[rofb[i] + kk * 4 * sbk];
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -191,6 +224,28 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
   }
 
   // ---- epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 tile
+  if (g.ksplit > 1) {
+    // raw partial sums; alpha/beta and the strided store happen in k_splitk_reduce
+    double* wsb = g.ws + (long long)bs * g.M * g.N * EC;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gj = tn * BN + wn * 32 + j * 16 + (lane & 15);
+      if (gj >= g.N) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = tm * BM + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+          if (gi >= g.M) continue;
+          double* p = wsb + ((long long)gi * g.N + gj) * EC;
+          if constexpr (CC)
+            *reinterpret_cast<double2*>(p) = make_double2(acc_re[i][j][r], acc_im[i][j][r]);
+          else
+            *p = acc_re[i][j][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int gj = tn * BN + wn * 32 + j * 16 + (lane & 15);
@@ -225,21 +280,63 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
   }
 }
 
+// C(i,j) = alpha * sum_s ws[b][s][i][j] + beta * C(i,j); slices summed in fixed order
+template <bool CC>
+__global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs g, int batch) {
+  constexpr int EC = CC ? 2 : 1;
+  const long long mn = (long long)g.M * g.N;
+  const long long total = mn * batch;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int b = (int)(t / mn);
+    const long long ij = t - (long long)b * mn;
+    const int i = (int)(ij / g.N), j = (int)(ij - (long long)i * g.N);
+    const double* w = g.ws + ((long long)b * g.ksplit * mn + ij) * EC;
+    double xr = 0, xi = 0;
+    for (int s = 0; s < g.ksplit; ++s) {
+      xr += w[(long long)s * mn * EC];
+      if (CC) xi += w[(long long)s * mn * EC + 1];
+    }
+    double* p = g.C + ((long long)b * g.sbC + idx_off(g.mC, i) + idx_off(g.nC, j)) * EC;
+    if (CC) {
+      double2 o = make_double2(g.alpha_re * xr - g.alpha_im * xi, g.alpha_re * xi + g.alpha_im * xr);
+      if (g.use_beta) {
+        const double2 c0 = *reinterpret_cast<const double2*>(p);
+        o.x += g.beta_re * c0.x - g.beta_im * c0.y;
+        o.y += g.beta_re * c0.y + g.beta_im * c0.x;
+      }
+      *reinterpret_cast<double2*>(p) = o;
+    } else {
+      double o = g.alpha_re * xr;
+      if (g.use_beta) o += g.beta_re * (*p);
+      *p = o;
+    }
+  }
+}
+
 bool to_map(const mpse_index& s, IdxMap* m) {
   if (s.ext < 0 || s.ext > 0x7fffffffLL) return false;
   m->ext = (int)s.ext;
   long long lo = s.lo_ext <= 0 ? 1 : s.lo_ext;
-  if (lo > 0x7fffffffLL) lo = 0x7fffffffLL;
-  m->lo = (int)lo;
   m->s_hi = s.s_hi;
   m->s_lo = s.s_lo;
+  // canonical single-level forms: lo >= ext ; lo == 1 (only the hi level moves) ; contiguous levels
+  if (lo >= s.ext) {
+    m->s_hi = 0;
+  } else if (lo == 1) {
+    m->s_lo = s.s_hi;
+    m->s_hi = 0;
+    lo = s.ext;
+  } else if (s.s_hi == lo * s.s_lo) {
+    m->s_hi = 0;
+    lo = s.ext;
+  }
+  if (lo >= s.ext) lo = 0x7fffffffLL;
+  m->lo = (int)lo;
   return true;
 }
 
-long long fast_stride(const mpse_index& s) {
-  long long a = s.s_lo < 0 ? -s.s_lo : s.s_lo;
-  return s.ext <= 1 ? (long long)1 << 60 : a;
-}
+inline bool is_single(const IdxMap& m) { return m.lo == 0x7fffffff; }
 
 // ---- (d0,d1,d2) -> (d0,d2,d1) copy through a 32x32 LDS tile
 template <bool CPLX>
@@ -301,8 +398,9 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
   g.K = g.kA.ext;
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
-  g.a_kfast = fast_stride(d->k_a) <= fast_stride(d->m_a);
-  g.b_kfast = fast_stride(d->k_b) <= fast_stride(d->n_b);
+  auto fast = [](const IdxMap& m) { return m.ext <= 1 ? (long long)1 << 60 : (m.s_lo < 0 ? -m.s_lo : m.s_lo); };
+  g.a_kfast = fast(g.kA) <= fast(g.mA);
+  g.b_kfast = fast(g.kB) <= fast(g.nB);
   g.conjA = d->conj_a && d->dtype_a == MPSE_C128;
   g.conjB = d->conj_b && d->dtype_b == MPSE_C128;
   g.alpha_re = d->alpha_re;
@@ -310,10 +408,30 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
   g.beta_re = d->beta_re;
   g.beta_im = d->beta_im;
   g.use_beta = (d->beta_re != 0.0 || d->beta_im != 0.0);
-  long long nblk = (long long)g.tiles_m * g.tiles_n * d->batch;
+  const bool ca = d->dtype_a == MPSE_C128, cb = d->dtype_b == MPSE_C128;
+  // split-K when the output tiles alone cannot fill the 256 CUs (skinny results with long K)
+  const long long base_blocks = (long long)g.tiles_m * g.tiles_n * d->batch;
+  const int nkt_all = (g.K + BK - 1) / BK;
+  g.ksplit = 1;
+  g.kt_per_split = nkt_all > 0 ? nkt_all : 1;
+  g.ws = nullptr;
+  TmpBuf WSB(ctx);
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  if (base_blocks < n_cu && nkt_all >= 4) {
+    int want = (int)((2LL * n_cu + base_blocks - 1) / base_blocks);  // aim at ~2 workgroups per CU
+    int maxs = nkt_all / 2;                                           // at least two k-tiles per slice
+    int S = want < maxs ? want : maxs;
+    if (S > 1) {
+      g.kt_per_split = (nkt_all + S - 1) / S;
+      g.ksplit = (nkt_all + g.kt_per_split - 1) / g.kt_per_split;
+      const size_t esz = (ca || cb) ? 16 : 8;
+      MPSE_TRY(WSB.alloc(size_t(d->batch) * g.ksplit * size_t(g.M) * size_t(g.N) * esz));
+      g.ws = WSB.as<double>();
+    }
+  }
+  long long nblk = base_blocks * g.ksplit;
   if (nblk > 0x7fffffffLL) return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpse_gemm: grid too large");
   dim3 grid((unsigned)nblk), block(256);
-  const bool ca = d->dtype_a == MPSE_C128, cb = d->dtype_b == MPSE_C128;
   mpse_ctx::ProfRec rec;
   if (ctx->prof_on) {
     auto get_event = [&](hipEvent_t* e) {
@@ -334,14 +452,32 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
                                     double(g.M) * g.N * ((ca || cb) ? 16 : 8) * (g.use_beta ? 2 : 1));
     MPSE_HIP(ctx, hipEventRecord(rec.e0, ctx->stream));
   }
+  const bool ks = is_single(g.kA) && is_single(g.kB);
+#define MPSE_LAUNCH(CA_, CB_)                                                                         \
+  do {                                                                                                \
+    if (ks)                                                                                           \
+      hipLaunchKernelGGL((k_gemm<CA_, CB_, true>), grid, block, 0, ctx->stream, g);                   \
+    else                                                                                              \
+      hipLaunchKernelGGL((k_gemm<CA_, CB_, false>), grid, block, 0, ctx->stream, g);                  \
+  } while (0)
   if (ca && cb)
-    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, g);
+    MPSE_LAUNCH(true, true);
   else if (ca)
-    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, g);
+    MPSE_LAUNCH(true, false);
   else if (cb)
-    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, g);
+    MPSE_LAUNCH(false, true);
   else
-    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, g);
+    MPSE_LAUNCH(false, false);
+#undef MPSE_LAUNCH
+  if (g.ksplit > 1) {
+    const long long tot = (long long)g.M * g.N * d->batch;
+    int rb = (int)((tot + 255) / 256);
+    if (rb > 4096) rb = 4096;
+    if (ca || cb)
+      hipLaunchKernelGGL((k_splitk_reduce<true>), dim3(rb), dim3(256), 0, ctx->stream, g, (int)d->batch);
+    else
+      hipLaunchKernelGGL((k_splitk_reduce<false>), dim3(rb), dim3(256), 0, ctx->stream, g, (int)d->batch);
+  }
   if (ctx->prof_on) {
     MPSE_HIP(ctx, hipEventRecord(rec.e1, ctx->stream));
     ctx->prof_pending.push_back(rec);

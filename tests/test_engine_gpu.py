@@ -43,6 +43,23 @@ def test_gemm_dtypes_and_edges(eng, ca, cb):
         assert _relerr(out, a.conj() @ b.conj()) < 1e-13, (M, N, K)
 
 
+@pytest.mark.parametrize("ca,cb", [(False, False), (True, False), (True, True)])
+def test_gemm_split_k(eng, ca, cb):
+    """Skinny outputs with long K take the split-K path (partials + fixed-order reduction)."""
+    rng = np.random.default_rng(12)
+    for (M, N, K) in [(100, 90, 3000), (256, 256, 1280), (7, 300, 1000), (64, 64, 64)]:
+        a, b = _rand(rng, (M, K), ca), _rand(rng, (K, N), cb)
+        c0 = _rand(rng, (M, N), ca or cb)
+        A, B, Cd = eng.asdevice(a), eng.asdevice(b), eng.asdevice(c0)
+        eng.gemm(A, B, Cd, E.idx1(M, K), E.idx1(K, 1), E.idx1(K, N), E.idx1(N, 1), E.idx1(M, N), E.idx1(N, 1),
+                 alpha=0.7, beta=-1.25)
+        ref = 0.7 * (a @ b) - 1.25 * c0
+        assert _relerr(Cd.to_host(), ref) < 1e-13, (M, N, K)
+        r1 = eng.matmul(A, B).to_host()
+        r2 = eng.matmul(A, B).to_host()
+        assert np.array_equal(r1, r2)
+
+
 def test_gemm_is_asymmetric_safe(eng):
     """A = I against an asymmetric B catches transposed operand / output maps."""
     n = 48
