@@ -11,6 +11,22 @@ int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
+int stage_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes) {
+  if (!bytes) return MPSE_OK;
+  if (!ctx->stage || bytes > ctx->stage_size / 4) return mpse_memcpy_h2d(ctx, dst, src_host, bytes);
+  const size_t need = (bytes + 255) & ~size_t(255);
+  if (ctx->stage_pos + need > ctx->stage_size) {
+    // wrap: every copy enqueued so far must have consumed its slice
+    MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stage_pos = 0;
+  }
+  char* slot = ctx->stage + ctx->stage_pos;
+  memcpy(slot, src_host, bytes);
+  ctx->stage_pos += need;
+  MPSE_HIP(ctx, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return MPSE_OK;
+}
+
 void prof_drain(mpse_ctx* ctx) {
   for (auto& r : ctx->prof_pending) {
     float ms = 0.f;
@@ -82,10 +98,12 @@ int mpse_ctx_create(int device, mpse_ctx** out) {
   }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void**)&ctx->pinned, 4096 * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&ctx->dscratch, (size_t(1) << 16) * sizeof(double)) != hipSuccess) {
+      hipMalloc((void**)&ctx->dscratch, (size_t(1) << 16) * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&ctx->stage, size_t(8) << 20) != hipSuccess) {
     delete ctx;
     return MPSE_ERR_HIP;
   }
+  ctx->stage_size = size_t(8) << 20;
   *out = ctx;
   return MPSE_OK;
 }
@@ -111,6 +129,7 @@ int mpse_ctx_destroy(mpse_ctx* ctx) {
   for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->dscratch) (void)hipFree(ctx->dscratch);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -42,12 +42,18 @@ struct mpse_ctx {
   double prof_bytes[4] = {0, 0, 0, 0};
   int64_t prof_launches[4] = {0, 0, 0, 0};
 
+  // pinned ring for small host->device uploads that must not stall the stream (index lists, descriptors)
+  char* stage = nullptr;
+  size_t stage_size = 0, stage_pos = 0;
+
   // small pinned staging buffer for scalar read-backs
   double* pinned = nullptr;     // 4096 doubles
   double* dscratch = nullptr;   // device scratch for reductions (1<<16 doubles)
 };
 
 int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...);
+// asynchronous upload of a small host array through the pinned ring (the host buffer may be reused at once)
+int stage_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes);
 // fold finished profiling records into the totals; call only when the stream is idle
 void prof_drain(mpse_ctx* ctx);
 
@@ -100,3 +106,14 @@ struct HhParam {  // per reflector: H = I - tau v v^H, v = (1, scale * tail)
 };
 int hh_factor_colmajor(mpse_ctx* ctx, bool cplx, double* ws, int mm, int nn, int k, HhParam* prm);
 int hh_formq_colmajor(mpse_ctx* ctx, bool cplx, double* q, const double* ws, int mm, int k, const HhParam* prm);
+
+// Batched panel-blocked Householder QR (mpse_qr2.hip): blocks live in one column-major workspace
+struct QrBlk {
+  long long ws_off;  // element offset of the mm x nn block inside the workspace
+  long long q_off;   // element offset of its mm x k Q inside the Q buffer
+  int mm, nn, k;
+  int prm_off;       // offset of its reflector parameters
+};
+constexpr int HH_BATCH_MAX_ROWS = 4096;
+int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm, const QrBlk* blks_host, int nblk,
+                  bool form_q);

@@ -231,6 +231,10 @@ inline int ew_blocks(int64_t n) {
 // reflectors; R ends up in the upper triangle, reflector tails below the diagonal).
 int hh_factor_colmajor(mpse_ctx* ctx, bool cplx, double* ws, int mm, int nn, int k, HhParam* prm) {
   if (k <= 0) return MPSE_OK;
+  if (mm <= HH_BATCH_MAX_ROWS) {
+    QrBlk b{0, 0, mm, nn, k, 0};
+    return hh_qr_batched(ctx, cplx, ws, nullptr, prm, &b, 1, false);
+  }
   if (cplx)
     hipLaunchKernelGGL((k_hh_first<true>), dim3(1), dim3(RED_THREADS), 0, ctx->stream, ws, mm, prm);
   else
@@ -265,16 +269,22 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
                   const int64_t* row_off, const int64_t* col_idx, const int64_t* col_off, int herm, void* U, void* Vt,
                   int64_t K) {
   constexpr size_t es = CPLX ? 16 : 8;
-  int64_t ktot = 0, maxws = 0, maxq = 0, maxk = 0;
+  int64_t ktot = 0, ws_tot = 0, q_tot = 0;
+  int max_mm = 0;
+  std::vector<QrBlk> blks;
+  std::vector<int> which;  // index of the source block
   for (int b = 0; b < nblocks; ++b) {
     const int64_t m = row_off[b + 1] - row_off[b], n = col_off[b + 1] - col_off[b];
     if (m < 0 || n < 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_qr: negative block extent");
     const int64_t k = m < n ? m : n;
+    if (k == 0) continue;
+    const int64_t mm = herm ? n : m, nn = herm ? m : n;
+    blks.push_back(QrBlk{(long long)ws_tot, (long long)q_tot, (int)mm, (int)nn, (int)k, (int)ktot});
+    which.push_back(b);
+    ws_tot += mm * nn;
+    q_tot += mm * k;
     ktot += k;
-    if (m * n > maxws) maxws = m * n;
-    const int64_t mm = herm ? n : m;
-    if (mm * k > maxq) maxq = mm * k;
-    if (k > maxk) maxk = k;
+    if (mm > max_mm) max_mm = (int)mm;
   }
   if (ktot != K) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_qr: K=%lld but blocks give %lld", (long long)K, (long long)ktot);
   if (ktot == 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
@@ -283,38 +293,45 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   const int64_t nri = row_off[nblocks], nci = col_off[nblocks];
   TmpBuf IDX(ctx), WS(ctx), Q(ctx), PRM(ctx);
   MPSE_TRY(IDX.alloc(size_t(nri + nci) * sizeof(int64_t)));
-  MPSE_TRY(WS.alloc(size_t(maxws) * es));
-  MPSE_TRY(Q.alloc(size_t(maxq) * es));
-  MPSE_TRY(PRM.alloc(size_t(maxk + 1) * sizeof(HhParam)));
-  // index lists -> device (host arrays are caller owned: copy synchronously)
-  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.p, row_idx, size_t(nri) * sizeof(int64_t)));
-  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.as<char>() + size_t(nri) * sizeof(int64_t), col_idx, size_t(nci) * sizeof(int64_t)));
+  MPSE_TRY(WS.alloc(size_t(ws_tot) * es));
+  MPSE_TRY(Q.alloc(size_t(q_tot) * es));
+  MPSE_TRY(PRM.alloc(size_t(ktot + 1) * sizeof(HhParam)));
+  MPSE_TRY(stage_h2d(ctx, IDX.p, row_idx, size_t(nri) * sizeof(int64_t)));
+  MPSE_TRY(stage_h2d(ctx, IDX.as<char>() + size_t(nri) * sizeof(int64_t), col_idx, size_t(nci) * sizeof(int64_t)));
   const long long* drows = IDX.as<long long>();
   const long long* dcols = IDX.as<long long>() + nri;
-  int64_t koff = 0;
-  for (int b = 0; b < nblocks; ++b) {
-    const int m = (int)(row_off[b + 1] - row_off[b]), n = (int)(col_off[b + 1] - col_off[b]);
-    const int k = m < n ? m : n;
-    if (k == 0) continue;
-    const int mm = herm ? n : m, nn = herm ? m : n;
+  double* ws = WS.as<double>();
+  double* q = Q.as<double>();
+  HhParam* prm = PRM.as<HhParam>();
+  constexpr int E = CPLX ? 2 : 1;
+  for (size_t i = 0; i < blks.size(); ++i) {
+    const QrBlk& B = blks[i];
+    const int b = which[i];
+    hipLaunchKernelGGL((k_gather_block<CPLX>), dim3(ew_blocks((int64_t)B.mm * B.nn)), dim3(256), 0, ctx->stream,
+                       ws + B.ws_off * E, (const double*)coef, (long long)ncol, drows + row_off[b], dcols + col_off[b],
+                       B.mm, B.nn, herm);
+  }
+  if (max_mm <= HH_BATCH_MAX_ROWS) {
+    MPSE_TRY(hh_qr_batched(ctx, CPLX, ws, q, prm, blks.data(), (int)blks.size(), true));
+  } else {
+    for (const QrBlk& B : blks) {
+      MPSE_TRY(hh_factor_colmajor(ctx, CPLX, ws + B.ws_off * E, B.mm, B.nn, B.k, prm + B.prm_off));
+      MPSE_TRY(hh_formq_colmajor(ctx, CPLX, q + B.q_off * E, ws + B.ws_off * E, B.mm, B.k, prm + B.prm_off));
+    }
+  }
+  for (size_t i = 0; i < blks.size(); ++i) {
+    const QrBlk& B = blks[i];
+    const int b = which[i];
     const long long* rows = drows + row_off[b];
     const long long* cols = dcols + col_off[b];
-    double* ws = WS.as<double>();
-    double* q = Q.as<double>();
-    HhParam* prm = PRM.as<HhParam>();
-    hipLaunchKernelGGL((k_gather_block<CPLX>), dim3(ew_blocks((int64_t)mm * nn)), dim3(256), 0, ctx->stream, ws,
-                       (const double*)coef, (long long)ncol, rows, cols, mm, nn, herm);
-    MPSE_TRY(hh_factor_colmajor(ctx, CPLX, ws, mm, nn, k, prm));
-    MPSE_TRY(hh_formq_colmajor(ctx, CPLX, q, ws, mm, k, prm));
-    hipLaunchKernelGGL((k_scatter_q<CPLX>), dim3(ew_blocks((int64_t)mm * k)), dim3(256), 0, ctx->stream, (double*)U,
-                       (double*)Vt, (const double*)q, (long long)K, (long long)ncol, rows, cols, mm, k,
-                       (long long)koff, herm);
-    hipLaunchKernelGGL((k_scatter_r<CPLX>), dim3(ew_blocks((int64_t)k * nn)), dim3(256), 0, ctx->stream, (double*)U,
-                       (double*)Vt, (const double*)ws, (long long)K, (long long)ncol, rows, cols, mm, nn, k,
-                       (long long)koff, herm);
-    MPSE_HIP(ctx, hipGetLastError());
-    koff += k;
+    hipLaunchKernelGGL((k_scatter_q<CPLX>), dim3(ew_blocks((int64_t)B.mm * B.k)), dim3(256), 0, ctx->stream,
+                       (double*)U, (double*)Vt, (const double*)(q + B.q_off * E), (long long)K, (long long)ncol, rows,
+                       cols, B.mm, B.k, (long long)B.prm_off, herm);
+    hipLaunchKernelGGL((k_scatter_r<CPLX>), dim3(ew_blocks((int64_t)B.k * B.nn)), dim3(256), 0, ctx->stream,
+                       (double*)U, (double*)Vt, (const double*)(ws + B.ws_off * E), (long long)K, (long long)ncol, rows,
+                       cols, B.mm, B.nn, B.k, (long long)B.prm_off, herm);
   }
+  MPSE_HIP(ctx, hipGetLastError());
   return MPSE_OK;
 }
 
@@ -375,11 +392,11 @@ int mpse_gather_cols(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_
   if (nrow * ncol_out <= 0) return MPSE_OK;
   TmpBuf IDX(ctx);
   MPSE_TRY(IDX.alloc(size_t(ncol_out) * 16));
-  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.p, cols_host, size_t(ncol_out) * 8));
+  MPSE_TRY(stage_h2d(ctx, IDX.p, cols_host, size_t(ncol_out) * 8));
   double* dscale = nullptr;
   if (scale_host) {
     dscale = IDX.as<double>() + ncol_out;
-    MPSE_TRY(mpse_memcpy_h2d(ctx, dscale, scale_host, size_t(ncol_out) * 8));
+    MPSE_TRY(stage_h2d(ctx, dscale, scale_host, size_t(ncol_out) * 8));
   }
   const int nb = ew_blocks(nrow * ncol_out);
   if (dtype == MPSE_C128)
@@ -400,11 +417,11 @@ int mpse_gather_rows(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_
   if (nrow_out * ncol <= 0) return MPSE_OK;
   TmpBuf IDX(ctx);
   MPSE_TRY(IDX.alloc(size_t(nrow_out) * 16));
-  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.p, rows_host, size_t(nrow_out) * 8));
+  MPSE_TRY(stage_h2d(ctx, IDX.p, rows_host, size_t(nrow_out) * 8));
   double* dscale = nullptr;
   if (scale_host) {
     dscale = IDX.as<double>() + nrow_out;
-    MPSE_TRY(mpse_memcpy_h2d(ctx, dscale, scale_host, size_t(nrow_out) * 8));
+    MPSE_TRY(stage_h2d(ctx, dscale, scale_host, size_t(nrow_out) * 8));
   }
   const int nb = ew_blocks(nrow_out * ncol);
   if (dtype == MPSE_C128)

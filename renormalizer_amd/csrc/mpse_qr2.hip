@@ -1,0 +1,401 @@
+// Batched, panel-blocked Householder QR on column-major workspaces.
+//
+// All quantum-number blocks of a decomposition are factorised by the SAME launches (grid.y =
+// block), and the dependent chain of reflectors is cut into panels of NB columns:
+//   k_hh_panel       : ONE 1024-thread workgroup per block keeps the m x NB panel in registers
+//                      and factorises it (one block-wide reduction per column delivers the column
+//                      norm and all inner products with the remaining panel columns at once);
+//   k_hh_apply_panel : one 256-thread workgroup per trailing column keeps that column in
+//                      registers and applies the NB new reflectors back to back (reflector tails
+//                      stream from L2);
+//   k_hh_formq_b     : one workgroup per column of Q, column in registers, reflectors applied
+//                      in reverse.
+// Per NB columns this costs 2 launches instead of NB, and the trailing matrix is read and written
+// once per panel instead of once per reflector.  Conventions are LAPACK's (?geqr2 / ?ung2r):
+// H_j = I - tau_j v_j v_j^H, v_j = (0.., 1, scale_j * tail_j), tails stored UNSCALED below the
+// diagonal, R on and above it.
+#include "mpse_device.h"
+#include "mpse_internal.h"
+
+namespace {
+
+template <bool CPLX>
+struct Cx;
+template <>
+struct Cx<true> {
+  static constexpr int E = 2;
+  __device__ static double2 ld(const double* p, long long i) { return reinterpret_cast<const double2*>(p)[i]; }
+  __device__ static void st(double* p, long long i, double2 v) { reinterpret_cast<double2*>(p)[i] = v; }
+};
+template <>
+struct Cx<false> {
+  static constexpr int E = 1;
+  __device__ static double2 ld(const double* p, long long i) { return make_double2(p[i], 0.0); }
+  __device__ static void st(double* p, long long i, double2 v) { p[i] = v.x; }
+};
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cmulc(double2 a, double2 b) {  // conj(a) * b
+  return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+}
+
+__device__ __forceinline__ void make_reflector(double2 alpha, double s, HhParam* p, double* beta_out) {
+  if (s == 0.0 && alpha.y == 0.0) {
+    p->tau_re = p->tau_im = p->scale_re = p->scale_im = 0.0;  // H = I
+    *beta_out = alpha.x;
+  } else {
+    const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + s);
+    const double beta = alpha.x >= 0.0 ? -nrm : nrm;
+    p->tau_re = (beta - alpha.x) / beta;
+    p->tau_im = -alpha.y / beta;
+    const double dr = alpha.x - beta, di = alpha.y;
+    const double den = dr * dr + di * di;
+    p->scale_re = dr / den;
+    p->scale_im = -di / den;
+    *beta_out = beta;
+  }
+}
+
+// ---- panel factorisation: 1024 threads, thread owns rows tid + 1024 q (q < RPT), NB columns.
+// The column loop is NOT unrolled (an 8x unrolled body is ~90 KB of code and the kernel becomes
+// instruction-fetch bound): the pivot is always register column 0 and the panel is rotated by one
+// column after each reflector, so every iteration runs the same code with static register indices.
+template <bool CPLX, int RPT, int NB>
+__global__ __launch_bounds__(1024) void k_hh_panel(double* ws_base, const QrBlk* __restrict__ blks, HhParam* prm_base,
+                                                   int j0) {
+  constexpr int E = Cx<CPLX>::E;
+  constexpr int NV = 2 * NB;  // [0] = |tail|^2, [1] unused, then (re, im) of the dot with panel column t >= 1
+  __shared__ double s_part[16][NV];
+  __shared__ double s_f[NB][4];
+  __shared__ double s_par[2];
+  __shared__ double s_head[2 * NB];
+  const QrBlk B = blks[blockIdx.x];
+  if (j0 >= B.k) return;
+  const int nbb = min(NB, B.k - j0);
+  const int mm = B.mm;
+  double* a = ws_base + B.ws_off * E;
+  HhParam* prm = prm_base + B.prm_off;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  double2 x[RPT][NB];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int r = tid + 1024 * q;
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      x[q][c] = (r >= j0 && r < mm && c < nbb) ? Cx<CPLX>::ld(a, r + (long long)(j0 + c) * mm) : make_double2(0.0, 0.0);
+  }
+
+#pragma unroll 1
+  for (int jj = 0; jj < nbb; ++jj) {
+    const int j = j0 + jj;
+    // --- one reduction: tail norm of the pivot column and its inner products with the other panel columns
+    double val[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) val[t] = 0.0;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + 1024 * q;
+      if (r > j && r < mm) {
+        const double2 v = x[q][0];
+        val[0] += v.x * v.x + v.y * v.y;
+#pragma unroll
+        for (int t = 1; t < NB; ++t) {
+          const double2 t2 = cmulc(v, x[q][t]);
+          val[2 * t] += t2.x;
+          val[2 * t + 1] += t2.y;
+        }
+      }
+      if (r == j) {  // owner of the diagonal row publishes alpha and the heads of the other columns
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          s_head[2 * t] = x[q][t].x;
+          s_head[2 * t + 1] = x[q][t].y;
+        }
+      }
+    }
+    // wave-level reduction of all NV values with a halving butterfly: each exchange sums partner halves
+    // and keeps half of the values, so NV values cost NV + log2(64/NV) shuffles instead of 6 NV
+#pragma unroll
+    for (int half = NV / 2, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+      const bool up = (lane & bit) != 0;
+#pragma unroll
+      for (int t = 0; t < half; ++t) {
+        const double send = up ? val[t] : val[t + half];
+        const double keep = up ? val[t + half] : val[t];
+        val[t] = keep + __shfl_xor(send, bit, 64);
+      }
+    }
+    {
+      constexpr int LOWBITS = 64 / NV;  // lanes sharing one value
+#pragma unroll
+      for (int o = LOWBITS / 2; o >= 1; o >>= 1) val[0] += __shfl_xor(val[0], o, 64);
+      if ((lane & (LOWBITS - 1)) == 0) {
+        int idx = 0;  // the lane bits that selected the upper halves, most significant first
+#pragma unroll
+        for (int half = NV / 2, bit = 32; half >= 1; half >>= 1, bit >>= 1) idx += (lane & bit) ? half : 0;
+        s_part[wave][idx] = val[0];
+      }
+    }
+    __syncthreads();  // (A) partial sums and the diagonal row are in LDS
+    // --- the scalar work (f64 sqrt / divisions) is done once, by wave 0
+    if (wave == 0) {
+      double tot = 0.0;
+      if (lane < NV) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += s_part[w][lane];
+      }
+      const double ssq = __shfl(tot, 0, 64);
+      HhParam p;
+      double beta;
+      const double2 alpha = make_double2(s_head[0], s_head[1]);
+      make_reflector(alpha, ssq, &p, &beta);
+      const double2 tau = make_double2(p.tau_re, p.tau_im), scale = make_double2(p.scale_re, p.scale_im);
+      // lane t (1 <= t < NB) turns its inner product into the update coefficients of panel column t
+      const int t = (lane >= 1 && lane < NB) ? lane : 1;
+      const double2 d = make_double2(__shfl(tot, 2 * t, 64), __shfl(tot, 2 * t + 1, 64));
+      if (lane >= 1 && lane < NB) {
+        const double2 head = make_double2(s_head[2 * t], s_head[2 * t + 1]);
+        const double2 sc = cmulc(scale, d);
+        const double2 fc = cmulc(tau, make_double2(head.x + sc.x, head.y + sc.y));
+        const double2 fsc = cmul(fc, scale);
+        s_f[t][0] = fc.x;
+        s_f[t][1] = fc.y;
+        s_f[t][2] = fsc.x;
+        s_f[t][3] = fsc.y;
+      }
+      if (lane == 0) {
+        prm[j] = p;
+        s_par[0] = beta;
+        s_par[1] = (p.tau_re == 0.0 && p.tau_im == 0.0) ? alpha.y : 0.0;
+      }
+    }
+    __syncthreads();  // (B) coefficients published
+    const double beta = s_par[0], diag_im = s_par[1];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + 1024 * q;
+      const double2 v = x[q][0];
+      if (r == j) x[q][0] = make_double2(beta, diag_im);
+#pragma unroll
+      for (int t = 1; t < NB; ++t) {
+        if (r > j && r < mm) {
+          const double2 t2 = cmul(make_double2(s_f[t][2], s_f[t][3]), v);
+          x[q][t].x -= t2.x;
+          x[q][t].y -= t2.y;
+        } else if (r == j) {
+          x[q][t].x -= s_f[t][0];
+          x[q][t].y -= s_f[t][1];
+        }
+      }
+      // the pivot column is final: store it, then rotate the panel by one column
+      if (r >= j0 && r < mm) Cx<CPLX>::st(a, r + (long long)j * mm, x[q][0]);
+#pragma unroll
+      for (int t = 1; t < NB; ++t) x[q][t - 1] = x[q][t];
+      x[q][NB - 1] = make_double2(0.0, 0.0);
+    }
+    // no barrier here: the next column writes s_part / s_head, which nobody reads after (B); s_f / s_par are
+    // rewritten only after the next (A), which every thread reaches after finishing its update above
+  }
+}
+
+// ---- apply reflectors j0 .. j0+nbb-1 (H^H, in order) to trailing column c; 256 threads, rows tid + 256 q
+template <bool CPLX, int RPT>
+__global__ __launch_bounds__(256) void k_hh_apply_panel(double* ws_base, const QrBlk* __restrict__ blks,
+                                                        const HhParam* __restrict__ prm_base, int j0, int nb) {
+  constexpr int E = Cx<CPLX>::E;
+  __shared__ double s_head[2];
+  const QrBlk B = blks[blockIdx.y];
+  if (j0 >= B.k) return;
+  const int nbb = min(nb, B.k - j0);
+  const int c = j0 + nbb + blockIdx.x;
+  if (c >= B.nn) return;
+  const int mm = B.mm;
+  double* a = ws_base + B.ws_off * E;
+  const HhParam* prm = prm_base + B.prm_off;
+  double* col = a + (long long)c * mm * E;
+  const int tid = threadIdx.x;
+  double2 x[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int r = tid + 256 * q;
+    x[q] = (r >= j0 && r < mm) ? Cx<CPLX>::ld(col, r) : make_double2(0.0, 0.0);
+  }
+  for (int jj = 0; jj < nbb; ++jj) {
+    const int j = j0 + jj;
+    const HhParam p = prm[j];
+    const double2 tau = make_double2(p.tau_re, p.tau_im), scale = make_double2(p.scale_re, p.scale_im);
+    if (tau.x == 0.0 && tau.y == 0.0) continue;  // block-uniform
+    const double* vj = a + (long long)j * mm * E;
+    double2 v[RPT];
+    double dr = 0, di = 0;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + 256 * q;
+      v[q] = (r > j && r < mm) ? Cx<CPLX>::ld(vj, r) : make_double2(0.0, 0.0);
+      const double2 t2 = cmulc(v[q], x[q]);
+      dr += t2.x;
+      di += t2.y;
+      if (r == j) {
+        s_head[0] = x[q].x;
+        s_head[1] = x[q].y;
+      }
+    }
+    block_allsum2(dr, di);  // two barriers inside: s_head is visible afterwards
+    const double2 head = make_double2(s_head[0], s_head[1]);
+    const double2 sc = cmulc(scale, make_double2(dr, di));
+    const double2 f = cmulc(tau, make_double2(head.x + sc.x, head.y + sc.y));
+    const double2 fs = cmul(f, scale);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + 256 * q;
+      const double2 t2 = cmul(fs, v[q]);  // v is zero outside the tail
+      x[q].x -= t2.x;
+      x[q].y -= t2.y;
+      if (r == j) {
+        x[q].x -= f.x;
+        x[q].y -= f.y;
+      }
+    }
+    __syncthreads();  // s_head reused by the next reflector
+  }
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int r = tid + 256 * q;
+    if (r >= j0 && r < mm) Cx<CPLX>::st(col, r, x[q]);
+  }
+}
+
+// ---- column c of Q = H_0 ... H_c e_c ; 256 threads, column in registers
+template <bool CPLX, int RPT>
+__global__ __launch_bounds__(256) void k_hh_formq_b(double* q_base, const double* __restrict__ ws_base,
+                                                    const QrBlk* __restrict__ blks,
+                                                    const HhParam* __restrict__ prm_base) {
+  constexpr int E = Cx<CPLX>::E;
+  __shared__ double s_head[2];
+  const QrBlk B = blks[blockIdx.y];
+  const int c = blockIdx.x;
+  if (c >= B.k) return;
+  const int mm = B.mm;
+  const double* a = ws_base + B.ws_off * E;
+  const HhParam* prm = prm_base + B.prm_off;
+  double* col = q_base + (B.q_off + (long long)c * mm) * E;
+  const int tid = threadIdx.x;
+  double2 x[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) x[q] = make_double2((tid + 256 * q) == c ? 1.0 : 0.0, 0.0);
+  for (int j = c; j >= 0; --j) {
+    const HhParam p = prm[j];
+    const double2 tau = make_double2(p.tau_re, p.tau_im), scale = make_double2(p.scale_re, p.scale_im);
+    if (tau.x == 0.0 && tau.y == 0.0) continue;
+    const double* vj = a + (long long)j * mm * E;
+    double2 v[RPT];
+    double dr = 0, di = 0;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + 256 * q;
+      v[q] = (r > j && r < mm) ? Cx<CPLX>::ld(vj, r) : make_double2(0.0, 0.0);
+      const double2 t2 = cmulc(v[q], x[q]);
+      dr += t2.x;
+      di += t2.y;
+      if (r == j) {
+        s_head[0] = x[q].x;
+        s_head[1] = x[q].y;
+      }
+    }
+    block_allsum2(dr, di);
+    const double2 head = make_double2(s_head[0], s_head[1]);
+    const double2 sc = cmulc(scale, make_double2(dr, di));
+    const double2 f = cmul(tau, make_double2(head.x + sc.x, head.y + sc.y));  // H, not H^H
+    const double2 fs = cmul(f, scale);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + 256 * q;
+      const double2 t2 = cmul(fs, v[q]);
+      x[q].x -= t2.x;
+      x[q].y -= t2.y;
+      if (r == j) {
+        x[q].x -= f.x;
+        x[q].y -= f.y;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int r = tid + 256 * q;
+    if (r < mm) Cx<CPLX>::st(col, r, x[q]);
+  }
+}
+
+template <bool CPLX>
+int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk* dblk, int nblk, int max_mm,
+                int max_nn, int max_k, bool form_q) {
+  // register-resident configurations: panel kernel holds RPT1024 x NB elements, the column kernels RPT256
+  const int cfg = max_mm <= 1024 ? 0 : max_mm <= 2048 ? 1 : 2;
+  const int nb = 4;
+  for (int j0 = 0; j0 < max_k; j0 += nb) {
+    switch (cfg) {
+      case 0:
+        hipLaunchKernelGGL((k_hh_panel<CPLX, 1, 4>), dim3(nblk), dim3(1024), 0, ctx->stream, ws, dblk, prm, j0);
+        break;
+      case 1:
+        hipLaunchKernelGGL((k_hh_panel<CPLX, 2, 4>), dim3(nblk), dim3(1024), 0, ctx->stream, ws, dblk, prm, j0);
+        break;
+      default:
+        hipLaunchKernelGGL((k_hh_panel<CPLX, 4, 4>), dim3(nblk), dim3(1024), 0, ctx->stream, ws, dblk, prm, j0);
+    }
+    const int trailing = max_nn - j0 - 1;  // upper bound on columns to the right of any block's panel
+    if (trailing > 0) {
+      dim3 grid(trailing, nblk);
+      switch (cfg) {
+        case 0:
+          hipLaunchKernelGGL((k_hh_apply_panel<CPLX, 4>), grid, dim3(256), 0, ctx->stream, ws, dblk, prm, j0, nb);
+          break;
+        case 1:
+          hipLaunchKernelGGL((k_hh_apply_panel<CPLX, 8>), grid, dim3(256), 0, ctx->stream, ws, dblk, prm, j0, nb);
+          break;
+        default:
+          hipLaunchKernelGGL((k_hh_apply_panel<CPLX, 16>), grid, dim3(256), 0, ctx->stream, ws, dblk, prm, j0, nb);
+      }
+    }
+  }
+  if (form_q && max_k > 0) {
+    dim3 grid(max_k, nblk);
+    switch (cfg) {
+      case 0:
+        hipLaunchKernelGGL((k_hh_formq_b<CPLX, 4>), grid, dim3(256), 0, ctx->stream, q, ws, dblk, prm);
+        break;
+      case 1:
+        hipLaunchKernelGGL((k_hh_formq_b<CPLX, 8>), grid, dim3(256), 0, ctx->stream, q, ws, dblk, prm);
+        break;
+      default:
+        hipLaunchKernelGGL((k_hh_formq_b<CPLX, 16>), grid, dim3(256), 0, ctx->stream, q, ws, dblk, prm);
+    }
+  }
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
+}  // namespace
+
+// Factorise (and optionally form Q for) nblk column-major blocks living in one workspace.
+// Requires max mm <= HH_BATCH_MAX_ROWS; callers fall back to the unblocked kernels otherwise.
+int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm, const QrBlk* blks_host, int nblk,
+                  bool form_q) {
+  if (nblk <= 0) return MPSE_OK;
+  int max_mm = 0, max_nn = 0, max_k = 0;
+  for (int b = 0; b < nblk; ++b) {
+    max_mm = blks_host[b].mm > max_mm ? blks_host[b].mm : max_mm;
+    max_nn = blks_host[b].nn > max_nn ? blks_host[b].nn : max_nn;
+    max_k = blks_host[b].k > max_k ? blks_host[b].k : max_k;
+  }
+  if (max_mm > HH_BATCH_MAX_ROWS) return mpse_fail(ctx, MPSE_ERR_SHAPE, "hh_qr_batched: block too tall");
+  TmpBuf DB(ctx);
+  MPSE_TRY(DB.alloc(size_t(nblk) * sizeof(QrBlk)));
+  MPSE_TRY(stage_h2d(ctx, DB.p, blks_host, size_t(nblk) * sizeof(QrBlk)));
+  if (cplx) return run_batched<true>(ctx, ws, q, prm, DB.as<QrBlk>(), nblk, max_mm, max_nn, max_k, form_q);
+  return run_batched<false>(ctx, ws, q, prm, DB.as<QrBlk>(), nblk, max_mm, max_nn, max_k, form_q);
+}

@@ -244,8 +244,8 @@ int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, 
   MPSE_TRY(SIG.alloc(size_t(maxk) * 8));
   MPSE_TRY(PERM.alloc(size_t(maxk) * 8));
   MPSE_TRY(CNT.alloc(64));
-  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.p, row_idx, size_t(nri) * 8));
-  MPSE_TRY(mpse_memcpy_h2d(ctx, IDX.as<char>() + size_t(nri) * 8, col_idx, size_t(nci) * 8));
+  MPSE_TRY(stage_h2d(ctx, IDX.p, row_idx, size_t(nri) * 8));
+  MPSE_TRY(stage_h2d(ctx, IDX.as<char>() + size_t(nri) * 8, col_idx, size_t(nci) * 8));
   const long long* drows = IDX.as<long long>();
   const long long* dcols = IDX.as<long long>() + nri;
   std::vector<double> sig;
@@ -288,7 +288,7 @@ int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, 
     std::iota(perm.begin(), perm.end(), 0LL);
     std::stable_sort(perm.begin(), perm.end(), [&](long long x, long long y) { return sig[x] > sig[y]; });
     for (int j = 0; j < nn; ++j) S_host[koff + j] = sig[perm[j]];
-    MPSE_TRY(mpse_memcpy_h2d(ctx, PERM.p, perm.data(), size_t(nn) * 8));
+    MPSE_TRY(stage_h2d(ctx, PERM.p, perm.data(), size_t(nn) * 8));
     const double smax = sig[perm[0]];
     const double thresh = smax * 2.220446049250313e-16 * (double)mm;
     double* un = Q.as<double>();

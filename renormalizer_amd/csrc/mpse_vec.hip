@@ -103,11 +103,24 @@ __global__ void k_scale_into(double* dst, const double* __restrict__ src, long l
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_doubles; i += stride) dst[i] = src[i] * s;
 }
 
+// dst = src / sqrt(*b2)   (scale by a device-resident squared norm)
+__global__ void k_scale_into_dev(double* dst, const double* __restrict__ src, long long n_doubles,
+                                 const double* __restrict__ b2) {
+  const double s = 1.0 / sqrt(*b2);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_doubles; i += stride) dst[i] = src[i] * s;
+}
+
 // Lanczos three-term update fused with the norm: w -= a*v1 + b*v0 ; partial = sum |w|^2
-// (lib/krylov/krylov.py:70-71; a, b real)
+// (lib/krylov/krylov.py:70-71).  a = *ap and b = sqrt(*b2p) are read from device memory so that the
+// recurrence never waits for the host.
 __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update(double* __restrict__ w, const double* __restrict__ v1,
                                                                 const double* __restrict__ v0, long long n_doubles,
-                                                                double a, double b, double* __restrict__ partial) {
+                                                                const double* __restrict__ ap,
+                                                                const double* __restrict__ b2p,
+                                                                double* __restrict__ partial) {
+  const double a = *ap;
+  const double b = v0 ? sqrt(*b2p) : 0.0;
   double s = 0, zero = 0;
   const long long stride = (long long)gridDim.x * RED_THREADS;
   for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n_doubles; i += stride) {
@@ -331,72 +344,116 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
   const size_t es = dtype_size(dtype);
   const int64_t nd = n * (cplx ? 2 : 1);  // doubles per vector
   const std::complex<double> dt(dt_re, dt_im);
-
-  double nrm2 = 0, dummy = 0;
-  MPSE_TRY(dotc_sync(ctx, dtype, Cin, Cin, n, &nrm2, &dummy));
-  const double nrmv = sqrt(nrm2);
-  if (!(nrmv > 0)) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: zero start vector");
+  const double tiny = 100.0 * double(n) * 2.220446049250313e-16;
 
   int cap = 16;
-  TmpBuf V(ctx), W(ctx), RES(ctx), FLAG(ctx);
+  TmpBuf V(ctx), W(ctx), RES(ctx), SCAL(ctx);
   MPSE_TRY(V.alloc(size_t(cap) * n * es));
   MPSE_TRY(W.alloc(size_t(n) * es));
-  MPSE_TRY(FLAG.alloc(64));
+  // device-resident recurrence scalars: [0..1] |v|^2 ; per j: alpha (re,im) at 4+4j, beta^2 at 6+4j ; flag at the end
+  const int SC_FLAG = 4 + 4 * 130;
+  MPSE_TRY(SCAL.alloc(size_t(SC_FLAG + 2) * sizeof(double)));
+  double* scal = SCAL.as<double>();
   const int eb = ew_blocks(nd);
   const int nb = red_blocks(nd);
   double* partial = ctx->dscratch;
-  double* result = ctx->dscratch + 2 * RED_MAX_BLOCKS;
-  hipLaunchKernelGGL(k_scale_into, dim3(eb), dim3(256), 0, ctx->stream, V.as<double>(), (const double*)Cin,
-                     (long long)nd, 1.0 / nrmv);
+
+  auto dot_into = [&](const void* x, const void* y, double* dst) {
+    if (cplx)
+      hipLaunchKernelGGL((k_dot_partial<true>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
+                         (const double*)y, (long long)n, partial);
+    else
+      hipLaunchKernelGGL((k_dot_partial<false>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
+                         (const double*)y, (long long)n, partial);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, partial, nb, dst);
+  };
+
+  // v0 = C / |C|
+  dot_into(Cin, Cin, scal);
+  hipLaunchKernelGGL(k_scale_into_dev, dim3(eb), dim3(256), 0, ctx->stream, V.as<double>(), (const double*)Cin,
+                     (long long)nd, (const double*)scal);
+  MPSE_HIP(ctx, hipGetLastError());
 
   std::vector<double> alpha, beta;
+  double nrmv = 0.0;
   bool have_res = false;
   auto vec = [&](int j) { return V.as<char>() + size_t(j) * n * es; };
+  // bring the scalars of iterations [alpha.size(), upto] to the host (one copy, one sync)
+  auto fetch = [&](int upto) -> int {
+    const int cnt = 4 + 4 * (upto + 1);
+    MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + 16, scal, size_t(cnt) * sizeof(double), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->prof_pending.size() > 2048) prof_drain(ctx);
+    const double* p = ctx->pinned + 16;
+    nrmv = sqrt(p[0]);
+    for (int j = (int)alpha.size(); j <= upto; ++j) {
+      alpha.push_back(p[4 + 4 * j]);
+      beta.push_back(sqrt(p[6 + 4 * j]));
+    }
+    return MPSE_OK;
+  };
   auto finish = [&](int m, const void* prev, int* flag_out) -> int {
-    // out (or RES) = V[:m]^T coef ; optional closeness test against prev
+    // out = V[:m]^T coef ; optional closeness test against prev (numpy allclose semantics)
     Coefs c;
     expm_coefs(m, alpha, beta, nrmv, dt, &c);
-    if (prev) MPSE_HIP(ctx, hipMemsetAsync(FLAG.p, 0, sizeof(int), ctx->stream));
+    int* dflag = reinterpret_cast<int*>(scal + SC_FLAG);
+    if (prev) MPSE_HIP(ctx, hipMemsetAsync(dflag, 0, sizeof(int), ctx->stream));
     if (cplx)
       hipLaunchKernelGGL((k_lincomb<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)out,
-                         V.as<double>(), (long long)n, m, c, (const double*)prev, rtol, atol, FLAG.as<int>());
+                         V.as<double>(), (long long)n, m, c, (const double*)prev, rtol, atol, dflag);
     else
       hipLaunchKernelGGL((k_lincomb<false>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)out,
-                         V.as<double>(), (long long)n, m, c, (const double*)prev, rtol, atol, FLAG.as<int>());
+                         V.as<double>(), (long long)n, m, c, (const double*)prev, rtol, atol, dflag);
     MPSE_HIP(ctx, hipGetLastError());
     if (prev && flag_out) {
-      MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + 8, FLAG.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + 8, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
       *flag_out = *reinterpret_cast<int*>(ctx->pinned + 8);
     }
     return MPSE_OK;
   };
+  // the reference stops at the first j with beta_j < tiny (krylov.py:72-74); scalars arrive late here, so the
+  // test is applied retroactively: vectors past a breakdown are never used
+  auto breakdown_at = [&](int upto) -> int {
+    for (int j = 0; j <= upto && j < (int)beta.size(); ++j)
+      if (!(beta[j] >= tiny)) return j;
+    return -1;
+  };
 
   for (int j = 0;; ++j) {
     MPSE_TRY(mpse_heff_apply(ctx, dtype, h, vec(j), W.p));
-    double are = 0, aim = 0;
-    MPSE_TRY(dotc_sync(ctx, dtype, W.p, vec(j), n, &are, &aim));
-    alpha.push_back(are);
-    if (j == n - 1) {  // Krylov space == full space (krylov.py:59-61)
-      MPSE_TRY(finish(j + 1, nullptr, nullptr));
-      if (nvec) *nvec = j + 1;
+    dot_into(W.p, vec(j), scal + 4 + 4 * j);                      // alpha_j = Re <w, v_j>
+    if (j == n - 1) {                                              // Krylov space == full space (krylov.py:59-61)
+      MPSE_TRY(fetch(j));
+      if (!(nrmv > 0)) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: zero start vector");
+      int bd = breakdown_at(j - 1);
+      const int m = bd >= 0 ? bd + 1 : j + 1;
+      MPSE_TRY(finish(m, nullptr, nullptr));
+      if (nvec) *nvec = m;
       return MPSE_OK;
     }
     hipLaunchKernelGGL(k_lanczos_update, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
                        (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
-                       (long long)nd, alpha[j], j > 0 ? beta[j - 1] : 0.0, partial);
-    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, partial, nb, result);
+                       (long long)nd, (const double*)(scal + 4 + 4 * j),
+                       (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), partial);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, partial, nb, scal + 6 + 4 * j);
     MPSE_HIP(ctx, hipGetLastError());
-    double b2 = 0;
-    MPSE_TRY(read_scalar2(ctx, result, &b2, nullptr));
-    const double bj = sqrt(b2);
-    beta.push_back(bj);
-    if (bj < 100.0 * double(n) * 2.220446049250313e-16) {  // breakdown (krylov.py:72-74)
-      MPSE_TRY(finish(j + 1, nullptr, nullptr));
-      if (nvec) *nvec = j + 1;
-      return MPSE_OK;
+    const bool check = (j > 3 && j % 2 == 0);                      // krylov.py:76-81
+    const bool last = (j + 1 >= max_dim);
+    if (check || last) {
+      MPSE_TRY(fetch(j));
+      if (!(nrmv > 0)) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: zero start vector");
+      const int bd = breakdown_at(j);
+      if (bd >= 0) {
+        // what the reference would have returned at iteration bd - unless one of its convergence tests
+        // (even jj > 3, jj < bd) had fired earlier; those tests all ran here already and failed
+        MPSE_TRY(finish(bd + 1, nullptr, nullptr));
+        if (nvec) *nvec = bd + 1;
+        return MPSE_OK;
+      }
     }
-    if (j > 3 && j % 2 == 0) {  // convergence test on successive approximations (krylov.py:76-81)
+    if (check) {
       if (!have_res) {
         MPSE_TRY(RES.alloc(size_t(n) * es));
         MPSE_TRY(finish(j + 1, nullptr, nullptr));
@@ -412,7 +469,7 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
         MPSE_TRY(mpse_memcpy_d2d(ctx, RES.p, out, size_t(n) * es));
       }
     }
-    if (j + 1 >= max_dim) {
+    if (last) {
       if (nvec) *nvec = j + 1;
       return mpse_fail(ctx, MPSE_ERR_NOCONV, "expm_lanczos: no convergence within %d Krylov vectors", max_dim);
     }
@@ -424,8 +481,8 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
       std::swap(V.p, V2.p);
       cap = ncap;
     }
-    hipLaunchKernelGGL(k_scale_into, dim3(eb), dim3(256), 0, ctx->stream, (double*)vec(j + 1), W.as<const double>(),
-                       (long long)nd, 1.0 / bj);
+    hipLaunchKernelGGL(k_scale_into_dev, dim3(eb), dim3(256), 0, ctx->stream, (double*)vec(j + 1),
+                       W.as<const double>(), (long long)nd, (const double*)(scal + 6 + 4 * j));
   }
 }
 
