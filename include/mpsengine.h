@@ -62,7 +62,9 @@ int mpse_device_info(mpse_ctx* ctx, char* name, size_t name_len, int* n_cu, void
 /* Optional per-launch timing of the contraction kernel with HIP events on the context stream
  * (no reference counterpart; used by bench.py for the roofline figures).  variant indexes the
  * operand types of mpse_gemm: 0 = f64 x f64, 1 = c128 x f64, 2 = f64 x c128, 3 = c128 x c128.
- * Totals cover the launches since the last reset; algorithmic flops use 2/4/4/8 per MAC. */
+ * Totals cover the TIMED launches since the last reset; algorithmic flops use 2/4/4/8 per MAC.
+ * on == 1 times every launch, on == N > 1 every N-th launch (sampling: two HIP events per timed launch
+ * cost a few microseconds of stream time each). */
 int mpse_prof_enable(mpse_ctx* ctx, int on);
 int mpse_prof_reset(mpse_ctx* ctx);
 int mpse_prof_get(mpse_ctx* ctx, int variant, double* total_ms, double* total_flops, double* total_bytes,

@@ -49,6 +49,8 @@ int mpse_prof_enable(mpse_ctx* ctx, int on) {
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   prof_drain(ctx);
   ctx->prof_on = on != 0;
+  ctx->prof_stride = on > 1 ? on : 1;
+  ctx->prof_counter = 0;
   return MPSE_OK;
 }
 

@@ -433,7 +433,8 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
   if (nblk > 0x7fffffffLL) return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpse_gemm: grid too large");
   dim3 grid((unsigned)nblk), block(256);
   mpse_ctx::ProfRec rec;
-  if (ctx->prof_on) {
+  const bool prof_this = ctx->prof_on && (ctx->prof_counter++ % ctx->prof_stride == 0);
+  if (prof_this) {
     auto get_event = [&](hipEvent_t* e) {
       if (!ctx->prof_free_events.empty()) {
         *e = ctx->prof_free_events.back();
@@ -478,7 +479,7 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
     else
       hipLaunchKernelGGL((k_splitk_reduce<false>), dim3(rb), dim3(256), 0, ctx->stream, g, (int)d->batch);
   }
-  if (ctx->prof_on) {
+  if (prof_this) {
     MPSE_HIP(ctx, hipEventRecord(rec.e1, ctx->stream));
     ctx->prof_pending.push_back(rec);
   }

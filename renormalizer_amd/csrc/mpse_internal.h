@@ -35,6 +35,8 @@ struct mpse_ctx {
     double flops, bytes;
   };
   bool prof_on = false;
+  int prof_stride = 1;      // time every prof_stride-th contraction launch (sampling keeps the overhead small)
+  long long prof_counter = 0;
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_free_events;
   double prof_ms[4] = {0, 0, 0, 0};

@@ -319,6 +319,7 @@ class Engine:
 
     # -- kernel profiling (HIP events on the engine stream)
     def prof_enable(self, on=True):
+        """on: False/0 off, True/1 every launch, N > 1 every N-th launch."""
         self._check(self.lib.mpse_prof_enable(self.ctx, int(on)))
 
     def prof_reset(self):
