@@ -46,6 +46,13 @@ def build_workload(nmol, pdim, bond_dim, seed, init):
     mpo = Mpo(model, offset=Quantity(e0))
     if init == "random":
         mps = Mps.random(model, 1, bond_dim, percent=1.0, rng=np.random.default_rng(seed))
+    elif init == "physical":
+        # transport/dynamics.py:173-199: vacuum, electron created on the centre molecule, bonds expanded
+        # with states reachable through H (device-resident apply / add / QR / SVD sweeps)
+        mps = Mpo.onsite(model, r"a^\dagger", dof_set={nmol // 2}).apply(Mps.ground_state(model, False))
+        mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=bond_dim)
+        mps = mps.expand_bond_dimension(mpo)
+        mps.canonicalise()
     else:
         raise SystemExit(f"unknown --init {init}")
     mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=bond_dim)
@@ -99,7 +106,7 @@ def main():
     ap.add_argument("--pdim", type=int, default=16)
     ap.add_argument("--bond-dim", type=int, default=256)
     ap.add_argument("--dt", type=float, default=10.0)
-    ap.add_argument("--init", default="random")
+    ap.add_argument("--init", default="physical", choices=["physical", "random"])
     ap.add_argument("--cpu-updates", type=int, default=9, help="site updates in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -167,7 +174,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "c128",
-            "data": "synthetic (random quantum-number-conserving MPS, 1 exciton; std.yaml Holstein parameters)",
+            "data": ("synthetic (std.yaml Holstein parameters; electron created on the centre molecule of the phonon "
+                     "vacuum, bonds expanded to Dbond with expand_bond_dimension, as transport/dynamics.py:173-199)"
+                     if args.init == "physical" else
+                     "synthetic (random quantum-number-conserving MPS, 1 exciton; std.yaml Holstein parameters)"),
             "config": {"workload": "configs[2]: 50-site Holstein chain TDVP-PS, one trajectory per GPU",
                        "nsite": nsite, "bond_dim": args.bond_dim, "dphys": [2, args.pdim], "mpo_bond": max(mpo.bond_dims),
                        "dt": args.dt, "init": args.init, "mean_krylov_dim": float(np.mean(kry)),

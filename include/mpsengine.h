@@ -82,6 +82,10 @@ int mpse_memcpy_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes
 int mpse_memcpy_d2h(mpse_ctx* ctx, void* dst_host, const void* src, size_t bytes);
 int mpse_memcpy_d2d(mpse_ctx* ctx, void* dst, const void* src, size_t bytes);
 int mpse_memset_zero(mpse_ctx* ctx, void* dst, size_t bytes);
+/* strided block copy (height rows of width_bytes; pitches in bytes): the sub-block assignments of
+ * MatrixProduct.add (mps/mp.py:386-398) and dstack/vstack of the edge sites. */
+int mpse_memcpy_2d(mpse_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
+                   size_t height);
 
 /* ------------------------------------------------------ vector primitives */
 /* The Lanczos / Davidson vector algebra of lib/krylov/krylov.py:54-82 and

@@ -237,6 +237,14 @@ int mpse_memcpy_d2d(mpse_ctx* ctx, void* dst, const void* src, size_t bytes) {
   return MPSE_OK;
 }
 
+int mpse_memcpy_2d(mpse_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
+                   size_t height) {
+  if (!ctx || ((width_bytes && height) && (!dst || !src))) return MPSE_ERR_ARG;
+  if (!width_bytes || !height) return MPSE_OK;
+  MPSE_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDeviceToDevice, ctx->stream));
+  return MPSE_OK;
+}
+
 int mpse_memset_zero(mpse_ctx* ctx, void* dst, size_t bytes) {
   if (!ctx || (bytes && !dst)) return MPSE_ERR_ARG;
   if (!bytes) return MPSE_OK;

@@ -72,7 +72,7 @@ __global__ void k_set_identity(double* v, int n) {
 // one round-robin step: workgroup b handles the pair (p,q) of step `step` (circle method on N = even(nn))
 template <bool CPLX>
 __global__ __launch_bounds__(RED_THREADS) void k_jacobi_step(double* a, double* v, int mm, int nn, int N, int step,
-                                                             double tol, int* nrot) {
+                                                             double tol, double null2, int* nrot) {
   constexpr int E = Cx<CPLX>::E;
   const int kk = blockIdx.x;
   int p, q;
@@ -102,7 +102,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_jacobi_step(double* a, double* 
   block_allsum2(alpha, beta);
   block_allsum2(gr, gi);
   const double g = sqrt(gr * gr + gi * gi);
-  if (g == 0.0 || !(g > tol * sqrt(alpha * beta))) return;  // already orthogonal (block-uniform decision)
+  // A column whose norm is below (largest column norm) * eps * m can only belong to singular values that are
+  // numerically zero; it is zeroed and replaced by the null-space completion afterwards, so rotating it
+  // (endlessly, at rounding level) is pointless.  Also avoids forming alpha*beta, which underflows.
+  if (g == 0.0 || alpha <= null2 || beta <= null2) return;
+  if (!(g > tol * sqrt(alpha) * sqrt(beta))) return;  // already orthogonal (block-uniform decision)
   // phase of gamma and the real Jacobi rotation for [[alpha, g], [g, beta]]
   const double pr = gr / g, pi = gi / g;
   const double zeta = (beta - alpha) / (2.0 * g);
@@ -267,12 +271,20 @@ int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, 
     if (nn > 1) {
       const int N = (nn + 1) & ~1;
       const double tol = 2.220446049250313e-16 * sqrt((double)mm);
+      hipLaunchKernelGGL((k_col_norms<CPLX>), dim3(nn), dim3(RED_THREADS), 0, ctx->stream, (const double*)ws, mm,
+                         SIG.as<double>());
+      sig.resize(nn);
+      MPSE_TRY(mpse_memcpy_d2h(ctx, sig.data(), SIG.p, size_t(nn) * 8));
+      double cmax = 0.0;
+      for (double x : sig) cmax = x > cmax ? x : cmax;
+      const double nullnorm = cmax * 2.220446049250313e-16 * (double)mm;
+      const double null2 = nullnorm * nullnorm;
       bool converged = false;
       for (int sweep = 0; sweep < 60 && !converged; ++sweep) {
         MPSE_HIP(ctx, hipMemsetAsync(CNT.p, 0, sizeof(int), ctx->stream));
         for (int step = 0; step < N - 1; ++step)
           hipLaunchKernelGGL((k_jacobi_step<CPLX>), dim3(N / 2), dim3(RED_THREADS), 0, ctx->stream, ws, vm, mm, nn, N,
-                             step, tol, CNT.as<int>());
+                             step, tol, null2, CNT.as<int>());
         MPSE_HIP(ctx, hipGetLastError());
         MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + 8, CNT.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "mpse_memcpy_d2h": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "mpse_memcpy_d2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "mpse_memset_zero": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "mpse_memcpy_2d": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t],
     "mpse_cast_f64_to_c128": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64],
     "mpse_conj_inplace": [C.c_void_p, C.c_void_p, C.c_int64],
     "mpse_scal": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_double, C.c_double],
@@ -365,6 +366,15 @@ class Engine:
         if a.size:
             self._check(self.lib.mpse_memcpy_h2d(self.ctx, t.ptr, a.ctypes.data, a.nbytes))
         return t
+
+    def copy_block(self, dst, dst_row0, dst_col0, src):
+        """dst[dst_row0 + r, dst_col0 + c] = src[r, c] for 2-D views of equal dtype (device to device)."""
+        assert dst.dtype == src.dtype and dst.ndim == 2 and src.ndim == 2
+        es = dst.dtype.itemsize
+        rows, cols = src.shape
+        assert dst_row0 + rows <= dst.shape[0] and dst_col0 + cols <= dst.shape[1]
+        self._check(self.lib.mpse_memcpy_2d(self.ctx, dst.ptr + (dst_row0 * dst.shape[1] + dst_col0) * es,
+                                            dst.shape[1] * es, src.ptr, cols * es, cols * es, rows))
 
     def ones(self, shape, dtype=np.float64):
         return self.asdevice(np.ones(shape, dtype=dtype))

@@ -22,6 +22,12 @@ from ..model import Op, OpSum
 from ..utils import Quantity
 
 
+def add_outer_qn(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return a.reshape(a.shape[:-1] + (1,) * (b.ndim - 1) + a.shape[-1:]) + b
+
+
 def _local_ops_of_term(model, term):
     """{site: Op without factor} for the non-identity part of a term, plus the coefficient."""
     per_site = defaultdict(lambda: ([], [], []))
@@ -185,6 +191,9 @@ class Mpo:
         if len(terms) == 0:
             raise ValueError("Terms all have factor 0.")
         ws, qn, qntot = construct_mpo_tensors(model, terms, offset.as_au())
+        # qn[i] (i <= qnidx) is the quantum number accumulated to the left of bond i; the right edge holds the
+        # complementary (R-system) value, i.e. zero
+        qn[-1] = np.zeros_like(qn[-1])
         self._mp = ws
         self.qn = qn
         self.qntot = qntot
@@ -252,6 +261,50 @@ class Mpo:
         if key not in self._dev:
             self._dev[key] = eng.asdevice(self._mp[i])
         return self._dev[key]
+
+    def apply(self, mp, canonicalise: bool = False):
+        """Exact mpo @ mps, bond dimensions multiply (mpo.py:331-389): site = einsum("apqb,cqd->acpbd")."""
+        from ..engine import get_engine, idx1, idx2
+        eng = get_engine()
+        assert self.site_num == mp.site_num
+        new = mp.copy()
+        cplx = mp.is_complex or self.is_complex
+        if cplx:
+            new = new.to_complex()
+        for i in range(self.site_num):
+            w = self.device(i, eng)
+            a = new[i]
+            wl, d, d2, wr = w.shape
+            Dl, d3, Dr = a.shape
+            assert d2 == d3
+            out = eng.empty((wl * Dl, d, wr * Dr), np.complex128 if cplx else np.float64)
+            for il in range(wl):
+                # out[il, l, p, (b, r)] = sum_q W[il, p, q, b] A[l, q, r]   (batch over l)
+                eng.gemm(w.row_block(il, il + 1), a, out.row_block(il * Dl, (il + 1) * Dl),
+                         idx2(d, wr, d * wr, 1), idx1(d, wr), idx1(d, Dr), idx1(Dr, 1),
+                         idx2(d, wr, wr * Dr, Dr), idx1(Dr, 1), batch=Dl, sb_a=0, sb_b=d * Dr, sb_c=d * wr * Dr)
+            new[i] = out
+        orig_idx = new.qnidx
+        new.move_qnidx(self.qnidx)
+        new.qn = [add_outer_qn(np.array(qo), np.array(qm)).reshape(-1, np.array(qo).shape[1])
+                  for qo, qm in zip(self.qn, new.qn)]
+        new.qntot = new.qntot + self.qntot
+        new.move_qnidx(orig_idx)
+        if canonicalise:
+            new.canonicalise()
+        return new
+
+    def __matmul__(self, other):
+        return self.apply(other)
+
+    def contract(self, mps, algo="svd"):
+        """mpo @ mps followed by canonicalise + compress (mpo.py:391-425)."""
+        if algo != "svd":
+            raise NotImplementedError("only the svd contraction is implemented")
+        new = self.apply(mps)
+        new.canonicalise()
+        new.compress()
+        return new
 
     def todense(self):
         """Full matrix (mpo.py:463-473); small systems only."""

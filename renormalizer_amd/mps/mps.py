@@ -446,12 +446,110 @@ class Mps:
         width = max(len(s) for s in s_list)
         return self, np.array([np.pad(s, (0, width - len(s))) for s in s_list])
 
+    # ------------------------------------------------------------------ sums of states
+    def add(self, other: "Mps") -> "Mps":
+        """Direct sum of the bond spaces (block-diagonal site tensors), mps/mp.py:374-435."""
+        eng = get_engine()
+        assert np.all(self.qntot == other.qntot)
+        assert self.site_num == other.site_num
+        new = self.metacopy()
+        cplx = self.is_complex or other.is_complex
+        dt = np.dtype(np.complex128 if cplx else np.float64)
+        new.dtype = dt
+        n = self.site_num
+        sites = []
+        for i in range(n):
+            a = self[i].to_complex() if cplx else self[i]
+            b = other[i].to_complex() if cplx else other[i]
+            d = a.shape[1]
+            assert d == b.shape[1]
+            la, ra, lb, rb = a.shape[0], a.shape[2], b.shape[0], b.shape[2]
+            if n == 1:
+                raise NotImplementedError("add of single-site states")
+            if i == 0:
+                L, R, l0, r0 = 1, ra + rb, 0, ra
+            elif i == n - 1:
+                L, R, l0, r0 = la + lb, 1, la, 0
+            else:
+                L, R, l0, r0 = la + lb, ra + rb, la, ra
+            out = eng.zeros((L, d, R), dt)
+            o2 = out.reshape(L * d, R)
+            eng.copy_block(o2, 0, 0, a.reshape(la * d, ra))
+            eng.copy_block(o2, l0 * d, r0, b.reshape(lb * d, rb))
+            sites.append(out)
+        new._mp = sites
+        new.move_qnidx(other.qnidx)
+        new.to_right = other.to_right
+        new.qn = [np.concatenate([q1, q2]) for q1, q2 in zip(new.qn, other.qn)]
+        q = len(self.qntot)
+        new.qn[0] = np.zeros((1, q), dtype=int)
+        new.qn[-1] = np.zeros((1, q), dtype=int)
+        return new
+
+    __add__ = add
+
+    def distance(self, other) -> float:
+        """mps/mp.py:1009-1023"""
+        l1 = self.dot(self, self_is_conj=False)
+        l2 = other.dot(other, self_is_conj=False)
+        l12 = self.dot(other, self_is_conj=False)
+        d2 = (l1 + l2 - l12 - l12.conjugate()).real
+        if d2 < 0:
+            assert d2 / l1.real < 1e-8
+            return 0.0
+        return float(np.sqrt(d2))
+
+    def expand_bond_dimension(self, hint_mpo=None, coef=1e-10, include_ex=True):
+        """Grow the bonds to ``compress_config.max_dims`` with states reachable through ``hint_mpo``
+        (repeated H|psi>, compressed sums) added with a tiny weight; mps/mps.py:1934-2023."""
+        mps = self
+        ex_mps = None
+        if hint_mpo is not None and include_ex:
+            ex_state = Mps.ground_state(mps.model, False)
+            assert mps.model.qn_size == 1
+            for _ in range(int(mps.qntot[0])):
+                ex_state = Mpo.onsite(mps.model, r"a^\dagger").apply(ex_state)
+            ex_state.compress_config = mps.compress_config
+            ex_state.move_qnidx(mps.qnidx)
+            ex_state.to_right = mps.to_right
+            ex_mps = ex_state
+        mps.compress_config.set_bonddim(len(mps.bond_dims))
+        m_target = np.minimum(np.array(mps.compress_config.max_dims) - np.array(mps.bond_dims), mps.bond_dims_exact)
+        m_target = np.array(m_target, dtype=int)
+        if hint_mpo is None:
+            expander = Mps.random(mps.model, mps.qntot, m_target)
+            expander.compress_config = mps.compress_config.copy()
+        else:
+            lastone = mps if ex_mps is None else mps + ex_mps
+            expander_list = []
+            expander_dims = np.zeros_like(m_target)
+            while True:
+                lastone = hint_mpo.apply(lastone).normalize("mps_and_coeff")
+                lastone = lastone.canonicalise().compress(int(np.max(m_target)))
+                expander_list.append(lastone)
+                expander = compressed_sum(expander_list, temp_m_trunc=m_target)
+                if np.all(np.array(expander.bond_dims) >= m_target):
+                    break
+                if np.all(np.array(expander.bond_dims) == expander_dims):
+                    logger.warning("Expander does not increase anymore. The expand target is too high")
+                    m_target2 = int(np.max(m_target - np.array(expander_dims)))
+                    expander2 = hint_mpo.apply(lastone).canonicalise().compress(max(m_target2, 1))
+                    expander = expander + expander2
+                    break
+                expander_dims = np.array(expander.bond_dims)
+                temp = int(np.max(m_target) / np.max(hint_mpo.bond_dims)) + 1
+                lastone = lastone.canonicalise().compress(temp)
+        summed = mps + expander.scale(coef * mps.norm, inplace=True)
+        return summed.canonicalise().compress(mps.compress_config.max_dims).normalize("mps_norm_to_coeff")
+
     # ------------------------------------------------------------------ time evolution
     def evolve(self, mpo, evolve_dt, normalize=True) -> "Mps":
         """mps/mps.py:644-662"""
         method = self.evolve_config.method
         if method is EvolveMethod.tdvp_ps:
             new_mps = self._evolve_tdvp_ps(mpo, evolve_dt)
+        elif method is EvolveMethod.prop_and_compress:
+            new_mps = self._evolve_prop_and_compress(mpo, evolve_dt)
         else:
             raise NotImplementedError(f"{method} is not implemented in the MI355X engine yet (TDVP-PS is)")
         if normalize:
@@ -525,3 +623,57 @@ class Mps:
                                       max=int(np.max(local_steps)), mean=float(np.mean(local_steps)),
                                       steps=list(local_steps))
         return mps
+
+
+# Taylor coefficients of exp(x) up to 4th order (utils/rk.py "C_RK4" tableau used by P&C, configs.py:364-369)
+_TAYLOR4 = [1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24]
+
+
+def _evolve_prop_and_compress(self, mpo, evolve_dt) -> "Mps":
+    """Global propagation & compression with a Taylor propagator, fixed step (mps/mps.py:794-885 without
+    the adaptive branch): terms H^k|psi> by contract (apply, canonicalise, compress), scaled by
+    (-i dt)^k c_k and summed with compression."""
+    from ..utils import CompressCriteria
+    config = self.evolve_config
+    if config.adaptive:
+        raise NotImplementedError("adaptive P&C is not implemented")
+    coeff = _TAYLOR4[: config.taylor_order + 1] if config.taylor_order <= 4 else None
+    if coeff is None:
+        import math
+        coeff = [1.0 / math.factorial(k) for k in range(config.taylor_order + 1)]
+    termlist = [self]
+    orig = self.compress_config
+    tmp = self.compress_config.copy()
+    if tmp.criteria is CompressCriteria.threshold:
+        tmp.criteria = CompressCriteria.both
+    self.compress_config = tmp
+    while len(termlist) < len(coeff):
+        termlist.append(mpo.contract(termlist[-1]))
+    self.compress_config = orig
+    for t in termlist:
+        t.compress_config = orig
+    scaled = [t.scale((-1.0j * evolve_dt) ** k * coeff[k]) for k, t in enumerate(termlist)]
+    return compressed_sum(scaled)
+
+
+Mps._evolve_prop_and_compress = _evolve_prop_and_compress
+
+
+def compressed_sum(mps_list, batchsize=5, temp_m_trunc=None):
+    """mps/lib.py:417-439"""
+    from collections import deque
+    assert len(mps_list) != 0
+    queue = deque(mps_list)
+    if len(queue) == 1:
+        new = mps_list[0].canonicalise()
+        new.compress(temp_m_trunc=temp_m_trunc)
+        return new
+    while len(queue) != 1:
+        terms = [queue.popleft() for _ in range(min(batchsize, len(queue)))]
+        s = terms[0]
+        for t in terms[1:]:
+            s = s.add(t)
+        s.canonicalise()
+        s.compress(temp_m_trunc=temp_m_trunc)
+        queue.append(s)
+    return queue[0]

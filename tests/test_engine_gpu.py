@@ -396,3 +396,22 @@ def test_block_svd_shapes_and_rank(eng, cplx):
         assert _relerr((u * s) @ vt, a) < 1e-13
         assert np.abs(u.conj().T @ u - np.eye(k)).max() < 1e-12
         assert np.abs(vt @ vt.conj().T - np.eye(k)).max() < 1e-12
+
+
+def test_block_svd_extreme_dynamic_range(eng, golden_dir):
+    """Regression input captured from expand_bond_dimension: column norms 0.7, 2e-21, 2e-119, 4e-142, 3e-152
+    inside one block (products of squared norms underflow).  Jacobi must converge and still return isometries."""
+    z = np.load(os.path.join(golden_dir, "svd_dynamic_range.npz"))
+    c = z["c"]
+    u, s, vt, blocks = dev_block_svd(eng, c, z["qbl"], z["qbr"], z["qntot"])
+    mat = c.reshape(u.shape[0], -1)
+    assert _relerr((u * s) @ vt, mat) < 1e-13
+    assert np.abs(u.conj().T @ u - np.eye(u.shape[1])).max() < 1e-12
+    assert np.abs(vt @ vt.conj().T - np.eye(vt.shape[0])).max() < 1e-12
+    koff = 0
+    for nl, nr, ls, rs in blocks:
+        k = min(len(ls), len(rs))
+        sref = np.linalg.svd(mat[np.ix_(ls, rs)], compute_uv=False)
+        assert abs(s[koff] - sref[0]) < 1e-14
+        assert np.all(s[koff + 1: koff + k] < 1e-15)        # the rest is numerically zero either way
+        koff += k
