@@ -94,6 +94,13 @@ int mpse_cast_f64_to_c128(mpse_ctx* ctx, void* dst, const void* src, int64_t n);
 int mpse_conj_inplace(mpse_ctx* ctx, void* x, int64_t n);                       /* C128 only */
 int mpse_scal(mpse_ctx* ctx, int dtype, void* x, int64_t n, double a_re, double a_im);
 int mpse_axpy(mpse_ctx* ctx, int dtype, void* y, const void* x, int64_t n, double a_re, double a_im);
+/* x_i *= m_i with real weights m (quantum-number mask of mps/gs.py:236-237, 520-523 kept as a dense 0/1 vector) */
+int mpse_mul_real(mpse_ctx* ctx, int dtype, void* x, const void* m_f64, int64_t n);
+/* Davidson preconditioner out = r / (hdiag - e + shift), zero where mask == 0 (mps/gs.py:530-531; mask may be NULL) */
+int mpse_davidson_precond(mpse_ctx* ctx, int dtype, void* out, const void* r, const void* hdiag_f64,
+                          const void* mask_f64, int64_t n, double e, double shift);
+/* out_i = Re z_i */
+int mpse_real_part(mpse_ctx* ctx, void* out_f64, const void* z_c128, int64_t n);
 /* out_host[0..1] = sum conj(x_i) y_i  (xp.vdot); synchronous */
 int mpse_dotc(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n, double* out_host);
 /* out_host[0] = ||x||_2 (xp.linalg.norm); synchronous */
@@ -203,6 +210,15 @@ int mpse_block_svd(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int
                    int nblocks, const int64_t* row_idx_host, const int64_t* row_off_host,
                    const int64_t* col_idx_host, const int64_t* col_off_host,
                    void* U, void* Vt, double* S_host, int64_t K);
+
+/* full_matrices=True variant (mps/svd_qn.py:65-86, 187-213 as called by MatrixProduct._update_mps, mps/mp.py:693-695):
+ * after the K singular triplets, block b contributes extra_host[b] null-space vectors of its taller side (zero
+ * singular value; 0 <= extra <= |m_b - n_b|): extra columns of U (nrow x KU) for m_b >= n_b, extra rows of
+ * Vt (KV x ncol) otherwise, appended after column/row K in block order.  extra_host == NULL means none. */
+int mpse_block_svd_full(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int64_t ncol,
+                        int nblocks, const int64_t* row_idx_host, const int64_t* row_off_host,
+                        const int64_t* col_idx_host, const int64_t* col_off_host, const int64_t* extra_host,
+                        void* U, int64_t KU, void* Vt, int64_t KV, double* S_host, int64_t K);
 
 /* out[:, j] = in[:, cols_host[j]] * scale_host[j]  (column gather of a row-major matrix,
  * replaces the per-column copies of mps/lib.py:303-316 select_basis; scale_host may be NULL). */

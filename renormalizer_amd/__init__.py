@@ -18,6 +18,9 @@ def __getattr__(name):
     if name == "Mps":
         from .mps.mps import Mps
         return Mps
+    if name == "optimize_mps":
+        from .mps.gs import optimize_mps
+        return optimize_mps
     if name == "backend":
         from .mps.backend import backend
         return backend

@@ -107,7 +107,9 @@ struct HhParam {  // per reflector: H = I - tau v v^H, v = (1, scale * tail)
   double scale_re, scale_im;
 };
 int hh_factor_colmajor(mpse_ctx* ctx, bool cplx, double* ws, int mm, int nn, int k, HhParam* prm);
-int hh_formq_colmajor(mpse_ctx* ctx, bool cplx, double* q, const double* ws, int mm, int k, const HhParam* prm);
+// nq >= k columns of Q are formed (columns beyond k span the orthogonal complement)
+int hh_formq_colmajor(mpse_ctx* ctx, bool cplx, double* q, const double* ws, int mm, int k, const HhParam* prm,
+                      int nq);
 
 // Batched panel-blocked Householder QR (mpse_qr2.hip): blocks live in one column-major workspace
 struct QrBlk {

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_hh_formq(double* q, const doubl
   double* col = q + (long long)c * mm * E;
   for (int r = threadIdx.x; r < mm; r += RED_THREADS) Cx<CPLX>::st(col, r, make_double2(r == c ? 1.0 : 0.0, 0.0));
   __syncthreads();
-  for (int j = c; j >= 0; --j) {
+  // columns c >= kref (orthogonal complement, used for full_matrices SVD) receive all reflectors
+  for (int j = (c < kref ? c : kref - 1); j >= 0; --j) {
     const HhParam p = prm[j];
     const double2 tau = make_double2(p.tau_re, p.tau_im), scale = make_double2(p.scale_re, p.scale_im);
     if (tau.x == 0.0 && tau.y == 0.0) continue;
@@ -252,12 +253,14 @@ int hh_factor_colmajor(mpse_ctx* ctx, bool cplx, double* ws, int mm, int nn, int
 }
 
 // explicit Q (mm x k, column-major) from a factored workspace
-int hh_formq_colmajor(mpse_ctx* ctx, bool cplx, double* q, const double* ws, int mm, int k, const HhParam* prm) {
+int hh_formq_colmajor(mpse_ctx* ctx, bool cplx, double* q, const double* ws, int mm, int k, const HhParam* prm,
+                      int nq) {
   if (k <= 0) return MPSE_OK;
+  if (nq < k) nq = k;
   if (cplx)
-    hipLaunchKernelGGL((k_hh_formq<true>), dim3(k), dim3(RED_THREADS), 0, ctx->stream, q, ws, mm, k, prm);
+    hipLaunchKernelGGL((k_hh_formq<true>), dim3(nq), dim3(RED_THREADS), 0, ctx->stream, q, ws, mm, k, prm);
   else
-    hipLaunchKernelGGL((k_hh_formq<false>), dim3(k), dim3(RED_THREADS), 0, ctx->stream, q, ws, mm, k, prm);
+    hipLaunchKernelGGL((k_hh_formq<false>), dim3(nq), dim3(RED_THREADS), 0, ctx->stream, q, ws, mm, k, prm);
   MPSE_HIP(ctx, hipGetLastError());
   return MPSE_OK;
 }
@@ -316,7 +319,7 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   } else {
     for (const QrBlk& B : blks) {
       MPSE_TRY(hh_factor_colmajor(ctx, CPLX, ws + B.ws_off * E, B.mm, B.nn, B.k, prm + B.prm_off));
-      MPSE_TRY(hh_formq_colmajor(ctx, CPLX, q + B.q_off * E, ws + B.ws_off * E, B.mm, B.k, prm + B.prm_off));
+      MPSE_TRY(hh_formq_colmajor(ctx, CPLX, q + B.q_off * E, ws + B.ws_off * E, B.mm, B.k, prm + B.prm_off, B.k));
     }
   }
   for (size_t i = 0; i < blks.size(); ++i) {

@@ -176,6 +176,7 @@ __global__ void k_scatter_svd(double* U, double* Vt, const double* __restrict__ 
                               const double* __restrict__ vm, const long long* __restrict__ perm, long long K,
                               long long ncol, const long long* __restrict__ rows, const long long* __restrict__ cols,
                               int mm, int nn, long long koff, int herm) {
+  // K is the leading dimension of U (number of columns of the output U)
   const long long totq = (long long)mm * nn, totv = (long long)nn * nn;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < totq + totv; t += stride) {
@@ -220,12 +221,33 @@ __global__ void k_scatter_svd(double* U, double* Vt, const double* __restrict__ 
   }
 }
 
+// null-space vectors of the tall side: columns nn .. nn+extra-1 of the completed isometry q
+//   !herm: U[rows[r], uoff+e] = q[r, nn+e]   ;   herm: Vt[voff+e, cols[r]] = conj(q[r, nn+e])
+template <bool CPLX>
+__global__ void k_scatter_null(double* U, double* Vt, const double* __restrict__ q, long long ldU, long long ncol,
+                               const long long* __restrict__ rows, const long long* __restrict__ cols, int mm, int nn,
+                               int extra, long long off, int herm) {
+  const long long total = (long long)mm * extra;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    if (!herm) {
+      const int e = (int)(t % extra), r = (int)(t / extra);
+      Cx<CPLX>::st(U, rows[r] * ldU + off + e, Cx<CPLX>::ld(q, r + (long long)(nn + e) * mm));
+    } else {
+      const int r = (int)(t % mm), e = (int)(t / mm);
+      double2 x = Cx<CPLX>::ld(q, r + (long long)(nn + e) * mm);
+      x.y = -x.y;
+      Cx<CPLX>::st(Vt, (off + e) * ncol + cols[r], x);
+    }
+  }
+}
+
 template <bool CPLX>
 int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, int nblocks, const int64_t* row_idx,
                    const int64_t* row_off, const int64_t* col_idx, const int64_t* col_off, void* U, void* Vt,
-                   double* S_host, int64_t K) {
+                   double* S_host, int64_t K, const int64_t* extra_host, int64_t KU, int64_t KV) {
   constexpr size_t es = CPLX ? 16 : 8;
-  int64_t ktot = 0, maxws = 0, maxk = 0;
+  int64_t ktot = 0, maxws = 0, maxk = 0, maxq = 0, nu = 0, nv = 0;
   for (int b = 0; b < nblocks; ++b) {
     const int64_t m = row_off[b + 1] - row_off[b], n = col_off[b + 1] - col_off[b];
     if (m < 0 || n < 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_svd: negative block extent");
@@ -233,15 +255,24 @@ int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, 
     ktot += k;
     maxws = std::max(maxws, m * n);
     maxk = std::max(maxk, k);
+    int64_t ex = extra_host ? extra_host[b] : 0;
+    if (ex < 0 || ex > std::max(m, n) - k) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_svd: bad extra count");
+    if (k == 0) ex = 0;
+    maxq = std::max(maxq, std::max(m, n) * (k + ex));
+    if (m >= n) nu += ex; else nv += ex;
   }
+  if (KU != ktot + nu || KV != ktot + nv)
+    return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_svd: KU/KV (%lld,%lld) do not match the blocks (%lld,%lld)",
+                     (long long)KU, (long long)KV, (long long)(ktot + nu), (long long)(ktot + nv));
   if (ktot != K) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_svd: K=%lld but blocks give %lld", (long long)K, (long long)ktot);
   if (ktot == 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
-  MPSE_TRY(mpse_memset_zero(ctx, U, size_t(nrow * K) * es));
-  MPSE_TRY(mpse_memset_zero(ctx, Vt, size_t(K * ncol) * es));
+  MPSE_TRY(mpse_memset_zero(ctx, U, size_t(nrow * KU) * es));
+  MPSE_TRY(mpse_memset_zero(ctx, Vt, size_t(KV * ncol) * es));
   const int64_t nri = row_off[nblocks], nci = col_off[nblocks];
+  long long uoff = K, voff = K;  // where the next block's null vectors go
   TmpBuf IDX(ctx), WS(ctx), Q(ctx), VM(ctx), PRM(ctx), SIG(ctx), PERM(ctx), CNT(ctx);
   MPSE_TRY(IDX.alloc(size_t(nri + nci) * 8));
-  MPSE_TRY(WS.alloc(size_t(maxws) * es));
+  MPSE_TRY(WS.alloc(size_t(std::max(maxws, maxq)) * es));
   MPSE_TRY(Q.alloc(size_t(maxws) * es));
   MPSE_TRY(VM.alloc(size_t(maxk * maxk) * es));
   MPSE_TRY(PRM.alloc(size_t(maxk + 1) * sizeof(HhParam)));
@@ -307,11 +338,19 @@ int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, 
     hipLaunchKernelGGL((k_normalise_perm<CPLX>), dim3(ew_blocks((int64_t)mm * nn)), dim3(256), 0, ctx->stream, un,
                        (const double*)ws, mm, nn, SIG.as<const double>(), PERM.as<const long long>(), thresh);
     MPSE_TRY(hh_factor_colmajor(ctx, CPLX, un, mm, nn, nn, PRM.as<HhParam>()));
-    MPSE_TRY(hh_formq_colmajor(ctx, CPLX, ws, un, mm, nn, PRM.as<HhParam>()));
+    const int extra = extra_host ? (int)extra_host[b] : 0;
+    MPSE_TRY(hh_formq_colmajor(ctx, CPLX, ws, un, mm, nn, PRM.as<HhParam>(), nn + extra));
     hipLaunchKernelGGL((k_scatter_svd<CPLX>), dim3(ew_blocks((int64_t)mm * nn + (int64_t)nn * nn)), dim3(256), 0,
                        ctx->stream, (double*)U, (double*)Vt, (const double*)un, (const double*)ws,
-                       (const double*)vm, PERM.as<const long long>(), (long long)K, (long long)ncol, rows, cols, mm, nn,
-                       (long long)koff, herm);
+                       (const double*)vm, PERM.as<const long long>(), (long long)KU, (long long)ncol, rows, cols, mm,
+                       nn, (long long)koff, herm);
+    if (extra > 0) {
+      long long& off = herm ? voff : uoff;
+      hipLaunchKernelGGL((k_scatter_null<CPLX>), dim3(ew_blocks((int64_t)mm * extra)), dim3(256), 0, ctx->stream,
+                         (double*)U, (double*)Vt, (const double*)ws, (long long)KU, (long long)ncol, rows, cols, mm, nn,
+                         extra, off, herm);
+      off += extra;
+    }
     MPSE_HIP(ctx, hipGetLastError());
     // PERM / SIG are rewritten for the next block only after this block's scatter: same stream, in order
     koff += k;
@@ -321,17 +360,26 @@ int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, 
 
 }  // namespace
 
-extern "C" int mpse_block_svd(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int64_t ncol, int nblocks,
-                              const int64_t* row_idx_host, const int64_t* row_off_host, const int64_t* col_idx_host,
-                              const int64_t* col_off_host, void* U, void* Vt, double* S_host, int64_t K) {
+extern "C" int mpse_block_svd_full(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int64_t ncol, int nblocks,
+                                   const int64_t* row_idx_host, const int64_t* row_off_host,
+                                   const int64_t* col_idx_host, const int64_t* col_off_host,
+                                   const int64_t* extra_host, void* U, int64_t KU, void* Vt, int64_t KV,
+                                   double* S_host, int64_t K) {
   if (!ctx || !coef || !U || !Vt || !S_host || !row_idx_host || !row_off_host || !col_idx_host || !col_off_host)
     return MPSE_ERR_ARG;
   if (nblocks <= 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
   if (dtype == MPSE_C128)
     return block_svd_impl<true>(ctx, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host,
-                                col_off_host, U, Vt, S_host, K);
+                                col_off_host, U, Vt, S_host, K, extra_host, KU, KV);
   if (dtype == MPSE_F64)
     return block_svd_impl<false>(ctx, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host,
-                                 col_off_host, U, Vt, S_host, K);
+                                 col_off_host, U, Vt, S_host, K, extra_host, KU, KV);
   return mpse_fail(ctx, MPSE_ERR_ARG, "block_svd: unknown dtype");
+}
+
+extern "C" int mpse_block_svd(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int64_t ncol, int nblocks,
+                              const int64_t* row_idx_host, const int64_t* row_off_host, const int64_t* col_idx_host,
+                              const int64_t* col_off_host, void* U, void* Vt, double* S_host, int64_t K) {
+  return mpse_block_svd_full(ctx, dtype, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host,
+                             col_off_host, nullptr, U, K, Vt, K, S_host, K);
 }

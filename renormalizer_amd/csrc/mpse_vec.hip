@@ -137,6 +137,43 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update(double* __restri
   }
 }
 
+// x[i] *= m[i]  (real mask / weights on a real or complex vector)
+template <bool CPLX>
+__global__ void k_mul_real(double* x, const double* __restrict__ m, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (CPLX) {
+      double2 v = reinterpret_cast<double2*>(x)[i];
+      v.x *= m[i];
+      v.y *= m[i];
+      reinterpret_cast<double2*>(x)[i] = v;
+    } else {
+      x[i] *= m[i];
+    }
+  }
+}
+
+// Davidson preconditioner out = r / (hdiag - e + shift), zero where mask == 0  (mps/gs.py:530-531)
+template <bool CPLX>
+__global__ void k_precond(double* out, const double* __restrict__ r, const double* __restrict__ hdiag,
+                          const double* __restrict__ mask, long long n, double e, double shift) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double w = (mask && mask[i] == 0.0) ? 0.0 : 1.0 / (hdiag[i] - e + shift);
+    if (CPLX) {
+      const double2 v = reinterpret_cast<const double2*>(r)[i];
+      reinterpret_cast<double2*>(out)[i] = make_double2(v.x * w, v.y * w);
+    } else {
+      out[i] = r[i] * w;
+    }
+  }
+}
+
+__global__ void k_real_part(double* out, const double* __restrict__ z, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = z[2 * i];
+}
+
 struct Coefs {
   double re[128];
   double im[128];
@@ -307,6 +344,42 @@ int mpse_axpy(mpse_ctx* ctx, int dtype, void* y, const void* x, int64_t n, doubl
   else
     hipLaunchKernelGGL((k_axpy<false>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)y, (const double*)x,
                        (long long)n, a_re, 0.0);
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
+int mpse_mul_real(mpse_ctx* ctx, int dtype, void* x, const void* m_f64, int64_t n) {
+  if (!ctx || (n && (!x || !m_f64))) return MPSE_ERR_ARG;
+  if (n <= 0) return MPSE_OK;
+  if (dtype == MPSE_C128)
+    hipLaunchKernelGGL((k_mul_real<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)x,
+                       (const double*)m_f64, (long long)n);
+  else
+    hipLaunchKernelGGL((k_mul_real<false>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)x,
+                       (const double*)m_f64, (long long)n);
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
+int mpse_davidson_precond(mpse_ctx* ctx, int dtype, void* out, const void* r, const void* hdiag_f64,
+                          const void* mask_f64, int64_t n, double e, double shift) {
+  if (!ctx || (n && (!out || !r || !hdiag_f64))) return MPSE_ERR_ARG;
+  if (n <= 0) return MPSE_OK;
+  if (dtype == MPSE_C128)
+    hipLaunchKernelGGL((k_precond<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)out,
+                       (const double*)r, (const double*)hdiag_f64, (const double*)mask_f64, (long long)n, e, shift);
+  else
+    hipLaunchKernelGGL((k_precond<false>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)out,
+                       (const double*)r, (const double*)hdiag_f64, (const double*)mask_f64, (long long)n, e, shift);
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
+int mpse_real_part(mpse_ctx* ctx, void* out_f64, const void* z_c128, int64_t n) {
+  if (!ctx || (n && (!out_f64 || !z_c128))) return MPSE_ERR_ARG;
+  if (n <= 0) return MPSE_OK;
+  hipLaunchKernelGGL(k_real_part, dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)out_f64,
+                     (const double*)z_c128, (long long)n);
   MPSE_HIP(ctx, hipGetLastError());
   return MPSE_OK;
 }

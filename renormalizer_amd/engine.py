@@ -95,6 +95,10 @@ _SIGNATURES = {
     "mpse_conj_inplace": [C.c_void_p, C.c_void_p, C.c_int64],
     "mpse_scal": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_double, C.c_double],
     "mpse_axpy": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double],
+    "mpse_mul_real": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64],
+    "mpse_davidson_precond": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                              C.c_double, C.c_double],
+    "mpse_real_part": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64],
     "mpse_dotc": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, _dblp],
     "mpse_nrm2": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, _dblp],
     "mpse_gemm": [C.c_void_p, C.POINTER(mpse_gemm_desc), C.c_void_p, C.c_void_p, C.c_void_p],
@@ -108,6 +112,8 @@ _SIGNATURES = {
                       C.c_int, C.c_void_p, C.c_void_p, C.c_int64],
     "mpse_block_svd": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _i64p, _i64p, _i64p, _i64p,
                        C.c_void_p, C.c_void_p, _dblp, C.c_int64],
+    "mpse_block_svd_full": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _i64p, _i64p, _i64p, _i64p,
+                            _i64p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, _dblp, C.c_int64],
     "mpse_gather_cols": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, _i64p, _dblp, C.c_int64],
     "mpse_gather_rows": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, _i64p, _dblp, C.c_int64],
 }

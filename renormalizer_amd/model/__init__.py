@@ -3,3 +3,4 @@ from .basis import (BasisSet, BasisSHO, BasisSimpleElectron, BasisHalfSpin, Basi
                     BasisMultiElectronVac)
 from .phonon import Phonon, Mol
 from .model import Model, HolsteinModel, SpinBosonModel, construct_j_matrix
+from . import h_qc

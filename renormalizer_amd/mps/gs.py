@@ -1,0 +1,159 @@
+"""DMRG ground-state optimisation on the device.
+
+Counterpart of renormalizer/mps/gs.py: ``optimize_mps`` (:54-171) macro loop over the ``procedure`` of
+``OptimizeConfig``, ``single_sweep`` (:174-304) over the sites, the iterative eigensolver set-up
+``get_ham_iterative`` / ``eigh_iterative`` (:410-576).  Differences by design: the quantum-number mask is kept
+as a dense 0/1 weight vector on the device (the reference compresses vectors to the allowed entries on the
+host, gs.py:260, 520-523 - same iterates, no host round trip), every centre is solved with the Davidson
+iteration (the reference diagonalises centres below 1000 elements densely with SciPy, gs.py:245-247), and only
+``nroots == 1`` is implemented."""
+import logging
+
+import numpy as np
+
+from ..engine import get_engine, idx1, idx2
+from ..lib.davidson import davidson
+from ..utils import CompressConfig, CompressCriteria
+from .hop_expr import hop_expr
+from .lib import Environ
+from .svd_qn import get_qn_mask
+
+logger = logging.getLogger("renormalizer_amd")
+
+
+def _hdiag(eng, l, r, cmo):
+    """Diagonal of the effective Hamiltonian (gs.py:423-445) from strided diagonal views of L, W, R:
+    1-site ba,bcg,gf->acf ; 2-site ba,bce,edg,gf->acdf.  Returns a float64 device tensor."""
+    cplx = l.is_complex or r.is_complex or any(w.is_complex for w in cmo)
+    dt = np.complex128 if cplx else np.float64
+    Dl, wl = l.shape[0], l.shape[1]
+    Dr, wr = r.shape[0], r.shape[1]
+    w0 = cmo[0]
+    d0, w0r = w0.shape[1], w0.shape[3]
+    # X1[a,(c,g)] = sum_b L[a,b,a] W0[b,c,c,g]
+    x1 = eng.empty((Dl, d0 * w0r), dt)
+    eng.gemm(l, w0, x1, idx1(Dl, wl * Dl + 1), idx1(wl, Dl), idx1(wl, d0 * d0 * w0r), idx2(d0, w0r, d0 * w0r + w0r, 1),
+             idx1(Dl, d0 * w0r), idx1(d0 * w0r, 1))
+    if len(cmo) == 1:
+        # hd[(a,c),f] = sum_g X1[(a,c),g] R[f,g,f]
+        out = eng.empty((Dl, d0, Dr), dt)
+        eng.gemm(x1, r, out, idx1(Dl * d0, wr), idx1(wr, 1), idx1(wr, Dr), idx1(Dr, wr * Dr + 1),
+                 idx1(Dl * d0, Dr), idx1(Dr, 1))
+    else:
+        w1 = cmo[1]
+        wm, d1 = w1.shape[0], w1.shape[1]
+        # X2[(e,d),f] = sum_g W1[e,d,d,g] R[f,g,f]
+        x2 = eng.empty((wm * d1, Dr), dt)
+        eng.gemm(w1, r, x2, idx2(wm, d1, d1 * d1 * wr, d1 * wr + wr), idx1(wr, 1), idx1(wr, Dr), idx1(Dr, wr * Dr + 1),
+                 idx1(wm * d1, Dr), idx1(Dr, 1))
+        # hd[(a,c),(d,f)] = sum_e X1[(a,c),e] X2[e,(d,f)]
+        out = eng.empty((Dl, d0, d1, Dr), dt)
+        eng.gemm(x1, x2, out, idx1(Dl * d0, wm), idx1(wm, 1), idx1(wm, d1 * Dr), idx1(d1 * Dr, 1),
+                 idx1(Dl * d0, d1 * Dr), idx1(d1 * Dr, 1))
+    if cplx:
+        re = eng.empty(out.shape, np.float64)
+        eng._check(eng.lib.mpse_real_part(eng.ctx, re.ptr, out.ptr, out.size))
+        return re
+    return out
+
+
+def eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, cguess):
+    """gs.py:486-576 with algo == "davidson" and nroots == 1."""
+    eng = get_engine()
+    inverse = mps.optimize_config.inverse
+    if inverse != 1.0:
+        raise NotImplementedError("optimize_config.inverse != 1")
+    cshape = qn_mask.shape
+    hop = hop_expr(ltensor, rtensor, cmo, cshape)
+    hdiag = _hdiag(eng, hop.l, hop.r, hop.cmo)
+    mask = eng.asdevice(qn_mask.astype(np.float64))
+    e, c, ncyc = davidson(lambda x: hop(x), cguess.reshape(cshape), hdiag, mask=mask, tol=1e-12, max_cycle=100,
+                          max_space=12, lindep=1e-14)
+    return e, c, ncyc
+
+
+def single_sweep(mps, mpo, environ, percent, last_opt_e_idx):
+    """gs.py:174-304 (nroots == 1, no omega, no site swapping)."""
+    eng = get_engine()
+    method = mps.optimize_config.method
+    res_mps = None
+    micro = []
+    hops = []
+    for imps in mps.iter_idx_list(full=True):
+        if method == "2site" and ((mps.to_right and imps == mps.site_num - 1) or ((not mps.to_right) and imps == 0)):
+            break
+        lmethod, rmethod = ("System", "Enviro") if mps.to_right else ("Enviro", "System")
+        if method == "1site":
+            lidx, cidx, ridx = imps - 1, [imps], imps + 1
+        elif mps.to_right:
+            lidx, cidx, ridx = imps - 1, [imps, imps + 1], imps + 2
+        else:
+            lidx, cidx, ridx = imps - 2, [imps - 1, imps], imps + 1
+        ltensor = environ.GetLR("L", lidx, mps, mpo, itensor=None, method=lmethod)
+        rtensor = environ.GetLR("R", ridx, mps, mpo, itensor=None, method=rmethod)
+        qnbigl, qnbigr, qnmat = mps._get_big_qn(cidx)
+        qn_mask = get_qn_mask(qnmat, mps.qntot)
+        cmo = [mpo.device(i, eng) for i in cidx]
+        if method == "1site":
+            guess = mps[cidx[0]]
+        else:
+            a, b = mps[cidx[0]], mps[cidx[1]]
+            guess = eng.matmul(a.reshape(-1, a.shape[-1]), b.reshape(b.shape[0], -1))
+        e, c, ncyc = eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, guess)
+        hops.append(ncyc)
+        micro.append((e, cidx))
+        cstruct = c.reshape(qn_mask.shape)
+        if cidx == last_opt_e_idx:
+            res_mps = mps.copy()
+            res_mps._update_mps(cstruct, cidx, qnbigl, qnbigr, percent)
+        mps._update_mps(cstruct, cidx, qnbigl, qnbigr, percent)
+    mps._switch_direction()
+    logger.debug(f"Davidson cycles per site: {hops}")
+    return micro, res_mps
+
+
+def optimize_mps(mps, mpo, omega: float = None):
+    """DMRG ground state (gs.py:54-171).  Returns (list of the lowest energy of every macro sweep, optimised mps).
+    The input mps is overwritten, as in the reference."""
+    if omega is not None:
+        raise NotImplementedError("the (H - omega)^2 functional is not implemented")
+    if mps.optimize_config.nroots != 1:
+        raise NotImplementedError("state-averaged DMRG (nroots > 1) is not implemented")
+    assert mps.optimize_config.method in ["2site", "1site"]
+    if mps.is_left_canonical:
+        mps.ensure_right_canonical()
+        env = "R"
+    else:
+        mps.ensure_left_canonical()
+        env = "L"
+    compress_config_bk = mps.compress_config
+    environ = Environ(mps, mpo, env)
+    macro = []
+    opt_e_idx = None
+    res_mps = None
+    for isweep, (cfg, percent) in enumerate(mps.optimize_config.procedure):
+        if isinstance(cfg, CompressConfig):
+            mps.compress_config = cfg
+        elif isinstance(cfg, (int, np.integer)):
+            mps.compress_config = CompressConfig(criteria=CompressCriteria.fixed, max_bonddim=int(cfg))
+        else:
+            raise TypeError(cfg)
+        micro, res, = single_sweep(mps, mpo, environ, percent, opt_e_idx)
+        if res is not None:
+            res_mps = res
+        opt_e = min(micro, key=lambda x: x[0])
+        macro.append(opt_e[0])
+        opt_e_idx = opt_e[1]
+        logger.debug(f"{isweep + 1} sweeps are finished, lowest energy = {min(macro)}")
+        if isweep > 0 and percent == 0:
+            v1, v2 = sorted(macro)[:2]
+            if np.allclose(v1, v2, rtol=mps.optimize_config.e_rtol, atol=mps.optimize_config.e_atol):
+                logger.info("DMRG has converged!")
+                break
+    else:
+        logger.warning("DMRG did not converge! Please increase the procedure!")
+    if res_mps is None:          # a single macro sweep: nothing was recorded at the optimal centre yet
+        res_mps = mps.copy()
+    res_mps = res_mps.normalize("mps_only").ensure_left_canonical().canonicalise()
+    res_mps.compress_config = compress_config_bk
+    return macro, res_mps

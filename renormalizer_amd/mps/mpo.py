@@ -66,37 +66,58 @@ def construct_mpo_tensors(model, terms, offset=0.0):
     """Return (list of W arrays (w_l, d, d, w_r), list of bond qn arrays, qntot)."""
     nsite = model.nsite
     qn_size = model.qn_size
-    # ---- per-site tables of distinct local operators (id 0 = identity)
-    op_tables = [{"I": 0} for _ in range(nsite)]
-    op_objs = [[Op.identity(model.basis[i].dofs[0], qn_size)] for i in range(nsite)]
+    # ---- per-site tables of distinct local operators (id 0 = identity).  Operators that are proportional
+    # as matrices share one id (the factor moves into the term coefficient): "Z Z" = I, "Z +" = -"+", ...
+    op_cache = [dict() for _ in range(nsite)]          # symbol key -> (id, factor)
+    op_mats = [[np.eye(model.basis[i].nbas)] for i in range(nsite)]
+    op_qn = [[np.zeros(qn_size, dtype=int)] for _ in range(nsite)]
 
     def op_id(site, op):
         key = (op.symbol, tuple(op.dofs))
-        tab = op_tables[site]
-        if key not in tab:
-            tab[key] = len(op_objs[site])
-            op_objs[site].append(op)
-        return tab[key]
+        cache = op_cache[site]
+        if key in cache:
+            return cache[key]
+        m = np.asarray(model.basis[site].op_mat(op))
+        res = None
+        piv = np.unravel_index(np.argmax(np.abs(m)), m.shape)
+        if m[piv] == 0:
+            res = (0, 0.0)
+        else:
+            for oid, c in enumerate(op_mats[site]):
+                if c[piv] != 0:
+                    f = m[piv] / c[piv]
+                    if np.allclose(m, f * c, rtol=1e-13, atol=1e-13 * abs(m[piv])):
+                        res = (oid, f.real if abs(np.imag(f)) == 0 else f)
+                        break
+        if res is None:
+            op_mats[site].append(m)
+            op_qn[site].append(np.asarray(op.qn, dtype=int).reshape(qn_size))
+            res = (len(op_mats[site]) - 1, 1.0)
+        cache[key] = res
+        return res
 
     strings = defaultdict(complex)
     for t in terms:
         loc, coef = _local_ops_of_term(model, t)
-        key = tuple(op_id(s, loc[s]) if s in loc else 0 for s in range(nsite))
-        strings[key] += coef
+        key = []
+        for s_ in range(nsite):
+            if s_ in loc:
+                oid, f = op_id(s_, loc[s_])
+                coef = coef * f
+                key.append(oid)
+            else:
+                key.append(0)
+        if coef != 0:
+            strings[tuple(key)] += coef
     if offset != 0:
         strings[(0,) * nsite] -= offset
-    strings = {k: v for k, v in strings.items() if v != 0}
+    strings = {k: v for k, v in strings.items() if abs(v) > 0}
     if not strings:
         strings = {(0,) * nsite: 0.0}
     cplx = any(abs(complex(v).imag) > 0 for v in strings.values())
     cdtype = complex if cplx else float
 
-    op_qn = [[np.asarray(o.qn, dtype=int).reshape(qn_size) for o in objs] for objs in op_objs]
-    op_mats = [[None] * len(objs) for objs in op_objs]
-
     def mat(site, oid):
-        if op_mats[site][oid] is None:
-            op_mats[site][oid] = np.asarray(model.basis[site].op_mat(op_objs[site][oid]))
         return op_mats[site][oid]
 
     # ---- sweep: remainders = {(channel, suffix of op ids): coefficient}

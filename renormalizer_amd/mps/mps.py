@@ -446,6 +446,126 @@ class Mps:
         width = max(len(s) for s in s_list)
         return self, np.array([np.pad(s, (0, width - len(s))) for s in s_list])
 
+    # ------------------------------------------------------------------ DMRG support
+    @property
+    def is_left_canonical(self):
+        """mps/mp.py:192-197 (position of the qn centre only)"""
+        return self.qnidx == self.site_num - 1
+
+    @property
+    def is_right_canonical(self):
+        return self.qnidx == 0
+
+    def ensure_left_canonical(self):
+        """mps/mp.py:206-216.  The orthogonality check of the reference is replaced by always re-canonicalising
+        (one QR sweep) - cheaper than downloading the sites to test them."""
+        self.move_qnidx(0)
+        self.to_right = True
+        return self.canonicalise()
+
+    def ensure_right_canonical(self):
+        """mps/mp.py:218-228"""
+        self.move_qnidx(self.site_num - 1)
+        self.to_right = False
+        return self.canonicalise()
+
+    def _update_mps(self, cstruct, cidx, qnbigl, qnbigr, percent=0):
+        """Basis selection update after a DMRG / two-site step, mps/mp.py:651-888 for a single state:
+        full block SVD of the centre, m_trunc from the compress config, ``select_basis`` (equal quota per qn
+        block for ``percent`` of the slots, then by singular value), new site = selected vectors, the
+        complementary part (sigma-weighted) goes to the neighbour."""
+        from .basis_select import select_basis_indices
+        eng = get_engine()
+        system = "L" if self.to_right else "R"
+        if self.compress_config.bonddim_should_set:
+            self.compress_config.set_bonddim(len(self) + 1)
+        U, SU, qnlnew, V, SV, qnrnew = svd_qn.svd_qn(cstruct, qnbigl, qnbigr, self.qntot, system=system)
+        Vt = V.T
+        q = len(self.qntot)
+        if self.to_right:
+            m_trunc = self.compress_config.compute_m_trunc(SU, cidx[0], self.to_right)
+            sidx = select_basis_indices(SU, qnlnew, m_trunc, percent)
+            sset, qnsel, nsel = SU, qnlnew, len(sidx)
+        else:
+            m_trunc = self.compress_config.compute_m_trunc(SV, cidx[-1], self.to_right)
+            sidx = select_basis_indices(SV, qnrnew, m_trunc, percent)
+            sset, qnsel, nsel = SV, qnrnew, len(sidx)
+        msqn = np.array([qnsel[i] for i in sidx], dtype=int).reshape(nsel, q)
+        idx = np.array(sidx, dtype=np.int64)
+        sig = np.ascontiguousarray(np.asarray(sset, dtype=float)[idx])
+        nrow, ncol = U.shape[0], Vt.shape[1]
+        lib = eng.lib
+
+        def cols_of(mat, index, scale):
+            """columns `index` of a row-major matrix; columns past its width are zero (lib.py:311-314)"""
+            width = mat.shape[1]
+            ok = index < width
+            out = eng.empty((mat.shape[0], len(index)), mat.dtype)
+            sc = None if scale is None else np.where(ok, scale, 0.0)
+            if scale is None and not ok.all():
+                sc = ok.astype(float)
+            safe = np.ascontiguousarray(np.where(ok, index, 0))
+            eng._check(lib.mpse_gather_cols(eng.ctx, mat.code, out.ptr, mat.ptr, mat.shape[0], width, svd_qn._p64(safe),
+                                            None if sc is None else np.ascontiguousarray(sc).ctypes.data_as(
+                                                ctypes.POINTER(ctypes.c_double)), len(index)))
+            return out
+
+        def rows_of(mat, index, scale):
+            height = mat.shape[0]
+            ok = index < height
+            out = eng.empty((len(index), mat.shape[1]), mat.dtype)
+            sc = None if scale is None else np.where(ok, scale, 0.0)
+            if scale is None and not ok.all():
+                sc = ok.astype(float)
+            safe = np.ascontiguousarray(np.where(ok, index, 0))
+            eng._check(lib.mpse_gather_rows(eng.ctx, mat.code, out.ptr, mat.ptr, mat.shape[1], svd_qn._p64(safe),
+                                            None if sc is None else np.ascontiguousarray(sc).ctypes.data_as(
+                                                ctypes.POINTER(ctypes.c_double)), len(index)))
+            return out
+
+        lshape = list(np.asarray(qnbigl).shape[:-1])
+        rshape = list(np.asarray(qnbigr).shape[:-1])
+        if self.to_right:
+            ms = cols_of(U, idx, None).reshape(lshape + [nsel])                 # (D_l, d, M)
+            compms = rows_of(Vt, idx, sig).reshape([nsel] + rshape)             # (M, [d,] D_r) = moveaxis(V sigma)
+        else:
+            ms = rows_of(Vt, idx, None).reshape([nsel] + rshape)                # (M, d, D_r)
+            compms = cols_of(U, idx, sig).reshape(lshape + [nsel])              # (D_l, [d,] M)
+        if len(cidx) == 1:
+            c = cidx[0]
+            self[c] = ms
+            if self.to_right:
+                if c != self.site_num - 1:
+                    nxt = self[c + 1]
+                    self[c + 1] = eng.matmul(compms.reshape(nsel, -1), nxt.reshape(nxt.shape[0], -1)) \
+                        .reshape((nsel,) + nxt.shape[1:])
+                    self.qn[c + 1] = msqn
+                    self.qnidx = c + 1
+                else:
+                    self[c] = eng.matmul(ms.reshape(-1, nsel), compms.reshape(nsel, -1)).reshape(lshape + [-1])
+                    self.qnidx = self.site_num - 1
+            else:
+                if c != 0:
+                    prv = self[c - 1]
+                    self[c - 1] = eng.matmul(prv.reshape(-1, prv.shape[-1]), compms.reshape(-1, nsel)) \
+                        .reshape(prv.shape[:-1] + (nsel,))
+                    self.qn[c] = msqn
+                    self.qnidx = c - 1
+                else:
+                    self[c] = eng.matmul(compms.reshape(-1, nsel), ms.reshape(nsel, -1)).reshape([-1] + rshape)
+                    self.qnidx = 0
+        else:
+            if self.to_right:
+                self[cidx[0]] = ms
+                self[cidx[1]] = compms
+                self.qnidx = cidx[1]
+            else:
+                self[cidx[1]] = ms
+                self[cidx[0]] = compms
+                self.qnidx = cidx[0]
+            self.qn[cidx[1]] = msqn
+        return None
+
     # ------------------------------------------------------------------ sums of states
     def add(self, other: "Mps") -> "Mps":
         """Direct sum of the bond spaces (block-diagonal site tensors), mps/mp.py:374-435."""

@@ -82,19 +82,47 @@ def svd_qn(coef_array, qnbigl, qnbigr, qntot, QR=False, system=None, full_matric
     for b, k in zip(blocks, dims):
         new_qnl += [b[0].tolist()] * k
         new_qnr += [b[1].tolist()] * k
-    if full_matrices:
-        raise NotImplementedError("full_matrices=True is handled by the DMRG update path")
-    u = eng.empty((nrow, K), coef.dtype)
-    vt = eng.empty((K, ncol), coef.dtype)
     if QR:
+        if full_matrices:
+            raise NotImplementedError("full_matrices QR is not used by the sweep algorithms")
         if system not in ("L", "R"):
             raise ValueError("system must be 'L' or 'R' for QR")
+        u = eng.empty((nrow, K), coef.dtype)
+        vt = eng.empty((K, ncol), coef.dtype)
         eng._check(eng.lib.mpse_block_qr(eng.ctx, coef.code, coef.ptr, nrow, ncol, len(blocks), _p64(rows), _p64(roff),
                                          _p64(cols), _p64(coff), int(system == "R"), u.ptr, vt.ptr, K))
         return u, new_qnl, TransposedView(vt), new_qnr
     s = np.zeros(K)
+    sp = s.ctypes.data_as(C.POINTER(C.c_double))
+    if full_matrices:
+        # null-space completion of the taller side of every block (svd_qn.py:12-49, 65-86): all of it while the
+        # aspect ratio is below 3, otherwise as many vectors as the block has singular values
+        extra = np.zeros(len(blocks), dtype=np.int64)
+        qnl0, qnr0 = [], []
+        for ib, (b, k) in enumerate(zip(blocks, dims)):
+            m, n = len(b[2]), len(b[3])
+            tall = max(m, n)
+            ex = tall - k
+            if opt_full_matrices and not (1 / 3 < m / n < 3):
+                ex = min(ex, k)
+            extra[ib] = ex
+            if m >= n:
+                qnl0 += [b[0].tolist()] * ex
+            else:
+                qnr0 += [b[1].tolist()] * ex
+        KU, KV = K + len(qnl0), K + len(qnr0)
+        u = eng.empty((nrow, KU), coef.dtype)
+        vt = eng.empty((KV, ncol), coef.dtype)
+        eng._check(eng.lib.mpse_block_svd_full(eng.ctx, coef.code, coef.ptr, nrow, ncol, len(blocks), _p64(rows),
+                                               _p64(roff), _p64(cols), _p64(coff), _p64(extra), u.ptr, KU, vt.ptr, KV,
+                                               sp, K))
+        su = np.concatenate([s, np.zeros(KU - K)])
+        sv = np.concatenate([s, np.zeros(KV - K)])
+        return u, su, new_qnl + qnl0, TransposedView(vt), sv, new_qnr + qnr0
+    u = eng.empty((nrow, K), coef.dtype)
+    vt = eng.empty((K, ncol), coef.dtype)
     eng._check(eng.lib.mpse_block_svd(eng.ctx, coef.code, coef.ptr, nrow, ncol, len(blocks), _p64(rows), _p64(roff),
-                                      _p64(cols), _p64(coff), u.ptr, vt.ptr, s.ctypes.data_as(C.POINTER(C.c_double)), K))
+                                      _p64(cols), _p64(coff), u.ptr, vt.ptr, sp, K))
     # economic SVD: globally sort by singular value, descending (svd_qn.py:231-239)
     order = np.argsort(s)[::-1].astype(np.int64)
     if not np.array_equal(order, np.arange(K)):

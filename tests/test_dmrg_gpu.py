@@ -1,0 +1,62 @@
+"""GPU parity of the DMRG path (optimize_mps: environments, Heff matvec, Davidson, full block SVD + basis
+selection) against the reference's own known answers.  pytest -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from renormalizer_amd import HolsteinModel, Model, Mol, Mpo, Phonon, Quantity
+from renormalizer_amd.model import h_qc
+from renormalizer_amd.utils import constant
+
+pytestmark = pytest.mark.gpu
+
+
+def _holstein_test_model():
+    """renormalizer/tests/parameter.py:7-34 (3 molecules x 2 modes, 4 phonon levels)."""
+    omega = [Quantity(106.51, "cm^{-1}"), Quantity(1555.55, "cm^{-1}")]
+    dis = [Quantity(30.1370), Quantity(8.7729)]
+    ph_list = [Phonon.simple_phonon(o, d, 4) for o, d in zip(omega, dis)]
+    j = np.array([[0.0, -0.1, -0.2], [-0.1, 0.0, -0.3], [-0.2, -0.3, 0.0]]) / constant.au2ev
+    return HolsteinModel([Mol(Quantity(2.67, "eV"), ph_list, 15.45)] * 3, j, 3)
+
+
+@pytest.mark.parametrize("method", ["2site", "1site"])
+def test_holstein_ground_state(method):
+    """mps/tests/test_gs.py:21-37: E_gs = 0.08401412 + ZPE (rel 1e-5) and <H> of the returned state."""
+    from renormalizer_amd.mps.gs import optimize_mps
+    from renormalizer_amd.mps.mps import Mps
+    model = _holstein_test_model()
+    mpo = Mpo(model)
+    gs_e = 0.08401412 + model.gs_zpe
+    procedure = [[10, 0.4], [20, 0.2], [30, 0.1], [40, 0], [40, 0]]
+    mps = Mps.random(model, 1, procedure[0][0], rng=np.random.default_rng(2019))
+    mps.optimize_config.procedure = procedure
+    mps.optimize_config.method = method
+    energies, opt = optimize_mps(mps.copy(), mpo)
+    assert energies[-1] == pytest.approx(gs_e, rel=1e-5)
+    assert opt.expectation(mpo) == pytest.approx(gs_e, rel=1e-5)
+    assert abs(opt.mp_norm - 1.0) < 1e-10
+    # 1-site sweep energies of the reference for this model converge to the same value
+    assert min(energies) == pytest.approx(0.0953734687866298, abs=2e-7)
+
+
+def test_h2o_sto3g_fci_energy(golden_dir):
+    """example/h2o_qc.py: water STO-3G (10e, 7o), 2-site DMRG at M = 50 reaches the FCI energy -75.008697516450."""
+    from renormalizer_amd.mps.gs import optimize_mps
+    from renormalizer_amd.mps.mps import Mps
+    sh, aseri, nuc = h_qc.read_fcidump(os.path.join(golden_dir, "h2o_fcidump.txt"), 7)
+    basis, terms = h_qc.qc_model(sh, aseri)
+    model = Model(basis, terms)
+    mpo = Mpo(model)
+    assert mpo.bond_dims == [1, 4, 16, 33, 46, 71, 92, 77, 60, 69, 54, 33, 16, 4, 1]     # reference, algo "qr"
+    M = 50
+    mps = Mps.random(model, [5, 5], M, percent=1.0, rng=np.random.default_rng(1))
+    mps.optimize_config.procedure = [[M, 0.4], [M, 0.2], [M, 0.1], [M, 0], [M, 0], [M, 0], [M, 0]]
+    mps.optimize_config.method = "2site"
+    energies, opt = optimize_mps(mps.copy(), mpo)
+    gs_e = min(energies) + nuc
+    assert abs(gs_e - (-75.008697516450)) < 1e-8
+    assert abs(opt.expectation(mpo) + nuc - (-75.008697516450)) < 1e-7
+    # particle numbers are conserved exactly by the block structure
+    assert opt.qntot.tolist() == [5, 5]
