@@ -58,16 +58,16 @@ __device__ __forceinline__ void make_reflector(double2 alpha, double s, HhParam*
   }
 }
 
-// ---- panel factorisation: 1024 threads, thread owns rows tid + 1024 q (q < RPT), NB columns.
+// ---- panel factorisation: NT threads, thread owns rows tid + NT q (q < RPT), NB columns.
 // The column loop is NOT unrolled (an 8x unrolled body is ~90 KB of code and the kernel becomes
 // instruction-fetch bound): the pivot is always register column 0 and the panel is rotated by one
 // column after each reflector, so every iteration runs the same code with static register indices.
-template <bool CPLX, int RPT, int NB>
-__global__ __launch_bounds__(1024) void k_hh_panel(double* ws_base, const QrBlk* __restrict__ blks, HhParam* prm_base,
+template <bool CPLX, int NT, int RPT, int NB>
+__global__ __launch_bounds__(NT) void k_hh_panel(double* ws_base, const QrBlk* __restrict__ blks, HhParam* prm_base,
                                                    int j0) {
   constexpr int E = Cx<CPLX>::E;
   constexpr int NV = 2 * NB;  // [0] = |tail|^2, [1] unused, then (re, im) of the dot with panel column t >= 1
-  __shared__ double s_part[16][NV];
+  __shared__ double s_part[NT / 64][NV];
   __shared__ double s_f[NB][4];
   __shared__ double s_par[2];
   __shared__ double s_head[2 * NB];
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(1024) void k_hh_panel(double* ws_base, const QrBlk*
   double2 x[RPT][NB];
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
-    const int r = tid + 1024 * q;
+    const int r = tid + NT * q;
 #pragma unroll
     for (int c = 0; c < NB; ++c)
       x[q][c] = (r >= j0 && r < mm && c < nbb) ? Cx<CPLX>::ld(a, r + (long long)(j0 + c) * mm) : make_double2(0.0, 0.0);
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(1024) void k_hh_panel(double* ws_base, const QrBlk*
     for (int t = 0; t < NV; ++t) val[t] = 0.0;
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-      const int r = tid + 1024 * q;
+      const int r = tid + NT * q;
       if (r > j && r < mm) {
         const double2 v = x[q][0];
         val[0] += v.x * v.x + v.y * v.y;
@@ -116,28 +116,11 @@ __global__ __launch_bounds__(1024) void k_hh_panel(double* ws_base, const QrBlk*
         }
       }
     }
-    // wave-level reduction of all NV values with a halving butterfly: each exchange sums partner halves
-    // and keeps half of the values, so NV values cost NV + log2(64/NV) shuffles instead of 6 NV
+    // wave-level sums on the VALU (DPP), one partial per wave and value
 #pragma unroll
-    for (int half = NV / 2, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
-      const bool up = (lane & bit) != 0;
-#pragma unroll
-      for (int t = 0; t < half; ++t) {
-        const double send = up ? val[t] : val[t + half];
-        const double keep = up ? val[t + half] : val[t];
-        val[t] = keep + __shfl_xor(send, bit, 64);
-      }
-    }
-    {
-      constexpr int LOWBITS = 64 / NV;  // lanes sharing one value
-#pragma unroll
-      for (int o = LOWBITS / 2; o >= 1; o >>= 1) val[0] += __shfl_xor(val[0], o, 64);
-      if ((lane & (LOWBITS - 1)) == 0) {
-        int idx = 0;  // the lane bits that selected the upper halves, most significant first
-#pragma unroll
-        for (int half = NV / 2, bit = 32; half >= 1; half >>= 1, bit >>= 1) idx += (lane & bit) ? half : 0;
-        s_part[wave][idx] = val[0];
-      }
+    for (int t = 0; t < NV; ++t) {
+      const double w = wave_sum(val[t]);
+      if (lane == 0) s_part[wave][t] = w;
     }
     __syncthreads();  // (A) partial sums and the diagonal row are in LDS
     // --- the scalar work (f64 sqrt / divisions) is done once, by wave 0
@@ -145,7 +128,7 @@ __global__ __launch_bounds__(1024) void k_hh_panel(double* ws_base, const QrBlk*
       double tot = 0.0;
       if (lane < NV) {
 #pragma unroll
-        for (int w = 0; w < 16; ++w) tot += s_part[w][lane];
+        for (int w = 0; w < NT / 64; ++w) tot += s_part[w][lane];
       }
       const double ssq = __shfl(tot, 0, 64);
       HhParam p;
@@ -176,7 +159,7 @@ __global__ __launch_bounds__(1024) void k_hh_panel(double* ws_base, const QrBlk*
     const double beta = s_par[0], diag_im = s_par[1];
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-      const int r = tid + 1024 * q;
+      const int r = tid + NT * q;
       const double2 v = x[q][0];
       if (r == j) x[q][0] = make_double2(beta, diag_im);
 #pragma unroll
@@ -223,43 +206,56 @@ __global__ __launch_bounds__(256) void k_hh_apply_panel(double* ws_base, const Q
     const int r = tid + 256 * q;
     x[q] = (r >= j0 && r < mm) ? Cx<CPLX>::ld(col, r) : make_double2(0.0, 0.0);
   }
+  // reflector tails stream from L2: the loads for reflector jj+1 are issued before the reduction of jj
+  double2 v[RPT], vn[RPT];
+  auto load_v = [&](int jj, double2* dst) {
+    const int j = j0 + jj;
+    const double* vj = a + (long long)j * mm * E;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + 256 * q;
+      dst[q] = (r > j && r < mm) ? Cx<CPLX>::ld(vj, r) : make_double2(0.0, 0.0);
+    }
+  };
+  load_v(0, v);
   for (int jj = 0; jj < nbb; ++jj) {
     const int j = j0 + jj;
+    if (jj + 1 < nbb) load_v(jj + 1, vn);
     const HhParam p = prm[j];
     const double2 tau = make_double2(p.tau_re, p.tau_im), scale = make_double2(p.scale_re, p.scale_im);
-    if (tau.x == 0.0 && tau.y == 0.0) continue;  // block-uniform
-    const double* vj = a + (long long)j * mm * E;
-    double2 v[RPT];
-    double dr = 0, di = 0;
+    if (tau.x != 0.0 || tau.y != 0.0) {  // block-uniform
+      double dr = 0, di = 0;
 #pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-      const int r = tid + 256 * q;
-      v[q] = (r > j && r < mm) ? Cx<CPLX>::ld(vj, r) : make_double2(0.0, 0.0);
-      const double2 t2 = cmulc(v[q], x[q]);
-      dr += t2.x;
-      di += t2.y;
-      if (r == j) {
-        s_head[0] = x[q].x;
-        s_head[1] = x[q].y;
+      for (int q = 0; q < RPT; ++q) {
+        const int r = tid + 256 * q;
+        const double2 t2 = cmulc(v[q], x[q]);
+        dr += t2.x;
+        di += t2.y;
+        if (r == j) {
+          s_head[0] = x[q].x;
+          s_head[1] = x[q].y;
+        }
       }
-    }
-    block_allsum2(dr, di);  // two barriers inside: s_head is visible afterwards
-    const double2 head = make_double2(s_head[0], s_head[1]);
-    const double2 sc = cmulc(scale, make_double2(dr, di));
-    const double2 f = cmulc(tau, make_double2(head.x + sc.x, head.y + sc.y));
-    const double2 fs = cmul(f, scale);
+      block_allsum2(dr, di);  // two barriers inside: s_head is visible afterwards
+      const double2 head = make_double2(s_head[0], s_head[1]);
+      const double2 sc = cmulc(scale, make_double2(dr, di));
+      const double2 f = cmulc(tau, make_double2(head.x + sc.x, head.y + sc.y));
+      const double2 fs = cmul(f, scale);
 #pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-      const int r = tid + 256 * q;
-      const double2 t2 = cmul(fs, v[q]);  // v is zero outside the tail
-      x[q].x -= t2.x;
-      x[q].y -= t2.y;
-      if (r == j) {
-        x[q].x -= f.x;
-        x[q].y -= f.y;
+      for (int q = 0; q < RPT; ++q) {
+        const int r = tid + 256 * q;
+        const double2 t2 = cmul(fs, v[q]);  // v is zero outside the tail
+        x[q].x -= t2.x;
+        x[q].y -= t2.y;
+        if (r == j) {
+          x[q].x -= f.x;
+          x[q].y -= f.y;
+        }
       }
+      __syncthreads();  // s_head reused by the next reflector
     }
-    __syncthreads();  // s_head reused by the next reflector
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) v[q] = vn[q];
   }
 #pragma unroll
   for (int q = 0; q < RPT; ++q) {
@@ -333,19 +329,22 @@ __global__ __launch_bounds__(256) void k_hh_formq_b(double* q_base, const double
 template <bool CPLX>
 int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk* dblk, int nblk, int max_mm,
                 int max_nn, int max_k, bool form_q) {
-  // register-resident configurations: panel kernel holds RPT1024 x NB elements, the column kernels RPT256
+  // Register-resident configurations: 4 rows x 4 columns per thread, so the workgroup grows with the block
+  // height.  Per column the kernel pays the cross-lane reductions (VALU-issue bound, ~200 cycles per value and
+  // wave - tools/ubench/sync_cost.hip - and serialised between the waves of a SIMD) plus the per-thread dot /
+  // update work; 4x4 balances the two (measured against 8x4 and 16x4 per thread).
   const int cfg = max_mm <= 1024 ? 0 : max_mm <= 2048 ? 1 : 2;
   const int nb = 4;
   for (int j0 = 0; j0 < max_k; j0 += nb) {
     switch (cfg) {
       case 0:
-        hipLaunchKernelGGL((k_hh_panel<CPLX, 1, 4>), dim3(nblk), dim3(1024), 0, ctx->stream, ws, dblk, prm, j0);
+        hipLaunchKernelGGL((k_hh_panel<CPLX, 256, 4, 4>), dim3(nblk), dim3(256), 0, ctx->stream, ws, dblk, prm, j0);
         break;
       case 1:
-        hipLaunchKernelGGL((k_hh_panel<CPLX, 2, 4>), dim3(nblk), dim3(1024), 0, ctx->stream, ws, dblk, prm, j0);
+        hipLaunchKernelGGL((k_hh_panel<CPLX, 512, 4, 4>), dim3(nblk), dim3(512), 0, ctx->stream, ws, dblk, prm, j0);
         break;
       default:
-        hipLaunchKernelGGL((k_hh_panel<CPLX, 4, 4>), dim3(nblk), dim3(1024), 0, ctx->stream, ws, dblk, prm, j0);
+        hipLaunchKernelGGL((k_hh_panel<CPLX, 1024, 4, 4>), dim3(nblk), dim3(1024), 0, ctx->stream, ws, dblk, prm, j0);
     }
     const int trailing = max_nn - j0 - 1;  // upper bound on columns to the right of any block's panel
     if (trailing > 0) {
