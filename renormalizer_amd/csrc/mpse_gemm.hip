@@ -48,17 +48,19 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ long long idx_off(const IdxMap& m, int i) {
-  // branch-free: single-level maps are canonicalised on the host to lo >= ext (hi == 0)
+  // single-level maps are canonicalised on the host to lo == INT_MAX: skip the integer division (uniform branch)
+  if (m.lo == 0x7fffffff) return (long long)i * m.s_lo;
   const int hi = i / m.lo;
   const int l = i - hi * m.lo;
   return (long long)hi * m.s_hi + (long long)l * m.s_lo;
 }
 
-constexpr int BM = 64, BN = 64, BK = 16, LD = 80, LDK = 17;  // panel = BK*LD >= BM*LDK doubles
+constexpr int BM = 64, BN = 64, BK = 16, LD = 80, LDK = BK + 1;  // panel = BK*LD >= BM*LDK doubles
+constexpr int NLD = BM * BK / 256;                             // staged elements per thread and operand
 
 // KS: both K maps are single level -> no integer division in the K loop
 template <bool CA, bool CB, bool KS>
-__global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void k_gemm(const GemmArgs g) {
   constexpr bool CC = CA || CB;
   constexpr int EA = CA ? 2 : 1, EB = CB ? 2 : 1, EC = CC ? 2 : 1;
   // one LDS object: [Are | Aim? | Bre | Bim?], each BK x LD doubles
@@ -87,20 +89,20 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
   double* C = g.C + (long long)b * g.sbC * EC;
 
   // ---- per-thread staging coordinates (4 elements of each operand tile)
-  int ai[4], ak[4], bj[4], bk[4];
-  long long aoff[4], boff[4];
+  int ai[NLD], ak[NLD], bj[NLD], bk[NLD];
+  long long aoff[NLD], boff[NLD];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < NLD; ++r) {
     if (g.a_kfast) {
-      ak[r] = tid & 15;
-      ai[r] = (tid >> 4) + 16 * r;
+      ak[r] = tid % BK;
+      ai[r] = tid / BK + (256 / BK) * r;
     } else {
       ai[r] = tid & 63;
       ak[r] = (tid >> 6) + 4 * r;
     }
     if (g.b_kfast) {
-      bk[r] = tid & 15;
-      bj[r] = (tid >> 4) + 16 * r;
+      bk[r] = tid % BK;
+      bj[r] = tid / BK + (256 / BK) * r;
     } else {
       bj[r] = tid & 63;
       bk[r] = (tid >> 6) + 4 * r;
@@ -113,11 +115,11 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
     boff[r] = idx_off(g.nB, gj);
   }
 
-  double2 ra[4], rb[4];
-  bool ka_in[4], kb_in[4];
+  double2 ra[NLD], rb[NLD];
+  bool ka_in[NLD], kb_in[NLD];
   auto load_tile = [&](int kt) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NLD; ++r) {
       {
         const int k = kt * BK + ak[r];
         const bool kin = k < g.K;
@@ -171,9 +173,9 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
   // LDS strides (in doubles) of element (i, k) of each panel
   const int sai = g.a_kfast ? LDK : 1, sak = g.a_kfast ? 1 : LD;
   const int sbj = g.b_kfast ? LDK : 1, sbk = g.b_kfast ? 1 : LD;
-  int wofa[4], wofb[4], rofa[2], rofb[2];
+  int wofa[NLD], wofb[NLD], rofa[2], rofb[2];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < NLD; ++r) {
     wofa[r] = ai[r] * sai + ak[r] * sak;
     wofb[r] = bj[r] * sbj + bk[r] * sbk;
   }
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs g) {
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NLD; ++r) {
       sAr[wofa[r]] = ka_in[r] ? ra[r].x : 0.0;
       if constexpr (CA) sAi[wofa[r]] = ka_in[r] ? sgn_a * ra[r].y : 0.0;
       sBr[wofb[r]] = kb_in[r] ? rb[r].x : 0.0;
@@ -417,8 +419,9 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
   g.ws = nullptr;
   TmpBuf WSB(ctx);
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-  if (base_blocks < n_cu && nkt_all >= 4) {
-    int want = (int)((2LL * n_cu + base_blocks - 1) / base_blocks);  // aim at ~2 workgroups per CU
+  if (base_blocks < 2 * n_cu && nkt_all >= 4) {
+    // aim at ~2 workgroups per CU (a single workgroup per CU cannot hide its own barrier / staging phases)
+    int want = base_blocks < n_cu ? (int)((2LL * n_cu + base_blocks - 1) / base_blocks) : 2;
     int maxs = nkt_all / 2;                                           // at least two k-tiles per slice
     int S = want < maxs ? want : maxs;
     if (S > 1) {
