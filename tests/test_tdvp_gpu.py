@@ -164,3 +164,26 @@ def test_expand_bond_dimension_then_tdvp(golden_dir):
         mps = mps.evolve(mpo, float(z["dt"]))
         occ = mps.e_occupations
         assert np.abs(occ - z["obs_values"][step + 1]).max() < 1e-6, (step, occ, z["obs_values"][step + 1])
+
+
+def test_spin_boson_config2_sigma_z():
+    """BASELINE config 2 at full size: spin + 20 bath modes (dphys 8), Dbond 64, TDVP-PS dt = 0.1; <sigma_z>(t)
+    of the reference run, tolerance 1e-6 as in the north star."""
+    from renormalizer_amd.mps.mps import Mps
+    from renormalizer_amd.sbm import param2model
+    model, delta = param2model(0.05, Quantity(1), Quantity(20), 1, 20, 8)
+    assert abs(delta - 0.8784670041569083) < 1e-12
+    mpo = Mpo(model)
+    assert max(mpo.bond_dims) == 3 and len(mpo) == 21
+    mps = Mps.ground_state(model, False)
+    mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=64)
+    mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    mps = mps.expand_bond_dimension(mpo, coef=1e-16, include_ex=False)
+    sz = Mpo(model, Op("sigma_z", "spin"))
+    ref = [1.0, 0.9846060563460243, 0.9389039214679588, 0.8643177094118863, 0.7631714975081663, 0.6386167803697902,
+           0.49453409941361465, 0.33541192144804705, 0.16620655032362253, -0.00781255235784125, -0.18122720641516832]
+    vals = [mps.expectation(sz)]
+    for _ in range(10):
+        mps = mps.evolve(mpo, 0.1)
+        vals.append(mps.expectation(sz))
+    assert np.abs(np.array(vals) - np.array(ref)).max() < 1e-6, vals
