@@ -339,5 +339,30 @@ def gen_mpo():
     print("mpo_dense.npz written; bond dims:", {k: v.tolist() for k, v in out.items() if k.endswith("bond")})
 
 
+def gen_tdvp_ps2():
+    """Two-site TDVP (mps.py:1406-1517) on the reduced headline model."""
+    from renormalizer.model import Phonon, Mol, HolsteinModel, Op
+    from renormalizer.mps import Mps, Mpo
+    from renormalizer.utils import Quantity, CompressConfig, EvolveConfig, EvolveMethod, CompressCriteria
+    nmol, pdim = 4, 4
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), pdim)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
+    gs = Mps.ground_state(model, max_entangled=False)
+    init = Mpo.onsite(model, r"a^\dagger", dof_set={nmol // 2}).apply(gs)
+    e0 = Quantity(init.expectation(Mpo(model)))
+    mpo = Mpo(model, offset=e0)
+    # a product state cannot grow its bonds under 2-site TDVP here (electron sites are separated by a phonon
+    # site), so start from the expanded state like the reference's transport job does
+    init.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=8)
+    init.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps2)
+    np.random.seed(9012)
+    init = init.expand_bond_dimension(mpo)
+    init.canonicalise()
+    occ = [Mpo(model, Op(r"a^\dagger a", dof)) for dof in model.e_dofs]
+    _tdvp_run(model, mpo, init, occ, 5, 10.0, "tdvp_ps2_holstein_small.npz")
+
+
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("mpo",)):
     gen_mpo()
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("ps2",)):
+    gen_tdvp_ps2()

@@ -628,3 +628,71 @@ def compress(state: MpsState, criteria="threshold", threshold=1e-3, max_dims=Non
         _update_ms(state, idx, u, v.T, s, qnl, qnr, m)
     state.switch_direction()
     return state, s_list
+
+
+def update_mps_2site(state: MpsState, cstruct, cidx, criteria, threshold, max_dims, percent=0.0, rng=None):
+    """MatrixProduct._update_mps for a two-site centre and a single state, mps/mp.py:651-888."""
+    qnbigl, qnbigr, _ = get_big_qn(state.qn[cidx[0]], state.qn[cidx[1] + 1],
+                                   [state.sigmaqn[cidx[0]], state.sigmaqn[cidx[1]]], state.to_right)
+    system = "L" if state.to_right else "R"
+    U, SU, qnl, V, SV, qnr = svd_qn(cstruct, qnbigl, qnbigr, state.qntot, system=system, rng=rng)
+    q = len(state.qntot)
+    if state.to_right:
+        bond = cidx[0] + 1
+        m = compute_m_trunc(SU, criteria, threshold, None if max_dims is None else max_dims[bond])
+        ms, dim, msqn, comp = select_basis(U, SU, qnl, V, m, percent)
+        state.sites[cidx[0]] = ms.reshape(qnbigl.shape[:-1] + (dim,))
+        state.sites[cidx[1]] = np.moveaxis(comp.reshape(qnbigr.shape[:-1] + (dim,)), -1, 0)
+        state.qnidx = cidx[1]
+    else:
+        bond = cidx[1]
+        m = compute_m_trunc(SV, criteria, threshold, None if max_dims is None else max_dims[bond])
+        ms, dim, msqn, comp = select_basis(V, SV, qnr, U, m, percent)
+        state.sites[cidx[1]] = np.moveaxis(ms.reshape(qnbigr.shape[:-1] + (dim,)), -1, 0)
+        state.sites[cidx[0]] = comp.reshape(qnbigl.shape[:-1] + (dim,))
+        state.qnidx = cidx[0]
+    state.qn[cidx[1]] = np.asarray(msqn).reshape(dim, q)
+
+
+def tdvp_ps2_step(state: MpsState, mpo, dt, criteria="fixed", threshold=1e-3, max_dims=None,
+                  normalize_after=True) -> MpsState:
+    """One ``Mps.evolve`` with EvolveMethod.tdvp_ps2 (Krylov solver), mps/mps.py:1406-1517."""
+    st = state.copy()
+    st.sites = [s.astype(complex) for s in st.sites]
+    n = st.nsite
+    env = build_environ(st.sites, mpo, None)
+    dims = []
+    for _ in range(2):
+        for imps in st.iter_idx_list(full=False):
+            if st.to_right:
+                lidx, c0, c1, ridx = imps - 1, imps, imps + 1, imps + 2
+                c2, last = c1, n - 2
+            else:
+                lidx, c0, c1, ridx = imps - 2, imps - 1, imps, imps + 1
+                c2, last = c0, 1
+            l, r = env[("L", lidx)], env[("R", ridx)]
+            ms2 = np.tensordot(st.sites[c0], st.sites[c1], axes=1)
+            shape = ms2.shape
+            c, k = expm_krylov(lambda y: hop_apply(l, r, [mpo[c0], mpo[c1]], y.reshape(shape)).ravel(),
+                               -1j * dt / 2, ms2.ravel())
+            dims.append(k)
+            update_mps_2site(st, c.reshape(shape), [c0, c1], criteria, threshold, max_dims)
+            if imps == last:
+                continue
+            if st.to_right:
+                l = contract_one_site(l, st.sites[lidx + 1], mpo[lidx + 1], "L")
+                env[("L", lidx + 1)] = l
+            else:
+                r = contract_one_site(r, st.sites[ridx - 1], mpo[ridx - 1], "R")
+                env[("R", ridx - 1)] = r
+            ms1 = st.sites[c2]
+            b, k = expm_krylov(lambda y: hop_apply(l, r, [mpo[c2]], y.reshape(ms1.shape)).ravel(),
+                               1j * dt / 2, ms1.ravel())
+            dims.append(k)
+            st.sites[c2] = b.reshape(ms1.shape)
+            push_cano(st, c2)
+        st.switch_direction()
+    st.krylov_dims = dims
+    if normalize_after:
+        normalize(st, "mps_only")
+    return st

@@ -668,6 +668,8 @@ class Mps:
         method = self.evolve_config.method
         if method is EvolveMethod.tdvp_ps:
             new_mps = self._evolve_tdvp_ps(mpo, evolve_dt)
+        elif method is EvolveMethod.tdvp_ps2:
+            new_mps = self._evolve_tdvp_ps2(mpo, evolve_dt)
         elif method is EvolveMethod.prop_and_compress:
             new_mps = self._evolve_prop_and_compress(mpo, evolve_dt)
         else:
@@ -743,6 +745,56 @@ class Mps:
                                       max=int(np.max(local_steps)), mean=float(np.mean(local_steps)),
                                       steps=list(local_steps))
         return mps
+
+
+def _evolve_tdvp_ps2(self, mpo, evolve_dt) -> "Mps":
+    """Two-site TDVP with projector splitting, mps/mps.py:1406-1517: forward step -i dt/2 of the two-site
+    centre, ``_update_mps`` (block SVD + truncation), environment update, backward step +i dt/2 of the
+    next one-site centre, ``_push_cano``; the last pair of each half sweep is not stepped back."""
+    if self.evolve_config.ivp_solver != "krylov":
+        raise NotImplementedError("only the Krylov (Lanczos) local propagator is implemented")
+    eng = get_engine()
+    mps = self.copy() if np.iscomplex(evolve_dt) else self.to_complex()
+    evolve_dt = complex(evolve_dt)
+    n = len(mps)
+    environ = Environ(mps, mpo, "R" if mps.to_right else "L")
+    local_steps = []
+    for _ in range(2):
+        for imps in mps.iter_idx_list(full=False):
+            if mps.to_right:
+                lidx, c0, c1, ridx = imps - 1, imps, imps + 1, imps + 2
+                c2, last_idx = c1, n - 2
+            else:
+                lidx, c0, c1, ridx = imps - 2, imps - 1, imps, imps + 1
+                c2, last_idx = c0, 1
+            l_array = environ.read("L", lidx)
+            r_array = environ.read("R", ridx)
+            a, b = mps[c0], mps[c1]
+            ms2 = eng.matmul(a.reshape(-1, a.shape[-1]), b.reshape(b.shape[0], -1)).reshape(a.shape[:-1] + b.shape[1:])
+            hop = hop_expr(l_array, r_array, [mpo.device(c0, eng), mpo.device(c1, eng)], ms2.shape)
+            mps_t, j = expm_krylov(hop, -1j * evolve_dt / 2, ms2)
+            local_steps.append(j)
+            qnbigl, qnbigr, _ = mps._get_big_qn([c0, c1])
+            mps._update_mps(mps_t.reshape(ms2.shape), [c0, c1], qnbigl, qnbigr)
+            if imps == last_idx:
+                continue
+            if mps.to_right:
+                l_array = environ.GetLR("L", lidx + 1, mps, mpo, itensor=l_array, method="System")
+            else:
+                r_array = environ.GetLR("R", ridx - 1, mps, mpo, itensor=r_array, method="System")
+            ms1 = mps[c2]
+            hop1 = hop_expr(l_array, r_array, [mpo.device(c2, eng)], ms1.shape)
+            mps_b, j = expm_krylov(hop1, 1j * evolve_dt / 2, ms1)
+            local_steps.append(j)
+            mps[c2] = mps_b.reshape(ms1.shape)
+            mps._push_cano(c2)
+        mps._switch_direction()
+    mps.evolve_config.stat = dict(nobs=len(local_steps), min=int(np.min(local_steps)), max=int(np.max(local_steps)),
+                                  mean=float(np.mean(local_steps)), steps=list(local_steps))
+    return mps
+
+
+Mps._evolve_tdvp_ps2 = _evolve_tdvp_ps2
 
 
 # Taylor coefficients of exp(x) up to 4th order (utils/rk.py "C_RK4" tableau used by P&C, configs.py:364-369)

@@ -166,3 +166,18 @@ def test_tdvp_ps_end_to_end(golden_dir, fname):
             for a, b in zip(st.qn, ref1.qn):
                 assert np.array_equal(_sorted_rows(a), _sorted_rows(b))
             assert st.qnidx == ref1.qnidx and st.to_right == ref1.to_right
+
+
+def test_tdvp_ps2_end_to_end(golden_dir):
+    z = np.load(os.path.join(golden_dir, "tdvp_ps2_holstein_small.npz"))
+    n = int(z["mpo_nsite"])
+    mpo = [z[f"mpo_w_{i}"] for i in range(n)]
+    obs = [[z[f"obs{j}_w_{i}"] for i in range(n)] for j in range(int(z["nobs"]))]
+    sigmaqn = [z[f"sigmaqn_{i}"] for i in range(n)]
+    st = _load_state(z, "init_", sigmaqn)
+    for step in range(len(z["obs_values"]) - 1):
+        st = orc.tdvp_ps2_step(st, mpo, float(z["dt"]), criteria="fixed", max_dims=np.full(n + 1, 8))
+        vals = [orc.expectation(st.sites, o) for o in obs]
+        assert np.abs(np.array(vals) - z["obs_values"][step + 1]).max() < 1e-8
+        assert list(st.bond_dims) == list(z["bond_dims"][step])
+        assert len(st.krylov_dims) == int(z["krylov_stat"][step][0])

@@ -187,3 +187,17 @@ def test_spin_boson_config2_sigma_z():
         mps = mps.evolve(mpo, 0.1)
         vals.append(mps.expectation(sz))
     assert np.abs(np.array(vals) - np.array(ref)).max() < 1e-6, vals
+
+
+def test_tdvp_ps2_matches_reference(golden_dir):
+    """Two-site TDVP (block SVD + truncation path) against the reference run in tests/golden."""
+    z, mpo, obs, mps, ost = _load(golden_dir, "tdvp_ps2_holstein_small.npz")
+    mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps2)
+    mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=8)
+    for step in range(len(z["obs_values"]) - 1):
+        mps = mps.evolve(mpo, float(z["dt"]))
+        vals = mps.expectations(obs)
+        assert np.abs(vals - z["obs_values"][step + 1]).max() < 1e-8
+        assert abs(mps.expectation(mpo) - z["energies"][step + 1]) < 1e-9
+        assert list(mps.bond_dims) == list(z["bond_dims"][step])
+        assert mps.evolve_config.stat["nobs"] == int(z["krylov_stat"][step][0])
