@@ -202,6 +202,37 @@ class Mps:
         """Download all site tensors (debugging / checkpointing)."""
         return [t.to_host() for t in self._mp]
 
+    # ------------------------------------------------------------------ checkpoint wire format
+    def dump(self, fname):
+        """Write the reference's npz protocol "0.4" (mps/mp.py:1085-1113, mps/mps.py:1795-1796): ``mt_i`` site
+        arrays, ``qnidx``, ``qntot``, ``qn`` (object array) + ``subqn_i``, ``to_right``, ``coeff`` - files are
+        interchangeable with ``renormalizer.Mps.load`` / ``dump``."""
+        data = {"version": "0.4", "nsites": self.site_num}
+        for i, t in enumerate(self._mp):
+            data[f"mt_{i}"] = t.to_host()
+        qn = np.empty(len(self.qn), object)
+        qn[:] = [np.asarray(q) for q in self.qn]
+        data.update(qnidx=self.qnidx, qntot=self.qntot, qn=qn, to_right=self.to_right, coeff=self.coeff)
+        for i, q in enumerate(self.qn):
+            data[f"subqn_{i}"] = np.asarray(q)
+        np.savez(fname, **data)
+
+    @classmethod
+    def load(cls, model, fname: str):
+        """Read protocol 0.3 / 0.4 files (mps/mps.py:352-386)."""
+        z = np.load(fname, allow_pickle=True)
+        version = str(z["version"])
+        if version not in ("0.3", "0.4"):
+            raise ValueError(f"Unknown dump version: {version}")
+        n = int(z["nsites"])
+        arrays = [z[f"mt_{i}"] for i in range(n)]
+        if f"subqn_{n}" in z.files:
+            qn = [np.asarray(z[f"subqn_{i}"]).astype(int) for i in range(n + 1)]
+        else:
+            qn = [np.asarray(q).astype(int) for q in z["qn"]]
+        return cls.from_arrays(model, arrays, qn, int(z["qnidx"]), np.asarray(z["qntot"]).astype(int),
+                               bool(z["to_right"]), z["coeff"].item(0))
+
     def _get_sigmaqn(self, idx):
         return np.array(self.model.basis[idx].sigmaqn)
 

@@ -201,3 +201,27 @@ def test_tdvp_ps2_matches_reference(golden_dir):
         assert abs(mps.expectation(mpo) - z["energies"][step + 1]) < 1e-9
         assert list(mps.bond_dims) == list(z["bond_dims"][step])
         assert mps.evolve_config.stat["nobs"] == int(z["krylov_stat"][step][0])
+
+
+def test_checkpoint_wire_format(golden_dir, tmp_path):
+    """A checkpoint written by the reference (protocol 0.4) loads into the device MPS and gives the same
+    expectation values; our own dump round-trips and keeps the reference's key set."""
+    from renormalizer_amd.mps.mps import Mps
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), 4)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * 3, Quantity(3.0e-2), 3)
+    mps = Mps.load(model, os.path.join(golden_dir, "ref_dump_v04.npz"))
+    exp = np.load(os.path.join(golden_dir, "ref_dump_v04_expect.npz"))
+    assert list(mps.bond_dims) == list(exp["bond"])
+    assert abs(mps.expectation(Mpo(model)) - float(exp["energy"])) < 1e-12
+    assert np.abs(mps.e_occupations - exp["occ"]).max() < 1e-12
+    assert mps.coeff == 0.5 + 0.25j
+    out = str(tmp_path / "ours.npz")
+    mps.dump(out)
+    a, b = np.load(out, allow_pickle=True), np.load(os.path.join(golden_dir, "ref_dump_v04.npz"), allow_pickle=True)
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        if k == "qn":
+            continue
+        assert np.array_equal(a[k], b[k]), k
+    again = Mps.load(model, out)
+    assert abs(again.expectation(Mpo(model)) - float(exp["energy"])) < 1e-12
