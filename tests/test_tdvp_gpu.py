@@ -225,3 +225,47 @@ def test_checkpoint_wire_format(golden_dir, tmp_path):
         assert np.array_equal(a[k], b[k]), k
     again = Mps.load(model, out)
     assert abs(again.expectation(Mpo(model)) - float(exp["energy"])) < 1e-12
+
+
+def test_imaginary_time_tdvp_real_dtype():
+    """Imaginary-time TDVP-PS keeps a real MPS real (mps.py:1273-1278: complex evolve_dt -> real local steps)
+    and lowers the energy; compared with the oracle on the same inputs."""
+    from renormalizer_amd.mps.mps import Mps
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), 4)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * 3, Quantity(3.0e-2), 3)
+    mpo = Mpo(model)
+    mps = Mps.random(model, 1, 8, rng=np.random.default_rng(5))
+    mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    ost = orc.MpsState(mps.to_arrays(), [q.copy() for q in mps.qn], mps.qnidx, mps.qntot.copy(), mps.to_right,
+                       [np.array(b.sigmaqn) for b in model.basis])
+    w = [mpo[i] for i in range(len(mpo))]
+    e_prev = mps.expectation(mpo)
+    for _ in range(3):
+        mps = mps.evolve(mpo, -20.0j)
+        ost = orc.tdvp_ps_step(ost, w, -20.0j)
+        assert not mps.is_complex
+        e = mps.expectation(mpo)
+        assert e < e_prev
+        e_prev = e
+        assert abs(e - orc.expectation(ost.sites, w)) < 1e-10
+        assert abs(mps.mp_norm - 1) < 1e-12
+
+
+def test_headline_size_invariants():
+    """BASELINE headline size (50 sites, dphys 2/16, Dbond 256): properties that do not need the oracle -
+    norm and particle number conserved, energy conserved by the unitary step, mirror symmetry of the chain."""
+    import bench
+    model, mpo, mps = bench.build_workload(25, 16, 256, 0, "physical")
+    assert max(mps.bond_dims) == 256 and len(mps) == 50
+    e0 = mps.expectation(mpo)
+    occ0 = mps.e_occupations
+    assert abs(occ0[12] - 1) < 1e-9 and abs(e0) < 1e-9          # offset = initial energy
+    for _ in range(2):
+        mps = mps.evolve(mpo, 10.0)
+    occ = mps.e_occupations
+    assert abs(mps.mp_norm - 1) < 1e-12
+    assert abs(occ.sum() - 1) < 1e-9
+    assert np.abs(occ - occ[::-1]).max() < 1e-7                    # chain and initial state are mirror symmetric
+    assert abs(mps.expectation(mpo) - e0) < 1e-6                   # TDVP conserves <H>
+    assert occ[12] < 0.99 and occ[11] > 1e-3                       # the carrier moved
+    assert mps.qntot.tolist() == [1] and all(len(q) == d for q, d in zip(mps.qn, mps.bond_dims))
