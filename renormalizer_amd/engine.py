@@ -415,12 +415,24 @@ class Engine:
 
 _ENGINE = None
 _LOCK = threading.Lock()
+_TLS = threading.local()
 
 
 def get_engine() -> Engine:
-    """Process-wide engine, created on first use."""
+    """Engine of the calling thread (see ``use_engine``), else the process-wide one, created on first use."""
+    eng = getattr(_TLS, "engine", None)
+    if eng is not None:
+        return eng
     global _ENGINE
     with _LOCK:
         if _ENGINE is None:
             _ENGINE = Engine()
         return _ENGINE
+
+
+def use_engine(eng):
+    """Bind ``eng`` (own HIP stream + memory pool) to the calling thread: several independent trajectories can
+    then share one GPU from different threads - ctypes releases the GIL inside the engine, and kernels of
+    different streams overlap, so one trajectory's latency-bound phases (QR panels, small solves) hide under
+    another's contractions.  Pass None to return to the process-wide engine."""
+    _TLS.engine = eng
