@@ -24,6 +24,12 @@ from .svd_qn import add_outer, get_qn_mask
 logger = logging.getLogger("renormalizer_amd")
 
 
+def _is_identity_site(w):
+    """MPO site tensor (w_l, d, d, w_r) that is exactly the identity pass-through."""
+    w = np.asarray(w)
+    return w.shape[0] == 1 and w.shape[3] == 1 and np.array_equal(w[0, :, :, 0], np.eye(w.shape[1]))
+
+
 class Mps:
     def __init__(self):
         self._mp: List[DeviceTensor] = []
@@ -376,9 +382,57 @@ class Mps:
         return float(val.real) if np.isclose(val.imag, 0) else val
 
     def expectations(self, mpos, self_conj: "Mps" = None, opt=True) -> np.ndarray:
-        """mps/mps.py:527-575 (shared-prefix caching is left to a later round: observables are
-        outside the timed sweep)."""
-        return np.array([self.expectation(m, self_conj) for m in mpos])
+        """Expectation values of several operators with shared environments, mps/mps.py:527-575 and
+        ``_construct_freq_environ`` :2103-2146.  The reference caches L/R prefixes keyed by the hash of the MPO
+        site matrices; here every MPO is split into [identity sites | non-trivial window | identity sites], the
+        identity-MPO environments (plain overlap matrices, w = 1) are built once for all operators, and only the
+        window of each operator is contracted."""
+        mpos = [Mpo(self.model, m) if isinstance(m, (Op, OpSum)) else m for m in mpos]
+        if not opt or len(mpos) < 2:
+            return np.array([self.expectation(m, self_conj) for m in mpos])
+        eng = get_engine()
+        n = len(self)
+        conj_sites = None if self_conj is None else self_conj._mp
+        windows = []
+        for m in mpos:
+            nontrivial = [i for i in range(n) if not _is_identity_site(m[i])]
+            windows.append((nontrivial[0], nontrivial[-1]) if nontrivial else (0, -1))
+        lmax = max([w[0] for w in windows if w[1] >= 0], default=0)       # L environments needed up to lmax-1
+        rmin = min([w[1] for w in windows if w[1] >= 0], default=n - 1)   # R environments needed from rmin+1
+        ident = {}
+
+        def ident_w(i):
+            d = self[i].shape[1]
+            if d not in ident:
+                ident[d] = eng.asdevice(np.eye(d).reshape(1, d, d, 1))
+            return ident[d]
+
+        def cj(i):
+            return None if conj_sites is None else conj_sites[i]
+
+        sentinel = eng.ones((1, 1, 1), np.float64)
+        lenv = {-1: sentinel}
+        for i in range(0, lmax):
+            lenv[i] = contract_one_site(lenv[i - 1], self[i], ident_w(i), "L", ms_conj=cj(i))
+        renv = {n: sentinel}
+        for i in range(n - 1, rmin, -1):
+            renv[i] = contract_one_site(renv[i + 1], self[i], ident_w(i), "R", ms_conj=cj(i))
+        out = []
+        for m, (first, last) in zip(mpos, windows):
+            if last < 0:                       # pure identity (possibly scaled): fall back to the plain path
+                out.append(self.expectation(m, self_conj))
+                continue
+            t = lenv[first - 1]
+            for i in range(first, last + 1):
+                t = contract_one_site(t, self[i], m.device(i, eng), "L", ms_conj=cj(i))
+            r = renv[last + 1]
+            # close: sum_{a,c} t[a,0,c] r[a,0,c]   (both (D_bra, 1, D_ket))
+            a = t.to_complex() if (t.is_complex or r.is_complex) else t
+            b = r.to_complex() if (t.is_complex or r.is_complex) else r
+            prod = eng.matmul(a.reshape(1, -1), b.reshape(-1, 1)).to_host().reshape(-1)[0]
+            prod = complex(prod)
+            out.append(float(prod.real) if np.isclose(prod.imag, 0) else prod)
+        return np.array(out)
 
     @property
     def e_occupations(self):

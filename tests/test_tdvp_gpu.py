@@ -269,3 +269,22 @@ def test_headline_size_invariants():
     assert abs(mps.expectation(mpo) - e0) < 1e-6                   # TDVP conserves <H>
     assert occ[12] < 0.99 and occ[11] > 1e-3                       # the carrier moved
     assert mps.qntot.tolist() == [1] and all(len(q) == d for q, d in zip(mps.qn, mps.bond_dims))
+
+
+def test_expectations_shared_environments():
+    """mps/tests/test_mps.py:30-43: the cached ``expectations`` equals operator-by-operator ``expectation``."""
+    from renormalizer_amd.mps.mps import Mps
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), 4)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * 4, Quantity(3.0e-2), 3)
+    mps = Mps.random(model, 1, 10, rng=np.random.default_rng(11)).to_complex()
+    mps = mps.scale(0.7 - 0.2j)
+    mpos = [Mpo(model, Op(r"a^\dagger a", d)) for d in model.e_dofs]
+    mpos += [Mpo(model, Op(r"a^\dagger a", [0, 3], 0.5)), Mpo(model, Op("x", (1, 0), 2.0)), Mpo(model),
+             Mpo(model, Op(r"a^\dagger a", 1) * Op("x^2", (2, 0)))]
+    fast = mps.expectations(mpos)
+    slow = np.array([mps.expectation(m) for m in mpos])
+    assert np.abs(fast - slow).max() < 1e-13 * max(1.0, np.abs(slow).max())
+    bra = Mps.random(model, 1, 7, rng=np.random.default_rng(12))
+    fast = mps.expectations(mpos[:5], self_conj=bra)
+    slow = np.array([mps.expectation(m, self_conj=bra) for m in mpos[:5]])
+    assert np.abs(fast - slow).max() < 1e-13
