@@ -55,12 +55,15 @@ __device__ __forceinline__ long long idx_off(const IdxMap& m, int i) {
   return (long long)hi * m.s_hi + (long long)l * m.s_lo;
 }
 
+#ifndef MPSE_GEMM_3M
+#define MPSE_GEMM_3M 1
+#endif
 constexpr int BM = 64, BN = 64, BK = 16, LD = 80, LDK = BK + 1;  // panel = BK*LD >= BM*LDK doubles
 constexpr int NLD = BM * BK / 256;                             // staged elements per thread and operand
 
 // KS: both K maps are single level -> no integer division in the K loop
 template <bool CA, bool CB, bool KS>
-__global__ __launch_bounds__(256, 2) void k_gemm(const GemmArgs g) {
+__global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(const GemmArgs g) {
   constexpr bool CC = CA || CB;
   constexpr int EA = CA ? 2 : 1, EB = CB ? 2 : 1, EC = CC ? 2 : 1;
   // one LDS object: [Are | Aim? | Bre | Bim?], each BK x LD doubles
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const GemmArgs g) {
 
   double2 ra[NLD], rb[NLD];
   bool ka_in[NLD], kb_in[NLD];
-  auto load_tile = [&](int kt) {
+  // generic tile load: two-level K maps and the (only possibly partial) last K tile
+  auto load_edge = [&](int kt) {
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
       {
@@ -154,20 +158,92 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const GemmArgs g) {
       }
     }
   };
+  const int nkt_all = (g.K + BK - 1) / BK;
+  const int kt_begin = ks_id * g.kt_per_split;
+  const int kt_end = min(nkt_all, kt_begin + g.kt_per_split);
+  // fast path (single-level K maps, full K tile): running pointers, no clamps, no index arithmetic in the loop
+  const double* pa[NLD];
+  const double* pb[NLD];
+  long long step_a = 0, step_b = 0;
+  if constexpr (KS) {
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+      pa[r] = A + (aoff[r] + (long long)(kt_begin * BK + ak[r]) * g.kA.s_lo) * EA;
+      pb[r] = B + (boff[r] + (long long)(kt_begin * BK + bk[r]) * g.kB.s_lo) * EB;
+    }
+    step_a = (long long)BK * g.kA.s_lo * EA;
+    step_b = (long long)BK * g.kB.s_lo * EB;
+  }
+  // FULL: every k of the tile is < K.  Otherwise (at most the last K tile of a GEMM) lanes past K skip the
+  // load and stage zeros.
+  auto load_ks = [&](int kt, bool full) {
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+      const bool ina = full || kt * BK + ak[r] < g.K;
+      const bool inb = full || kt * BK + bk[r] < g.K;
+      ra[r] = make_double2(0.0, 0.0);
+      rb[r] = make_double2(0.0, 0.0);
+      if (ina) {
+        if constexpr (CA)
+          ra[r] = *reinterpret_cast<const double2*>(pa[r]);
+        else
+          ra[r].x = *pa[r];
+      }
+      if (inb) {
+        if constexpr (CB)
+          rb[r] = *reinterpret_cast<const double2*>(pb[r]);
+        else
+          rb[r].x = *pb[r];
+      }
+      pa[r] += step_a;
+      pb[r] += step_b;
+    }
+  };
+  auto load_full = [&]() {
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+      if constexpr (CA) {
+        ra[r] = *reinterpret_cast<const double2*>(pa[r]);
+      } else {
+        ra[r].x = *pa[r];
+        ra[r].y = 0.0;
+      }
+      pa[r] += step_a;
+      if constexpr (CB) {
+        rb[r] = *reinterpret_cast<const double2*>(pb[r]);
+      } else {
+        rb[r].x = *pb[r];
+        rb[r].y = 0.0;
+      }
+      pb[r] += step_b;
+    }
+  };
+  auto load_tile = [&](int kt) {
+    if constexpr (KS) {
+      if ((kt + 1) * BK <= g.K)
+        load_full();
+      else
+        load_ks(kt, false);
+    } else {
+      load_edge(kt);
+    }
+  };
   const double sgn_a = g.conjA ? -1.0 : 1.0, sgn_b = g.conjB ? -1.0 : 1.0;
 
-  v4d acc_re[2][2], acc_im[2][2];
+  // complex x complex uses the 3M scheme (three real products per complex product instead of four):
+  //   T1 = Ar Br, T2 = Ai Bi, T3 = (Ar + Ai)(Br + Bi)  =>  re = T1 - T2, im = T3 - T1 - T2
+  // acc_re holds T1, acc_im holds T3, acc_t2 holds T2 until the epilogue combines them.
+  constexpr bool M3 = CA && CB && MPSE_GEMM_3M;
+  v4d acc_re[2][2], acc_im[2][2], acc_t2[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       acc_re[i][j] = v4d{0, 0, 0, 0};
       acc_im[i][j] = v4d{0, 0, 0, 0};
+      acc_t2[i][j] = v4d{0, 0, 0, 0};
     }
 
-  const int nkt_all = (g.K + BK - 1) / BK;
-  const int kt_begin = ks_id * g.kt_per_split;
-  const int kt_end = min(nkt_all, kt_begin + g.kt_per_split);
   if (kt_begin < kt_end) load_tile(kt_begin);
   const int frow = lane & 15, fk = lane >> 4;
   // LDS strides (in doubles) of element (i, k) of each panel
@@ -185,46 +261,87 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const GemmArgs g) {
     rofb[i] = (wn * 32 + i * 16 + frow) * sbj + fk * sbk;
   }
 
+  // operand fragments of one k-group (4 of K): double buffered so that the ds_reads of group kk+1 are in
+  // flight under the 16 MFMAs of group kk
+  double f_ar[2][2], f_ai[2][2], f_br[2][2], f_bi[2][2];
+  auto read_frag = [&](int buf, int kk) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f_ar[buf][i] = sAr[rofa[i] + kk * 4 * sak];
+      if constexpr (CA) f_ai[buf][i] = sAi[rofa[i] + kk * 4 * sak];
+      f_br[buf][i] = sBr[rofb[i] + kk * 4 * sbk];
+      if constexpr (CB) f_bi[buf][i] = sBi[rofb[i] + kk * 4 * sbk];
+    }
+  };
+
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
-      sAr[wofa[r]] = ka_in[r] ? ra[r].x : 0.0;
-      if constexpr (CA) sAi[wofa[r]] = ka_in[r] ? sgn_a * ra[r].y : 0.0;
-      sBr[wofb[r]] = kb_in[r] ? rb[r].x : 0.0;
-      if constexpr (CB) sBi[wofb[r]] = kb_in[r] ? sgn_b * rb[r].y : 0.0;
+      if constexpr (KS) {  // out-of-range k were staged as zeros by load_ks
+        sAr[wofa[r]] = ra[r].x;
+        if constexpr (CA) sAi[wofa[r]] = sgn_a * ra[r].y;
+        sBr[wofb[r]] = rb[r].x;
+        if constexpr (CB) sBi[wofb[r]] = sgn_b * rb[r].y;
+      } else {
+        sAr[wofa[r]] = ka_in[r] ? ra[r].x : 0.0;
+        if constexpr (CA) sAi[wofa[r]] = ka_in[r] ? sgn_a * ra[r].y : 0.0;
+        sBr[wofb[r]] = kb_in[r] ? rb[r].x : 0.0;
+        if constexpr (CB) sBi[wofb[r]] = kb_in[r] ? sgn_b * rb[r].y : 0.0;
+      }
     }
     __syncthreads();
     if (kt + 1 < kt_end) load_tile(kt + 1);
 
+    read_frag(0, 0);
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      double ar[2], aim[2], br[2], bim[2];
+      const int cb = kk & 1;
+      if (kk + 1 < BK / 4) read_frag(cb ^ 1, kk + 1);
+      if constexpr (M3) {
+        double as[2], bs[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ar[i] = sAr[rofa[i] + kk * 4 * sak];
-        if constexpr (CA) aim[i] = sAi[rofa[i] + kk * 4 * sak];
-        br[i] = sBr[rofb[i] + kk * 4 * sbk];
-        if constexpr (CB) bim[i] = sBi[rofb[i] + kk * 4 * sbk];
+        for (int i = 0; i < 2; ++i) {
+          as[i] = f_ar[cb][i] + f_ai[cb][i];
+          bs[i] = f_br[cb][i] + f_bi[cb][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_br[cb][j], acc_re[i][j], 0, 0, 0);
+            acc_t2[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ai[cb][i], f_bi[cb][j], acc_t2[i][j], 0, 0, 0);
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[i], bs[j], acc_im[i][j], 0, 0, 0);
+          }
+        continue;
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], br[j], acc_re[i][j], 0, 0, 0);
+          acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_br[cb][j], acc_re[i][j], 0, 0, 0);
           if constexpr (CA && CB) {
-            acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-aim[i], bim[j], acc_re[i][j], 0, 0, 0);
-            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], bim[j], acc_im[i][j], 0, 0, 0);
-            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[i], br[j], acc_im[i][j], 0, 0, 0);
+            acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-f_ai[cb][i], f_bi[cb][j], acc_re[i][j], 0, 0, 0);
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_bi[cb][j], acc_im[i][j], 0, 0, 0);
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ai[cb][i], f_br[cb][j], acc_im[i][j], 0, 0, 0);
           } else if constexpr (CA) {
-            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[i], br[j], acc_im[i][j], 0, 0, 0);
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ai[cb][i], f_br[cb][j], acc_im[i][j], 0, 0, 0);
           } else if constexpr (CB) {
-            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], bim[j], acc_im[i][j], 0, 0, 0);
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_bi[cb][j], acc_im[i][j], 0, 0, 0);
           }
         }
     }
   }
 
+  if constexpr (M3) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc_im[i][j] = acc_im[i][j] - acc_re[i][j] - acc_t2[i][j];
+        acc_re[i][j] = acc_re[i][j] - acc_t2[i][j];
+      }
+  }
   // ---- epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 tile
   if (g.ksplit > 1) {
     // raw partial sums; alpha/beta and the strided store happen in k_splitk_reduce

@@ -13,7 +13,8 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmpsengine.so")
+# RENO_MPSENGINE overrides the in-tree library; there is still no CPU fallback
+LIB_PATH = os.environ.get("RENO_MPSENGINE") or os.path.join(_HERE, "csrc", "libmpsengine.so")
 
 F64, C128 = 0, 1
 DOMAIN_L, DOMAIN_R = 0, 1
