@@ -149,6 +149,8 @@ typedef struct {
   int64_t d0, d1;           /* physical dims of the centre site(s); d1 unused for 0/1-site */
   int64_t danc;             /* ancilla dim of an MPDM site, 1 for an MPS */
   int64_t wl, wm, wr;       /* mpo bonds: left, middle (2-site only), right */
+  int64_t env_unit;         /* mpse_env_update only: 1-based MPO-bond channel b with env[:, b, :] == identity
+                               (see mpse_env_unit_channel); 0 = none / unknown */
 } mpse_dims;
 
 /* Environment update, replaces mps/lib.py:169-250 contract_one_site
@@ -164,6 +166,14 @@ int mpse_env_update(mpse_ctx* ctx, int dtype, int domain, const mpse_dims* dims,
                     const void* env, int env_dtype, const void* ket, const void* bra, int bra_conj,
                     const void* W, int w_dtype, void* out);
 
+/* Finds an MPO-bond channel b of a square environment env (D, w, D) with max|env[:, b, :] - 1| <= tol: the
+ * channel in which no operator has acted yet is the identity matrix when the sites behind it are canonical
+ * (the reference contracts it like any other, mps/lib.py:200-205).  *unit_host = b + 1, or 0 if there is none.
+ * The result is passed as mpse_dims.env_unit / mpse_heff.l_unit / r_unit so that the big GEMMs skip that channel.
+ * Synchronous (one small read-back). */
+int mpse_env_unit_channel(mpse_ctx* ctx, int dtype, const void* env, int64_t D, int64_t w, double tol,
+                          int64_t* unit_host);
+
 /* Effective Hamiltonian applied to the centre, replaces the closures built by
  * mps/hop_expr.py:57-115 (0-site abc,lbk,ck->al ; 1-site abc,bdef,lfk,cek->adl ;
  * 2-site abc,bdef,fghj,ljk,cehk->adgl ; ancilla variants), order (L.C).W.R.
@@ -175,6 +185,8 @@ typedef struct {
   const void* L; int l_dtype;
   const void* R; int r_dtype;
   const void* W0; const void* W1; int w_dtype;
+  int64_t l_unit, r_unit;   /* 1-based channel along which L (resp. R) is the identity matrix, 0 = none:
+                               that slice of the contraction is a copy instead of a GEMM */
 } mpse_heff;
 
 int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, void* out);

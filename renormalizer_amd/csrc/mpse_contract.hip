@@ -6,6 +6,74 @@
 
 using namespace mpse_plan;
 
+namespace {
+
+__device__ __forceinline__ long long off2(const mpse_index m, long long i) {
+  if (m.lo_ext >= m.ext) return i * m.s_lo;
+  const long long hi = i / m.lo_ext;
+  return hi * m.s_hi + (i - hi * m.lo_ext) * m.s_lo;
+}
+
+// dst(i,j) = src(i,j) through two-level row / column maps; one 16 B (complex) or 8 B element per thread,
+// threads run along j so contiguous columns coalesce
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy_strided(T* dst, const T* src, mpse_index mi, mpse_index ni, mpse_index mo,
+                                                      mpse_index no) {
+  const long long nn = ni.ext;
+  const long long total = mi.ext * nn;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const long long i = t / nn, j = t - i * nn;
+    dst[off2(mo, i) + off2(no, j)] = src[off2(mi, i) + off2(ni, j)];
+  }
+}
+
+// dev[b] = max_{a,c} | E[a,b,c] - delta(a,c) | for an environment E (D, w, D); doubles are non-negative, so
+// their bit patterns order like integers and atomicMax on the 64-bit pattern is an exact max
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_unit_deviation(const double* env, int D, int w, unsigned long long* dev) {
+  constexpr int E = CPLX ? 2 : 1;
+  const int a = blockIdx.x;
+  __shared__ double red[4];
+  for (int b = 0; b < w; ++b) {
+    const double* row = env + ((long long)a * w + b) * D * E;
+    double m = 0.0;
+    for (int c = threadIdx.x; c < D; c += 256) {
+      double re = row[c * E] - (c == a ? 1.0 : 0.0);
+      double v = fabs(re);
+      if (CPLX) v = fmax(v, fabs(row[c * E + 1]));
+      if (!(v <= 1e300)) v = 1e300;  // NaN / inf never pass for a unit channel
+      m = fmax(m, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+      atomicMax(dev + b, (unsigned long long)__double_as_longlong(m));
+    }
+    __syncthreads();
+  }
+}
+
+int copy_call(mpse_ctx* ctx, int dtype, const void* src, void* dst, mpse_index mi, mpse_index ni, mpse_index mo,
+              mpse_index no) {
+  const long long total = mi.ext * ni.ext;
+  if (total <= 0) return MPSE_OK;
+  long long nb = (total + 255) / 256;
+  if (nb > 65536) nb = 65536;
+  if (dtype == MPSE_C128)
+    hipLaunchKernelGGL((k_copy_strided<double2>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, (double2*)dst,
+                       (const double2*)src, mi, ni, mo, no);
+  else
+    hipLaunchKernelGGL((k_copy_strided<double>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, (double*)dst,
+                       (const double*)src, mi, ni, mo, no);
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
+}  // namespace
+
 static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in[B_COUNT]) {
   if (p.error) return mpse_fail(ctx, MPSE_ERR_SHAPE, "%s", p.error);
   const void* bufs[B_COUNT];
@@ -32,8 +100,12 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
       return mpse_fail(ctx, MPSE_ERR_ARG, "plan step dtype mismatch (got %d want %d)", dtc, dtype);
     char* c = (char*)const_cast<void*>(bufs[s.c]) + size_t(s.c_off) * dtype_size(dtc);
     if (!bufs[s.a] || !bufs[s.b] || !bufs[s.c]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing buffer");
+    if (s.kind == K_COPY) {
+      MPSE_TRY(copy_call(ctx, dtc, a, c, s.ma, s.ka, s.mc, s.nc));
+      continue;
+    }
     MPSE_TRY(gemm_call(ctx, s.dta, s.dtb, s.conja, s.conjb, s.ma, s.ka, s.kb, s.nb, s.mc, s.nc, s.batch, s.sba,
-                       s.sbb, s.sbc, a, b, c));
+                       s.sbb, s.sbc, a, b, c, 1.0, s.beta));
   }
   return MPSE_OK;
 }
@@ -72,4 +144,28 @@ extern "C" int mpse_env_update(mpse_ctx* ctx, int dtype, int domain, const mpse_
   bufs[B_BRA] = bra;
   bufs[B_OUT] = out;
   return run_plan(ctx, dtype, p, bufs);
+}
+
+extern "C" int mpse_env_unit_channel(mpse_ctx* ctx, int dtype, const void* env, int64_t D, int64_t w, double tol,
+                                     int64_t* unit_host) {
+  if (!ctx || !env || !unit_host) return MPSE_ERR_ARG;
+  *unit_host = 0;
+  if (D <= 0 || w <= 0 || w > 2048) return MPSE_OK;
+  unsigned long long* dev = reinterpret_cast<unsigned long long*>(ctx->dscratch);
+  MPSE_HIP(ctx, hipMemsetAsync(dev, 0, size_t(w) * sizeof(double), ctx->stream));
+  if (dtype == MPSE_C128)
+    hipLaunchKernelGGL((k_unit_deviation<true>), dim3((unsigned)D), dim3(256), 0, ctx->stream, (const double*)env, (int)D,
+                       (int)w, dev);
+  else
+    hipLaunchKernelGGL((k_unit_deviation<false>), dim3((unsigned)D), dim3(256), 0, ctx->stream, (const double*)env,
+                       (int)D, (int)w, dev);
+  MPSE_HIP(ctx, hipGetLastError());
+  MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + 32, dev, size_t(w) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int64_t b = 0; b < w; ++b)
+    if (ctx->pinned[32 + b] <= tol) {
+      *unit_host = b + 1;
+      break;
+    }
+  return MPSE_OK;
 }

@@ -18,6 +18,8 @@ namespace mpse_plan {
 
 enum Buf { B_L = 0, B_R, B_W0, B_W1, B_C, B_BRA, B_OUT, B_T1, B_T2, B_T3, B_COUNT };
 
+enum Kind { K_GEMM = 0, K_COPY = 1 };
+
 struct Step {
   int a, b, c;                 // buffer ids
   int64_t a_off, b_off, c_off; // element offsets into the buffers
@@ -25,6 +27,8 @@ struct Step {
   int conja, conjb;
   mpse_index ma, ka, kb, nb, mc, nc;
   int64_t batch, sba, sbb, sbc;
+  int kind = K_GEMM;           // K_COPY: C(i,j) = A(i,j) with A indexed by (ma, ka), C by (mc, nc); b unused
+  double beta = 0.0;           // K_GEMM: C = A.B + beta C
 };
 
 struct Plan {
@@ -42,6 +46,57 @@ inline void push(Plan& p, int a, int64_t ao, int dta, int conja, int b, int64_t 
                  int64_t co, mpse_index ma, mpse_index ka, mpse_index kb, mpse_index nb, mpse_index mc,
                  mpse_index nc, int64_t batch = 1, int64_t sba = 0, int64_t sbb = 0, int64_t sbc = 0) {
   p.steps.push_back(Step{a, b, c, ao, bo, co, dta, dtb, conja, conjb, ma, ka, kb, nb, mc, nc, batch, sba, sbb, sbc});
+}
+
+// Skipping a unit channel trades a (m x k x n) slice of a GEMM for a strided copy kernel: below ~1e8 multiply-adds
+// the slice costs less than the extra launch, so small centres keep the plain GEMM.
+inline bool unit_pays(int64_t m, int64_t k, int64_t n) { return m * k * n >= (int64_t(1) << 27); }
+
+inline void push_copy(Plan& p, int src, int64_t so, int dst, int64_t dof, int dtype, mpse_index mi, mpse_index ni,
+                      mpse_index mo, mpse_index no) {
+  Step s{src, src, dst, so, 0, dof, dtype, dtype, 0, 0, mi, ni, ni, no, mo, no, 1, 0, 0, 0};
+  s.kind = K_COPY;
+  p.steps.push_back(s);
+}
+
+// X[a,b,n] = sum_c E[a,b,c] K[c,n] for an environment E (rows, w, cols) and a matrix K (cols, N); X (rows, w, N).
+// `unit` (1-based, 0 = none) names an MPO-bond channel b along which E[:, b, :] is the identity matrix (what a
+// canonical MPS gives for the channel in which no operator has acted yet): that slice of X is a copy of K and
+// the GEMM runs over the remaining channels only.
+inline void push_env_times(Plan& p, int ebuf, int e_dtype, int kbuf, int k_dtype, int xbuf, int64_t rows, int64_t w,
+                           int64_t cols, int64_t N, int64_t unit) {
+  const int64_t u = (unit >= 1 && unit <= w && rows == cols && unit_pays(rows, cols, N)) ? unit - 1 : -1;
+  if (u >= 0) push_copy(p, kbuf, 0, xbuf, u * N, k_dtype, i1(rows, N), i1(N, 1), i1(rows, w * N), i1(N, 1));
+  const int64_t lo[2] = {0, u + 1}, hi[2] = {u >= 0 ? u : w, u >= 0 ? w : 0};
+  for (int r = 0; r < 2; ++r) {
+    const int64_t b0 = lo[r], nb = hi[r] - lo[r];
+    if (nb <= 0) continue;
+    push(p, ebuf, b0 * cols, e_dtype, 0, kbuf, 0, k_dtype, 0, xbuf, b0 * N, i2(rows, nb, w * cols, cols),
+         i1(cols, 1), i1(cols, N), i1(N, 1), i2(rows, nb, w * N, N), i1(N, 1));
+  }
+}
+
+// out[(m,g),l] = sum_{f,k} T[m,f,g,k] E[l,f,k] for T (M1, w, anc, Dk) and an environment E (Dout, w, Dk).
+// `unit` as above: E[:, f, :] = identity contributes T[m,f,g,l] itself (needs Dout == Dk).
+inline void push_times_env(Plan& p, int tbuf, int t_dtype, int ebuf, int e_dtype, int obuf, int64_t M1, int64_t anc,
+                           int64_t w, int64_t Dk, int64_t Dout, int64_t unit) {
+  const int64_t u = (unit >= 1 && unit <= w && Dout == Dk && unit_pays(M1 * anc, Dk, Dout)) ? unit - 1 : -1;
+  double beta = 0.0;
+  if (u >= 0) {
+    push_copy(p, tbuf, u * anc * Dk, obuf, 0, t_dtype, i2(M1, anc, w * anc * Dk, Dk), i1(Dk, 1), i1(M1 * anc, Dout),
+              i1(Dout, 1));
+    beta = 1.0;
+  }
+  const int64_t lo[2] = {0, u + 1}, hi[2] = {u >= 0 ? u : w, u >= 0 ? w : 0};
+  for (int r = 0; r < 2; ++r) {
+    const int64_t f0 = lo[r], nf = hi[r] - lo[r];
+    if (nf <= 0) continue;
+    push(p, tbuf, f0 * anc * Dk, t_dtype, 0, ebuf, f0 * Dk, e_dtype, 0, obuf, 0,
+         /*A: m=(m1 | g)*/ i2(M1, anc, w * anc * Dk, Dk), /*k=(f | k)*/ i2(nf, Dk, anc * Dk, 1),
+         /*B=E: k=(f,k), n=l*/ i1(nf * Dk, 1), i1(Dout, w * Dk), i1(M1 * anc, Dout), i1(Dout, 1));
+    p.steps.back().beta = beta;
+    beta = 1.0;
+  }
 }
 
 // T_out[a, d, f, n] = sum_{b,e} W[b,d,e,f] T_in[a, b, e, n]   (W (wl,d,d,wr) row-major; batch over a)
@@ -70,10 +125,8 @@ inline Plan plan_heff(int dtype, const mpse_heff& h) {
       return p;
     }
     p.tmp_elems[0] = Dl * wl * Dr;
-    push(p, B_L, 0, h.l_dtype, 0, B_C, 0, dtype, 0, B_T1, 0, i1(Dl * wl, Dl), i1(Dl, 1), i1(Dl, Dr), i1(Dr, 1),
-         i1(Dl * wl, Dr), i1(Dr, 1));
-    push(p, B_T1, 0, dtype, 0, B_R, 0, h.r_dtype, 0, B_OUT, 0, i1(Dl, wl * Dr), i1(wl * Dr, 1), i1(wr * Dr, 1),
-         i1(Dr, wr * Dr), i1(Dl, Dr), i1(Dr, 1));
+    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, Dr, h.l_unit);
+    push_times_env(p, B_T1, dtype, B_R, h.r_dtype, B_OUT, Dl, 1, wr, Dr, Dr, h.r_unit);
     return p;
   }
   if (h.nsite == 1) {
@@ -82,14 +135,11 @@ inline Plan plan_heff(int dtype, const mpse_heff& h) {
     p.tmp_elems[0] = Dl * wl * N;
     p.tmp_elems[1] = Dl * d * wr * Nb;
     // T1[a,b,(e,g,k)] = sum_c L[(a,b),c] C[c,(e,g,k)]
-    push(p, B_L, 0, h.l_dtype, 0, B_C, 0, dtype, 0, B_T1, 0, i1(Dl * wl, Dl), i1(Dl, 1), i1(Dl, N), i1(N, 1),
-         i1(Dl * wl, N), i1(N, 1));
+    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, N, h.l_unit);
     // T2[a,d,f,(g,k)] = sum_{b,e} W[b,d,e,f] T1[a,b,e,(g,k)]
     push_w(p, B_W0, h.w_dtype, B_T1, B_T2, dtype, Dl, wl, d, wr, Nb);
     // out[(a,d,g),l] = sum_{f,k} T2[a,d,f,g,k] R[l,f,k]
-    push(p, B_T2, 0, dtype, 0, B_R, 0, h.r_dtype, 0, B_OUT, 0,
-         /*A: m=((a,d) | g)*/ i2(Dl * d, anc, wr * anc * Dr, Dr), /*k=(f | k)*/ i2(wr, Dr, anc * Dr, 1),
-         /*B=R: k=(f,k), n=l*/ i1(wr * Dr, 1), i1(Dr, wr * Dr), i1(Dl * d * anc, Dr), i1(Dr, 1));
+    push_times_env(p, B_T2, dtype, B_R, h.r_dtype, B_OUT, Dl * d, anc, wr, Dr, Dr, h.r_unit);
     return p;
   }
   if (h.nsite == 2) {
@@ -102,8 +152,7 @@ inline Plan plan_heff(int dtype, const mpse_heff& h) {
     p.tmp_elems[1] = Dl * d0 * wm * n1;
     p.tmp_elems[2] = Dl * d0 * anc * d1 * wr * n2;
     // T1[a,b,(e,m,h,n,k)]
-    push(p, B_L, 0, h.l_dtype, 0, B_C, 0, dtype, 0, B_T1, 0, i1(Dl * wl, Dl), i1(Dl, 1), i1(Dl, N), i1(N, 1),
-         i1(Dl * wl, N), i1(N, 1));
+    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, N, h.l_unit);
     // T2[a,d,f,(m,h,n,k)]
     push_w(p, B_W0, h.w_dtype, B_T1, B_T2, dtype, Dl, wl, d0, wm, n1);
     // T3[(a,d),m,g,j,(n,k)] = sum_{f,h} W1[f,g,h,j] T2[(a,d),f,m,h,(n,k)]   batch (a,d); one step per m
@@ -113,8 +162,7 @@ inline Plan plan_heff(int dtype, const mpse_heff& h) {
            /*B: k=(f | h)*/ i2(wm, d1, anc * d1 * n2, n2), i1(n2, 1),
            /*C: (g,j),(n,k)*/ i1(d1 * wr, n2), i1(n2, 1), Dl * d0, 0, wm * anc * d1 * n2, anc * d1 * wr * n2);
     // out[(a,d,m,g,n),l] = sum_{j,k} T3[a,d,m,g,j,n,k] R[l,j,k]
-    push(p, B_T3, 0, dtype, 0, B_R, 0, h.r_dtype, 0, B_OUT, 0, i2(Dl * d0 * anc * d1, anc, wr * anc * Dr, Dr),
-         i2(wr, Dr, anc * Dr, 1), i1(wr * Dr, 1), i1(Dr, wr * Dr), i1(Dl * d0 * anc * d1 * anc, Dr), i1(Dr, 1));
+    push_times_env(p, B_T3, dtype, B_R, h.r_dtype, B_OUT, Dl * d0 * anc * d1, anc, wr, Dr, Dr, h.r_unit);
     return p;
   }
   p.error = "heff: nsite must be 0, 1 or 2";
@@ -134,8 +182,7 @@ inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, i
     p.tmp_elems[0] = Dlb * wl * N;
     p.tmp_elems[1] = Dlb * d * wr * anc * Drk;
     // X[a,b,(e,g,h)] = sum_c L[(a,b),c] A[c,(e,g,h)]
-    push(p, B_L, 0, env_dtype, 0, B_C, 0, dtype, 0, B_T1, 0, i1(Dlb * wl, Dlk), i1(Dlk, 1), i1(Dlk, N), i1(N, 1),
-         i1(Dlb * wl, N), i1(N, 1));
+    push_env_times(p, B_L, env_dtype, B_C, dtype, B_T1, Dlb, wl, Dlk, N, s.env_unit);
     // Y[a,d,f,(g,h)] = sum_{b,e} W[b,d,e,f] X[a,b,e,(g,h)]
     push_w(p, B_W0, w_dtype, B_T1, B_T2, dtype, Dlb, wl, d, wr, anc * Drk);
     // out[p,(f,h)] = sum_{a,d,g} bra*[(a,d,g),p] Y[a,d,f,g,h]
@@ -150,8 +197,19 @@ inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, i
     p.tmp_elems[0] = Dlk * d * anc * wr * Drb;
     p.tmp_elems[1] = Dlk * wl * d * anc * Drb;
     // X[(h,e,g),(b,a)] = sum_c A[(h,e,g),c] R[a,b,c]   (n ordered (b | a) through the strides of R)
-    push(p, B_C, 0, dtype, 0, B_L, 0, env_dtype, 0, B_T1, 0, i1(Dlk * d * anc, Drk), i1(Drk, 1), i1(Drk, 1),
-         i2(wr, Drb, Drk, wr * Drk), i1(Dlk * d * anc, wr * Drb), i1(wr * Drb, 1));
+    {
+      const int64_t M = Dlk * d * anc;
+      const int64_t u = (s.env_unit >= 1 && s.env_unit <= wr && Drb == Drk && unit_pays(M, Drk, Drb)) ? s.env_unit - 1 : -1;
+      // unit channel: R[a,u,c] = delta(a,c)  =>  X[m,u,a] = A[m,a]
+      if (u >= 0) push_copy(p, B_C, 0, B_T1, u * Drb, dtype, i1(M, Drk), i1(Drk, 1), i1(M, wr * Drb), i1(Drb, 1));
+      const int64_t lo[2] = {0, u + 1}, hi[2] = {u >= 0 ? u : wr, u >= 0 ? wr : 0};
+      for (int r = 0; r < 2; ++r) {
+        const int64_t b0 = lo[r], nb = hi[r] - lo[r];
+        if (nb <= 0) continue;
+        push(p, B_C, 0, dtype, 0, B_L, b0 * Drk, env_dtype, 0, B_T1, b0 * Drb, i1(M, Drk), i1(Drk, 1), i1(Drk, 1),
+             i2(nb, Drb, Drk, wr * Drk), i1(M, wr * Drb), i1(nb * Drb, 1));
+      }
+    }
     // Y[h,q,d,g,a] = sum_{e,b} W[q,d,e,b] X[h,e,g,b,a] ; batch h ; one step per ancilla value g
     for (int64_t g = 0; g < anc; ++g)
       push(p, B_W0, 0, w_dtype, 0, B_T1, g * wr * Drb, dtype, 0, B_T2, g * Drb,

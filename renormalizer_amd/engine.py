@@ -45,14 +45,15 @@ class mpse_gemm_desc(C.Structure):
 class mpse_dims(C.Structure):
     _fields_ = [("Dl_bra", C.c_int64), ("Dl_ket", C.c_int64), ("Dr_bra", C.c_int64), ("Dr_ket", C.c_int64),
                 ("d0", C.c_int64), ("d1", C.c_int64), ("danc", C.c_int64),
-                ("wl", C.c_int64), ("wm", C.c_int64), ("wr", C.c_int64)]
+                ("wl", C.c_int64), ("wm", C.c_int64), ("wr", C.c_int64), ("env_unit", C.c_int64)]
 
 
 class mpse_heff(C.Structure):
     _fields_ = [("nsite", C.c_int), ("dims", mpse_dims),
                 ("L", C.c_void_p), ("l_dtype", C.c_int),
                 ("R", C.c_void_p), ("r_dtype", C.c_int),
-                ("W0", C.c_void_p), ("W1", C.c_void_p), ("w_dtype", C.c_int)]
+                ("W0", C.c_void_p), ("W1", C.c_void_p), ("w_dtype", C.c_int),
+                ("l_unit", C.c_int64), ("r_unit", C.c_int64)]
 
 
 def idx1(ext, stride):
@@ -107,6 +108,7 @@ _SIGNATURES = {
     "mpse_env_update": [C.c_void_p, C.c_int, C.c_int, C.POINTER(mpse_dims), C.c_void_p, C.c_int, C.c_void_p,
                         C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p],
     "mpse_heff_apply": [C.c_void_p, C.c_int, C.POINTER(mpse_heff), C.c_void_p, C.c_void_p],
+    "mpse_env_unit_channel": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_double, _i64p],
     "mpse_expm_lanczos": [C.c_void_p, C.c_int, C.POINTER(mpse_heff), C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                           C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int)],
     "mpse_block_qr": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _i64p, _i64p, _i64p, _i64p,
@@ -166,7 +168,7 @@ class DeviceTensor:
     Plays the role of the reference's ``Matrix`` (mps/matrix.py:13-186) except that the
     data never lives on the host: slicing-free, reshape is a free view, ``to_host``
     is the only PCIe crossing."""
-    __slots__ = ("eng", "buf", "offset", "shape", "dtype", "sigmaqn")
+    __slots__ = ("eng", "buf", "offset", "shape", "dtype", "sigmaqn", "unit")
 
     def __init__(self, eng, buf, offset, shape, dtype):
         self.eng = eng
@@ -175,6 +177,7 @@ class DeviceTensor:
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
         self.sigmaqn = None
+        self.unit = 0       # environments only: 1-based MPO channel that is the identity matrix (mpse_env_unit_channel)
 
     # -- basic properties
     @property

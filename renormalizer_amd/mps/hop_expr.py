@@ -37,6 +37,7 @@ class Hop:
         d.d1 = self.cmo[1].shape[1] if nsite == 2 else 1
         d.wm = self.cmo[0].shape[3] if nsite == 2 else 1
         h.L, h.l_dtype, h.R, h.r_dtype = self.l.ptr, self.l.code, self.r.ptr, self.r.code
+        h.l_unit, h.r_unit = self.l.unit, self.r.unit
         if nsite >= 1:
             h.W0, h.w_dtype = self.cmo[0].ptr, self.cmo[0].code
         if nsite == 2:

@@ -36,6 +36,7 @@ def contract_one_site(environ, ms, mo, domain, ms_conj=None):
     d.d0, d.d1 = ket.shape[1], 1
     d.danc = ket.shape[2] if ket.ndim == 4 else 1
     d.wl, d.wr, d.wm = mo.shape[0], mo.shape[3], 1
+    d.env_unit = environ.unit
     if domain == "L":
         assert environ.shape == (d.Dl_bra, d.wl, d.Dl_ket), (environ.shape, bra.shape, mo.shape, ket.shape)
         oshape = (d.Dr_bra, d.wr, d.Dr_ket)
@@ -46,7 +47,23 @@ def contract_one_site(environ, ms, mo, domain, ms_conj=None):
     eng._check(eng.lib.mpse_env_update(
         eng.ctx, out.code, DOMAIN_L if domain == "L" else DOMAIN_R, C.byref(d), environ.ptr, environ.code,
         ket.ptr, bra.ptr, 1 if ms_conj is None else 0, mo.ptr, mo.code, out.ptr))
+    if ms_conj is None and oshape[0] == oshape[2]:
+        out.unit = find_unit_channel(out)
     return out
+
+
+UNIT_TOL = 1e-12
+
+
+def find_unit_channel(env):
+    """1-based MPO-bond channel along which the environment is the identity matrix to UNIT_TOL (0 if none).  With
+    a canonical MPS the channel in which no operator has acted yet is exactly that; the contraction plans then
+    replace its share of the two big GEMMs of every matvec / environment update by a copy."""
+    eng = env.eng
+    unit = C.c_int64(0)
+    eng._check(eng.lib.mpse_env_unit_channel(eng.ctx, env.code, env.ptr, env.shape[0], env.shape[1], UNIT_TOL,
+                                             C.byref(unit)))
+    return int(unit.value)
 
 
 class Environ:
@@ -58,6 +75,7 @@ class Environ:
         self.eng = get_engine()
         self._virtual_disk = {}
         self.sentinel = self.eng.ones((1, 1, 1), np.float64)
+        self.sentinel.unit = 1
         self._construct(mps, mpo, domain, mps_conj)
 
     def _mo(self, mpo, idx):

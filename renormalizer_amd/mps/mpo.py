@@ -160,7 +160,17 @@ def construct_mpo_tensors(model, terms, offset=0.0):
                 continue
             sel, x = _rank_basis_rows(sub[:, used])
             for k, s in enumerate(sel):
-                y_rows.append(cmat[idx[s]])
+                y = cmat[idx[s]]
+                nz = np.nonzero(y)[0]
+                if len(nz) == 1:
+                    # a channel with one continuation (typically "every operator already applied": identities up
+                    # to the right end) carries a unit coefficient, its weight stays in this site's tensor.  The
+                    # pass-through blocks of that channel are then exact identities on every later site, which is
+                    # what lets the engine treat the matching slice of a right environment as a unit matrix.
+                    x = x.copy() if k == 0 else x
+                    x[:, k] *= y[nz[0]]
+                    y = y / y[nz[0]]
+                y_rows.append(y)
                 new_chan_qn.append(np.array(q, dtype=int))
             x_blocks.append((idx, x))
         w_r = len(y_rows)

@@ -411,6 +411,7 @@ class Mps:
             return None if conj_sites is None else conj_sites[i]
 
         sentinel = eng.ones((1, 1, 1), np.float64)
+        sentinel.unit = 1
         lenv = {-1: sentinel}
         for i in range(0, lmax):
             lenv[i] = contract_one_site(lenv[i - 1], self[i], ident_w(i), "L", ms_conj=cj(i))

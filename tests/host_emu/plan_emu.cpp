@@ -36,10 +36,21 @@ static void naive_gemm(const Step& s, const void* A, const void* B, void* C) {
                  ld(B, s.dtb, b * s.sbb + off(s.kb, k) + off(s.nb, j), s.conjb);
         int64_t o = b * s.sbc + off(s.mc, i) + off(s.nc, j);
         if (dtc == MPSE_C128)
-          ((cd*)C)[o] = acc;
+          ((cd*)C)[o] = acc + (s.beta != 0.0 ? s.beta * ((cd*)C)[o] : cd(0));
         else
-          ((double*)C)[o] = acc.real();
+          ((double*)C)[o] = acc.real() + (s.beta != 0.0 ? s.beta * ((double*)C)[o] : 0.0);
       }
+}
+
+static void naive_copy(const Step& s, int dt, const void* A, void* C) {
+  for (int64_t i = 0; i < s.ma.ext; ++i)
+    for (int64_t j = 0; j < s.ka.ext; ++j) {
+      const int64_t si = off(s.ma, i) + off(s.ka, j), di = off(s.mc, i) + off(s.nc, j);
+      if (dt == MPSE_C128)
+        ((cd*)C)[di] = ((const cd*)A)[si];
+      else
+        ((double*)C)[di] = ((const double*)A)[si];
+    }
 }
 
 static int run(int dtype, const Plan& p, const void* bufs_in[B_COUNT]) {
@@ -56,6 +67,10 @@ static int run(int dtype, const Plan& p, const void* bufs_in[B_COUNT]) {
     const size_t ea = s.dta == MPSE_C128 ? 16 : 8, eb = s.dtb == MPSE_C128 ? 16 : 8;
     const int dtc = (s.dta == MPSE_C128 || s.dtb == MPSE_C128) ? MPSE_C128 : MPSE_F64;
     if (dtc != dtype) return MPSE_ERR_ARG;
+    if (s.kind == K_COPY) {
+      naive_copy(s, dtc, (const char*)bufs[s.a] + s.a_off * ea, (char*)const_cast<void*>(bufs[s.c]) + s.c_off * es);
+      continue;
+    }
     naive_gemm(s, (const char*)bufs[s.a] + s.a_off * ea, (const char*)bufs[s.b] + s.b_off * eb,
                (char*)const_cast<void*>(bufs[s.c]) + s.c_off * es);
   }

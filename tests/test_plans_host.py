@@ -35,12 +35,13 @@ def _c(a):
     return np.ascontiguousarray(a)
 
 
-def emu_heff(lib, l, r, cmo, c):
+def emu_heff(lib, l, r, cmo, c, l_unit=0, r_unit=0):
     cplx = np.iscomplexobj(c)
     dt = E.C128 if cplx else E.F64
     ns = len(cmo)
     h = E.mpse_heff()
     h.nsite = ns
+    h.l_unit, h.r_unit = l_unit, r_unit
     anc = 1
     if ns >= 1 and c.ndim == 2 * ns + 2:
         anc = c.shape[2]
@@ -66,7 +67,7 @@ def emu_heff(lib, l, r, cmo, c):
     return out
 
 
-def emu_env(lib, env, ket, mo, dom, bra=None, bra_conj=True):
+def emu_env(lib, env, ket, mo, dom, bra=None, bra_conj=True, env_unit=0):
     cplx = np.iscomplexobj(ket) or np.iscomplexobj(env)
     wdt = complex if cplx else float
     ket = _c(ket.astype(wdt))
@@ -79,6 +80,7 @@ def emu_env(lib, env, ket, mo, dom, bra=None, bra_conj=True):
     d.d0 = ket.shape[1]
     d.danc = ket.shape[2] if ket.ndim == 4 else 1
     d.wl, d.wr = mo.shape[0], mo.shape[3]
+    d.env_unit = env_unit
     if dom == "L":
         oshape = (d.Dr_bra, d.wr, d.Dr_ket)
     else:
@@ -156,3 +158,51 @@ def test_heff_plans_odd_shapes(emu):
             c = _rand(rng, (Dl, Dr), cplx)
             ref = orc.hop_apply(l, r0, [], c)
             assert np.abs(emu_heff(emu, l, r0, [], c) - ref).max() < 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_plans_unit_channels(emu, cplx):
+    """Environments whose channel u is the identity matrix (canonical MPS, no operator applied yet): with
+    l_unit / r_unit / env_unit set the plans copy that slice instead of multiplying by it; same result."""
+    rng = np.random.default_rng(23)
+
+    def with_unit(D, w, u):
+        e = _rand(rng, (D, w, D), cplx)
+        e[:, u, :] = np.eye(D)
+        return e
+    for (Dl, Dr, d0, d1, wl, wm, wr, ul, ur) in ((5, 4, 3, 2, 3, 2, 4, 0, 3), (4, 6, 2, 3, 4, 3, 3, 2, 1),
+                                                 (3, 3, 2, 2, 1, 2, 1, 0, 0), (6, 5, 4, 2, 5, 2, 2, 4, 0)):
+        l, r = with_unit(Dl, wl, ul), with_unit(Dr, wr, ur)
+        w0 = _rand(rng, (wl, d0, d0, wr), False)
+        for anc in (False, True):
+            c = _rand(rng, (Dl, d0, 2, Dr) if anc else (Dl, d0, Dr), cplx)
+            ref = orc.hop_apply(l, r, [w0], c)
+            for lu, ru in ((ul + 1, ur + 1), (ul + 1, 0), (0, ur + 1)):
+                out = emu_heff(emu, l, r, [w0], c, l_unit=lu, r_unit=ru)
+                assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max()
+        w0m = _rand(rng, (wl, d0, d0, wm), False)
+        w1 = _rand(rng, (wm, d1, d1, wr), False)
+        for anc in (False, True):
+            c = _rand(rng, (Dl, d0, 2, d1, 2, Dr) if anc else (Dl, d0, d1, Dr), cplx)
+            ref = orc.hop_apply(l, r, [w0m, w1], c)
+            out = emu_heff(emu, l, r, [w0m, w1], c, l_unit=ul + 1, r_unit=ur + 1)
+            assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max()
+        if wl == wr or True:
+            r0 = with_unit(Dr, wl, min(ur, wl - 1))
+            c = _rand(rng, (Dl, Dr), cplx)
+            ref = orc.hop_apply(l, r0, [], c)
+            out = emu_heff(emu, l, r0, [], c, l_unit=ul + 1, r_unit=min(ur, wl - 1) + 1)
+            assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max()
+        # environment updates (bra = ket so that the bonds agree)
+        for anc in (False, True):
+            ket = _rand(rng, (Dl, d0, 2, Dr) if anc else (Dl, d0, Dr), cplx)
+            ref = orc.contract_one_site(l, ket, w0, "L")
+            assert np.abs(emu_env(emu, l, ket, w0, "L", env_unit=ul + 1) - ref).max() < 1e-11 * np.abs(ref).max()
+            ref = orc.contract_one_site(r, ket, w0, "R")
+            assert np.abs(emu_env(emu, r, ket, w0, "R", env_unit=ur + 1) - ref).max() < 1e-11 * np.abs(ref).max()
+    # a unit flag on a rectangular environment (bra and ket bonds differ) must be ignored, not misapplied
+    ket, bra = _rand(rng, (4, 3, 6), cplx), _rand(rng, (3, 3, 5), cplx)
+    mo = _rand(rng, (2, 3, 3, 4), False)
+    env = _rand(rng, (3, 2, 4), cplx)
+    ref = orc.contract_one_site(env, ket, mo, "L", ms_conj=bra.conj())
+    assert np.abs(emu_env(emu, env, ket, mo, "L", bra=bra, env_unit=1) - ref).max() < 1e-11 * np.abs(ref).max()
