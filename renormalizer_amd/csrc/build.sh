@@ -5,15 +5,17 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 SRCS="mpse_core.hip mpse_gemm.hip mpse_contract.hip mpse_vec.hip mpse_qr.hip mpse_qr2.hip mpse_svd.hip"
 OBJS=""
+PIDS=""
 for s in $SRCS; do
   [ -f "$s" ] || continue
   o="build/${s%.hip}.o"
   mkdir -p build
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer "$o" 2>/dev/null)" ] || [ ../../include/mpsengine.h -nt "$o" ]; then
     $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" "$@" &
+    PIDS="$PIDS $!"
   fi
   OBJS="$OBJS $o"
 done
-wait
+for p in $PIDS; do wait "$p" || { echo "compile failed" >&2; exit 1; }; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC $OBJS -o libmpsengine.so
 echo "built $(pwd)/libmpsengine.so"

@@ -399,36 +399,44 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
   }
 }
 
-// C(i,j) = alpha * sum_s ws[b][s][i][j] + beta * C(i,j); slices summed in fixed order
+// C(i,j) = alpha * sum_s ws[b][s][i][j] + beta * C(i,j); slices summed in fixed order.
+// One output row per blockIdx.y step (row index arithmetic is wave-uniform), threads run along j.
 template <bool CC>
 __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs g, int batch) {
   constexpr int EC = CC ? 2 : 1;
   const long long mn = (long long)g.M * g.N;
-  const long long total = mn * batch;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int b = (int)(t / mn);
-    const long long ij = t - (long long)b * mn;
-    const int i = (int)(ij / g.N), j = (int)(ij - (long long)i * g.N);
-    const double* w = g.ws + ((long long)b * g.ksplit * mn + ij) * EC;
-    double xr = 0, xi = 0;
-    for (int s = 0; s < g.ksplit; ++s) {
-      xr += w[(long long)s * mn * EC];
-      if (CC) xi += w[(long long)s * mn * EC + 1];
-    }
-    double* p = g.C + ((long long)b * g.sbC + idx_off(g.mC, i) + idx_off(g.nC, j)) * EC;
-    if (CC) {
-      double2 o = make_double2(g.alpha_re * xr - g.alpha_im * xi, g.alpha_re * xi + g.alpha_im * xr);
-      if (g.use_beta) {
-        const double2 c0 = *reinterpret_cast<const double2*>(p);
-        o.x += g.beta_re * c0.x - g.beta_im * c0.y;
-        o.y += g.beta_re * c0.y + g.beta_im * c0.x;
+  const int rows = g.M * batch;
+  for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+    const int b = row / g.M;
+    const int i = row - b * g.M;
+    const double* wrow = g.ws + ((long long)b * g.ksplit * mn + (long long)i * g.N) * EC;
+    double* crow = g.C + ((long long)b * g.sbC + idx_off(g.mC, i)) * EC;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < g.N; j += gridDim.x * 256) {
+      const double* w = wrow + (long long)j * EC;
+      double xr = 0, xi = 0;
+      for (int s = 0; s < g.ksplit; ++s) {
+        if constexpr (CC) {
+          const double2 v = *reinterpret_cast<const double2*>(w + (long long)s * mn * EC);
+          xr += v.x;
+          xi += v.y;
+        } else {
+          xr += w[(long long)s * mn];
+        }
       }
-      *reinterpret_cast<double2*>(p) = o;
-    } else {
-      double o = g.alpha_re * xr;
-      if (g.use_beta) o += g.beta_re * (*p);
-      *p = o;
+      double* p = crow + idx_off(g.nC, j) * EC;
+      if constexpr (CC) {
+        double2 o = make_double2(g.alpha_re * xr - g.alpha_im * xi, g.alpha_re * xi + g.alpha_im * xr);
+        if (g.use_beta) {
+          const double2 c0 = *reinterpret_cast<const double2*>(p);
+          o.x += g.beta_re * c0.x - g.beta_im * c0.y;
+          o.y += g.beta_re * c0.y + g.beta_im * c0.x;
+        }
+        *reinterpret_cast<double2*>(p) = o;
+      } else {
+        double o = g.alpha_re * xr;
+        if (g.use_beta) o += g.beta_re * (*p);
+        *p = o;
+      }
     }
   }
 }
@@ -591,13 +599,12 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
     MPSE_LAUNCH(false, false);
 #undef MPSE_LAUNCH
   if (g.ksplit > 1) {
-    const long long tot = (long long)g.M * g.N * d->batch;
-    int rb = (int)((tot + 255) / 256);
-    if (rb > 4096) rb = 4096;
+    const long long rows = (long long)g.M * d->batch;
+    const dim3 rgrid((unsigned)((g.N + 255) / 256 > 64 ? 64 : (g.N + 255) / 256), (unsigned)(rows > 32768 ? 32768 : rows));
     if (ca || cb)
-      hipLaunchKernelGGL((k_splitk_reduce<true>), dim3(rb), dim3(256), 0, ctx->stream, g, (int)d->batch);
+      hipLaunchKernelGGL((k_splitk_reduce<true>), rgrid, dim3(256), 0, ctx->stream, g, (int)d->batch);
     else
-      hipLaunchKernelGGL((k_splitk_reduce<false>), dim3(rb), dim3(256), 0, ctx->stream, g, (int)d->batch);
+      hipLaunchKernelGGL((k_splitk_reduce<false>), rgrid, dim3(256), 0, ctx->stream, g, (int)d->batch);
   }
   if (prof_this) {
     MPSE_HIP(ctx, hipEventRecord(rec.e1, ctx->stream));

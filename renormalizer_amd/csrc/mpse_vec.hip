@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int RED_MAX_BLOCKS = 1024;
+constexpr int RED_MAX_BLOCKS = 512;  // two blocks per CU; consumers of the partials re-sum all of them per block
 
 inline int red_blocks(int64_t n_doubles) {
   int64_t b = (n_doubles + RED_THREADS * 8 - 1) / (RED_THREADS * 8);
@@ -41,6 +41,19 @@ __global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const double* __res
     partial[2 * blockIdx.x] = re;
     partial[2 * blockIdx.x + 1] = im;
   }
+}
+
+// Sum of a producer kernel's per-block partials, evaluated redundantly by every block of the consumer kernel
+// (same order everywhere, so all blocks see the same value): saves the single-block k_reduce_final launch
+// between producer and consumer.  blockDim.x must be RED_THREADS.
+__device__ __forceinline__ void sum_partials(const double* __restrict__ partial, int nb, double& re, double& im) {
+  re = 0;
+  im = 0;
+  for (int i = threadIdx.x; i < nb; i += RED_THREADS) {
+    re += partial[2 * i];
+    im += partial[2 * i + 1];
+  }
+  block_allsum2(re, im);
 }
 
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_final(const double* __restrict__ partial, int nb,
@@ -103,10 +116,19 @@ __global__ void k_scale_into(double* dst, const double* __restrict__ src, long l
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_doubles; i += stride) dst[i] = src[i] * s;
 }
 
-// dst = src / sqrt(*b2)   (scale by a device-resident squared norm)
-__global__ void k_scale_into_dev(double* dst, const double* __restrict__ src, long long n_doubles,
-                                 const double* __restrict__ b2) {
-  const double s = 1.0 / sqrt(*b2);
+// dst = src / sqrt(b2) where b2 = sum of the nb partials of the preceding norm kernel; block 0 also stores b2
+// (and the unused imaginary slot) to b2_out for the host and for the next recurrence step
+__global__ __launch_bounds__(RED_THREADS) void k_scale_into_dev(double* dst, const double* __restrict__ src,
+                                                                long long n_doubles,
+                                                                const double* __restrict__ partial, int nb,
+                                                                double* __restrict__ b2_out) {
+  double b2, im;
+  sum_partials(partial, nb, b2, im);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    b2_out[0] = b2;
+    b2_out[1] = im;
+  }
+  const double s = 1.0 / sqrt(b2);
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_doubles; i += stride) dst[i] = src[i] * s;
 }
@@ -116,10 +138,17 @@ __global__ void k_scale_into_dev(double* dst, const double* __restrict__ src, lo
 // recurrence never waits for the host.
 __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update(double* __restrict__ w, const double* __restrict__ v1,
                                                                 const double* __restrict__ v0, long long n_doubles,
-                                                                const double* __restrict__ ap,
+                                                                const double* __restrict__ a_partial, int a_nb,
+                                                                double* __restrict__ a_out,
                                                                 const double* __restrict__ b2p,
                                                                 double* __restrict__ partial) {
-  const double a = *ap;
+  // a = Re <w, v1>: summed here from the partials of the preceding k_dot_partial; block 0 records it
+  double a, a_im;
+  sum_partials(a_partial, a_nb, a, a_im);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a_out[0] = a;
+    a_out[1] = a_im;
+  }
   const double b = v0 ? sqrt(*b2p) : 0.0;
   double s = 0, zero = 0;
   const long long stride = (long long)gridDim.x * RED_THREADS;
@@ -427,24 +456,24 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
   const int SC_FLAG = 4 + 4 * 130;
   MPSE_TRY(SCAL.alloc(size_t(SC_FLAG + 2) * sizeof(double)));
   double* scal = SCAL.as<double>();
-  const int eb = ew_blocks(nd);
   const int nb = red_blocks(nd);
-  double* partial = ctx->dscratch;
+  // two partial-sum areas: a kernel that consumes one set of partials writes its own into the other
+  double* part_a = ctx->dscratch;                          // <w, v_j> partials
+  double* part_b = ctx->dscratch + 4 * RED_MAX_BLOCKS;     // |.|^2 partials
 
-  auto dot_into = [&](const void* x, const void* y, double* dst) {
+  auto dot_partials = [&](const void* x, const void* y, double* dst_partial) {
     if (cplx)
       hipLaunchKernelGGL((k_dot_partial<true>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
-                         (const double*)y, (long long)n, partial);
+                         (const double*)y, (long long)n, dst_partial);
     else
       hipLaunchKernelGGL((k_dot_partial<false>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
-                         (const double*)y, (long long)n, partial);
-    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, partial, nb, dst);
+                         (const double*)y, (long long)n, dst_partial);
   };
 
   // v0 = C / |C|
-  dot_into(Cin, Cin, scal);
-  hipLaunchKernelGGL(k_scale_into_dev, dim3(eb), dim3(256), 0, ctx->stream, V.as<double>(), (const double*)Cin,
-                     (long long)nd, (const double*)scal);
+  dot_partials(Cin, Cin, part_b);
+  hipLaunchKernelGGL(k_scale_into_dev, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, V.as<double>(),
+                     (const double*)Cin, (long long)nd, (const double*)part_b, nb, scal);
   MPSE_HIP(ctx, hipGetLastError());
 
   std::vector<double> alpha, beta;
@@ -496,8 +525,9 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
 
   for (int j = 0;; ++j) {
     MPSE_TRY(mpse_heff_apply(ctx, dtype, h, vec(j), W.p));
-    dot_into(W.p, vec(j), scal + 4 + 4 * j);                      // alpha_j = Re <w, v_j>
+    dot_partials(W.p, vec(j), part_a);                             // alpha_j = Re <w, v_j> (partials)
     if (j == n - 1) {                                              // Krylov space == full space (krylov.py:59-61)
+      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, part_a, nb, scal + 4 + 4 * j);
       MPSE_TRY(fetch(j));
       if (!(nrmv > 0)) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: zero start vector");
       int bd = breakdown_at(j - 1);
@@ -508,12 +538,15 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
     }
     hipLaunchKernelGGL(k_lanczos_update, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
                        (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
-                       (long long)nd, (const double*)(scal + 4 + 4 * j),
-                       (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), partial);
-    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, partial, nb, scal + 6 + 4 * j);
-    MPSE_HIP(ctx, hipGetLastError());
+                       (long long)nd, (const double*)part_a, nb, scal + 4 + 4 * j,
+                       (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b);
+    // beta_j^2: needed by the host at a check and by the next update; k_scale_into_dev stores it when it runs
+    // (every path that continues), the returning paths below read it through k_reduce_final
     const bool check = (j > 3 && j % 2 == 0);                      // krylov.py:76-81
     const bool last = (j + 1 >= max_dim);
+    if (check || last)
+      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, part_b, nb, scal + 6 + 4 * j);
+    MPSE_HIP(ctx, hipGetLastError());
     if (check || last) {
       MPSE_TRY(fetch(j));
       if (!(nrmv > 0)) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: zero start vector");
@@ -554,8 +587,8 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
       std::swap(V.p, V2.p);
       cap = ncap;
     }
-    hipLaunchKernelGGL(k_scale_into_dev, dim3(eb), dim3(256), 0, ctx->stream, (double*)vec(j + 1),
-                       W.as<const double>(), (long long)nd, (const double*)(scal + 6 + 4 * j));
+    hipLaunchKernelGGL(k_scale_into_dev, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
+                       W.as<const double>(), (long long)nd, (const double*)part_b, nb, scal + 6 + 4 * j);
   }
 }
 

@@ -298,8 +298,9 @@ class Mps:
         else:
             self.qnidx, self.to_right = 0, True
 
-    def _get_big_qn(self, cidx: List[int], swap=False):
-        """mps/mp.py:308-352"""
+    def _get_big_qn(self, cidx: List[int], swap=False, need_mat=True):
+        """mps/mp.py:308-352.  ``need_mat=False`` skips the full outer sum (the DMRG mask); QR / SVD only need
+        the row and column quantum numbers."""
         cidx = sorted(cidx)
         assert len(cidx) in (1, 2) and self.qnidx in cidx
         sigmaqn = [self._get_sigmaqn(i) for i in cidx]
@@ -314,7 +315,7 @@ class Mps:
                 qnbigl, qnbigr = qnl, add_outer(sigmaqn[0], qnr)
         else:
             qnbigl, qnbigr = add_outer(qnl, sigmaqn[0]), add_outer(sigmaqn[1], qnr)
-        return qnbigl, qnbigr, add_outer(qnbigl, qnbigr)
+        return qnbigl, qnbigr, (add_outer(qnbigl, qnbigr) if need_mat else None)
 
     # ------------------------------------------------------------------ scalar products and norms
     def dot(self, other: "Mps", self_is_conj=True) -> complex:
@@ -483,7 +484,7 @@ class Mps:
 
     def _push_cano(self, idx):
         """mps/mp.py:890-908"""
-        qnbigl, qnbigr, _ = self._get_big_qn([idx])
+        qnbigl, qnbigr, _ = self._get_big_qn([idx], need_mat=False)
         system = "L" if self.to_right else "R"
         u, qnlset, v, qnrset = svd_qn.svd_qn(self[idx], qnbigl, qnbigr, self.qntot, QR=True, system=system,
                                              full_matrices=False)
@@ -513,7 +514,7 @@ class Mps:
         system = "L" if self.to_right else "R"
         s_list = []
         for idx in self.iter_idx_list(full=False):
-            qnbigl, qnbigr, _ = self._get_big_qn([idx])
+            qnbigl, qnbigr, _ = self._get_big_qn([idx], need_mat=False)
             u, sigma, qnlset, v, sigma, qnrset = svd_qn.svd_qn(self[idx], qnbigl, qnbigr, self.qntot, system=system,
                                                                full_matrices=False)
             s_list.append(sigma)
@@ -797,7 +798,7 @@ class Mps:
                 hop = hop_expr(l_array, r_array, [w], shape)
                 mps_t, j = expm_krylov(hop, -1j * evolve_dt / 2, mps[imps])
                 local_steps.append(j)
-                qnbigl, qnbigr, _ = mps._get_big_qn([imps])
+                qnbigl, qnbigr, _ = mps._get_big_qn([imps], need_mat=False)
                 if (not mps.to_right and imps != 0) or (mps.to_right and imps != n - 1):
                     u, qnlset, v, qnrset = svd_qn.svd_qn(mps_t, qnbigl, qnbigr, mps.qntot, QR=True, system=system,
                                                          full_matrices=False)
@@ -860,7 +861,7 @@ def _evolve_tdvp_ps2(self, mpo, evolve_dt) -> "Mps":
             hop = hop_expr(l_array, r_array, [mpo.device(c0, eng), mpo.device(c1, eng)], ms2.shape)
             mps_t, j = expm_krylov(hop, -1j * evolve_dt / 2, ms2)
             local_steps.append(j)
-            qnbigl, qnbigr, _ = mps._get_big_qn([c0, c1])
+            qnbigl, qnbigr, _ = mps._get_big_qn([c0, c1], need_mat=False)
             mps._update_mps(mps_t.reshape(ms2.shape), [c0, c1], qnbigl, qnbigr)
             if imps == last_idx:
                 continue

@@ -43,6 +43,41 @@ def qn_blocks(qnbigl, qnbigr, qntot):
     return out
 
 
+_PLAN_CACHE = {}
+_PLAN_CACHE_MAX = 4096
+
+
+def block_plan(qnbigl, qnbigr, qntot):
+    """Everything ``svd_qn`` derives from the quantum numbers alone: concatenated row / column index lists of the
+    blocks, their offsets, the number of singular values per block and the qn labels of the new bond.  A fixed-bond
+    sweep meets the same (qnbigl, qnbigr, qntot) at a site again every half-sweep, so the plan is memoised on the
+    bytes of the three integer arrays (the host is otherwise busy with np.unique / argsort while the GPU idles)."""
+    qntot = np.ascontiguousarray(np.asarray(qntot, dtype=np.int64))
+    q = len(qntot)
+    lq = np.ascontiguousarray(np.asarray(qnbigl, dtype=np.int64).reshape(-1, q))
+    rq = np.ascontiguousarray(np.asarray(qnbigr, dtype=np.int64).reshape(-1, q))
+    key = (lq.tobytes(), rq.tobytes(), qntot.tobytes())
+    plan = _PLAN_CACHE.get(key)
+    if plan is not None:
+        return plan
+    blocks = qn_blocks(lq, rq, qntot)
+    if len(blocks) == 0:
+        raise ValueError("Invalid quantum number")
+    dims = [min(len(b[2]), len(b[3])) for b in blocks]
+    new_qnl, new_qnr = [], []
+    for b, k in zip(blocks, dims):
+        new_qnl += [b[0].tolist()] * k
+        new_qnr += [b[1].tolist()] * k
+    plan = dict(blocks=blocks, dims=dims, K=int(sum(dims)), new_qnl=new_qnl, new_qnr=new_qnr,
+                rows=np.concatenate([b[2] for b in blocks]), cols=np.concatenate([b[3] for b in blocks]),
+                roff=np.cumsum([0] + [len(b[2]) for b in blocks]).astype(np.int64),
+                coff=np.cumsum([0] + [len(b[3]) for b in blocks]).astype(np.int64))
+    if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+        _PLAN_CACHE.clear()
+    _PLAN_CACHE[key] = plan
+    return plan
+
+
 class TransposedView:
     """What the reference returns as ``v`` (ncol x K); the engine produces v.T directly."""
 
@@ -69,19 +104,10 @@ def svd_qn(coef_array, qnbigl, qnbigr, qntot, QR=False, system=None, full_matric
     ncol = int(np.prod(np.asarray(qnbigr).shape[:-1]))
     if coef.size != nrow * ncol:
         raise ValueError(f"coefficient array {coef.shape} does not match quantum numbers ({nrow}x{ncol})")
-    blocks = qn_blocks(qnbigl, qnbigr, qntot)
-    if len(blocks) == 0:
-        raise ValueError("Invalid quantum number")
-    rows = np.concatenate([b[2] for b in blocks])
-    cols = np.concatenate([b[3] for b in blocks])
-    roff = np.cumsum([0] + [len(b[2]) for b in blocks]).astype(np.int64)
-    coff = np.cumsum([0] + [len(b[3]) for b in blocks]).astype(np.int64)
-    dims = [min(len(b[2]), len(b[3])) for b in blocks]
-    K = int(sum(dims))
-    new_qnl, new_qnr = [], []
-    for b, k in zip(blocks, dims):
-        new_qnl += [b[0].tolist()] * k
-        new_qnr += [b[1].tolist()] * k
+    plan = block_plan(qnbigl, qnbigr, qntot)
+    blocks, dims, K = plan["blocks"], plan["dims"], plan["K"]
+    rows, cols, roff, coff = plan["rows"], plan["cols"], plan["roff"], plan["coff"]
+    new_qnl, new_qnr = list(plan["new_qnl"]), list(plan["new_qnr"])
     if QR:
         if full_matrices:
             raise NotImplementedError("full_matrices QR is not used by the sweep algorithms")
