@@ -34,6 +34,20 @@ PROF_STRIDE = 7                   # HIP-event timing of every 7th contraction la
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (AMD datasheet)
 
 
+def _roctx():
+    """ROCTx pause / resume hooks: under `rocprofv3 --selected-regions` only the timed region is profiled, so the
+    committed kernel-trace summary (profiles/) covers exactly the launches the roofline numbers are taken from.
+    No-ops when the library is absent or no profiler is attached."""
+    import ctypes
+    try:
+        lib = ctypes.CDLL("librocprofiler-sdk-roctx.so")
+        lib.roctxProfilerResume.argtypes = [ctypes.c_uint64]
+        lib.roctxProfilerPause.argtypes = [ctypes.c_uint64]
+        return lib
+    except (OSError, AttributeError):
+        return None
+
+
 def build_workload(nmol, pdim, bond_dim, seed, init):
     from renormalizer_amd import (HolsteinModel, Phonon, Mol, Quantity, Mpo, CompressConfig, CompressCriteria,
                                   EvolveConfig, EvolveMethod)
@@ -155,11 +169,16 @@ def main():
             engines[t].prof_enable(PROF_STRIDE)
             engines[t].sync()
             sync.wait()                    # all trajectories ready -> main thread takes t0
+            rtx = _roctx()
+            if rtx is not None:
+                rtx.roctxProfilerResume(0)
             kry = []
             for _ in range(args.steps):
                 mps = mps.evolve(mpo, args.dt)
                 kry.append(mps.evolve_config.stat["mean"])
             engines[t].sync()
+            if rtx is not None:
+                rtx.roctxProfilerPause(0)
             sync.wait()                    # all done -> main thread takes t1
             engines[t].prof_enable(False)
             results[t] = dict(model=model, mpo=mpo, mps=mps, kry=kry, prof=engines[t].prof_get())

@@ -167,9 +167,15 @@ def construct_mpo_tensors(model, terms, offset=0.0):
                     # to the right end) carries a unit coefficient, its weight stays in this site's tensor.  The
                     # pass-through blocks of that channel are then exact identities on every later site, which is
                     # what lets the engine treat the matching slice of a right environment as a unit matrix.
-                    x = x.copy() if k == 0 else x
                     x[:, k] *= y[nz[0]]
                     y = y / y[nz[0]]
+                    # rows that are multiples of this unit row get their own coefficient back exactly
+                    # ((c_i / c_s) * c_s is not c_i in floating point, and 1 must stay 1)
+                    for li, i in enumerate(idx):
+                        rnz = np.nonzero(cmat[i])[0]
+                        if len(rnz) == 1 and rnz[0] == nz[0]:
+                            x[li, :] = 0.0
+                            x[li, k] = cmat[i, nz[0]]
                 y_rows.append(y)
                 new_chan_qn.append(np.array(q, dtype=int))
             x_blocks.append((idx, x))
@@ -193,8 +199,58 @@ def construct_mpo_tensors(model, terms, offset=0.0):
             for ir in np.nonzero(yrow)[0]:
                 remainders[(beta, col_keys[ir])] = yrow[ir]
     assert w_list[-1].shape[3] == 1, w_list[-1].shape
+    _order_unit_channels(w_list, qn_list)
     qntot = qn_list[-1][0].copy()
     return w_list, qn_list, qntot
+
+
+def _order_unit_channels(w_list, qn_list):
+    """Permute the channels of every MPO bond (a gauge choice) so that the channel in which nothing has been applied
+    yet comes first and the channel in which everything has been applied comes last.  Left environments of a
+    canonical MPS are the identity matrix along the former, right environments along the latter; with the two at the
+    ends of the bond the engine skips them by shortening one index range instead of splitting a GEMM in two."""
+    n = len(w_list)
+
+    def is_pass(w, b, g):
+        blk = w[b, :, :, g]
+        return np.array_equal(blk, np.eye(blk.shape[0])) and not np.any(np.delete(w[:, :, :, g], b, axis=0))
+
+    def swap_bond(i, a, b):          # exchange channels a and b of the bond between sites i and i + 1
+        if a == b:
+            return
+        w_list[i][:, :, :, [a, b]] = w_list[i][:, :, :, [b, a]]
+        w_list[i + 1][[a, b]] = w_list[i + 1][[b, a]]
+        qn_list[i + 1][[a, b]] = qn_list[i + 1][[b, a]]
+
+    u = 0
+    for i in range(n - 1):           # left chain: W[u, :, :, g] = 1 and nothing else feeds g
+        cand = [g for g in range(w_list[i].shape[3]) if is_pass(w_list[i], u, g)]
+        if not cand:
+            break
+        swap_bond(i, cand[0], 0)
+        u = 0
+    v = 0
+    for i in range(n - 1, 0, -1):    # right chain: W[b, :, :, v] = 1 and b feeds nothing else
+        w = w_list[i]
+        cand = [b for b in range(w.shape[0])
+                if np.array_equal(w[b, :, :, v], np.eye(w.shape[1])) and not np.any(np.delete(w[b], v, axis=2))]
+        last = w.shape[0] - 1
+        cand = [b for b in cand if not (b == 0 and last != 0 and _is_left_unit(w_list, i))]
+        if not cand:
+            break
+        swap_bond(i - 1, cand[0], last)
+        v = last
+
+
+def _is_left_unit(w_list, i):
+    """channel 0 of the bond left of site i is the left unit channel (set by the first pass of the ordering)"""
+    u = 0
+    for k in range(i):
+        blk = w_list[k][u, :, :, 0]
+        if not (np.array_equal(blk, np.eye(blk.shape[0])) and not np.any(np.delete(w_list[k][:, :, :, 0], u, axis=0))):
+            return False
+        u = 0
+    return True
 
 
 class Mpo:
