@@ -223,6 +223,16 @@ def main():
         assert occ_table.shape[0] == world
 
     if rank == 0:
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+        # tools/pmc_traffic.py, gfx950 correction 2 x fetch + write) committed under profiles/: counters cannot be
+        # collected from inside this process
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as fh:
+                traffic = json.load(fh)["kernels"]["void k_gemm<true, true, true>"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --init random)"
+        except (OSError, KeyError, ValueError):
+            pass
         zz = prof["c128xc128"]
         achieved = zz["flops"] / (zz["ms"] * 1e-3) / 1e12 if zz["ms"] > 0 else 0.0
         total_ms = sum(v["ms"] for v in prof.values())
@@ -249,7 +259,9 @@ def main():
                        "device": eng.device_name},
             "roofline": {"bound": "mfma", "kernel": "k_gemm<c128,c128> (FP64 MFMA strided contraction)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
+                         "compulsory_bytes_per_launch": zz["bytes"] / max(1, zz["launches"]),
                          "timed_launches": zz["launches"], "sampling_stride": PROF_STRIDE, "avg_launch_ms": zz["ms"] / max(1, zz["launches"]),
                          "alg_flops_per_launch": zz["flops"] / max(1, zz["launches"]),
                          "contraction_time_share_of_wall_est": PROF_STRIDE * 1e-3 * total_ms / elapsed / T},

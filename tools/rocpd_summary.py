@@ -20,6 +20,17 @@ def main():
         short = short.split("(")[0][:80]
         lines.append(f"| {short} | {n} | {tot / 1e6:.3f} | {avg / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | {100 * tot / total:.1f} |")
     lines.append(f"\ntotal kernel time {total / 1e6:.2f} ms over {sum(r[1] for r in rows)} dispatches")
+    # bench.py's roofline times one c128 x c128 contraction call = k_gemm<true, true, *> plus, for split-K calls,
+    # its k_splitk_reduce<true>; the matching trace figure is (their summed time) / (number of k_gemm launches)
+    g = [r for r in rows if re.search(r"k_gemm<true, true, (true|false)>", r[0])]
+    red = [r for r in rows if "k_splitk_reduce<true>" in r[0]]
+    if g:
+        ng = sum(r[1] for r in g)
+        tg = sum(r[2] for r in g)
+        tr = sum(r[2] for r in red)
+        lines.append(f"\nc128 x c128 contraction calls: {ng}; k_gemm alone {tg / ng / 1e3:.2f} us/call; "
+                     f"with split-K reduce {(tg + tr) / ng / 1e3:.2f} us/call "
+                     f"(compare bench.py roofline.avg_launch_ms)")
     out = "\n".join(lines)
     print(out)
     if len(sys.argv) > 2:
