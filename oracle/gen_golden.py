@@ -362,6 +362,45 @@ def gen_tdvp_ps2():
     _tdvp_run(model, mpo, init, occ, 5, 10.0, "tdvp_ps2_holstein_small.npz")
 
 
+def gen_obs():
+    """Observables of a fixed complex MPS: occupations, one-site / electronic reduced density matrices, bond
+    singular values and entropies (mps/mps.py:578-609, 1547-1598, 1657-1795)."""
+    from renormalizer.model import Phonon, Mol, HolsteinModel
+    from renormalizer.mps import Mps, Mpo
+    from renormalizer.utils import Quantity, CompressConfig, EvolveConfig, EvolveMethod, CompressCriteria
+    nmol, pdim = 3, 4
+    ph = [Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), pdim),
+          Phonon.simple_phonon(Quantity(3.1e-3), Quantity(9.5), 3)]
+    model = HolsteinModel([Mol(Quantity(0), ph)] * nmol, Quantity(3.0e-2), 3)
+    np.random.seed(2468)
+    mps = Mps.random(model, 1, 8)
+    mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=8)
+    mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    mpo = Mpo(model)
+    mps = mps.to_complex().evolve(mpo, 8.0).evolve(mpo, 8.0)
+    mps.canonicalise().normalize("mps_only")
+    out = {}
+    for i, b in enumerate(model.basis):
+        out[f"sigmaqn_{i}"] = np.asarray(b.sigmaqn).reshape(b.nbas, -1).astype(np.int64)
+    _dump_mps(out, "mps_", mps)
+    out["e_occupations"] = np.asarray(mps.e_occupations)
+    out["ph_occupations"] = np.asarray(mps.ph_occupations)
+    rdm = mps.calc_1site_rdm()
+    for k, v in rdm.items():
+        out[f"rdm1_{k}"] = np.asarray(v)
+    out["edof_rdm"] = np.asarray(mps.calc_edof_rdm())
+    out["bond_entropy"] = np.asarray(mps.calc_entropy("bond"))
+    s1 = mps.calc_entropy("1site")
+    out["site_entropy"] = np.array([s1[k] for k in range(len(mps))])
+    sv = mps.calc_bond_singular_values()
+    width = max(len(x) for x in sv)
+    out["bond_sv"] = np.array([np.pad(np.asarray(x), (0, width - len(x))) for x in sv])
+    np.savez_compressed(os.path.join(GOLD, "observables_holstein_small.npz"), **out)
+    print("observables_holstein_small.npz", out["e_occupations"], out["bond_entropy"][:3])
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("obs",)):
+    gen_obs()
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("mpo",)):
     gen_mpo()
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("ps2",)):

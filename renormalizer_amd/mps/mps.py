@@ -24,6 +24,15 @@ from .svd_qn import add_outer, get_qn_mask
 logger = logging.getLogger("renormalizer_amd")
 
 
+def _vn_entropy(p):
+    """-sum p ln p of normalised non-negative weights (utils/utils.py:41-48)"""
+    p = np.asarray(p, dtype=float)
+    assert np.allclose(p[p < 0], 0)
+    p = p / p.sum()
+    p = p[p > 0]
+    return float(-(p * np.log(p)).sum())
+
+
 def _is_identity_site(w):
     """MPO site tensor (w_l, d, d, w_r) that is exactly the identity pass-through."""
     w = np.asarray(w)
@@ -444,6 +453,103 @@ class Mps:
             self.model.mpos[key] = [Mpo(self.model, Op(r"a^\dagger a", dof)) for dof in self.model.e_dofs]
         return self.expectations(self.model.mpos[key])
 
+    @property
+    def ph_occupations(self):
+        """mps/mps.py:578-594: occupation numbers of the vibrational degrees of freedom, order of model.v_dofs"""
+        key = "ph_occupations"
+        if key not in self.model.mpos:
+            self.model.mpos[key] = [Mpo(self.model, Op("n", dof)) for dof in self.model.v_dofs]
+        return self.expectations(self.model.mpos[key])
+
+    def calc_1site_rdm(self, idx=None) -> Dict[int, np.ndarray]:
+        """One-site reduced density matrices (mps/mps.py:1547-1598): rdm[i][p, p'] = sum conj(A[a,p,b]) L[a,a']
+        R[b,b'] A[a',p',b'] with the identity-operator environments of the other sites.  The environments are one
+        right-to-left pass plus one left-to-right pass on the device; only the d x d results come to the host."""
+        from ..engine import idx1, idx2
+        eng = get_engine()
+        n = self.site_num
+        if idx is None:
+            idx = list(range(n))
+        elif isinstance(idx, (int, np.integer)):
+            idx = [int(idx)]
+        else:
+            idx = list(idx)
+        ident = [eng.asdevice(np.eye(self[i].shape[1]).reshape(1, self[i].shape[1], self[i].shape[1], 1))
+                 for i in range(n)]
+        sentinel = eng.ones((1, 1, 1), np.float64)
+        sentinel.unit = 1
+        renv = {n: sentinel}
+        for i in range(n - 1, 0, -1):
+            renv[i] = contract_one_site(renv[i + 1], self[i], ident[i], "R")
+        rdm = {}
+        lenv = sentinel
+        for i in range(n):
+            ms = self[i]
+            if ms.ndim != 3:
+                raise NotImplementedError("calc_1site_rdm: density-operator (4-leg) sites")
+            if i in idx:
+                Dl, d, Dr = ms.shape
+                L = lenv.reshape(lenv.shape[0], lenv.shape[2])
+                R = renv[i + 1].reshape(renv[i + 1].shape[0], renv[i + 1].shape[2])
+                # X[a', (p, b)] = sum_a L[a, a'] conj(A)[a, (p, b)] ; Y[(a', p), b'] = sum_b X[(a', p), b] R[b, b']
+                x = eng.matmul(L, ms.reshape(Dl, d * Dr), trans_a=True, conj_b=True)
+                y = eng.matmul(x.reshape(Dl * d, Dr), R)
+                a = ms.to_complex() if y.is_complex and not ms.is_complex else ms
+                # rdm[p, p'] = sum_{a', b'} Y[a', p, b'] A[a', p', b']
+                out = eng.empty((d, d), np.complex128 if (y.is_complex or a.is_complex) else np.float64)
+                eng.gemm(y, a, out, idx1(d, Dr), idx2(Dl, Dr, d * Dr, 1), idx2(Dl, Dr, d * Dr, 1), idx1(d, Dr),
+                         idx1(d, d), idx1(d, 1))
+                rdm[i] = out.to_host()
+                assert np.allclose(rdm[i], rdm[i].T.conj())
+            if i < n - 1:
+                lenv = contract_one_site(lenv, ms, ident[i], "L")
+        return rdm
+
+    def calc_edof_rdm(self) -> np.ndarray:
+        """rho_ij = <a_i^dagger a_j> over the electronic degrees of freedom (mps/mps.py:1657-1687)"""
+        key = "edof_reduced_density_matrix"
+        e_dofs = self.model.e_dofs
+        n_e = len(e_dofs)
+        if key not in self.model.mpos:
+            self.model.mpos[key] = [Mpo(self.model, Op(r"a^\dagger a", [d1, d2]))
+                                    for i, d1 in enumerate(e_dofs) for d2 in e_dofs[i:]]
+        vals = list(np.atleast_1d(self.expectations(self.model.mpos[key])))
+        rho = np.zeros((n_e, n_e), dtype=np.complex128)
+        k = 0
+        for i in range(n_e):
+            for j in range(i, n_e):
+                rho[i, j] = vals[k]
+                rho[j, i] = np.conj(vals[k])
+                k += 1
+        return rho
+
+    def calc_bond_singular_values(self) -> np.ndarray:
+        """mps/mps.py:1759-1773: singular values at every bond (rows padded with zeros), on a copy"""
+        mps = self.copy()
+        mps.ensure_right_canonical()
+        _, s_array = mps.compress(temp_m_trunc=np.inf, ret_s=True)
+        return s_array
+
+    def calc_bond_entropy(self, s_array=None) -> np.ndarray:
+        """von Neumann entropy of every bipartition (mps/mps.py:1775-1795)"""
+        if s_array is None:
+            s_array = self.calc_bond_singular_values()
+        return np.array([_vn_entropy(np.asarray(sigma) ** 2) for sigma in s_array])
+
+    def calc_entropy(self, entropy_type):
+        """mps/mps.py:1689-1732 for "1site" and "bond" """
+        if entropy_type == "1site":
+            out = {}
+            for k, dm in self.calc_1site_rdm().items():
+                w = np.linalg.eigvalsh(dm)
+                out[k] = _vn_entropy(w)
+            return out
+        if entropy_type == "bond":
+            return self.calc_bond_entropy()
+        if entropy_type in ("2site", "mutual"):
+            raise NotImplementedError("2-site reduced density matrices are not implemented")
+        raise ValueError(f"unsupported entropy type {entropy_type}")
+
     # ------------------------------------------------------------------ canonical form / compression
     def _update_ms(self, idx, u, vt, sigma=None, qnlset=None, qnrset=None, m_trunc=None):
         """mps/mp.py:245-295 for an MPS: keep the first m_trunc columns, push sigma/R to the neighbour."""
@@ -525,7 +631,7 @@ class Mps:
                     m_trunc = temp_m_trunc[idx + 1 if self.to_right else idx]
                 else:
                     m_trunc = temp_m_trunc
-                m_trunc = min(int(m_trunc), len(sigma))
+                m_trunc = len(sigma) if np.isinf(m_trunc) else min(int(m_trunc), len(sigma))
             self._update_ms(idx, u, v.T, sigma, qnlset, qnrset, m_trunc)
         self._switch_direction()
         if not ret_s:

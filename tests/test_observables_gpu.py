@@ -1,0 +1,66 @@
+"""GPU parity of the observable layer against values the real reference computed
+for a fixed complex MPS (tests/golden/observables_holstein_small.npz, oracle/gen_golden.py obs)."""
+import os
+
+import numpy as np
+import pytest
+
+from renormalizer_amd import HolsteinModel, Phonon, Mol, Quantity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def state(golden_dir):
+    from renormalizer_amd.mps.mps import Mps
+    z = np.load(os.path.join(golden_dir, "observables_holstein_small.npz"))
+    ph = [Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), 4),
+          Phonon.simple_phonon(Quantity(3.1e-3), Quantity(9.5), 3)]
+    model = HolsteinModel([Mol(Quantity(0), ph)] * 3, Quantity(3.0e-2), 3)
+    n = int(z["mps_nsite"])
+    assert n == model.nsite
+    for i, b in enumerate(model.basis):
+        assert np.array_equal(np.asarray(b.sigmaqn).reshape(b.nbas, -1), z[f"sigmaqn_{i}"])
+    mps = Mps.from_arrays(model, [z[f"mps_site_{i}"] for i in range(n)], [z[f"mps_qn_{i}"] for i in range(n + 1)],
+                          int(z["mps_qnidx"]), z["mps_qntot"], bool(z["mps_to_right"]), complex(z["mps_coeff"]))
+    return z, mps
+
+
+def test_occupations(state):
+    z, mps = state
+    assert np.abs(np.asarray(mps.e_occupations) - z["e_occupations"]).max() < 1e-12
+    assert np.abs(np.asarray(mps.ph_occupations) - z["ph_occupations"]).max() < 1e-12
+
+
+def test_one_site_rdm_and_entropy(state):
+    z, mps = state
+    rdm = mps.calc_1site_rdm()
+    assert sorted(rdm) == list(range(len(mps)))
+    for k, v in rdm.items():
+        assert v.shape == z[f"rdm1_{k}"].shape
+        assert np.abs(v - z[f"rdm1_{k}"]).max() < 1e-12
+    assert set(mps.calc_1site_rdm([2, 5])) == {2, 5}
+    s1 = mps.calc_entropy("1site")
+    assert np.abs(np.array([s1[k] for k in range(len(mps))]) - z["site_entropy"]).max() < 1e-10
+
+
+def test_edof_rdm(state):
+    z, mps = state
+    rho = mps.calc_edof_rdm()
+    assert np.abs(rho - z["edof_rdm"]).max() < 1e-12
+    assert np.allclose(np.diag(rho).real, mps.e_occupations)      # mps/tests/test_mps.py:46-53
+
+
+def test_bond_entropy(state):
+    z, mps = state
+    sv = mps.calc_bond_singular_values()
+    ref = z["bond_sv"]
+    w = min(sv.shape[1], ref.shape[1])
+    assert np.abs(sv[:, :w] - ref[:, :w]).max() < 1e-11
+    assert np.abs(mps.calc_entropy("bond") - z["bond_entropy"]).max() < 1e-10
+    # the state itself is untouched (the sweep runs on a copy)
+    assert np.abs(np.asarray(mps.e_occupations) - z["e_occupations"]).max() < 1e-12
+    # test_mps.py:74-88: the first / last bond entropy equals the one-site entropy of the edge sites
+    s1 = mps.calc_entropy("1site")
+    sb = mps.calc_entropy("bond")
+    assert abs(sb[0] - s1[0]) < 1e-10 and abs(sb[-1] - s1[len(mps) - 1]) < 1e-10
