@@ -81,3 +81,98 @@ def davidson(aop, x0, hdiag, mask=None, tol=1e-12, max_cycle=100, max_space=12, 
             break
         V.append(t.scale_(1.0 / tn))
     return e, x, ncyc
+
+
+def davidson_multi(aop, guesses, hdiag, nroots, mask=None, tol=1e-12, max_cycle=100, max_space=None, lindep=1e-14,
+                   shift=1e-4):
+    """``nroots`` lowest eigenpairs (block Davidson; davidson.py:73-441 with nroots > 1 as called at gs.py:533-538).
+    ``guesses``: list of device tensors (at least one); missing / dependent guesses are not replaced here - the
+    caller supplies random ones like the reference (gs.py:273-276).  Default ``max_space`` = 12 + 3 (nroots - 1).
+    Returns (list of e, list of x, ncycle); roots are converged when |de| < tol and |r| < sqrt(tol)."""
+    eng = get_engine()
+    if max_space is None:
+        max_space = 12 + (nroots - 1) * 3
+    toloose = np.sqrt(tol)
+    like = guesses[0]
+    n = like.size
+
+    def masked(v):
+        if mask is not None:
+            eng._check(eng.lib.mpse_mul_real(eng.ctx, v.code, v.ptr, mask.ptr, n))
+        return v
+
+    def orth_append(V, t):
+        """Gram-Schmidt twice against V; append when what is left is not negligible"""
+        for _ in range(2):
+            for v in V:
+                ov = complex(v.vdot(t))
+                eng._check(eng.lib.mpse_axpy(eng.ctx, t.code, t.ptr, v.ptr, n, -ov.real, -ov.imag))
+        tn = t.norm()
+        if tn ** 2 < lindep:
+            return False
+        V.append(t.scale_(1.0 / tn))
+        return True
+
+    V, W = [], []
+    for g in guesses:
+        g = masked(g.copy())
+        nrm = g.norm()
+        if nrm > 0:
+            orth_append(V, g.scale_(1.0 / nrm))
+    if not V:
+        raise ValueError("davidson: zero initial guesses")
+    e_last = None
+    es, xs = None, None
+    ncyc = 0
+    for ncyc in range(1, max_cycle + 1):
+        while len(W) < len(V):
+            W.append(masked(aop(V[len(W)])))
+        m = len(V)
+        hsub = np.zeros((m, m), dtype=complex)
+        for i in range(m):
+            for j in range(i, m):
+                hsub[i, j] = V[i].vdot(W[j])
+                hsub[j, i] = np.conj(hsub[i, j])
+        if not like.is_complex:
+            hsub = hsub.real
+        ew, ev = np.linalg.eigh(hsub)
+        k = min(nroots, m)
+        es = [float(x) for x in ew[:k]]
+        xs = [_lincomb(eng, V, ev[:, r], like) for r in range(k)]
+        hxs = [_lincomb(eng, W, ev[:, r], like) for r in range(k)]
+        rs, conv = [], []
+        for r in range(k):
+            res = hxs[r].copy()
+            eng._check(eng.lib.mpse_axpy(eng.ctx, res.code, res.ptr, xs[r].ptr, n, -es[r], 0.0))
+            rn = res.norm()
+            de = np.inf if (e_last is None or r >= len(e_last)) else es[r] - e_last[r]
+            conv.append((abs(de) < tol and rn < toloose) or rn < 1e-14)
+            rs.append(res)
+        e_last = es
+        if k == nroots and all(conv):
+            break
+        if m >= n:
+            break
+        todo = [r for r in range(k) if not conv[r]] or list(range(k))
+        if m + len(todo) > max_space:
+            # restart from the current Ritz vectors (orthonormal by construction up to rounding)
+            V, W = [], []
+            for r in range(k):
+                x, hx = xs[r].copy(), hxs[r].copy()
+                for _ in range(2):
+                    for v, w in zip(list(V), list(W)):
+                        ov = complex(v.vdot(x))
+                        eng._check(eng.lib.mpse_axpy(eng.ctx, x.code, x.ptr, v.ptr, n, -ov.real, -ov.imag))
+                        eng._check(eng.lib.mpse_axpy(eng.ctx, hx.code, hx.ptr, w.ptr, n, -ov.real, -ov.imag))
+                nx = x.norm()
+                V.append(x.scale_(1.0 / nx))
+                W.append(hx.scale_(1.0 / nx))
+        added = 0
+        for r in todo:
+            t = eng.empty(like.shape, like.dtype)
+            eng._check(eng.lib.mpse_davidson_precond(eng.ctx, t.code, t.ptr, rs[r].ptr, hdiag.ptr,
+                                                     None if mask is None else mask.ptr, n, es[r], shift))
+            added += bool(orth_append(V, t))
+        if added == 0:
+            break
+    return es, xs, ncyc

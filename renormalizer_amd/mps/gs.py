@@ -5,14 +5,15 @@ Counterpart of renormalizer/mps/gs.py: ``optimize_mps`` (:54-171) macro loop ove
 ``get_ham_iterative`` / ``eigh_iterative`` (:410-576).  Differences by design: the quantum-number mask is kept
 as a dense 0/1 weight vector on the device (the reference compresses vectors to the allowed entries on the
 host, gs.py:260, 520-523 - same iterates, no host round trip), every centre is solved with the Davidson
-iteration (the reference diagonalises centres below 1000 elements densely with SciPy, gs.py:245-247), and only
-``nroots == 1`` is implemented."""
+iteration (the reference diagonalises centres below 1000 elements densely with SciPy, gs.py:245-247).
+``nroots > 1`` (state-averaged DMRG) uses the block Davidson of lib/davidson.py and the averaged-density-matrix
+update of ``Mps._update_mps``; the (H - omega)^2 functional is not implemented."""
 import logging
 
 import numpy as np
 
 from ..engine import get_engine, idx1, idx2
-from ..lib.davidson import davidson
+from ..lib.davidson import davidson, davidson_multi
 from ..utils import CompressConfig, CompressCriteria
 from .hop_expr import hop_expr
 from .lib import Environ
@@ -67,8 +68,14 @@ def eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, cguess):
     hop = hop_expr(ltensor, rtensor, cmo, cshape)
     hdiag = _hdiag(eng, hop.l, hop.r, hop.cmo)
     mask = eng.asdevice(qn_mask.astype(np.float64))
-    e, c, ncyc = davidson(lambda x: hop(x), cguess.reshape(cshape), hdiag, mask=mask, tol=1e-12, max_cycle=100,
-                          max_space=12, lindep=1e-14)
+    nroots = mps.optimize_config.nroots
+    if nroots == 1:
+        e, c, ncyc = davidson(lambda x: hop(x), cguess.reshape(cshape), hdiag, mask=mask, tol=1e-12, max_cycle=100,
+                              max_space=12, lindep=1e-14)
+        return e, c, ncyc
+    guesses = [g.reshape(cshape) for g in cguess]
+    e, c, ncyc = davidson_multi(lambda x: hop(x), guesses, hdiag, nroots, mask=mask, tol=1e-12, max_cycle=100,
+                                lindep=1e-14)
     return e, c, ncyc
 
 
@@ -76,9 +83,12 @@ def single_sweep(mps, mpo, environ, percent, last_opt_e_idx):
     """gs.py:174-304 (nroots == 1, no omega, no site swapping)."""
     eng = get_engine()
     method = mps.optimize_config.method
+    nroots = mps.optimize_config.nroots
     res_mps = None
     micro = []
     hops = []
+    averaged_ms = None
+    rng = np.random.default_rng(mps.optimize_config.__dict__.get("guess_seed", 0))
     for imps in mps.iter_idx_list(full=True):
         if method == "2site" and ((mps.to_right and imps == mps.site_num - 1) or ((not mps.to_right) and imps == 0)):
             break
@@ -94,19 +104,41 @@ def single_sweep(mps, mpo, environ, percent, last_opt_e_idx):
         qnbigl, qnbigr, qnmat = mps._get_big_qn(cidx)
         qn_mask = get_qn_mask(qnmat, mps.qntot)
         cmo = [mpo.device(i, eng) for i in cidx]
-        if method == "1site":
-            guess = mps[cidx[0]]
+        def two_site(a, b):
+            return eng.matmul(a.reshape(-1, a.shape[-1]), b.reshape(b.shape[0], -1))
+
+        if nroots == 1:
+            guess = mps[cidx[0]] if method == "1site" else two_site(mps[cidx[0]], mps[cidx[1]])
         else:
-            a, b = mps[cidx[0]], mps[cidx[1]]
-            guess = eng.matmul(a.reshape(-1, a.shape[-1]), b.reshape(b.shape[0], -1))
+            # gs.py:262-276: the rotated roots of the previous centre, padded with random vectors
+            guess = []
+            for ms in (averaged_ms or [mps[cidx[0]] if method == "1site" else None]):
+                if ms is None:
+                    guess.append(two_site(mps[cidx[0]], mps[cidx[1]]))
+                elif method == "1site":
+                    guess.append(ms)
+                elif mps.to_right:
+                    guess.append(two_site(ms, mps[cidx[1]]))
+                else:
+                    guess.append(two_site(mps[cidx[0]], ms))
+            while len(guess) < nroots:
+                guess.append(eng.asdevice((rng.random(qn_mask.shape) - 0.5) * qn_mask))
         e, c, ncyc = eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, guess)
         hops.append(ncyc)
         micro.append((e, cidx))
-        cstruct = c.reshape(qn_mask.shape)
-        if cidx == last_opt_e_idx:
-            res_mps = mps.copy()
-            res_mps._update_mps(cstruct, cidx, qnbigl, qnbigr, percent)
-        mps._update_mps(cstruct, cidx, qnbigl, qnbigr, percent)
+        if nroots == 1:
+            cstruct = c.reshape(qn_mask.shape)
+            if cidx == last_opt_e_idx:
+                res_mps = mps.copy()
+                res_mps._update_mps(cstruct, cidx, qnbigl, qnbigr, percent)
+            mps._update_mps(cstruct, cidx, qnbigl, qnbigr, percent)
+        else:
+            cstruct = [x.reshape(qn_mask.shape) for x in c]
+            if cidx == last_opt_e_idx:
+                res_mps = [mps.copy() for _ in cstruct]
+                for r, cs in enumerate(cstruct):
+                    res_mps[r]._update_mps(cs, cidx, qnbigl, qnbigr, percent)
+            averaged_ms = mps._update_mps(cstruct, cidx, qnbigl, qnbigr, percent)
     mps._switch_direction()
     logger.debug(f"Davidson cycles per site: {hops}")
     return micro, res_mps
@@ -117,8 +149,7 @@ def optimize_mps(mps, mpo, omega: float = None):
     The input mps is overwritten, as in the reference."""
     if omega is not None:
         raise NotImplementedError("the (H - omega)^2 functional is not implemented")
-    if mps.optimize_config.nroots != 1:
-        raise NotImplementedError("state-averaged DMRG (nroots > 1) is not implemented")
+    nroots = mps.optimize_config.nroots
     assert mps.optimize_config.method in ["2site", "1site"]
     if mps.is_left_canonical:
         mps.ensure_right_canonical()
@@ -141,19 +172,26 @@ def optimize_mps(mps, mpo, omega: float = None):
         micro, res, = single_sweep(mps, mpo, environ, percent, opt_e_idx)
         if res is not None:
             res_mps = res
-        opt_e = min(micro, key=lambda x: x[0])
+        # gs.py:136-160: the centre with the lowest (summed, for several roots) energy marks the optimal position
+        # (energies of several roots compare like the reference's lists: lowest root first)
+        opt_e = min(micro, key=lambda x: x[0] if nroots == 1 else tuple(x[0]))
         macro.append(opt_e[0])
         opt_e_idx = opt_e[1]
-        logger.debug(f"{isweep + 1} sweeps are finished, lowest energy = {min(macro)}")
+        logger.debug(f"{isweep + 1} sweeps are finished, lowest energy = {opt_e[0]}")
         if isweep > 0 and percent == 0:
-            v1, v2 = sorted(macro)[:2]
+            v1, v2 = sorted(macro, key=lambda x: x if nroots == 1 else tuple(x))[:2]
             if np.allclose(v1, v2, rtol=mps.optimize_config.e_rtol, atol=mps.optimize_config.e_atol):
                 logger.info("DMRG has converged!")
                 break
     else:
         logger.warning("DMRG did not converge! Please increase the procedure!")
     if res_mps is None:          # a single macro sweep: nothing was recorded at the optimal centre yet
-        res_mps = mps.copy()
-    res_mps = res_mps.normalize("mps_only").ensure_left_canonical().canonicalise()
-    res_mps.compress_config = compress_config_bk
+        res_mps = mps.copy() if nroots == 1 else [mps.copy() for _ in range(nroots)]
+    if nroots == 1:
+        res_mps = res_mps.normalize("mps_only").ensure_left_canonical().canonicalise()
+        res_mps.compress_config = compress_config_bk
+    else:
+        res_mps = [m.normalize("mps_only").ensure_left_canonical().canonicalise() for m in res_mps]
+        for m in res_mps:
+            m.compress_config = compress_config_bk
     return macro, res_mps

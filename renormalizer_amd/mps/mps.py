@@ -672,9 +672,36 @@ class Mps:
         system = "L" if self.to_right else "R"
         if self.compress_config.bonddim_should_set:
             self.compress_config.set_bonddim(len(self) + 1)
-        U, SU, qnlnew, V, SV, qnrnew = svd_qn.svd_qn(cstruct, qnbigl, qnbigr, self.qntot, system=system)
-        Vt = V.T
         q = len(self.qntot)
+        roots = None
+        if isinstance(cstruct, (list, tuple)):
+            # state-averaged DMRG (mp.py:700-756): the eigenvectors of the averaged reduced density matrix
+            # sum_r c_r c_r^+ / nroots are the singular vectors of the root-stacked centre matrix, so the same
+            # block SVD (with null-space completion) serves; "singular values" handed on are the eigenvalues
+            roots = [eng.asdevice(c) for c in cstruct]
+            nroot = len(roots)
+            nrow = int(np.prod(np.asarray(qnbigl).shape[:-1]))
+            ncol = int(np.prod(np.asarray(qnbigr).shape[:-1]))
+            dt = np.complex128 if any(c.is_complex for c in roots) else np.float64
+            roots = [(c.to_complex() if dt == np.complex128 else c).reshape(nrow, ncol) for c in roots]
+            if self.to_right:
+                stack = eng.empty((nrow, nroot * ncol), dt)
+                for r, c in enumerate(roots):
+                    eng.copy_block(stack, 0, r * ncol, c)
+                qr_flat = np.asarray(qnbigr).reshape(ncol, q)
+                qnl_s, qnr_s = qnbigl, np.concatenate([qr_flat] * nroot, axis=0)
+            else:
+                stack = eng.empty((nroot * nrow, ncol), dt)
+                for r, c in enumerate(roots):
+                    eng.copy_block(stack, r * nrow, 0, c)
+                ql_flat = np.asarray(qnbigl).reshape(nrow, q)
+                qnl_s, qnr_s = np.concatenate([ql_flat] * nroot, axis=0), qnbigr
+            stack.scale_(1.0 / np.sqrt(nroot))
+            U, SU, qnlnew, V, SV, qnrnew = svd_qn.svd_qn(stack, qnl_s, qnr_s, self.qntot, system=system)
+            SU, SV = np.asarray(SU) ** 2, np.asarray(SV) ** 2
+        else:
+            U, SU, qnlnew, V, SV, qnrnew = svd_qn.svd_qn(cstruct, qnbigl, qnbigr, self.qntot, system=system)
+        Vt = V.T
         if self.to_right:
             m_trunc = self.compress_config.compute_m_trunc(SU, cidx[0], self.to_right)
             sidx = select_basis_indices(SU, qnlnew, m_trunc, percent)
@@ -718,7 +745,20 @@ class Mps:
 
         lshape = list(np.asarray(qnbigl).shape[:-1])
         rshape = list(np.asarray(qnbigr).shape[:-1])
-        if self.to_right:
+        rotated, averaged_ms = None, None
+        if roots is not None:
+            # new basis = selected eigenvectors; every root is rotated into it (mp.py:729-756)
+            averaged_ms = []
+            if self.to_right:
+                ms2 = cols_of(U, idx, None)                                     # (nrow, M)
+                ms = ms2.reshape(lshape + [nsel])
+                rotated = [eng.matmul(ms2, c, trans_a=True, conj_a=True).reshape([nsel] + rshape) for c in roots]
+            else:
+                ms2 = rows_of(Vt, idx, None)                                    # (M, ncol)
+                ms = ms2.reshape([nsel] + rshape)
+                rotated = [eng.matmul(c, ms2, trans_b=True, conj_b=True).reshape(lshape + [nsel]) for c in roots]
+            compms = rotated[0]
+        elif self.to_right:
             ms = cols_of(U, idx, None).reshape(lshape + [nsel])                 # (D_l, d, M)
             compms = rows_of(Vt, idx, sig).reshape([nsel] + rshape)             # (M, [d,] D_r) = moveaxis(V sigma)
         else:
@@ -727,6 +767,24 @@ class Mps:
         if len(cidx) == 1:
             c = cidx[0]
             self[c] = ms
+            if rotated is not None:
+                # better initial guesses for the next centre: every root absorbed into the neighbour (mp.py:838-868)
+                if self.to_right:
+                    if c != self.site_num - 1:
+                        nxt = self[c + 1]
+                        averaged_ms = [eng.matmul(rc.reshape(nsel, -1), nxt.reshape(nxt.shape[0], -1))
+                                       .reshape((nsel,) + nxt.shape[1:]) for rc in rotated]
+                    else:
+                        averaged_ms = [eng.matmul(ms.reshape(-1, nsel), rc.reshape(nsel, -1)).reshape(lshape + [-1])
+                                       for rc in rotated]
+                else:
+                    if c != 0:
+                        prv = self[c - 1]
+                        averaged_ms = [eng.matmul(prv.reshape(-1, prv.shape[-1]), rc.reshape(-1, nsel))
+                                       .reshape(prv.shape[:-1] + (nsel,)) for rc in rotated]
+                    else:
+                        averaged_ms = [eng.matmul(rc.reshape(-1, nsel), ms.reshape(nsel, -1)).reshape([-1] + rshape)
+                                       for rc in rotated]
             if self.to_right:
                 if c != self.site_num - 1:
                     nxt = self[c + 1]
@@ -757,7 +815,9 @@ class Mps:
                 self[cidx[0]] = compms
                 self.qnidx = cidx[0]
             self.qn[cidx[1]] = msqn
-        return None
+            if rotated is not None:
+                averaged_ms = rotated
+        return averaged_ms
 
     # ------------------------------------------------------------------ sums of states
     def add(self, other: "Mps") -> "Mps":

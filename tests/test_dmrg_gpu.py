@@ -60,3 +60,30 @@ def test_h2o_sto3g_fci_energy(golden_dir):
     assert abs(opt.expectation(mpo) + nuc - (-75.008697516450)) < 1e-7
     # particle numbers are conserved exactly by the block structure
     assert opt.qntot.tolist() == [5, 5]
+
+
+@pytest.mark.parametrize("method", ["2site", "1site"])
+def test_holstein_multistate(method):
+    """mps/tests/test_gs.py:40-61: state-averaged DMRG, four lowest one-exciton states of the test model."""
+    from renormalizer_amd.mps.gs import optimize_mps
+    from renormalizer_amd.mps.mps import Mps
+    model = _holstein_test_model()
+    mpo = Mpo(model)
+    procedure = [[10, 0.4], [20, 0.2], [30, 0.1], [40, 0], [40, 0]]
+    mps = Mps.random(model, 1, procedure[0][0], rng=np.random.default_rng(2019))
+    mps.optimize_config.procedure = procedure
+    mps.optimize_config.nroots = 4
+    mps.optimize_config.method = method
+    mps.optimize_config.e_atol = 1e-6
+    mps.optimize_config.e_rtol = 1e-6
+    energy, states = optimize_mps(mps, mpo)
+    energy_std = np.array([0.08401412, 0.08449771, 0.08449801, 0.08449945]) + model.gs_zpe
+    assert len(states) == 4
+    assert np.allclose(energy[-1], energy_std)
+    assert np.allclose([m.expectation(mpo) for m in states], energy_std)
+    # the states are orthonormal
+    for i, a in enumerate(states):
+        for j, b in enumerate(states):
+            ov = a.conj().dot(b) if hasattr(a, "conj") else None
+            if ov is not None:
+                assert abs(ov - (i == j)) < 1e-5
