@@ -7,7 +7,8 @@ as a dense 0/1 weight vector on the device (the reference compresses vectors to 
 host, gs.py:260, 520-523 - same iterates, no host round trip), every centre is solved with the Davidson
 iteration (the reference diagonalises centres below 1000 elements densely with SciPy, gs.py:245-247).
 ``nroots > 1`` (state-averaged DMRG) uses the block Davidson of lib/davidson.py and the averaged-density-matrix
-update of ``Mps._update_mps``; the (H - omega)^2 functional is not implemented."""
+update of ``Mps._update_mps``.  ``omega`` (excited states through the (H - omega)^2 functional, gs.py:106-112)
+runs the same sweeps on the product MPO (H - omega).(H - omega) rather than on two-layer environments."""
 import logging
 
 import numpy as np
@@ -148,7 +149,12 @@ def optimize_mps(mps, mpo, omega: float = None):
     """DMRG ground state (gs.py:54-171).  Returns (list of the lowest energy of every macro sweep, optimised mps).
     The input mps is overwritten, as in the reference."""
     if omega is not None:
-        raise NotImplementedError("the (H - omega)^2 functional is not implemented")
+        # gs.py:106-112 builds two-layer environments for (H - omega)^2.  P (H - omega)^2 P is the projected
+        # operator of the product MPO (H - omega).(H - omega), so the ordinary one-layer kernels are run on that
+        # operator (bond dimension (w + 1)^2) instead of adding a second MPO leg to every kernel.
+        from .mpo import Mpo
+        shifted = mpo.add(Mpo.identity(mpo.model).scale(-omega))
+        mpo = shifted.product(shifted)
     nroots = mps.optimize_config.nroots
     assert mps.optimize_config.method in ["2site", "1site"]
     if mps.is_left_canonical:

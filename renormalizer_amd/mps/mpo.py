@@ -382,7 +382,66 @@ class Mpo:
         return new
 
     def __matmul__(self, other):
+        if isinstance(other, Mpo):
+            return self.product(other)
         return self.apply(other)
+
+    # ---- operator algebra on the host (MPO tensors are KB-sized; mp.py:374-435, 1013-1031 for operators)
+    def _like(self, arrays, qn, qntot):
+        new = Mpo()
+        new.model = self.model
+        new._mp = arrays
+        new.qn = qn
+        new.qntot = np.asarray(qntot, dtype=int)
+        new.qnidx = len(arrays) - 1
+        new.to_right = False
+        return new
+
+    def scale(self, val):
+        """val * operator (the factor goes into the last site, where the builder keeps the coefficients)"""
+        arrays = [a.copy() for a in self._mp]
+        if np.iscomplexobj(val) and np.imag(val) != 0:
+            arrays[-1] = arrays[-1].astype(complex)
+        else:
+            val = float(np.real(val))
+        arrays[-1] = arrays[-1] * val
+        return self._like(arrays, [q.copy() for q in self.qn], self.qntot)
+
+    def add(self, other: "Mpo") -> "Mpo":
+        """Sum of two operators with equal total quantum number: direct sum of the bond spaces"""
+        assert self.site_num == other.site_num and np.array_equal(self.qntot, other.qntot)
+        assert self.qnidx == other.qnidx == self.site_num - 1
+        n = self.site_num
+        arrays = []
+        for i, (a, b) in enumerate(zip(self._mp, other._mp)):
+            dt = np.result_type(a.dtype, b.dtype)
+            if n == 1:
+                arrays.append((a + b).astype(dt))
+                continue
+            la, ra, lb, rb = a.shape[0], a.shape[3], b.shape[0], b.shape[3]
+            if i == 0:
+                w = np.concatenate([a, b], axis=3).astype(dt)
+            elif i == n - 1:
+                w = np.concatenate([a, b], axis=0).astype(dt)
+            else:
+                w = np.zeros((la + lb, a.shape[1], a.shape[2], ra + rb), dtype=dt)
+                w[:la, :, :, :ra] = a
+                w[la:, :, :, ra:] = b
+            arrays.append(w)
+        qn = [self.qn[0].copy()] + [np.concatenate([qa, qb], axis=0) for qa, qb in zip(self.qn[1:-1], other.qn[1:-1])] \
+            + [self.qn[-1].copy()]
+        return self._like(arrays, qn, self.qntot)
+
+    def product(self, other: "Mpo") -> "Mpo":
+        """self . other as one operator, bond dimensions multiply: W[(a,c),p,q,(b,d)] = sum_m A[a,p,m,b] B[c,m,q,d]"""
+        assert self.site_num == other.site_num
+        arrays, qn = [], []
+        for a, b in zip(self._mp, other._mp):
+            w = np.einsum("apmb,cmqd->acpqbd", a, b)
+            arrays.append(w.reshape(a.shape[0] * b.shape[0], a.shape[1], b.shape[2], a.shape[3] * b.shape[3]))
+        for qa, qb in zip(self.qn, other.qn):
+            qn.append((np.asarray(qa)[:, None, :] + np.asarray(qb)[None, :, :]).reshape(-1, np.asarray(qa).shape[1]))
+        return self._like(arrays, qn, self.qntot + other.qntot)
 
     def contract(self, mps, algo="svd"):
         """mpo @ mps followed by canonicalise + compress (mpo.py:391-425)."""

@@ -87,3 +87,48 @@ def test_holstein_multistate(method):
             ov = a.conj().dot(b) if hasattr(a, "conj") else None
             if ov is not None:
                 assert abs(ov - (i == j)) < 1e-5
+
+
+@pytest.mark.parametrize("nroots", [1, 4])
+def test_holstein_excited_states_omega(nroots):
+    """mps/tests/test_gs.py:64-86 (test_ex): minimising (H - omega)^2 around omega = 0.084 finds the same states."""
+    from renormalizer_amd.mps.gs import optimize_mps
+    from renormalizer_amd.mps.mps import Mps
+    model = _holstein_test_model()
+    mpo = Mpo(model)
+    procedure = [[10, 0.4], [20, 0.2], [30, 0.1], [40, 0], [40, 0]]
+    mps = Mps.random(model, 1, procedure[0][0], rng=np.random.default_rng(2019))
+    mps.optimize_config.procedure = procedure
+    mps.optimize_config.nroots = nroots
+    mps.optimize_config.method = "2site"
+    mps.optimize_config.e_atol = 1e-6
+    mps.optimize_config.e_rtol = 1e-6
+    energy, states = optimize_mps(mps, mpo, omega=0.084)
+    energy_std = np.array([0.08401412, 0.08449771, 0.08449801, 0.08449945]) + model.gs_zpe
+    if nroots == 1:
+        assert np.allclose(states.expectation(mpo), energy_std[0])
+    else:
+        assert np.allclose([m.expectation(mpo) for m in states], energy_std)
+
+
+def test_mpo_algebra_dense():
+    """Mpo.add / scale / product against dense matrices (operator algebra used by the omega functional)."""
+    model = _holstein_test_model()
+    from renormalizer_amd import Op
+    a = Mpo(model, Op(r"a^\dagger a", 0, 0.7))
+    b = Mpo(model, Op("x", (1, 0), 1.3))
+    h = Mpo(model)
+    ident = Mpo.identity(model)
+    shifted = h.add(ident.scale(-0.05))
+    assert shifted.bond_dims[1:-1] == [w + 1 for w in h.bond_dims[1:-1]]
+    # compare through expectation values on a random state (dense matrices of this model are 2^3 4^6 = 32768 wide)
+    from renormalizer_amd.mps.mps import Mps
+    psi = Mps.random(model, 1, 6, rng=np.random.default_rng(5))
+    e = psi.expectation(h)
+    assert abs(psi.expectation(shifted) - (e - 0.05)) < 1e-12
+    ab = a.product(b)
+    phi = b.apply(psi)
+    assert abs(psi.expectation(ab) - psi.conj().dot(a.apply(phi))) < 1e-12
+    h2 = shifted.product(shifted)
+    hpsi = shifted.apply(psi)
+    assert abs(psi.expectation(h2) - hpsi.conj().dot(hpsi)) < 1e-10
