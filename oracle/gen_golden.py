@@ -362,6 +362,51 @@ def gen_tdvp_ps2():
     _tdvp_run(model, mpo, init, occ, 5, 10.0, "tdvp_ps2_holstein_small.npz")
 
 
+def gen_adaptive():
+    """Adaptive-step TDVP-PS (mps.py:46-115) on the reduced headline model: observables and the step guesses."""
+    from renormalizer.model import Phonon, Mol, HolsteinModel, Op
+    from renormalizer.mps import Mps, Mpo
+    from renormalizer.utils import Quantity, CompressConfig, EvolveConfig, EvolveMethod, CompressCriteria
+    nmol, pdim = 4, 4
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), pdim)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
+    gs = Mps.ground_state(model, max_entangled=False)
+    init = Mpo.onsite(model, r"a^\dagger", dof_set={nmol // 2}).apply(gs)
+    e0 = Quantity(init.expectation(Mpo(model)))
+    mpo = Mpo(model, offset=e0)
+    init.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=8)
+    init.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps, adaptive=True, guess_dt=15.0, adaptive_rtol=5e-4)
+    np.random.seed(1357)
+    init = init.expand_bond_dimension(mpo)
+    init.canonicalise()
+    occ = [Mpo(model, Op(r"a^\dagger a", dof)) for dof in model.e_dofs]
+    out = {}
+    _dump_mpo(out, "mpo_", mpo)
+    for j, o in enumerate(occ):
+        _dump_mpo(out, f"obs{j}_", o)
+    out["nobs"] = np.array(len(occ))
+    for i, b in enumerate(model.basis):
+        out[f"sigmaqn_{i}"] = np.asarray(b.sigmaqn).reshape(b.nbas, -1).astype(np.int64)
+    _dump_mps(out, "init_", init)
+    mps = init
+    vals, guess, norms = [[mps.expectation(o) for o in occ]], [], []
+    for step in range(3):
+        mps = mps.evolve(mpo, 40.0)
+        vals.append([mps.expectation(o) for o in occ])
+        guess.append(mps.evolve_config.guess_dt)
+        norms.append(mps.mp_norm)
+    out["dt"] = np.array(40.0)
+    out["obs_values"] = np.array(vals, dtype=complex).real
+    out["guess_dt"] = np.array(guess, dtype=float)
+    out["norms"] = np.array(norms)
+    np.savez_compressed(os.path.join(GOLD, "tdvp_adaptive_holstein_small.npz"), **out)
+    print("tdvp_adaptive_holstein_small.npz", out["obs_values"][-1], out["guess_dt"])
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("adaptive",)):
+    gen_adaptive()
+
+
 def gen_obs():
     """Observables of a fixed complex MPS: occupations, one-site / electronic reduced density matrices, bond
     singular values and entropies (mps/mps.py:578-609, 1547-1598, 1657-1795)."""

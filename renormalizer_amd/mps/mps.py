@@ -919,10 +919,12 @@ class Mps:
     def evolve(self, mpo, evolve_dt, normalize=True) -> "Mps":
         """mps/mps.py:644-662"""
         method = self.evolve_config.method
-        if method is EvolveMethod.tdvp_ps:
-            new_mps = self._evolve_tdvp_ps(mpo, evolve_dt)
-        elif method is EvolveMethod.tdvp_ps2:
-            new_mps = self._evolve_tdvp_ps2(mpo, evolve_dt)
+        if method in (EvolveMethod.tdvp_ps, EvolveMethod.tdvp_ps2):
+            step = Mps._evolve_tdvp_ps if method is EvolveMethod.tdvp_ps else Mps._evolve_tdvp_ps2
+            if self.evolve_config.adaptive:
+                new_mps = _adaptive_tdvp(step, self, mpo, evolve_dt)
+            else:
+                new_mps = step(self, mpo, evolve_dt)
         elif method is EvolveMethod.prop_and_compress:
             new_mps = self._evolve_prop_and_compress(mpo, evolve_dt)
         else:
@@ -1082,6 +1084,38 @@ def _evolve_prop_and_compress(self, mpo, evolve_dt) -> "Mps":
 
 
 Mps._evolve_prop_and_compress = _evolve_prop_and_compress
+
+
+def _min_abs(t1, t2):
+    return t1 if abs(t1) < abs(t2) else t2
+
+
+def _adaptive_tdvp(fun, cur_mps, mpo, evolve_target_t):
+    """Step-size control of the projector-splitting integrators (mps/mps.py:46-115, J. Chem. Phys. 146, 174107):
+    a step dt is compared with two steps dt/2; the O(dt^3) splitting error sets the next step through
+    p = (0.75 rtol / relative distance)^(1/3), clipped to [0.1, 2]; p < 0.5 rejects the step."""
+    config = cur_mps.evolve_config.copy()
+    config.check_valid_dt(evolve_target_t)
+    p_restart, p_min, p_max = 0.5, 0.1, 2.0
+    evolved_t = 0
+    while True:
+        dt = _min_abs(config.guess_dt, evolve_target_t - evolved_t)
+        half1 = fun(cur_mps, mpo, dt / 2)
+        half2 = fun(half1, mpo, dt / 2)
+        full = fun(cur_mps, mpo, dt)
+        dis = full.distance(half2)
+        del half1, full
+        p = (0.75 * config.adaptive_rtol / (dis / half2.mp_norm + 1e-30)) ** (1.0 / 3)
+        p = min(max(p, p_min), p_max)
+        if p < p_restart:
+            config.guess_dt = dt * p
+            continue
+        evolved_t += dt
+        if np.allclose(evolved_t, evolve_target_t):
+            half2.evolve_config.guess_dt = config.guess_dt
+            return half2
+        config.guess_dt *= p
+        cur_mps = half2
 
 
 def compressed_sum(mps_list, batchsize=5, temp_m_trunc=None):

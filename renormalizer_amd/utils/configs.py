@@ -112,7 +112,7 @@ class EvolveMethod(Enum):
 
 
 class EvolveConfig:
-    def __init__(self, method: EvolveMethod = EvolveMethod.prop_and_compress, adaptive=False, guess_dt=None,
+    def __init__(self, method: EvolveMethod = EvolveMethod.prop_and_compress, adaptive=False, guess_dt=1e-1,
                  adaptive_rtol=5e-4, taylor_order: int = None, reg_epsilon=1e-10, ivp_rtol=1e-5, ivp_atol=1e-8,
                  ivp_solver="krylov", force_ovlp=True):
         self.method = method
@@ -131,6 +131,16 @@ class EvolveConfig:
     def is_tdvp(self):
         return self.method not in (EvolveMethod.prop_and_compress, EvolveMethod.prop_and_compress_tdrk4,
                                    EvolveMethod.prop_and_compress_tdrk)
+
+    def check_valid_dt(self, evolve_dt):
+        """utils/configs.py:394-402: the guessed and the requested step must be both real or both imaginary-time
+        and point the same way"""
+        info = f"in config: {self.guess_dt}, in arg: {evolve_dt}"
+        if bool(np.iscomplex(evolve_dt)) ^ bool(np.iscomplex(self.guess_dt)):
+            raise ValueError("real and imag not compatible. " + info)
+        if (np.iscomplex(evolve_dt) and np.imag(evolve_dt) * np.imag(self.guess_dt) < 0) or \
+                (not np.iscomplex(evolve_dt) and evolve_dt * self.guess_dt < 0):
+            raise ValueError("evolve into wrong direction. " + info)
 
     def copy(self):
         new = self.__class__.__new__(self.__class__)

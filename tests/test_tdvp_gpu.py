@@ -288,3 +288,22 @@ def test_expectations_shared_environments():
     fast = mps.expectations(mpos[:5], self_conj=bra)
     slow = np.array([mps.expectation(m, self_conj=bra) for m in mpos[:5]])
     assert np.abs(fast - slow).max() < 1e-13
+
+
+def test_adaptive_tdvp_ps_matches_reference(golden_dir):
+    """mps/mps.py:46-115: adaptive step control (dt vs 2 x dt/2); observables and the step guesses the reference
+    left behind after each evolve."""
+    z, mpo, obs, mps, _ = _load(golden_dir, "tdvp_adaptive_holstein_small.npz")
+    mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps, adaptive=True, guess_dt=15.0, adaptive_rtol=5e-4)
+    mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=8)
+    dt = float(z["dt"])
+    for step in range(3):
+        mps = mps.evolve(mpo, dt)
+        vals = np.array([mps.expectation(o) for o in obs])
+        assert np.abs(vals - z["obs_values"][step + 1]).max() < 1e-7
+        # the guess follows (distance)^(-1/3) of two nearly equal states: the distance itself comes out of a
+        # cancellation (|a|^2 + |b|^2 - 2 Re<a|b>) and carries ~1e-3 relative rounding noise in either code
+        assert abs(mps.evolve_config.guess_dt - z["guess_dt"][step]) < 2e-3 * abs(z["guess_dt"][step])
+        assert abs(mps.mp_norm - z["norms"][step]) < 1e-9
+    with pytest.raises(ValueError):
+        mps.evolve(mpo, -dt)           # against the direction of guess_dt (configs.py:394-402)
