@@ -407,6 +407,35 @@ if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("adaptive",
     gen_adaptive()
 
 
+def gen_thermal():
+    """Imaginary-time propagation of the T = infinity one-exciton density operator of the reference's test model
+    (mps/tests/test_mpdm.py) to 298 K: energies and occupations after every step, for P&C and fixed-step TDVP-PS."""
+    from renormalizer.mps import MpDm, ThermalProp
+    from renormalizer.tests import parameter
+    from renormalizer.utils import Quantity, EvolveConfig, EvolveMethod, CompressConfig, CompressCriteria
+    model = parameter.holstein_model
+    beta = Quantity(298, "K").to_beta()
+    out = {"beta": np.array(beta), "gs_zpe": np.array(model.gs_zpe)}
+    for tag, method, nsteps in (("pc", EvolveMethod.prop_and_compress, 10), ("ps", EvolveMethod.tdvp_ps, 10)):
+        init = MpDm.max_entangled_ex(model)
+        if tag == "ps":
+            init.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=12)
+        tp = ThermalProp(init, evolve_config=EvolveConfig(method, adaptive=False, guess_dt=0.1 / 1j))
+        if tag == "ps":
+            _dump_mps(out, "ps_init_", tp.latest_mps)      # the expanded D = 12 state the sweeps start from
+        tp.evolve(evolve_dt=beta / 2j / nsteps, nsteps=nsteps)
+        out[f"{tag}_energies"] = np.array(tp.energies, dtype=complex).real
+        out[f"{tag}_e_occ"] = np.array(tp.e_occupations_array)
+        out[f"{tag}_ph_occ"] = np.array(tp.ph_occupations_array)
+        out[f"{tag}_bond_dims"] = np.array(tp.latest_mps.bond_dims)
+        print(tag, out[f"{tag}_e_occ"][-1], out[f"{tag}_energies"][-1], tp.latest_mps.bond_dims)
+    np.savez_compressed(os.path.join(GOLD, "thermal_prop_holstein.npz"), **out)
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("thermal",)):
+    gen_thermal()
+
+
 def gen_obs():
     """Observables of a fixed complex MPS: occupations, one-site / electronic reduced density matrices, bond
     singular values and entropies (mps/mps.py:578-609, 1547-1598, 1657-1795)."""

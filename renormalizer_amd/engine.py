@@ -228,6 +228,11 @@ class DeviceTensor:
         inner = int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
         return DeviceTensor(self.eng, self.buf, self.offset + start * inner, (stop - start,) + self.shape[1:], self.dtype)
 
+    def shifted(self, nelem):
+        """Flat view of the same buffer starting ``nelem`` elements further on (operand offsets of strided GEMMs)."""
+        return DeviceTensor(self.eng, self.buf, self.offset + int(nelem) * self.dtype.itemsize,
+                            (self.size - int(nelem),), self.dtype)
+
     def copy(self):
         out = self.eng.empty(self.shape, self.dtype)
         self.eng._check(self.eng.lib.mpse_memcpy_d2d(self.eng.ctx, out.ptr, self.ptr, self.nbytes))

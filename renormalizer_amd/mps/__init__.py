@@ -1,3 +1,5 @@
 from .backend import backend
 from .mpo import Mpo
 from .mps import Mps
+from .mpdm import MpDm
+from .thermalprop import ThermalProp

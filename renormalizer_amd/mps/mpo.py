@@ -362,6 +362,21 @@ class Mpo:
             w = self.device(i, eng)
             a = new[i]
             wl, d, d2, wr = w.shape
+            if a.ndim == 4:
+                # density-operator site (Dl, q, r, Dr): out[(il,l), p, r, (b, dd)] = sum_q W[il,p,q,b] A[l,q,r,dd]
+                # (mpdm.py:130-160 applies the operator to the upper leg); one strided GEMM per (il, r)
+                Dl, d3, dn, Dr = a.shape
+                assert d2 == d3
+                out = eng.empty((wl * Dl, d, dn, wr * Dr), np.complex128 if cplx else np.float64)
+                for il in range(wl):
+                    for r in range(dn):
+                        eng.gemm(w.row_block(il, il + 1), a.shifted(r * Dr),
+                                 out.shifted(il * Dl * d * dn * wr * Dr + r * wr * Dr),
+                                 idx2(d, wr, d2 * wr, 1), idx1(d2, wr), idx1(d3, dn * Dr), idx1(Dr, 1),
+                                 idx2(d, wr, dn * wr * Dr, Dr), idx1(Dr, 1), batch=Dl, sb_a=0, sb_b=d3 * dn * Dr,
+                                 sb_c=d * dn * wr * Dr)
+                new[i] = out
+                continue
             Dl, d3, Dr = a.shape
             assert d2 == d3
             out = eng.empty((wl * Dl, d, wr * Dr), np.complex128 if cplx else np.float64)

@@ -204,6 +204,8 @@ class Mps:
     @property
     def bond_dims_exact(self):
         p = np.array(self.pbond_dims, dtype=float)
+        if self.is_mpdm:
+            p = p ** 2                      # mp.py:131-142: both physical legs count
         with np.errstate(over="ignore"):
             d1 = [1] + list(np.cumprod(p))
             d2 = ([1] + list(np.cumprod(p[::-1])))[::-1]
@@ -212,6 +214,8 @@ class Mps:
     @property
     def nexciton(self):
         return self.qntot
+
+    is_mps, is_mpo, is_mpdm = True, False, False
 
     def to_arrays(self):
         """Download all site tensors (debugging / checkpointing)."""
@@ -834,9 +838,10 @@ class Mps:
         for i in range(n):
             a = self[i].to_complex() if cplx else self[i]
             b = other[i].to_complex() if cplx else other[i]
-            d = a.shape[1]
-            assert d == b.shape[1]
-            la, ra, lb, rb = a.shape[0], a.shape[2], b.shape[0], b.shape[2]
+            assert a.shape[1:-1] == b.shape[1:-1]
+            phys = tuple(a.shape[1:-1])
+            d = int(np.prod(phys))
+            la, ra, lb, rb = a.shape[0], a.shape[-1], b.shape[0], b.shape[-1]
             if n == 1:
                 raise NotImplementedError("add of single-site states")
             if i == 0:
@@ -845,7 +850,7 @@ class Mps:
                 L, R, l0, r0 = la + lb, 1, la, 0
             else:
                 L, R, l0, r0 = la + lb, ra + rb, la, ra
-            out = eng.zeros((L, d, R), dt)
+            out = eng.zeros((L,) + phys + (R,), dt)
             o2 = out.reshape(L * d, R)
             eng.copy_block(o2, 0, 0, a.reshape(la * d, ra))
             eng.copy_block(o2, l0 * d, r0, b.reshape(lb * d, rb))
@@ -878,10 +883,14 @@ class Mps:
         mps = self
         ex_mps = None
         if hint_mpo is not None and include_ex:
-            ex_state = Mps.ground_state(mps.model, False)
-            assert mps.model.qn_size == 1
-            for _ in range(int(mps.qntot[0])):
-                ex_state = Mpo.onsite(mps.model, r"a^\dagger").apply(ex_state)
+            if mps.is_mpdm:
+                assert int(mps.qntot[0]) == 1
+                ex_state = mps.__class__.max_entangled_ex(mps.model)
+            else:
+                ex_state = Mps.ground_state(mps.model, False)
+                assert mps.model.qn_size == 1
+                for _ in range(int(mps.qntot[0])):
+                    ex_state = Mpo.onsite(mps.model, r"a^\dagger").apply(ex_state)
             ex_state.compress_config = mps.compress_config
             ex_state.move_qnidx(mps.qnidx)
             ex_state.to_right = mps.to_right
@@ -890,7 +899,7 @@ class Mps:
         m_target = np.minimum(np.array(mps.compress_config.max_dims) - np.array(mps.bond_dims), mps.bond_dims_exact)
         m_target = np.array(m_target, dtype=int)
         if hint_mpo is None:
-            expander = Mps.random(mps.model, mps.qntot, m_target)
+            expander = mps.__class__.random(mps.model, mps.qntot, m_target)
             expander.compress_config = mps.compress_config.copy()
         else:
             lastone = mps if ex_mps is None else mps + ex_mps
