@@ -21,6 +21,9 @@ def __getattr__(name):
     if name == "optimize_mps":
         from .mps.gs import optimize_mps
         return optimize_mps
+    if name in ("MpDm", "ThermalProp"):
+        from . import mps as _mps
+        return getattr(_mps, name)
     if name == "backend":
         from .mps.backend import backend
         return backend
