@@ -124,20 +124,28 @@ def main():
     ap.add_argument("--traj-per-gpu", type=int, default=1,
                     help="independent trajectories sharing each GPU (threads with their own stream); 1 = headline")
     ap.add_argument("--cpu-updates", type=int, default=9, help="site updates in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-gpu exercises the multi-rank flow on a single GPU (testing only)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use GPU 0 (testing only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.share_gpu:
+        local_rank = 0
     os.environ["RENO_GPU"] = str(local_rank)
 
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     from renormalizer_amd.engine import Engine, get_engine, use_engine
     T = max(1, args.traj_per_gpu)
@@ -150,8 +158,9 @@ def main():
             e.sync()
         if dist is not None:
             dist.barrier()
-            import torch
-            torch.cuda.synchronize()
+            if args.dist_backend == "nccl":
+                import torch
+                torch.cuda.synchronize()
 
     import threading
     sync = threading.Barrier(T + 1)
@@ -216,7 +225,7 @@ def main():
 
     if dist is not None:
         from renormalizer_amd.parallel import gather_observables, max_over_ranks
-        dev = f"cuda:{local_rank}"
+        dev = f"cuda:{local_rank}" if args.dist_backend == "nccl" else "cpu"
         elapsed = max_over_ranks(elapsed, device=dev)
         # the only collective of the whole job: all_gather of the per-trajectory observables (KBs)
         occ_table = gather_observables(np.asarray(mps.e_occupations)[None, :], [rank], world, device=dev)
