@@ -175,9 +175,11 @@ int mpse_malloc(mpse_ctx* ctx, size_t bytes, void** dptr) {
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) {
       // give cached blocks back to the driver and retry once
+      (void)hipGetLastError();  // the failed call leaves a sticky error that later hipGetLastError() checks would see
       mpse_pool_trim(ctx);
       e = hipMalloc(&p, b);
       if (e != hipSuccess) {
+        (void)hipGetLastError();
         *dptr = nullptr;
         return mpse_fail(ctx, MPSE_ERR_OOM, "hipMalloc(%zu) failed: %s (pool %zu B, in use %zu B)", b,
                          hipGetErrorString(e), ctx->pool_bytes, ctx->in_use_bytes);

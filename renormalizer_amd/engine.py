@@ -148,6 +148,7 @@ class _Buffer:
     def __init__(self, eng, nbytes):
         self.eng = eng
         self.nbytes = int(nbytes)
+        self.ptr = None                     # stays None if the allocation below raises (see __del__)
         p = C.c_void_p()
         eng._check(eng.lib.mpse_malloc(eng.ctx, max(self.nbytes, 16), C.byref(p)))
         self.ptr = p.value

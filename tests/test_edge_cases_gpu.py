@@ -1,0 +1,140 @@
+"""Edge cases of the hot path on the GPU: Krylov breakdown / zero vectors / tiny spaces, invalid quantum numbers,
+degenerate shapes (bond dimension 1, empty blocks, two-site chains), error reporting of the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import mps_oracle as orc
+from renormalizer_amd import (BasisHalfSpin, CompressConfig, CompressCriteria, EvolveConfig, EvolveMethod, Model, Mpo, Op)
+from renormalizer_amd import engine as E
+from renormalizer_amd.lib.krylov import expm_krylov
+from renormalizer_amd.mps import svd_qn
+from renormalizer_amd.mps.hop_expr import hop_expr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return E.get_engine()
+
+
+def _herm_env(rng, D, w):
+    a = rng.standard_normal((D, w, D)) + 1j * rng.standard_normal((D, w, D))
+    return (a + a.transpose(2, 1, 0).conj()) / 4
+
+
+def test_krylov_breakdown_on_an_eigenvector(eng):
+    """krylov.py:72-74: beta < 100 n eps stops the recurrence; an eigenvector start gives a 1-dimensional space"""
+    rng = np.random.default_rng(1)
+    D, d, w = 5, 3, 2
+    l, r = _herm_env(rng, D, w), _herm_env(rng, D, w)
+    wm = rng.standard_normal((w, d, d, w))
+    wm = (wm + wm.transpose(0, 2, 1, 3)) / 2
+    h = orc.hop_dense(l, r, [wm])
+    h = (h + h.conj().T) / 2
+    ev, U = np.linalg.eigh(h)
+    c = U[:, 3].reshape(D, d, D)
+    hop = hop_expr(eng.asdevice(l), eng.asdevice(r), [eng.asdevice(wm)], c.shape)
+    out, nv = expm_krylov(hop, -0.3j, eng.asdevice(c))
+    ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(l, r, [wm], y.reshape(c.shape)).ravel(), -0.3j, c.ravel())
+    assert nv == nref and nv <= 2
+    assert np.abs(out.to_host().ravel() - np.exp(-0.3j * ev[3]) * c.ravel()).max() < 1e-10
+
+
+def test_krylov_zero_vector_is_an_error(eng):
+    rng = np.random.default_rng(2)
+    l, r = _herm_env(rng, 3, 2), _herm_env(rng, 3, 2)
+    wm = rng.standard_normal((2, 2, 2, 2))
+    hop = hop_expr(eng.asdevice(l), eng.asdevice(r), [eng.asdevice(wm)], (3, 2, 3))
+    with pytest.raises(E.EngineError):
+        expm_krylov(hop, -0.1j, eng.zeros((3, 2, 3), np.complex128))
+
+
+def test_krylov_space_equals_full_space(eng):
+    """krylov.py:59-61: n = 2 centre, the second Lanczos vector completes the space and the result is exact"""
+    one = np.ones((1, 1, 1))
+    wm = np.array([[0.3, 0.7], [0.7, -0.2]]).reshape(1, 2, 2, 1)
+    c = np.array([0.6, 0.8j]).reshape(1, 2, 1)
+    hop = hop_expr(eng.asdevice(one), eng.asdevice(one), [eng.asdevice(wm)], c.shape)
+    out, nv = expm_krylov(hop, -1.7j, eng.asdevice(c))
+    ev, U = np.linalg.eigh(wm[0, :, :, 0])
+    exact = U @ (np.exp(-1.7j * ev) * (U.T @ c.ravel()))
+    assert nv == 2 and np.abs(out.to_host().ravel() - exact).max() < 1e-13
+
+
+def test_invalid_quantum_number_raises_value_error(eng):
+    """svd_qn.py:219-220: no row block has a partner column block"""
+    c = eng.asdevice(np.ones((2, 2)))
+    qnl = np.array([[0], [0]])
+    qnr = np.array([[0], [0]])
+    with pytest.raises(ValueError, match="Invalid quantum number"):
+        svd_qn.svd_qn(c, qnl, qnr, np.array([1]), QR=True, system="L", full_matrices=False)
+    with pytest.raises(ValueError):
+        svd_qn.svd_qn(eng.asdevice(np.ones((2, 3))), qnl, qnr, np.array([0]), QR=True, system="L", full_matrices=False)
+
+
+def test_block_decompositions_of_degenerate_shapes(eng):
+    """1 x 1 and 1 x n blocks, a block with more columns than rows, and an all-zero matrix"""
+    rng = np.random.default_rng(3)
+    for (m, n) in ((1, 1), (1, 5), (5, 1), (3, 7)):
+        a = rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))
+        qnl, qnr = np.zeros((m, 1), dtype=int), np.zeros((n, 1), dtype=int)
+        for system in ("L", "R"):
+            u, _, v, _ = svd_qn.svd_qn(eng.asdevice(a), qnl, qnr, np.array([0]), QR=True, system=system, full_matrices=False)
+            uh, vth = u.to_host(), v.T.to_host()
+            assert np.abs(uh @ vth - a).max() < 1e-12
+            iso = uh if system == "L" else vth.conj().T
+            assert np.abs(iso.conj().T @ iso - np.eye(iso.shape[1])).max() < 1e-12
+        u, s, _, v, _, _ = svd_qn.svd_qn(eng.asdevice(a), qnl, qnr, np.array([0]), full_matrices=False)
+        assert np.abs((u.to_host() * s) @ v.T.to_host() - a).max() < 1e-12
+        assert np.all(np.diff(s) <= 1e-14)
+    z = np.zeros((4, 3))
+    u, _, v, _ = svd_qn.svd_qn(eng.asdevice(z), np.zeros((4, 1), dtype=int), np.zeros((3, 1), dtype=int), np.array([0]),
+                               QR=True, system="L", full_matrices=False)
+    uh = u.to_host()
+    assert np.abs(uh.T @ uh - np.eye(3)).max() < 1e-13 and np.abs(v.T.to_host()).max() == 0     # Q stays an isometry
+
+
+def test_two_site_chain_tdvp_ps_vs_oracle():
+    """the smallest chain: both sites are edge sites, every environment is the 1 x 1 x 1 sentinel"""
+    from renormalizer_amd.mps.mps import Mps
+    ham = Op("sigma_+ sigma_-", [0, 1]) + Op("sigma_+ sigma_-", [1, 0]) + Op("Z", 0, 0.3)
+    model = Model([BasisHalfSpin(0), BasisHalfSpin(1)], ham)
+    mpo = Mpo(model)
+    mps = Mps.hartree_product_state(model, {0: [0.6, 0.8], 1: [1.0, 0.0]})
+    mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=2)
+    mps = mps.expand_bond_dimension(mpo, include_ex=False)
+    sig = [np.asarray(b.sigmaqn).reshape(b.nbas, -1) for b in model.basis]
+    st = orc.MpsState([t.to_host() for t in mps], [np.asarray(q) for q in mps.qn], mps.qnidx, mps.qntot, mps.to_right,
+                      sig, mps.coeff)
+    w = [mpo[i] for i in range(2)]
+    z = Mpo(model, Op("Z", 1))
+    for _ in range(3):
+        mps = mps.evolve(mpo, 0.4)
+        st = orc.tdvp_ps_step(st, w, 0.4)
+        assert abs(mps.expectation(z) - orc.expectation(st.sites, [z[i] for i in range(2)])) < 1e-10
+        assert abs(mps.expectation(mpo) - orc.expectation(st.sites, w)) < 1e-10
+
+
+def test_engine_reports_errors_instead_of_crashing(eng):
+    a = eng.asdevice(np.ones((4, 3)))
+    b = eng.asdevice(np.ones((5, 2)))
+    with pytest.raises(ValueError):
+        eng.matmul(a, b)
+    d = E.mpse_gemm_desc()
+    d.dtype_a = d.dtype_b = E.F64
+    d.m_a, d.k_a, d.k_b, d.n_b = E.idx1(4, 3), E.idx1(3, 1), E.idx1(5, 2), E.idx1(2, 1)     # K extents disagree
+    d.m_c, d.n_c = E.idx1(4, 2), E.idx1(2, 1)
+    d.batch = 1
+    out = eng.empty((4, 2), np.float64)
+    st = eng.lib.mpse_gemm(eng.ctx, C.byref(d), a.ptr, b.ptr, out.ptr)
+    assert st == 2                                                     # MPSE_ERR_SHAPE
+    assert b"extents disagree" in eng.lib.mpse_last_error(eng.ctx)
+    with pytest.raises(E.DeviceMemoryError):
+        eng.empty((1 << 20, 1 << 20), np.complex128)                   # 16 TiB: MPSE_ERR_OOM, not a crash
+    assert eng.lib.mpse_gemm(eng.ctx, None, a.ptr, b.ptr, out.ptr) == 5    # MPSE_ERR_ARG
+    # the context is still usable afterwards
+    assert np.allclose(eng.matmul(a, eng.asdevice(np.ones((3, 2)))).to_host(), 3.0)
