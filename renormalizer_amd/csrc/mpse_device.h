@@ -29,6 +29,46 @@ __device__ __forceinline__ double wave_sum(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// DPP move with a bank mask: only lanes of the selected banks (4-lane groups of a 16-lane row) receive data, the
+// others keep ``old``.  Two of these build a lane-xor-4 / lane-xor-8 exchange out of row shifts.
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_move_banks(double old, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, BANK, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, BANK, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_xor4(double v) {   // row_shl:4 into banks 0,2 ; row_shr:4 into banks 1,3
+  return dpp_move_banks<0x114, 0xA>(dpp_move_banks<0x104, 0x5>(0.0, v), v);
+}
+__device__ __forceinline__ double lane_xor8(double v) {   // row_shl:8 into banks 0,1 ; row_shr:8 into banks 2,3
+  return dpp_move_banks<0x118, 0xC>(dpp_move_banks<0x108, 0x3>(0.0, v), v);
+}
+
+// Eight values summed over the 16 lanes of each row in ~60 VALU instructions instead of 8 x 4 butterfly steps:
+// at every halving stage a lane keeps half of its values and trades the other half with its partner (lane xor 1,
+// 2, 4), so the work halves per stage; one plain xor-8 step finishes the row.  Returns, in lane l, the row sum of
+// v[rowsum8_index(l)].  (The naive per-value butterfly costs ~200 VALU cycles per value and wave and was the
+// largest item of the QR panel kernel, tools/ubench/sync_cost.hip.)
+__device__ __forceinline__ int rowsum8_index(int lane) { return ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1); }
+__device__ __forceinline__ double wave_rowsum8(const double (&v)[8], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  double w[4], u[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const double keep = b0 ? v[t + 4] : v[t], send = b0 ? v[t] : v[t + 4];
+    w[t] = keep + dpp_move<0xb1>(send);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const double keep = b1 ? w[t + 2] : w[t], send = b1 ? w[t] : w[t + 2];
+    u[t] = keep + dpp_move<0x4e>(send);
+  }
+  const double keep = b2 ? u[1] : u[0], send = b2 ? u[0] : u[1];
+  double x = keep + lane_xor4(send);
+  x += lane_xor8(x);
+  return x;
+}
+
 // Block-wide (256 threads) sum of two values in a fixed order; the totals are returned to
 // EVERY thread.  Contains two barriers; safe to call repeatedly.
 __device__ __forceinline__ void block_allsum2(double& a, double& b) {

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(NT) void k_hh_panel(double* ws_base, const QrBlk* _
                                                    int j0) {
   constexpr int E = Cx<CPLX>::E;
   constexpr int NV = 2 * NB;  // [0] = |tail|^2, [1] unused, then (re, im) of the dot with panel column t >= 1
-  __shared__ double s_part[NT / 64][NV];
+  // partial sums: one row of NV values per wave (generic path) or per 16-lane row (NB == 4 fast path)
+  constexpr int NPART = (NB == 4) ? NT / 16 : NT / 64;
+  __shared__ double s_part[NPART][NV];
   __shared__ double s_f[NB][4];
   __shared__ double s_par[2];
   __shared__ double s_head[2 * NB];
@@ -116,11 +118,17 @@ __global__ __launch_bounds__(NT) void k_hh_panel(double* ws_base, const QrBlk* _
         }
       }
     }
-    // wave-level sums on the VALU (DPP), one partial per wave and value
+    if constexpr (NB == 4) {
+      // all eight values reduced together over each 16-lane row (halving butterfly), one partial per row
+      const double w = wave_rowsum8(val, lane);
+      if ((lane & 8) == 0) s_part[wave * 4 + (lane >> 4)][rowsum8_index(lane)] = w;
+    } else {
+      // wave-level sums on the VALU (DPP), one partial per wave and value
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
-      const double w = wave_sum(val[t]);
-      if (lane == 0) s_part[wave][t] = w;
+      for (int t = 0; t < NV; ++t) {
+        const double w = wave_sum(val[t]);
+        if (lane == 0) s_part[wave][t] = w;
+      }
     }
     __syncthreads();  // (A) partial sums and the diagonal row are in LDS
     // --- the scalar work (f64 sqrt / divisions) is done once, by wave 0
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(NT) void k_hh_panel(double* ws_base, const QrBlk* _
       double tot = 0.0;
       if (lane < NV) {
 #pragma unroll
-        for (int w = 0; w < NT / 64; ++w) tot += s_part[w][lane];
+        for (int w = 0; w < NPART; ++w) tot += s_part[w][lane];
       }
       const double ssq = __shfl(tot, 0, 64);
       HhParam p;
