@@ -69,6 +69,39 @@ __device__ __forceinline__ double wave_rowsum8(const double (&v)[8], int lane) {
   return x;
 }
 
+// Cross-row steps of a wave reduction with the gfx950 row-swap instructions: v_permlane16_swap exchanges the odd
+// rows of one register with the even rows of another, so swap(x, x) yields the two halves of a lane-xor-16 pair.
+__device__ __forceinline__ double lane_xor16_sum(double v) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double lane_xor32_sum(double v) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+// wave_rowsum8 continued over the four rows: every lane ends with the full 64-lane sum of v[rowsum8_index(lane)]
+__device__ __forceinline__ double wave_sum8(const double (&v)[8], int lane) {
+  return lane_xor32_sum(lane_xor16_sum(wave_rowsum8(v, lane)));
+}
+
+// 1/x and 1/sqrt(x) to double precision from the hardware estimates and two Newton steps (the IEEE division /
+// square root sequences are ~25 dependent instructions each; the QR panel kernel does three per column on its
+// critical path).  x must be finite, non-zero (and positive for rsqrt).
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+
 // Block-wide (256 threads) sum of two values in a fixed order; the totals are returned to
 // EVERY thread.  Contains two barriers; safe to call repeatedly.
 __device__ __forceinline__ void block_allsum2(double& a, double& b) {

@@ -42,20 +42,29 @@ __device__ __forceinline__ double2 cmulc(double2 a, double2 b) {  // conj(a) * b
 }
 
 __device__ __forceinline__ void make_reflector(double2 alpha, double s, HhParam* p, double* beta_out) {
-  if (s == 0.0 && alpha.y == 0.0) {
-    p->tau_re = p->tau_im = p->scale_re = p->scale_im = 0.0;  // H = I
+  const double n2 = alpha.x * alpha.x + alpha.y * alpha.y + s;
+  if ((s == 0.0 && alpha.y == 0.0) || n2 < 1e-280) {
+    // H = I.  Besides the exact case this covers columns whose squared norm underflows (|column| < 1e-140): ?larfg
+    // would rescale and iterate; here the tail is dropped, an absolute perturbation below 1e-140 - the sweeps
+    // only ever see such columns as padding noise next to O(1) data - and no 0/0 can arise.
+    p->tau_re = p->tau_im = p->scale_re = p->scale_im = 0.0;
     *beta_out = alpha.x;
-  } else {
-    const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + s);
-    const double beta = alpha.x >= 0.0 ? -nrm : nrm;
-    p->tau_re = (beta - alpha.x) / beta;
-    p->tau_im = -alpha.y / beta;
-    const double dr = alpha.x - beta, di = alpha.y;
-    const double den = dr * dr + di * di;
-    p->scale_re = dr / den;
-    p->scale_im = -di / den;
-    *beta_out = beta;
+    return;
   }
+  double nrm, ibeta, iden;
+  const bool fast = n2 < 1e280;
+  // hardware estimates + Newton (mpse_device.h) instead of three IEEE sequences on the critical path of a column
+  nrm = fast ? n2 * fast_rsqrt(n2) : sqrt(n2);
+  const double beta = alpha.x >= 0.0 ? -nrm : nrm;
+  ibeta = fast ? fast_rcp(beta) : 1.0 / beta;
+  p->tau_re = (beta - alpha.x) * ibeta;
+  p->tau_im = -alpha.y * ibeta;
+  const double dr = alpha.x - beta, di = alpha.y;
+  const double den = dr * dr + di * di;
+  iden = fast ? fast_rcp(den) : 1.0 / den;
+  p->scale_re = dr * iden;
+  p->scale_im = -di * iden;
+  *beta_out = beta;
 }
 
 // ---- panel factorisation: NT threads, thread owns rows tid + NT q (q < RPT), NB columns.
@@ -67,8 +76,10 @@ __global__ __launch_bounds__(NT) void k_hh_panel(double* ws_base, const QrBlk* _
                                                    int j0) {
   constexpr int E = Cx<CPLX>::E;
   constexpr int NV = 2 * NB;  // [0] = |tail|^2, [1] unused, then (re, im) of the dot with panel column t >= 1
-  // partial sums: one row of NV values per wave (generic path) or per 16-lane row (NB == 4 fast path)
-  constexpr int NPART = (NB == 4) ? NT / 16 : NT / 64;
+  // partial sums in LDS: one row of NV values per 16-lane row of every wave (NB == 4: the halving butterfly
+  // stops at the row, measured cheaper than finishing the wave with row swaps / bpermutes) or per wave
+  constexpr bool ROWPART = (NB == 4) && (NT <= 256);   // one wave per SIMD: stop the butterfly at the 16-lane row
+  constexpr int NPART = ROWPART ? NT / 16 : NT / 64;
   __shared__ double s_part[NPART][NV];
   __shared__ double s_f[NB][4];
   __shared__ double s_par[2];
@@ -100,15 +111,15 @@ __global__ __launch_bounds__(NT) void k_hh_panel(double* ws_base, const QrBlk* _
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
       const int r = tid + NT * q;
-      if (r > j && r < mm) {
-        const double2 v = x[q][0];
-        val[0] += v.x * v.x + v.y * v.y;
+      // branch-free: rows outside the tail contribute zeros (a divergent region per row costs more than the flops)
+      const bool tail = (r > j) && (r < mm);
+      const double2 v = make_double2(tail ? x[q][0].x : 0.0, tail ? x[q][0].y : 0.0);
+      val[0] += v.x * v.x + v.y * v.y;
 #pragma unroll
-        for (int t = 1; t < NB; ++t) {
-          const double2 t2 = cmulc(v, x[q][t]);
-          val[2 * t] += t2.x;
-          val[2 * t + 1] += t2.y;
-        }
+      for (int t = 1; t < NB; ++t) {
+        const double2 t2 = cmulc(v, x[q][t]);
+        val[2 * t] += t2.x;
+        val[2 * t + 1] += t2.y;
       }
       if (r == j) {  // owner of the diagonal row publishes alpha and the heads of the other columns
 #pragma unroll
@@ -118,10 +129,14 @@ __global__ __launch_bounds__(NT) void k_hh_panel(double* ws_base, const QrBlk* _
         }
       }
     }
-    if constexpr (NB == 4) {
+    if constexpr (ROWPART) {
       // all eight values reduced together over each 16-lane row (halving butterfly), one partial per row
       const double w = wave_rowsum8(val, lane);
       if ((lane & 8) == 0) s_part[wave * 4 + (lane >> 4)][rowsum8_index(lane)] = w;
+    } else if constexpr (NB == 4) {
+      // several waves per SIMD: finish the wave with the row-swap steps, wave 0 then sums NT/64 partials only
+      const double w = wave_sum8(val, lane);
+      if (lane < 8) s_part[wave][rowsum8_index(lane)] = w;
     } else {
       // wave-level sums on the VALU (DPP), one partial per wave and value
 #pragma unroll
@@ -135,10 +150,19 @@ __global__ __launch_bounds__(NT) void k_hh_panel(double* ws_base, const QrBlk* _
     if (wave == 0) {
       double tot = 0.0;
       if (lane < NV) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // four chains: the adds are latency bound
+        static_assert(NPART % 4 == 0, "partial rows are summed four at a time");
 #pragma unroll
-        for (int w = 0; w < NPART; ++w) tot += s_part[w][lane];
+        for (int w = 0; w < NPART; w += 4) {
+          t0 += s_part[w][lane];
+          t1 += s_part[w + 1][lane];
+          t2 += s_part[w + 2][lane];
+          t3 += s_part[w + 3][lane];
+        }
+        tot = (t0 + t1) + (t2 + t3);
       }
-      const double ssq = __shfl(tot, 0, 64);
+      const double ssq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 0),
+                                          __builtin_amdgcn_readlane(__double2loint(tot), 0));
       HhParam p;
       double beta;
       const double2 alpha = make_double2(s_head[0], s_head[1]);
@@ -165,20 +189,31 @@ __global__ __launch_bounds__(NT) void k_hh_panel(double* ws_base, const QrBlk* _
     }
     __syncthreads();  // (B) coefficients published
     const double beta = s_par[0], diag_im = s_par[1];
+    double2 fc[NB], fs[NB];  // all coefficients fetched from LDS once, before any use
+#pragma unroll
+    for (int t = 1; t < NB; ++t) {
+      fc[t] = make_double2(s_f[t][0], s_f[t][1]);
+      fs[t] = make_double2(s_f[t][2], s_f[t][3]);
+    }
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
       const int r = tid + NT * q;
-      const double2 v = x[q][0];
-      if (r == j) x[q][0] = make_double2(beta, diag_im);
+      // tail rows: -= (f scale) v, done for every row with v zeroed outside the tail (one select per row instead of
+      // one divergent region per row and column); the single diagonal row is the only real branch left
+      const bool tail = (r > j) && (r < mm);
+      const double2 vt = make_double2(tail ? x[q][0].x : 0.0, tail ? x[q][0].y : 0.0);
 #pragma unroll
       for (int t = 1; t < NB; ++t) {
-        if (r > j && r < mm) {
-          const double2 t2 = cmul(make_double2(s_f[t][2], s_f[t][3]), v);
-          x[q][t].x -= t2.x;
-          x[q][t].y -= t2.y;
-        } else if (r == j) {
-          x[q][t].x -= s_f[t][0];
-          x[q][t].y -= s_f[t][1];
+        const double2 t2 = cmul(fs[t], vt);
+        x[q][t].x -= t2.x;
+        x[q][t].y -= t2.y;
+      }
+      if (r == j) {
+        x[q][0] = make_double2(beta, diag_im);
+#pragma unroll
+        for (int t = 1; t < NB; ++t) {
+          x[q][t].x -= fc[t].x;
+          x[q][t].y -= fc[t].y;
         }
       }
       // the pivot column is final: store it, then rotate the panel by one column
@@ -337,10 +372,10 @@ __global__ __launch_bounds__(256) void k_hh_formq_b(double* q_base, const double
 template <bool CPLX>
 int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk* dblk, int nblk, int max_mm,
                 int max_nn, int max_k, bool form_q) {
-  // Register-resident configurations: 4 rows x 4 columns per thread, so the workgroup grows with the block
-  // height.  Per column the kernel pays the cross-lane reductions (VALU-issue bound, ~200 cycles per value and
-  // wave - tools/ubench/sync_cost.hip - and serialised between the waves of a SIMD) plus the per-thread dot /
-  // update work; 4x4 balances the two (measured against 8x4 and 16x4 per thread).
+  // Register-resident configurations by block height: 256 threads x 4 rows, 512 x 4, 512 x 8 (4 panel columns
+  // each).  Per column the kernel pays one reduction round (eight values through the halving butterfly), the
+  // scalar reflector set-up in wave 0 and the branch-free update; the waves of one SIMD serialise on the VALU, so
+  // tall blocks prefer more rows per thread over more waves (cycle breakdown by s_memtime).
   const int cfg = max_mm <= 1024 ? 0 : max_mm <= 2048 ? 1 : 2;
   const int nb = 4;
   for (int j0 = 0; j0 < max_k; j0 += nb) {
@@ -352,7 +387,7 @@ int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk*
         hipLaunchKernelGGL((k_hh_panel<CPLX, 512, 4, 4>), dim3(nblk), dim3(512), 0, ctx->stream, ws, dblk, prm, j0);
         break;
       default:
-        hipLaunchKernelGGL((k_hh_panel<CPLX, 1024, 4, 4>), dim3(nblk), dim3(1024), 0, ctx->stream, ws, dblk, prm, j0);
+        hipLaunchKernelGGL((k_hh_panel<CPLX, 512, 8, 4>), dim3(nblk), dim3(512), 0, ctx->stream, ws, dblk, prm, j0);
     }
     const int trailing = max_nn - j0 - 1;  // upper bound on columns to the right of any block's panel
     if (trailing > 0) {

@@ -138,3 +138,21 @@ def test_engine_reports_errors_instead_of_crashing(eng):
     assert eng.lib.mpse_gemm(eng.ctx, None, a.ptr, b.ptr, out.ptr) == 5    # MPSE_ERR_ARG
     # the context is still usable afterwards
     assert np.allclose(eng.matmul(a, eng.asdevice(np.ones((3, 2)))).to_host(), 3.0)
+
+
+def test_block_qr_columns_with_denormal_squared_norms(eng):
+    """state preparation meets columns of norm 1e-160 and below: the squared norm is denormal or zero.  Such columns
+    get H = I (their sub-diagonal part, < 1e-140 in absolute terms, is dropped); nothing may turn into NaN
+    (regression: NaN in the bond expansion of the headline state)"""
+    rng = np.random.default_rng(7)
+    m, n = 300, 12
+    a = rng.standard_normal((m, n)) + 1j * rng.standard_normal((m, n))
+    a = a * np.array([1.0, 1e-100, 1e-150, 1e-160, 1e-165, 1e-170, 1e-200, 0.0, 1.0, 1e-158, 1e-162, 3.0])
+    qnl, qnr = np.zeros((m, 1), dtype=int), np.zeros((n, 1), dtype=int)
+    u, _, v, _ = svd_qn.svd_qn(eng.asdevice(a), qnl, qnr, np.array([0]), QR=True, system="L", full_matrices=False)
+    q, r = u.to_host(), v.T.to_host()
+    assert np.all(np.isfinite(q)) and np.all(np.isfinite(r))
+    assert np.abs(q.conj().T @ q - np.eye(n)).max() < 1e-12
+    err = np.abs(q @ r - a).max(axis=0)
+    scale = np.abs(a).max(axis=0)
+    assert np.all(err <= 1e-12 * scale + 1e-139)
