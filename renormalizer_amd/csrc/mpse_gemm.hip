@@ -544,9 +544,10 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
   g.ws = nullptr;
   TmpBuf WSB(ctx);
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-  if (base_blocks < 2 * n_cu && nkt_all >= 4) {
-    // aim at ~2 workgroups per CU (a single workgroup per CU cannot hide its own barrier / staging phases)
-    int want = base_blocks < n_cu ? (int)((2LL * n_cu + base_blocks - 1) / base_blocks) : 2;
+  if (base_blocks < n_cu && nkt_all >= 4) {
+    // fewer output tiles than CUs: slice K until ~2 workgroups per CU exist.  (One tile per CU runs as fast
+    // unsplit as split in two + reduction pass since the K loop prefetches fragments: measured, 4096x256 C-step.)
+    int want = (int)((2LL * n_cu + base_blocks - 1) / base_blocks);
     int maxs = nkt_all / 2;                                           // at least two k-tiles per slice
     int S = want < maxs ? want : maxs;
     if (S > 1) {
