@@ -407,6 +407,49 @@ if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("adaptive",
     gen_adaptive()
 
 
+def gen_pc_adaptive():
+    """Adaptive propagate & compress (mps.py:794-885, Taylor order 5 with the last term as error estimate)."""
+    from renormalizer.model import Phonon, Mol, HolsteinModel, Op
+    from renormalizer.mps import Mps, Mpo
+    from renormalizer.utils import Quantity, EvolveConfig, EvolveMethod
+    nmol, pdim = 4, 4
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), pdim)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
+    gs = Mps.ground_state(model, max_entangled=False)
+    init = Mpo.onsite(model, r"a^\dagger", dof_set={nmol // 2}).apply(gs)
+    e0 = Quantity(init.expectation(Mpo(model)))
+    mpo = Mpo(model, offset=e0)
+    init.evolve_config = EvolveConfig(EvolveMethod.prop_and_compress, adaptive=True, guess_dt=8.0)
+    occ = [Mpo(model, Op(r"a^\dagger a", dof)) for dof in model.e_dofs]
+    out = {}
+    _dump_mpo(out, "mpo_", mpo)
+    for j, o in enumerate(occ):
+        _dump_mpo(out, f"obs{j}_", o)
+    out["nobs"] = np.array(len(occ))
+    for i, b in enumerate(model.basis):
+        out[f"sigmaqn_{i}"] = np.asarray(b.sigmaqn).reshape(b.nbas, -1).astype(np.int64)
+    _dump_mps(out, "init_", init)
+    mps = init
+    vals, guess, norms, bdims = [[mps.expectation(o) for o in occ]], [], [], []
+    for step in range(4):
+        mps = mps.evolve(mpo, 20.0)
+        vals.append([mps.expectation(o) for o in occ])
+        guess.append(mps.evolve_config.guess_dt)
+        norms.append(mps.mp_norm)
+        bdims.append(list(mps.bond_dims))
+    out["dt"] = np.array(20.0)
+    out["obs_values"] = np.array(vals, dtype=complex).real
+    out["guess_dt"] = np.array(guess, dtype=float)
+    out["norms"] = np.array(norms)
+    out["bond_dims"] = np.array(bdims)
+    np.savez_compressed(os.path.join(GOLD, "pc_adaptive_holstein_small.npz"), **out)
+    print("pc_adaptive_holstein_small.npz", out["obs_values"][-1], out["guess_dt"], bdims[-1])
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("pc_adaptive",)):
+    gen_pc_adaptive()
+
+
 def gen_thermal():
     """Imaginary-time propagation of the T = infinity one-exciton density operator of the reference's test model
     (mps/tests/test_mpdm.py) to 298 K: energies and occupations after every step, for P&C and fixed-step TDVP-PS."""

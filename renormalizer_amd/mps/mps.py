@@ -1066,30 +1066,49 @@ _TAYLOR4 = [1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24]
 
 
 def _evolve_prop_and_compress(self, mpo, evolve_dt) -> "Mps":
-    """Global propagation & compression with a Taylor propagator, fixed step (mps/mps.py:794-885 without
-    the adaptive branch): terms H^k|psi> by contract (apply, canonicalise, compress), scaled by
-    (-i dt)^k c_k and summed with compression."""
+    """Global propagation & compression with a Taylor propagator (mps/mps.py:794-885): terms H^k|psi> by contract
+    (apply, canonicalise, compress), scaled by (-i dt)^k / k! and summed with compression.  Adaptive mode: the
+    distance between the sums with and without the last term estimates the local error and sets the next step
+    through p = (rtol / relative distance)^(1/order), clipped to [0.1, 2]; p < 0.5 repeats the sub-step."""
+    import math
     from ..utils import CompressCriteria
     config = self.evolve_config
-    if config.adaptive:
-        raise NotImplementedError("adaptive P&C is not implemented")
-    coeff = _TAYLOR4[: config.taylor_order + 1] if config.taylor_order <= 4 else None
-    if coeff is None:
-        import math
-        coeff = [1.0 / math.factorial(k) for k in range(config.taylor_order + 1)]
+    coeff = [1.0 / math.factorial(k) for k in range(config.taylor_order + 1)]
+    order = len(coeff) - 1
     termlist = [self]
     orig = self.compress_config
     tmp = self.compress_config.copy()
     if tmp.criteria is CompressCriteria.threshold:
-        tmp.criteria = CompressCriteria.both
+        tmp.criteria = CompressCriteria.both        # the bonds must not grow while contracting
     self.compress_config = tmp
     while len(termlist) < len(coeff):
         termlist.append(mpo.contract(termlist[-1]))
     self.compress_config = orig
     for t in termlist:
         t.compress_config = orig
-    scaled = [t.scale((-1.0j * evolve_dt) ** k * coeff[k]) for k, t in enumerate(termlist)]
-    return compressed_sum(scaled)
+    if not config.adaptive:
+        return compressed_sum([t.scale((-1.0j * evolve_dt) ** k * coeff[k]) for k, t in enumerate(termlist)])
+    config.check_valid_dt(evolve_dt)
+    p_restart, p_min, p_max = 0.5, 0.1, 2.0
+    while True:
+        dt = _min_abs(config.guess_dt, evolve_dt)
+        scaled = [t.scale((-1.0j * dt) ** k * coeff[k]) for k, t in enumerate(termlist)]
+        new_mps1 = compressed_sum(scaled[:-1])
+        new_mps2 = compressed_sum([new_mps1, scaled[-1]])
+        dis = new_mps1.distance(new_mps2)
+        p = (config.adaptive_rtol / (dis / new_mps2.mp_norm + 1e-30)) ** (1.0 / order)
+        if np.allclose(dt, evolve_dt):
+            if p < p_restart:                               # the last sub-step is not accurate enough: repeat it
+                config.guess_dt = dt * max(p_min, p)
+            else:
+                new_mps2.evolve_config.guess_dt = _min_abs(dt * p, config.guess_dt)
+                return new_mps2
+        elif p < p_restart:
+            config.guess_dt *= max(p_min, p)
+        else:
+            config.guess_dt *= min(p, p_max)
+            new_mps2.evolve_config.guess_dt = config.guess_dt
+            return new_mps2._evolve_prop_and_compress(mpo, evolve_dt - dt)
 
 
 Mps._evolve_prop_and_compress = _evolve_prop_and_compress

@@ -119,7 +119,8 @@ class EvolveConfig:
         self.adaptive = adaptive
         self.guess_dt = guess_dt
         self.adaptive_rtol = adaptive_rtol
-        self.taylor_order = 4 if taylor_order is None else taylor_order
+        # utils/configs.py:364-368: one order more when the last Taylor term serves as the error estimate
+        self.taylor_order = (5 if adaptive else 4) if taylor_order is None else taylor_order
         self.reg_epsilon = reg_epsilon
         self.ivp_rtol = ivp_rtol
         self.ivp_atol = ivp_atol
