@@ -261,8 +261,8 @@ def main():
                      "vacuum, bonds expanded to Dbond with expand_bond_dimension, as transport/dynamics.py:173-199)"
                      if args.init == "physical" else
                      "synthetic (random quantum-number-conserving MPS, 1 exciton; std.yaml Holstein parameters)"),
-            "config": {"workload": "configs[2]: 50-site Holstein chain TDVP-PS, %d independent trajector%s per GPU"
-                                   % (T, "y" if T == 1 else "ies"),
+            "config": {"workload": "configs[2]: %d-site Holstein chain TDVP-PS, %d independent trajector%s per GPU"
+                                   % (nsite, T, "y" if T == 1 else "ies"),
                        "nsite": nsite, "bond_dim": args.bond_dim, "dphys": [2, args.pdim], "mpo_bond": max(mpo.bond_dims),
                        "dt": args.dt, "init": args.init, "mean_krylov_dim": float(np.mean(kry)),
                        "device": eng.device_name},
