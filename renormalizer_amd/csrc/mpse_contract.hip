@@ -105,7 +105,7 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
       continue;
     }
     MPSE_TRY(gemm_call(ctx, s.dta, s.dtb, s.conja, s.conjb, s.ma, s.ka, s.kb, s.nb, s.mc, s.nc, s.batch, s.sba,
-                       s.sbb, s.sbc, a, b, c, 1.0, s.beta));
+                       s.sbb, s.sbc, a, b, c, 1.0, s.beta, s.skip_zero));
   }
   return MPSE_OK;
 }

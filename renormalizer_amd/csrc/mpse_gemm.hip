@@ -45,6 +45,13 @@ struct GemmArgs {
   int ksplit;          // number of K slices (1 = none)
   int kt_per_split;    // k-tiles per slice
   double* ws;          // split-K partial sums: [batch][ksplit][M][N] compact, dtype of C
+  // structural-zero skipping (optional, single-level K maps only): byte kt of amask[(b * tiles_m + tm) * nkw * 8 ..]
+  // is 1 if tile (tm, k-tile kt) of A holds a non-zero element, 0 otherwise; bmask likewise per column tile.
+  // (nkw 64-bit words of 8 flags per tile row.)  K tiles where either operand tile is entirely zero are never
+  // loaded or multiplied.
+  const unsigned long long* amask;
+  const unsigned long long* bmask;
+  int nkw;
 };
 
 __device__ __forceinline__ long long idx_off(const IdxMap& m, int i) {
@@ -244,7 +251,46 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
       acc_t2[i][j] = v4d{0, 0, 0, 0};
     }
 
-  if (kt_begin < kt_end) load_tile(kt_begin);
+  // next K tile >= from (and < kt_end) whose A and B tiles both hold non-zeros; kt_end if there is none
+  const unsigned long long* am = nullptr;
+  const unsigned long long* bm = nullptr;
+  if constexpr (KS) {
+    if (g.amask) am = g.amask + ((long long)b * g.tiles_m + tm) * g.nkw;
+    if (g.bmask) bm = g.bmask + ((long long)b * g.tiles_n + tn) * g.nkw;
+  }
+  auto next_kt = [&](int from) -> int {
+    if (!am && !bm) return from;
+    while (from < kt_end) {
+      const int w = from >> 3;                      // 8 byte flags per word
+      unsigned long long word = 0x0101010101010101ull;
+      if (am) word &= am[w];
+      if (bm) word &= bm[w];
+      word &= ~0ull << ((from & 7) * 8);
+      if (word) {
+        const int kt = (w << 3) + (__builtin_ctzll(word) >> 3);
+        return kt < kt_end ? kt : kt_end;
+      }
+      from = (w + 1) << 3;
+    }
+    return kt_end;
+  };
+  auto skip_to = [&](int cur_next, int target) {  // running pointers stand at tile cur_next; move them to target
+    if constexpr (KS) {
+      if (target != cur_next) {
+        const long long da = (long long)(target - cur_next) * step_a, db = (long long)(target - cur_next) * step_b;
+#pragma unroll
+        for (int r = 0; r < NLD; ++r) {
+          pa[r] += da;
+          pb[r] += db;
+        }
+      }
+    }
+  };
+  int kt = next_kt(kt_begin);
+  if (kt < kt_end) {
+    skip_to(kt_begin, kt);
+    load_tile(kt);
+  }
   const int frow = lane & 15, fk = lane >> 4;
   // LDS strides (in doubles) of element (i, k) of each panel
   const int sai = g.a_kfast ? LDK : 1, sak = g.a_kfast ? 1 : LD;
@@ -274,7 +320,7 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
     }
   };
 
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
+  while (kt < kt_end) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
@@ -291,7 +337,12 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
       }
     }
     __syncthreads();
-    if (kt + 1 < kt_end) load_tile(kt + 1);
+    const int nk = next_kt(kt + 1);
+    if (nk < kt_end) {
+      skip_to(kt + 1, nk);
+      load_tile(nk);
+    }
+    kt = nk;
 
     read_frag(0, 0);
 #pragma unroll
@@ -441,6 +492,58 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs g, int bat
   }
 }
 
+// Tile occupancy of both GEMM operands in one launch: one wave per (k tile, 64-row tile, batch x operand); lane r
+// scans the 16 k of its row and the wave stores the byte flag of the tile (1 = something non-zero).  "Rows" are
+// the M index for A and the N index for B.  The sweeps' tensors are block sparse by quantum number and every
+// kernel keeps their structural zeros exact, so whole tiles vanish.
+struct OccOperand {
+  const double* base;
+  IdxMap rmap, kmap;
+  int nrows, tiles, cplx, kfast;
+  long long sb;
+  unsigned char* flags;   // [batch][tiles][nkw * 8]
+};
+__global__ __launch_bounds__(256) void k_tile_occ(OccOperand oa, OccOperand ob, int K, int nkw, int batch) {
+  // one wave per k tile (4 per workgroup); 16 independent loads per lane, lanes along whichever index is contiguous
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kt = blockIdx.x * 4 + wave, t = blockIdx.y;
+  const bool second = (int)blockIdx.z >= batch;
+  const OccOperand& o = second ? ob : oa;
+  const int b = second ? blockIdx.z - batch : blockIdx.z;
+  if (t >= o.tiles || kt * BK >= K) return;
+  const int E = o.cplx ? 2 : 1;
+  const double* base = o.base + (long long)b * o.sb * E;
+  bool nz = false;
+  if (o.kfast) {   // k contiguous: 16 lanes span the 16 k of a row, 4 rows per pass
+    const int k = kt * BK + (lane & 15);
+    const bool kin = k < K;
+    const long long ko = idx_off(o.kmap, kin ? k : K - 1);
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+      const int r = t * BM + i * 4 + (lane >> 4);
+      if (r < o.nrows && kin) {
+        const double* q = base + (idx_off(o.rmap, r) + ko) * E;
+        nz |= (q[0] != 0.0);
+        if (o.cplx) nz |= (q[1] != 0.0);
+      }
+    }
+  } else {         // rows contiguous: one row per lane, 16 k per lane
+    const int r = t * BM + lane;
+    if (r < o.nrows) {
+      const double* p = base + idx_off(o.rmap, r) * E;
+      const int k1 = min(K, (kt + 1) * BK);
+#pragma unroll 4
+      for (int k = kt * BK; k < k1; ++k) {
+        const double* q = p + idx_off(o.kmap, k) * E;
+        nz |= (q[0] != 0.0);
+        if (o.cplx) nz |= (q[1] != 0.0);
+      }
+    }
+  }
+  const bool any = __ballot(nz) != 0ull;
+  if (lane == 0) o.flags[((long long)b * o.tiles + t) * nkw * 8 + kt] = any ? 1 : 0;
+}
+
 bool to_map(const mpse_index& s, IdxMap* m) {
   if (s.ext < 0 || s.ext > 0x7fffffffLL) return false;
   m->ext = (int)s.ext;
@@ -500,7 +603,7 @@ __global__ __launch_bounds__(256) void k_transpose_inner(double* out, const doub
 
 }  // namespace
 
-extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C) {
+static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C, int skip_zero) {
   if (!ctx || !d) return MPSE_ERR_ARG;
   if ((d->dtype_a != MPSE_F64 && d->dtype_a != MPSE_C128) || (d->dtype_b != MPSE_F64 && d->dtype_b != MPSE_C128))
     return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_gemm: unknown dtype");
@@ -542,7 +645,9 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
   g.ksplit = 1;
   g.kt_per_split = nkt_all > 0 ? nkt_all : 1;
   g.ws = nullptr;
-  TmpBuf WSB(ctx);
+  g.amask = g.bmask = nullptr;
+  g.nkw = 0;
+  TmpBuf WSB(ctx), MSK(ctx);
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   if (base_blocks < n_cu && nkt_all >= 4) {
     // fewer output tiles than CUs: slice K until ~2 workgroups per CU exist.  (One tile per CU runs as fast
@@ -560,6 +665,7 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
   }
   long long nblk = base_blocks * g.ksplit;
   if (nblk > 0x7fffffffLL) return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpse_gemm: grid too large");
+
   dim3 grid((unsigned)nblk), block(256);
   mpse_ctx::ProfRec rec;
   const bool prof_this = ctx->prof_on && (ctx->prof_counter++ % ctx->prof_stride == 0);
@@ -581,6 +687,24 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
     rec.bytes = double(d->batch) * (double(g.M) * g.K * (ca ? 16 : 8) + double(g.K) * g.N * (cb ? 16 : 8) +
                                     double(g.M) * g.N * ((ca || cb) ? 16 : 8) * (g.use_beta ? 2 : 1));
     MPSE_HIP(ctx, hipEventRecord(rec.e0, ctx->stream));
+  }
+  if (skip_zero && is_single(g.kA) && is_single(g.kB) && nkt_all >= 2 && d->batch <= 16384) {
+    // tile occupancy of both operands (one small scan launch), then only K tiles with data on both sides are visited
+    g.nkw = (nkt_all + 7) / 8;
+    const size_t wa = size_t(d->batch) * g.tiles_m * g.nkw, wb = size_t(d->batch) * g.tiles_n * g.nkw;
+    MPSE_TRY(MSK.alloc((wa + wb) * sizeof(unsigned long long)));
+    unsigned long long* am = MSK.as<unsigned long long>();
+    unsigned long long* bmk = am + wa;
+    // (flag bytes past the last k tile stay unwritten: next_kt never looks beyond kt_end)
+    // skip_zero bit 0: scan A, bit 1: scan B (an operand that is as large as the product itself is not worth a pass)
+    const bool sa = skip_zero & 1, sb_ = skip_zero & 2;
+    OccOperand oa{g.A, g.mA, g.kA, g.M, sa ? g.tiles_m : 0, ca ? 1 : 0, g.a_kfast, g.sbA, reinterpret_cast<unsigned char*>(am)};
+    OccOperand ob{g.B, g.nB, g.kB, g.N, sb_ ? g.tiles_n : 0, cb ? 1 : 0, g.b_kfast, g.sbB, reinterpret_cast<unsigned char*>(bmk)};
+    const int tmax = (sa ? g.tiles_m : 0) > (sb_ ? g.tiles_n : 0) ? (sa ? g.tiles_m : 0) : (sb_ ? g.tiles_n : 0);
+    const dim3 og((nkt_all + 3) / 4, tmax, (unsigned)(2 * d->batch));
+    hipLaunchKernelGGL(k_tile_occ, og, dim3(256), 0, ctx->stream, oa, ob, g.K, g.nkw, (int)d->batch);
+    g.amask = sa ? am : nullptr;
+    g.bmask = sb_ ? bmk : nullptr;
   }
   const bool ks = is_single(g.kA) && is_single(g.kB);
 #define MPSE_LAUNCH(CA_, CB_)                                                                         \
@@ -615,9 +739,13 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
   return MPSE_OK;
 }
 
+extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C) {
+  return gemm_impl(ctx, d, A, B, C, 0);
+}
+
 int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index ma, mpse_index ka, mpse_index kb,
               mpse_index nb, mpse_index mc, mpse_index nc, int64_t batch, int64_t sba, int64_t sbb, int64_t sbc,
-              const void* A, const void* B, void* C, double alpha, double beta) {
+              const void* A, const void* B, void* C, double alpha, double beta, int skip_zero) {
   mpse_gemm_desc d;
   d.dtype_a = dta;
   d.dtype_b = dtb;
@@ -637,7 +765,7 @@ int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index 
   d.alpha_im = 0.0;
   d.beta_re = beta;
   d.beta_im = 0.0;
-  return mpse_gemm(ctx, &d, A, B, C);
+  return gemm_impl(ctx, &d, A, B, C, skip_zero);
 }
 
 extern "C" int mpse_transpose_inner(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t d0, int64_t d1,

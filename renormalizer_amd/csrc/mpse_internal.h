@@ -96,7 +96,7 @@ static inline mpse_index idx2(int64_t hi_ext, int64_t lo_ext, int64_t s_hi, int6
 int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index ma, mpse_index ka,
               mpse_index kb, mpse_index nb, mpse_index mc, mpse_index nc, int64_t batch, int64_t sba,
               int64_t sbb, int64_t sbc, const void* A, const void* B, void* C, double alpha = 1.0,
-              double beta = 0.0);
+              double beta = 0.0, int skip_zero = 0);
 
 // reductions (mpse_vec.hip): results land in ctx->pinned after a stream sync
 int dotc_sync(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n, double* re, double* im);

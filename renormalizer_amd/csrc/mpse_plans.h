@@ -29,6 +29,7 @@ struct Step {
   int64_t batch, sba, sbb, sbc;
   int kind = K_GEMM;           // K_COPY: C(i,j) = A(i,j) with A indexed by (ma, ka), C by (mc, nc); b unused
   double beta = 0.0;           // K_GEMM: C = A.B + beta C
+  int skip_zero = 0;           // K_GEMM: scan both operands for all-zero tiles and skip them (block-sparse sweeps)
 };
 
 struct Plan {
@@ -51,6 +52,12 @@ inline void push(Plan& p, int a, int64_t ao, int dta, int conja, int b, int64_t 
 // Skipping a unit channel trades a (m x k x n) slice of a GEMM for a strided copy kernel: below ~1e8 multiply-adds
 // the slice costs less than the extra launch, so small centres keep the plain GEMM.
 inline bool unit_pays(int64_t m, int64_t k, int64_t n) { return m * k * n >= (int64_t(1) << 27); }
+// Scanning the operands of a GEMM for structurally zero tiles costs two small launches and one pass over the
+// operands; worth it from ~3e7 multiply-adds on.
+// The result says which operands to scan: bit 0 = A, bit 1 = B.
+inline int skip_pays(int64_t m, int64_t k, int64_t n, int which = 3) {
+  return m * k * n >= (int64_t(1) << 28) ? which : 0;
+}
 
 inline void push_copy(Plan& p, int src, int64_t so, int dst, int64_t dof, int dtype, mpse_index mi, mpse_index ni,
                       mpse_index mo, mpse_index no) {
@@ -59,20 +66,33 @@ inline void push_copy(Plan& p, int src, int64_t so, int dst, int64_t dof, int dt
   p.steps.push_back(s);
 }
 
-// X[a,b,n] = sum_c E[a,b,c] K[c,n] for an environment E (rows, w, cols) and a matrix K (cols, N); X (rows, w, N).
+// X[a,b,n] = sum_c E[a,b,c] K[c,n] for an environment E (rows, w, cols) and a matrix K (cols, N).
 // `unit` (1-based, 0 = none) names an MPO-bond channel b along which E[:, b, :] is the identity matrix (what a
 // canonical MPS gives for the channel in which no operator has acted yet): that slice of X is a copy of K and
 // the GEMM runs over the remaining channels only.
+// Layout of X: (rows, w, N) when b_outer == false; (w, rows, N) when b_outer == true.  With the channel as the
+// outer index every 64-row tile of the GEMM belongs to one MPO channel and one run of bond states, so the
+// quantum-number zero blocks of E show up as whole empty tiles (structural-zero skipping, mpse_gemm.hip).
 inline void push_env_times(Plan& p, int ebuf, int e_dtype, int kbuf, int k_dtype, int xbuf, int64_t rows, int64_t w,
-                           int64_t cols, int64_t N, int64_t unit) {
+                           int64_t cols, int64_t N, int64_t unit, bool b_outer) {
   const int64_t u = (unit >= 1 && unit <= w && rows == cols && unit_pays(rows, cols, N)) ? unit - 1 : -1;
-  if (u >= 0) push_copy(p, kbuf, 0, xbuf, u * N, k_dtype, i1(rows, N), i1(N, 1), i1(rows, w * N), i1(N, 1));
+  if (u >= 0) {
+    if (b_outer)
+      push_copy(p, kbuf, 0, xbuf, u * rows * N, k_dtype, i1(rows, N), i1(N, 1), i1(rows, N), i1(N, 1));
+    else
+      push_copy(p, kbuf, 0, xbuf, u * N, k_dtype, i1(rows, N), i1(N, 1), i1(rows, w * N), i1(N, 1));
+  }
   const int64_t lo[2] = {0, u + 1}, hi[2] = {u >= 0 ? u : w, u >= 0 ? w : 0};
   for (int r = 0; r < 2; ++r) {
     const int64_t b0 = lo[r], nb = hi[r] - lo[r];
     if (nb <= 0) continue;
-    push(p, ebuf, b0 * cols, e_dtype, 0, kbuf, 0, k_dtype, 0, xbuf, b0 * N, i2(rows, nb, w * cols, cols),
-         i1(cols, 1), i1(cols, N), i1(N, 1), i2(rows, nb, w * N, N), i1(N, 1));
+    if (b_outer)   // GEMM row i = (b - b0) * rows + a
+      push(p, ebuf, b0 * cols, e_dtype, 0, kbuf, 0, k_dtype, 0, xbuf, b0 * rows * N, i2(nb, rows, cols, w * cols),
+           i1(cols, 1), i1(cols, N), i1(N, 1), i1(nb * rows, N), i1(N, 1));
+    else           // GEMM row i = a * nb + (b - b0)
+      push(p, ebuf, b0 * cols, e_dtype, 0, kbuf, 0, k_dtype, 0, xbuf, b0 * N, i2(rows, nb, w * cols, cols),
+           i1(cols, 1), i1(cols, N), i1(N, 1), i2(rows, nb, w * N, N), i1(N, 1));
+    p.steps.back().skip_zero = skip_pays(rows * nb, cols, N);
   }
 }
 
@@ -95,17 +115,19 @@ inline void push_times_env(Plan& p, int tbuf, int t_dtype, int ebuf, int e_dtype
          /*A: m=(m1 | g)*/ i2(M1, anc, w * anc * Dk, Dk), /*k=(f | k)*/ i2(nf, Dk, anc * Dk, 1),
          /*B=E: k=(f,k), n=l*/ i1(nf * Dk, 1), i1(Dout, w * Dk), i1(M1 * anc, Dout), i1(Dout, 1));
     p.steps.back().beta = beta;
+    p.steps.back().skip_zero = skip_pays(M1 * anc, nf * Dk, Dout, 2);   // A = the big intermediate: environment side only
     beta = 1.0;
   }
 }
 
-// T_out[a, d, f, n] = sum_{b,e} W[b,d,e,f] T_in[a, b, e, n]   (W (wl,d,d,wr) row-major; batch over a)
+// T_out[a, d, f, n] = sum_{b,e} W[b,d,e,f] T_in[b, a, e, n]   (W (wl,d,d,wr) row-major; batch over a;
+// T_in in the channel-outer layout written by push_env_times(b_outer = true))
 inline void push_w(Plan& p, int wbuf, int w_dtype, int tin, int tout, int t_dtype, int64_t na, int64_t wl, int64_t d,
                    int64_t wr, int64_t N) {
   push(p, wbuf, 0, w_dtype, 0, tin, 0, t_dtype, 0, tout, 0,
        /*A=W: i=(d | f), k=(b | e)*/ i2(d, wr, d * wr, 1), i2(wl, d, d * d * wr, wr),
-       /*B=T_in[a]: k=(b,e), n*/ i1(wl * d, N), i1(N, 1),
-       /*C=T_out[a]: (d,f), n*/ i1(d * wr, N), i1(N, 1), na, 0, wl * d * N, d * wr * N);
+       /*B=T_in[:, a]: k=(b | e), n*/ i2(wl, d, na * d * N, N), i1(N, 1),
+       /*C=T_out[a]: (d,f), n*/ i1(d * wr, N), i1(N, 1), na, 0, d * N, d * wr * N);
 }
 
 // Effective Hamiltonian matvec, mps/hop_expr.py:57-115.
@@ -125,7 +147,7 @@ inline Plan plan_heff(int dtype, const mpse_heff& h) {
       return p;
     }
     p.tmp_elems[0] = Dl * wl * Dr;
-    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, Dr, h.l_unit);
+    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, Dr, h.l_unit, false);
     push_times_env(p, B_T1, dtype, B_R, h.r_dtype, B_OUT, Dl, 1, wr, Dr, Dr, h.r_unit);
     return p;
   }
@@ -135,7 +157,7 @@ inline Plan plan_heff(int dtype, const mpse_heff& h) {
     p.tmp_elems[0] = Dl * wl * N;
     p.tmp_elems[1] = Dl * d * wr * Nb;
     // T1[a,b,(e,g,k)] = sum_c L[(a,b),c] C[c,(e,g,k)]
-    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, N, h.l_unit);
+    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, N, h.l_unit, true);
     // T2[a,d,f,(g,k)] = sum_{b,e} W[b,d,e,f] T1[a,b,e,(g,k)]
     push_w(p, B_W0, h.w_dtype, B_T1, B_T2, dtype, Dl, wl, d, wr, Nb);
     // out[(a,d,g),l] = sum_{f,k} T2[a,d,f,g,k] R[l,f,k]
@@ -152,7 +174,7 @@ inline Plan plan_heff(int dtype, const mpse_heff& h) {
     p.tmp_elems[1] = Dl * d0 * wm * n1;
     p.tmp_elems[2] = Dl * d0 * anc * d1 * wr * n2;
     // T1[a,b,(e,m,h,n,k)]
-    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, N, h.l_unit);
+    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, N, h.l_unit, true);
     // T2[a,d,f,(m,h,n,k)]
     push_w(p, B_W0, h.w_dtype, B_T1, B_T2, dtype, Dl, wl, d0, wm, n1);
     // T3[(a,d),m,g,j,(n,k)] = sum_{f,h} W1[f,g,h,j] T2[(a,d),f,m,h,(n,k)]   batch (a,d); one step per m
@@ -182,7 +204,7 @@ inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, i
     p.tmp_elems[0] = Dlb * wl * N;
     p.tmp_elems[1] = Dlb * d * wr * anc * Drk;
     // X[a,b,(e,g,h)] = sum_c L[(a,b),c] A[c,(e,g,h)]
-    push_env_times(p, B_L, env_dtype, B_C, dtype, B_T1, Dlb, wl, Dlk, N, s.env_unit);
+    push_env_times(p, B_L, env_dtype, B_C, dtype, B_T1, Dlb, wl, Dlk, N, s.env_unit, true);
     // Y[a,d,f,(g,h)] = sum_{b,e} W[b,d,e,f] X[a,b,e,(g,h)]
     push_w(p, B_W0, w_dtype, B_T1, B_T2, dtype, Dlb, wl, d, wr, anc * Drk);
     // out[p,(f,h)] = sum_{a,d,g} bra*[(a,d,g),p] Y[a,d,f,g,h]
@@ -190,6 +212,7 @@ inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, i
     //   B = Y: k = ((a,d) | g): s_hi = wr*anc*Drk, s_lo = Drk ; n = (f | h): s_hi = anc*Drk, s_lo = 1
     push(p, B_BRA, 0, dtype, bra_conj, B_T2, 0, dtype, 0, B_OUT, 0, i1(Drb, 1), i1(Dlb * d * anc, Drb),
          i2(Dlb * d, anc, wr * anc * Drk, Drk), i2(wr, Drk, anc * Drk, 1), i1(Drb, wr * Drk), i1(wr * Drk, 1));
+    p.steps.back().skip_zero = skip_pays(Drb, Dlb * d * anc, wr * Drk, 1);   // B = the big intermediate: bra side only
     return p;
   }
   if (domain == MPSE_DOMAIN_R) {
@@ -208,6 +231,7 @@ inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, i
         if (nb <= 0) continue;
         push(p, B_C, 0, dtype, 0, B_L, b0 * Drk, env_dtype, 0, B_T1, b0 * Drb, i1(M, Drk), i1(Drk, 1), i1(Drk, 1),
              i2(nb, Drb, Drk, wr * Drk), i1(M, wr * Drb), i1(nb * Drb, 1));
+        p.steps.back().skip_zero = skip_pays(M, Drk, nb * Drb);
       }
     }
     // Y[h,q,d,g,a] = sum_{e,b} W[q,d,e,b] X[h,e,g,b,a] ; batch h ; one step per ancilla value g
@@ -219,6 +243,7 @@ inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, i
     // out[p,(q,h)] = sum_{d,g,a} bra*[p,(d,g,a)] Y[h,q,(d,g,a)]
     push(p, B_BRA, 0, dtype, bra_conj, B_T2, 0, dtype, 0, B_OUT, 0, i1(Dlb, d * anc * Drb), i1(d * anc * Drb, 1),
          i1(d * anc * Drb, 1), i2(wl, Dlk, d * anc * Drb, wl * d * anc * Drb), i1(Dlb, wl * Dlk), i1(wl * Dlk, 1));
+    p.steps.back().skip_zero = skip_pays(Dlb, d * anc * Drb, wl * Dlk, 1);
     return p;
   }
   p.error = "env: bad domain";
