@@ -132,6 +132,9 @@ typedef struct {
   int64_t sb_a, sb_b, sb_c; /* batch strides, elements */
   double alpha_re, alpha_im;
   double beta_re, beta_im;
+  int skip_zero_tiles;      /* hint for block-sparse operands: bit 0 scan A, bit 1 scan B for all-zero 64 x 16
+                               tiles and skip them in the K loop (same result; pays from ~1e8 multiply-adds);
+                               0 = plain dense GEMM */
 } mpse_gemm_desc;
 
 int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* desc, const void* A, const void* B, void* C);

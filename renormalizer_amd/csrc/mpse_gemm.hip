@@ -740,7 +740,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
 }
 
 extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C) {
-  return gemm_impl(ctx, d, A, B, C, 0);
+  return gemm_impl(ctx, d, A, B, C, d ? (d->skip_zero_tiles & 3) : 0);
 }
 
 int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index ma, mpse_index ka, mpse_index kb,
@@ -765,6 +765,7 @@ int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index 
   d.alpha_im = 0.0;
   d.beta_re = beta;
   d.beta_im = 0.0;
+  d.skip_zero_tiles = skip_zero;
   return gemm_impl(ctx, &d, A, B, C, skip_zero);
 }
 

@@ -39,7 +39,8 @@ class mpse_gemm_desc(C.Structure):
                 ("m_a", mpse_index), ("k_a", mpse_index), ("k_b", mpse_index), ("n_b", mpse_index),
                 ("m_c", mpse_index), ("n_c", mpse_index),
                 ("batch", C.c_int64), ("sb_a", C.c_int64), ("sb_b", C.c_int64), ("sb_c", C.c_int64),
-                ("alpha_re", C.c_double), ("alpha_im", C.c_double), ("beta_re", C.c_double), ("beta_im", C.c_double)]
+                ("alpha_re", C.c_double), ("alpha_im", C.c_double), ("beta_re", C.c_double), ("beta_im", C.c_double),
+                ("skip_zero_tiles", C.c_int)]
 
 
 class mpse_dims(C.Structure):
@@ -397,7 +398,7 @@ class Engine:
 
     # -- general contraction
     def gemm(self, A, B, Cout, m_a, k_a, k_b, n_b, m_c, n_c, conj_a=False, conj_b=False, batch=1,
-             sb_a=0, sb_b=0, sb_c=0, alpha=1.0, beta=0.0):
+             sb_a=0, sb_b=0, sb_c=0, alpha=1.0, beta=0.0, skip_zero_tiles=0):
         d = mpse_gemm_desc()
         d.dtype_a, d.dtype_b = A.code, B.code
         d.conj_a, d.conj_b = int(conj_a), int(conj_b)
@@ -405,6 +406,7 @@ class Engine:
         d.batch, d.sb_a, d.sb_b, d.sb_c = int(batch), int(sb_a), int(sb_b), int(sb_c)
         alpha, beta = complex(alpha), complex(beta)
         d.alpha_re, d.alpha_im, d.beta_re, d.beta_im = alpha.real, alpha.imag, beta.real, beta.imag
+        d.skip_zero_tiles = int(skip_zero_tiles)
         self._check(self.lib.mpse_gemm(self.ctx, C.byref(d), A.ptr, B.ptr, Cout.ptr))
         return Cout
 

@@ -415,3 +415,46 @@ def test_block_svd_extreme_dynamic_range(eng, golden_dir):
         assert abs(s[koff] - sref[0]) < 1e-14
         assert np.all(s[koff + 1: koff + k] < 1e-15)        # the rest is numerically zero either way
         koff += k
+
+
+@pytest.mark.parametrize("ca,cb", [(True, True), (False, True), (False, False)])
+def test_gemm_skip_zero_tiles_equals_dense(eng, ca, cb):
+    """Block-sparse operands with the tile-skipping hint: identical results (only all-zero 64 x 16 tiles are skipped),
+    for ragged shapes, blocks that straddle tile boundaries, K not a multiple of 16, split-K, beta accumulation, batches
+    and an all-zero operand."""
+    rng = np.random.default_rng(21)
+
+    def sparse(shape, cplx, row_blocks, col_blocks, fill=0.5):
+        a = _rand(rng, shape, cplx)
+        mask = np.zeros(shape[-2:], dtype=bool)
+        rb = np.linspace(0, shape[-2], row_blocks + 1).astype(int)
+        cbk = np.linspace(0, shape[-1], col_blocks + 1).astype(int)
+        for i in range(row_blocks):
+            for j in range(col_blocks):
+                if rng.random() < fill:
+                    mask[rb[i]:rb[i + 1], cbk[j]:cbk[j + 1]] = True
+        return a * mask
+    i1 = E.idx1
+    for (M, K, N, batch) in ((300, 520, 200, 1), (64, 1000, 70, 1), (130, 37, 260, 3), (700, 256, 900, 1)):
+        A = sparse((batch, M, K), ca, 3, 5)
+        B = sparse((batch, K, N), cb, 5, 2)
+        C0 = _rand(rng, (batch, M, N), ca or cb)
+        dA, dB = eng.asdevice(A), eng.asdevice(B)
+        maps = (i1(M, K), i1(K, 1), i1(K, N), i1(N, 1), i1(M, N), i1(N, 1))
+        kw = dict(batch=batch, sb_a=M * K, sb_b=K * N, sb_c=M * N, alpha=0.7, beta=-0.3)
+        dense = eng.asdevice(C0)
+        eng.gemm(dA, dB, dense, *maps, **kw)
+        for hint in (1, 2, 3):
+            out = eng.asdevice(C0)
+            eng.gemm(dA, dB, out, *maps, skip_zero_tiles=hint, **kw)
+            assert np.array_equal(out.to_host(), dense.to_host())
+        ref = 0.7 * (A @ B) - 0.3 * C0
+        assert _relerr(dense.to_host(), ref) < 1e-12
+    # one operand entirely zero: the result is beta * C
+    A = np.zeros((200, 400))
+    B = _rand(rng, (400, 300), cb)
+    C0 = _rand(rng, (200, 300), cb)
+    out = eng.asdevice(C0)
+    eng.gemm(eng.asdevice(A), eng.asdevice(B), out, i1(200, 400), i1(400, 1), i1(400, 300), i1(300, 1), i1(200, 300),
+             i1(300, 1), beta=2.0, skip_zero_tiles=3)
+    assert np.array_equal(out.to_host(), 2.0 * C0)
