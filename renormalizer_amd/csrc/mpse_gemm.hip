@@ -518,26 +518,34 @@ __global__ __launch_bounds__(256) void k_tile_occ(OccOperand oa, OccOperand ob, 
     const int k = kt * BK + (lane & 15);
     const bool kin = k < K;
     const long long ko = idx_off(o.kmap, kin ? k : K - 1);
-#pragma unroll 4
+    // all 16 loads are issued before the first compare (clamped addresses instead of predicated loads)
+    double v0[16], v1[16];
+#pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int r = t * BM + i * 4 + (lane >> 4);
-      if (r < o.nrows && kin) {
-        const double* q = base + (idx_off(o.rmap, r) + ko) * E;
-        nz |= (q[0] != 0.0);
-        if (o.cplx) nz |= (q[1] != 0.0);
-      }
+      const int r = min(t * BM + i * 4 + (lane >> 4), o.nrows - 1);
+      const double* q = base + (idx_off(o.rmap, r) + ko) * E;
+      v0[i] = q[0];
+      v1[i] = o.cplx ? q[1] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bool in = (t * BM + i * 4 + (lane >> 4)) < o.nrows && kin;
+      nz |= in && (v0[i] != 0.0 || v1[i] != 0.0);
     }
   } else {         // rows contiguous: one row per lane, 16 k per lane
     const int r = t * BM + lane;
     if (r < o.nrows) {
       const double* p = base + idx_off(o.rmap, r) * E;
-      const int k1 = min(K, (kt + 1) * BK);
-#pragma unroll 4
-      for (int k = kt * BK; k < k1; ++k) {
+      double v0[16], v1[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = min(kt * BK + i, K - 1);
         const double* q = p + idx_off(o.kmap, k) * E;
-        nz |= (q[0] != 0.0);
-        if (o.cplx) nz |= (q[1] != 0.0);
+        v0[i] = q[0];
+        v1[i] = o.cplx ? q[1] : 0.0;
       }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) nz |= (kt * BK + i < K) && (v0[i] != 0.0 || v1[i] != 0.0);
     }
   }
   const bool any = __ballot(nz) != 0ull;
