@@ -303,6 +303,9 @@ class Mpo:
 
     @classmethod
     def from_arrays(cls, model, arrays):
+        """Operator from raw site tensors.  The bond quantum numbers are unknown and set to zero: fine wherever the
+        operator is only contracted into environments (TDVP, DMRG, expectation values); ``apply / contract`` on a
+        quantum-number-conserving state needs the labels and therefore an operator built from the model."""
         m = cls()
         m.model = model
         m._mp = [np.asarray(a) for a in arrays]

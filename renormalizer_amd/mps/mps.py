@@ -120,6 +120,33 @@ class Mps:
         return cls.from_arrays(model, arrays, qn, model.nsite - 1, qntot, False)
 
     @classmethod
+    def from_dense(cls, model, wfn: np.ndarray) -> "Mps":
+        """Exact MPS of a dense wavefunction by successive QR (mps/mps.py:389-406: a debugging helper; host-side
+        state preparation like ``random``).  The quantum numbers are left empty (all zero), as in the reference."""
+        wfn = np.asarray(wfn)
+        dims = [b.nbas for b in model.basis]
+        res = wfn.reshape([1] + dims + [1])
+        arrays = []
+        for _ in range(len(dims) - 1):
+            q, r = np.linalg.qr(res.reshape(res.shape[0] * res.shape[1], -1))
+            arrays.append(q.reshape(res.shape[0], res.shape[1], q.shape[1]))
+            res = r.reshape([r.shape[0]] + list(res.shape[2:]))
+        arrays.append(res)
+        qsz = model.qn_size
+        qn = [np.zeros((a.shape[0], qsz), dtype=int) for a in arrays] + [np.zeros((1, qsz), dtype=int)]
+        return cls.from_arrays(model, arrays, qn, len(arrays) - 1, np.zeros(qsz, dtype=int), False)
+
+    def todense(self) -> np.ndarray:
+        """The full wavefunction (mp.py:996-1007), site by site on the device; exponential in the number of sites."""
+        eng = get_engine()
+        if int(np.prod([float(d) for d in self.pbond_dims])) > 2 ** 26:
+            raise ValueError("todense: the dense wavefunction would not fit")
+        t = self[0].reshape(-1, self[0].shape[-1])
+        for ms in self._mp[1:]:
+            t = eng.matmul(t, ms.reshape(ms.shape[0], -1)).reshape(-1, ms.shape[-1])
+        return t.to_host().reshape(list(self.pbond_dims)) * self.coeff
+
+    @classmethod
     def hartree_product_state(cls, model, condition: Dict = None, qn_idx: int = None):
         """mps/mps.py:187-262"""
         condition = dict(condition or {})

@@ -64,3 +64,22 @@ def test_bond_entropy(state):
     s1 = mps.calc_entropy("1site")
     sb = mps.calc_entropy("bond")
     assert abs(sb[0] - s1[0]) < 1e-10 and abs(sb[-1] - s1[len(mps) - 1]) < 1e-10
+
+
+def test_dense_round_trip():
+    """mps/tests/test_mps.py:91-96: todense / from_dense; and <H> from the dense vector against the MPS contraction"""
+    from renormalizer_amd import BasisSimpleElectron, Model, Mpo, Op
+    from renormalizer_amd.mps.mps import Mps
+    ham = sum((Op(r"a^\dagger a", [i, i + 1], 0.3) + Op(r"a^\dagger a", [i + 1, i], 0.3) for i in range(4)),
+              Op(r"a^\dagger a", 0, 0.1))
+    model = Model([BasisSimpleElectron(i) for i in range(5)], ham)
+    ref = Mps.random(model, 1, 20, rng=np.random.default_rng(4))
+    dense = ref.todense()
+    assert dense.shape == (2,) * 5 and abs(np.linalg.norm(dense) - 1) < 1e-12
+    loaded = Mps.from_dense(model, dense)
+    assert np.abs(loaded.todense() - dense).max() < 1e-13
+    h = Mpo(model)
+    hd = h.todense() if hasattr(h, "todense") else None
+    if hd is not None:
+        v = dense.ravel()
+        assert abs(v.conj() @ hd.reshape(32, 32) @ v - ref.expectation(h)) < 1e-12
