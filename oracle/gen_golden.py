@@ -450,6 +450,58 @@ if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("pc_adaptiv
     gen_pc_adaptive()
 
 
+def _fmo_model(nph):
+    import json
+    from renormalizer.model import Phonon, Mol, HolsteinModel
+    from renormalizer.utils import Quantity
+    from renormalizer.utils.constant import cm2au
+    sdf = np.array(json.load(open(os.path.join(GOLD, "fmo_sdf.json"))))
+    j_cm = np.array([[310, -98, 6, -6, 7, -12, -10, 38], [-98, 230, 30, 7, 2, 12, 5, 8], [6, 30, 0, -59, -2, -10, 5, 2],
+                     [-6, 7, -59, 180, -65, -17, -65, -2], [7, 2, -2, -65, 405, 89, -6, 5], [-12, 11, -10, -17, 89, 320, 32, -10],
+                     [-10, 5, 5, -64, -6, 32, 270, -11], [38, 8, 2, -2, 5, -10, -11, 505]])
+    om_cm = np.linspace(2, 300, nph)
+    om = om_cm * cm2au
+    hr = np.interp(om_cm, sdf[:, 0], sdf[:, 1])
+    hr *= 0.42 / hr.sum()
+    phonons = [Phonon.simplest_phonon(Quantity(o), Quantity(l), lam=True) for o, l in zip(om, hr * om)]
+    j = j_cm * cm2au
+    mols = [Mol(Quantity(e), phonons) for e in np.diag(j)]
+    arr = np.array([7, 5, 3, 1, 2, 4, 6]) - 1
+    return HolsteinModel(list(np.array(mols)[arr]), j[arr][:, arr])
+
+
+def gen_fmo():
+    """example/fmo.py (7 sites of the FMO complex, Holstein modes from the tabulated spectral density, T = 0) with
+    fewer modes per site and a smaller bond dimension: phonon dimensions picked by simplest_phonon, MPO bond
+    dimensions, populations after a few TDVP-PS steps."""
+    from renormalizer.mps import Mps, Mpo
+    from renormalizer.utils import Quantity, CompressConfig, CompressCriteria, EvolveConfig, EvolveMethod
+    nph = 6
+    model = _fmo_model(nph)
+    out = {"nph": np.array(nph), "pbond": np.array(model.pbond_list)}
+    gs = Mps.ground_state(model, max_entangled=False)
+    init = Mpo.onsite(model, r"a^\dagger", dof_set={model.mol_num // 2}).apply(gs)
+    mpo = Mpo(model, offset=Quantity(init.expectation(Mpo(model))))
+    out["mpo_bond_dims"] = np.array(mpo.bond_dims)
+    init.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=12)
+    init.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    np.random.seed(4242)
+    mps = init.expand_bond_dimension(mpo)
+    mps.canonicalise()
+    occ = [np.asarray(mps.e_occupations)]
+    for _ in range(4):
+        mps = mps.evolve(mpo, 160.0)
+        occ.append(np.asarray(mps.e_occupations))
+    out["e_occ"] = np.array(occ)
+    out["bond_dims"] = np.array(mps.bond_dims)
+    np.savez_compressed(os.path.join(GOLD, "fmo_small.npz"), **out)
+    print("fmo_small.npz pbond", model.pbond_list[:8], "mpo bonds", mpo.bond_dims[:10], "occ", occ[-1])
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("fmo",)):
+    gen_fmo()
+
+
 def gen_thermal():
     """Imaginary-time propagation of the T = infinity one-exciton density operator of the reference's test model
     (mps/tests/test_mpdm.py) to 298 K: energies and occupations after every step, for P&C and fixed-step TDVP-PS."""

@@ -16,6 +16,38 @@ class Phonon:
     def simple_phonon(cls, omega, displacement, n_phys_dim):
         return cls([omega, omega], [Quantity(0), displacement], n_phys_dim)
 
+    @classmethod
+    def simplest_phonon(cls, omega, displacement, temperature: Quantity = Quantity(0), lam: bool = False, max_pdim=128):
+        """Number of levels chosen automatically (model/phonon.py:31-60): halve / double a trial dimension until the
+        ground state of the displaced oscillator is resolved (weight of the upper half of the levels < 1e-4, last
+        coefficient < 1e-3), plus 10 kT / omega thermal levels.  ``lam=True``: the second argument is the
+        reorganisation energy instead of the displacement."""
+        if lam:
+            displacement = Quantity(np.sqrt(2 * displacement.as_au()) / omega.as_au())
+        pdim = 256
+        while True:
+            gs = cls.simple_phonon(omega, displacement, pdim).get_displacement_evecs()[:, 0]
+            if not (np.all(gs <= 1e-8) or np.all(gs >= -1e-8)):
+                raise ValueError("displaced-oscillator ground state changes sign")
+            if 0.9999 < gs[:len(gs) // 2].sum() / gs.sum():
+                pdim //= 2                      # too many levels
+            elif 0.001 < abs(gs[-1]):
+                if pdim == 256:
+                    raise ValueError(f"Too many phonon level required. omega: {omega}. displacement: {displacement}")
+                pdim *= 2                       # one halving too far
+                break
+            else:
+                break
+        pdim = min(pdim + int(temperature.as_au() * 10 / omega.as_au()), max_pdim)
+        return cls.simple_phonon(omega, displacement, pdim)
+
+    def get_displacement_evecs(self) -> np.ndarray:
+        """eigenvectors of b^+ b - g (b^+ + b) in the first n_phys_dim number states (model/phonon.py:83-94)"""
+        n = self.n_phys_dim
+        off = -self.coupling_constant * np.sqrt(np.arange(1, n))
+        h = np.diag(np.arange(n, dtype=float)) + np.diag(off, -1) + np.diag(off, 1)
+        return np.linalg.eigh(h)[1]
+
     @property
     def is_simple(self):
         return self.omega[0] == self.omega[1]

@@ -402,3 +402,18 @@ def test_adaptive_prop_and_compress_matches_reference(golden_dir):
         assert list(mps.bond_dims) == z["bond_dims"][step].tolist()
         assert abs(mps.mp_norm - z["norms"][step]) < 1e-9
         assert 0 < mps.evolve_config.guess_dt <= 2 * max(z["guess_dt"])
+
+
+def test_fmo_model_matches_reference(golden_dir):
+    """BASELINE config 4's model (example/fmo.py: 7 FMO sites, modes from the tabulated spectral density) at reduced
+    size: phonon level counts chosen by simplest_phonon, MPO bond dimensions, populations over four TDVP-PS steps."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fmo_example", os.path.join(os.path.dirname(golden_dir), "..", "examples", "fmo.py"))
+    fmo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fmo)
+    z = np.load(os.path.join(golden_dir, "fmo_small.npz"))
+    model = fmo.fmo_model(int(z["nph"]))
+    assert list(model.pbond_list) == z["pbond"].tolist()
+    assert Mpo(model).bond_dims == z["mpo_bond_dims"].tolist()
+    occ = fmo.run(model, 12, 4)
+    assert np.abs(occ - z["e_occ"]).max() < 1e-6
