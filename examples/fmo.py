@@ -2,7 +2,9 @@
 """Exciton dynamics in the FMO complex (example/fmo.py of the reference): 7 sites, Holstein modes sampled from
 the tabulated spectral density, T = 0, TDVP-PS at fixed bond dimension.
 
-    python examples/fmo.py [modes per site = 35] [D = 32] [steps = 5] [trajectories = 1]
+    python examples/fmo.py [modes per site = 35] [D = 32] [steps = 5] [trajectories = 1] [temperature / K = 0]
+
+A temperature > 0 switches to the thermofield form (BASELINE config 4): every mode is doubled, 7 + 2 x 7 x modes sites.
 
 With more than one trajectory, static disorder (Gaussian, 50 cm^-1) is added to the site energies with a seed per
 trajectory; under ``python -m torch.distributed.run --nproc-per-node N examples/fmo.py ...`` the trajectories are dealt
@@ -26,7 +28,7 @@ J_CM = np.array([[310, -98, 6, -6, 7, -12, -10, 38], [-98, 230, 30, 7, 2, 12, 5,
                  [-10, 5, 5, -64, -6, 32, 270, -11], [38, 8, 2, -2, 5, -10, -11, 505]], dtype=float)
 
 
-def fmo_model(n_phonons=35, total_hr=0.42, disorder_cm=0.0, rng=None):
+def fmo_model(n_phonons=35, total_hr=0.42, disorder_cm=0.0, rng=None, temperature_k=0.0):
     sdf = np.array(json.load(open(os.path.join(REPO, "tests", "golden", "fmo_sdf.json"))))
     om_cm = np.linspace(2, 300, n_phonons)
     om = om_cm * cm2au
@@ -39,6 +41,9 @@ def fmo_model(n_phonons=35, total_hr=0.42, disorder_cm=0.0, rng=None):
         eps = eps + rng.normal(0.0, disorder_cm * cm2au, size=len(eps))
     mols = [Mol(Quantity(e), phonons) for e in eps]
     arr = np.array([7, 5, 3, 1, 2, 4, 6]) - 1
+    if temperature_k > 0:
+        from renormalizer_amd.model import thermofield_holstein
+        return thermofield_holstein([mols[i] for i in arr], j[arr][:, arr], Quantity(temperature_k, "K"))
     return HolsteinModel([mols[i] for i in arr], j[arr][:, arr])
 
 
@@ -57,6 +62,7 @@ def run(model, D, nsteps, dt=160.0):
 
 if __name__ == "__main__":
     nph, D, nsteps, ntraj = [int(a) for a in sys.argv[1:5]] + [35, 32, 5, 1][len(sys.argv[1:5]):]
+    temperature_k = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     os.environ.setdefault("RENO_GPU", os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -68,7 +74,7 @@ if __name__ == "__main__":
     rows = []
     for u in mine:
         rng = np.random.default_rng(trajectory_seed(2024, u))
-        model = fmo_model(nph, disorder_cm=50.0 if ntraj > 1 else 0.0, rng=rng)
+        model = fmo_model(nph, disorder_cm=50.0 if ntraj > 1 else 0.0, rng=rng, temperature_k=temperature_k)
         rows.append(run(model, D, nsteps).ravel())
     table = gather_observables(np.array(rows), mine, ntraj,
                                device=f"cuda:{os.environ.get('LOCAL_RANK', 0)}" if world > 1 else "cpu")

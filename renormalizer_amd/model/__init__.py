@@ -3,4 +3,5 @@ from .basis import (BasisSet, BasisSHO, BasisSimpleElectron, BasisHalfSpin, Basi
                     BasisMultiElectronVac)
 from .phonon import Phonon, Mol
 from .model import Model, HolsteinModel, SpinBosonModel, construct_j_matrix
+from .thermofield import thermofield_holstein
 from . import h_qc

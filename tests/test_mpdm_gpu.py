@@ -116,3 +116,61 @@ def test_thermal_prop_dump(tmp_path):
     assert d["energies"].shape == (3,) and d["electron occupations array"].shape == (3, 3)
     assert np.allclose(d["time series"], [0, beta / 40, beta / 20])
     assert os.path.exists(os.path.join(str(tmp_path), "thermal_mps.npz"))
+
+
+def test_thermofield_agrees_with_purification():
+    """Two independent finite-temperature routes on a small Holstein dimer (1500 K, beta omega ~ 1): (i) purified
+    density operator - imaginary-time ThermalProp of the vibrational identity, electron created, real-time TDVP-PS on
+    the 4-leg sites; (ii) thermofield pure state - doubled modes with cosh / sinh couplings, ordinary MPS.  The
+    electronic populations must agree up to the truncation of the phonon ladders."""
+    from renormalizer_amd.model import thermofield_holstein
+    from renormalizer_amd.mps import MpDm, Mps, ThermalProp
+    temperature = Quantity(1500, "K")
+    ph = Phonon.simple_phonon(Quantity(0.005), Quantity(12.0), 12)
+    mols = [Mol(Quantity(0.0), [ph]), Mol(Quantity(0.002), [ph])]
+    j = np.array([[0.0, 0.003], [0.003, 0.0]])
+    dt, nsteps = 40.0, 6
+    # (i) purification
+    model = HolsteinModel(mols, j, 3)
+    rho = MpDm.max_entangled_gs(model)
+    beta = temperature.to_beta()
+    tp = ThermalProp(rho, evolve_config=EvolveConfig(EvolveMethod.prop_and_compress), auto_expand=False)
+    tp.evolve(evolve_dt=beta / 2j / 20, nsteps=20)
+    nbar = 1.0 / (np.exp(beta * 0.005) - 1.0)
+    assert np.allclose(tp.latest_mps.ph_occupations, nbar, rtol=2e-3)          # Bose-Einstein occupation of the bath
+    ex = Mpo.onsite(model, r"a^\dagger", dof_set={0}).apply(tp.latest_mps)
+    ex.normalize("mps_and_coeff")
+    ex.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=24)
+    ex.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    h = Mpo(model)
+    ex = ex.expand_bond_dimension(h)
+    occ_p = [np.asarray(ex.e_occupations)]
+    for _ in range(nsteps):
+        ex = ex.evolve(h, dt)
+        occ_p.append(np.asarray(ex.e_occupations))
+    # (ii) thermofield
+    tf = thermofield_holstein(mols, j, temperature)
+    psi = Mpo.onsite(tf, r"a^\dagger", dof_set={0}).apply(Mps.ground_state(tf, False))
+    psi.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=24)
+    psi.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    htf = Mpo(tf)
+    psi = psi.expand_bond_dimension(htf)
+    occ_t = [np.asarray(psi.e_occupations)]
+    for _ in range(nsteps):
+        psi = psi.evolve(htf, dt)
+        occ_t.append(np.asarray(psi.e_occupations))
+    occ_p, occ_t = np.array(occ_p), np.array(occ_t)
+    assert abs(occ_p[-1][1]) > 0.02                      # something happened
+    assert np.abs(occ_p - occ_t).max() < 2e-3
+    # and the zero-temperature limit of the thermofield model is the plain Holstein model
+    cold = thermofield_holstein(mols, j, Quantity(1e-3, "K"))
+    psi0 = Mpo.onsite(cold, r"a^\dagger", dof_set={0}).apply(Mps.ground_state(cold, False))
+    ref0 = Mpo.onsite(model, r"a^\dagger", dof_set={0}).apply(Mps.ground_state(model, False))
+    for s_, m_ in ((psi0, cold), (ref0, model)):
+        s_.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=16)
+        s_.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    hc, h0 = Mpo(cold), Mpo(model)
+    psi0, ref0 = psi0.expand_bond_dimension(hc), ref0.expand_bond_dimension(h0)
+    for _ in range(3):
+        psi0, ref0 = psi0.evolve(hc, dt), ref0.evolve(h0, dt)
+    assert np.abs(np.asarray(psi0.e_occupations) - np.asarray(ref0.e_occupations)).max() < 1e-8
