@@ -55,6 +55,22 @@ for nmol, D, ref in ((10, 64, "3.73 s, 10.7/s"), (10, 128, "31.6 s, 1.27/s"), (2
     t, _ = timed_evolves(psi, mpo, 10.0, 3)
     rows.append((f"#3 Holstein {2 * nmol} sites, d = 2/16, D = {D}, TDVP-PS (bond expansion {texp:.1f} s)", t, 4 * nmol / t, ref))
 
+# config 4: FMO, 7 sites x 35 modes, D = 32 (T = 0: 252 sites; thermofield at 77 K: 497 sites)
+import importlib.util  # noqa: E402
+spec = importlib.util.spec_from_file_location("fmo_example", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "fmo.py"))
+fmo = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(fmo)
+for temp in (0.0, 77.0):
+    model = fmo.fmo_model(35, temperature_k=temp)
+    psi = Mpo.onsite(model, r"a^\dagger", dof_set={model.mol_num // 2}).apply(Mps.ground_state(model, False))
+    mpo = Mpo(model, offset=Quantity(psi.expectation(Mpo(model))))
+    psi.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=32)
+    psi.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    psi = psi.expand_bond_dimension(mpo).canonicalise()
+    t, _ = timed_evolves(psi, mpo, 160.0, 3)
+    rows.append((f"#4 FMO {'T = 0' if temp == 0 else 'thermofield 77 K'}: {len(mpo)} sites, d <= {max(model.pbond_list)}, D = 32, "
+                 f"TDVP-PS, one trajectory", t, 2 * len(mpo) / t, "n/a"))
+
 # config 5: H2O STO-3G DMRG
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sh, aseri, nuc = h_qc.read_fcidump(os.path.join(repo, "tests", "golden", "h2o_fcidump.txt"), 7)
