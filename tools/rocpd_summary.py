@@ -24,13 +24,16 @@ def main():
     # its k_splitk_reduce<true>; the matching trace figure is (their summed time) / (number of k_gemm launches)
     g = [r for r in rows if re.search(r"k_gemm<true, true, (true|false)>", r[0])]
     red = [r for r in rows if "k_splitk_reduce<true>" in r[0]]
+    occ = [r for r in rows if "k_tile_occ" in r[0]]
     if g:
         ng = sum(r[1] for r in g)
         tg = sum(r[2] for r in g)
         tr = sum(r[2] for r in red)
+        to = sum(r[2] for r in occ)
         lines.append(f"\nc128 x c128 contraction calls: {ng}; k_gemm alone {tg / ng / 1e3:.2f} us/call; "
-                     f"with split-K reduce {(tg + tr) / ng / 1e3:.2f} us/call "
-                     f"(compare bench.py roofline.avg_launch_ms)")
+                     f"with split-K reduce {(tg + tr) / ng / 1e3:.2f} us/call; with reduce and occupancy scan "
+                     f"{(tg + tr + to) / ng / 1e3:.2f} us/call (bench.py roofline.avg_launch_ms brackets all three with "
+                     f"HIP events, which add ~2 us per side)")
     out = "\n".join(lines)
     print(out)
     if len(sys.argv) > 2:
