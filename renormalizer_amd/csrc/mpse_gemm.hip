@@ -4,20 +4,21 @@
 //   C[b](i,j) = alpha * sum_k opA(A[b](i,k)) opB(B[b](k,j)) + beta * C[b](i,j)
 //
 // Design for gfx950 (MI355X):
-//   * v_mfma_f64_16x16x4_f64 (64 cycles/SIMD): a wave owns a 32x32 output tile = 2x2
-//     MFMA tiles; complex x complex = 4 real MFMAs per tile pair on planar (re / im)
-//     operand fragments, complex x real = 2, real x real = 1.
-//   * a 256-thread workgroup (4 waves, 2x2) owns a 64x64 tile; K advances 16 at a
-//     time: global -> registers (issued one tile ahead, so HBM/L2 latency hides behind
-//     the 16..64 MFMAs of the current tile) -> LDS as planar (re / im) panels whose
-//     layout follows the operand's memory order: [i][k] rows of 17 doubles when k is the
-//     contiguous index, [k][i] rows of 80 doubles otherwise, so that both the staging
-//     ds_write_b64 (consecutive lanes -> consecutive addresses) and the fragment
-//     ds_read_b64 (16 rows x 2 k per half-wave on distinct bank pairs) are conflict free.
-//   * operands are read straight through two-level strides (no transpose copies: the
-//     reference's tensordot materialises a transposed copy before every ?gemm);
-//     complex128 elements are 16-byte loads; the thread->element map follows whichever
-//     logical index is contiguous in memory so wave loads coalesce.
+//   * v_mfma_f64_16x16x4_f64 (64 cycles/SIMD): a wave owns a 32x32 output tile = 2x2 MFMA tiles on planar
+//     (re / im) operand fragments.  complex x complex uses the 3M scheme (three real products per complex
+//     product: Ar Br, Ai Bi, (Ar + Ai)(Br + Bi)), complex x real = 2 MFMAs, real x real = 1.
+//   * a 256-thread workgroup (4 waves, 2x2) owns a 64x64 tile; K advances 16 at a time:
+//     global -> registers (issued one tile ahead through running pointers when both K maps are single level)
+//     -> LDS as planar (re / im) panels whose layout follows the operand's memory order ([i][k] rows of 17
+//     doubles when k is the contiguous index, [k][i] rows of 80 doubles otherwise, so that both the staging
+//     ds_write_b64 and the fragment ds_read_b64 are bank-conflict free) -> register fragments, double buffered
+//     per k-group of 4.
+//   * operands are read straight through two-level strides (no transpose copies: the reference's tensordot
+//     materialises a transposed copy before every ?gemm); complex128 elements are 16-byte loads; the
+//     thread->element map follows whichever logical index is contiguous in memory so wave loads coalesce.
+//   * split-K with a fixed-order reduction kernel when there are fewer output tiles than CUs.
+//   * optional structural-zero skipping: a scan kernel flags the 64 x 16 operand tiles that hold data, the K loop
+//     visits only K tiles with data on both sides (block-sparse tensors of the quantum-number-conserving sweeps).
 //   * accumulation order over k is fixed => bitwise reproducible results.
 #include "mpse_internal.h"
 
