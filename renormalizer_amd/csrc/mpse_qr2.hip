@@ -2,9 +2,11 @@
 //
 // All quantum-number blocks of a decomposition are factorised by the SAME launches (grid.y =
 // block), and the dependent chain of reflectors is cut into panels of NB columns:
-//   k_hh_panel       : ONE 1024-thread workgroup per block keeps the m x NB panel in registers
-//                      and factorises it (one block-wide reduction per column delivers the column
-//                      norm and all inner products with the remaining panel columns at once);
+//   k_hh_panel       : ONE workgroup (256 or 512 threads by block height) per block keeps the
+//                      m x NB panel in registers and factorises it: one block-wide reduction per
+//                      column delivers the column norm and all inner products with the remaining
+//                      panel columns at once (eight values through a halving DPP butterfly), the
+//                      dot and update phases are branch free;
 //   k_hh_apply_panel : one 256-thread workgroup per trailing column keeps that column in
 //                      registers and applies the NB new reflectors back to back (reflector tails
 //                      stream from L2);
