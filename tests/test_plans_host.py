@@ -206,3 +206,40 @@ def test_plans_unit_channels(emu, cplx):
     env = _rand(rng, (3, 2, 4), cplx)
     ref = orc.contract_one_site(env, ket, mo, "L", ms_conj=bra.conj())
     assert np.abs(emu_env(emu, env, ket, mo, "L", bra=bra, env_unit=1) - ref).max() < 1e-11 * np.abs(ref).max()
+
+
+def test_plans_random_shapes_property(emu):
+    """Randomised sweep over extents (ragged, 1-wide bonds, ancilla on/off, unit channels on/off, real / complex):
+    every plan the engine can generate must agree with the oracle's three tensordots."""
+    from hypothesis import given, settings, strategies as st
+
+    dims = st.integers(min_value=1, max_value=6)
+
+    @settings(max_examples=40, deadline=None)
+    @given(Dl=dims, Dr=dims, d0=st.integers(1, 4), d1=st.integers(1, 3), wl=st.integers(1, 4), wm=st.integers(1, 3),
+           wr=st.integers(1, 4), anc=st.booleans(), cplx=st.booleans(), unit=st.booleans(), seed=st.integers(0, 2 ** 16))
+    def check(Dl, Dr, d0, d1, wl, wm, wr, anc, cplx, unit, seed):
+        rng = np.random.default_rng(seed)
+        l, r = _rand(rng, (Dl, wl, Dl), cplx), _rand(rng, (Dr, wr, Dr), cplx)
+        ul = ur = 0
+        if unit:
+            ul, ur = int(rng.integers(0, wl)) + 1, int(rng.integers(0, wr)) + 1
+            l[:, ul - 1, :] = np.eye(Dl)
+            r[:, ur - 1, :] = np.eye(Dr)
+        w0 = _rand(rng, (wl, d0, d0, wr), False)
+        c = _rand(rng, (Dl, d0, 2, Dr) if anc else (Dl, d0, Dr), cplx)
+        ref = orc.hop_apply(l, r, [w0], c)
+        out = emu_heff(emu, l, r, [w0], c, l_unit=ul, r_unit=ur)
+        assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+        w0m, w1 = _rand(rng, (wl, d0, d0, wm), False), _rand(rng, (wm, d1, d1, wr), False)
+        c2 = _rand(rng, (Dl, d0, 2, d1, 2, Dr) if anc else (Dl, d0, d1, Dr), cplx)
+        ref = orc.hop_apply(l, r, [w0m, w1], c2)
+        out = emu_heff(emu, l, r, [w0m, w1], c2, l_unit=ul, r_unit=ur)
+        assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+        ket = _rand(rng, (Dl, d0, 2, Dr) if anc else (Dl, d0, Dr), cplx)
+        for dom, env, u in (("L", l, ul), ("R", r, ur)):
+            ref = orc.contract_one_site(env, ket, w0, dom)
+            out = emu_env(emu, env, ket, w0, dom, env_unit=u)
+            assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+    check()
