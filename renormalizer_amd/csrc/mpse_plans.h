@@ -51,7 +51,11 @@ inline void push(Plan& p, int a, int64_t ao, int dta, int conja, int b, int64_t 
 
 // Skipping a unit channel trades a (m x k x n) slice of a GEMM for a strided copy kernel: below ~1e8 multiply-adds
 // the slice costs less than the extra launch, so small centres keep the plain GEMM.
-inline bool unit_pays(int64_t m, int64_t k, int64_t n) { return m * k * n >= (int64_t(1) << 27); }
+inline int64_t& unit_threshold() {   // multiply-adds; a test hook lowers it so that small cases take the copy path
+  static int64_t v = int64_t(1) << 27;
+  return v;
+}
+inline bool unit_pays(int64_t m, int64_t k, int64_t n) { return m * k * n >= unit_threshold(); }
 // Scanning the operands of a GEMM for structurally zero tiles costs two small launches and one pass over the
 // operands; worth it from ~3e7 multiply-adds on.
 // The result says which operands to scan: bit 0 = A, bit 1 = B.

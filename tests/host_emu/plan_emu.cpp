@@ -101,3 +101,5 @@ extern "C" int emu_env_update(int dtype, int domain, const mpse_dims* dims, cons
   bufs[B_OUT] = out;
   return run(dtype, p, bufs);
 }
+
+extern "C" void emu_set_unit_threshold(long long macs) { unit_threshold() = macs; }

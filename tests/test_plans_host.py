@@ -23,6 +23,8 @@ def emu(tmp_path_factory):
     lib.emu_heff_apply.argtypes = [C.c_int, C.POINTER(E.mpse_heff), C.c_void_p, C.c_void_p]
     lib.emu_env_update.argtypes = [C.c_int, C.c_int, C.POINTER(E.mpse_dims), C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.emu_set_unit_threshold.argtypes = [C.c_longlong]
+    lib.emu_set_unit_threshold(0)        # the product takes the unit-channel copy path only for large slices
     return lib
 
 
