@@ -160,8 +160,12 @@ extern "C" int mpse_env_unit_channel(mpse_ctx* ctx, int dtype, const void* env, 
     hipLaunchKernelGGL((k_unit_deviation<false>), dim3((unsigned)D), dim3(256), 0, ctx->stream, (const double*)env,
                        (int)D, (int)w, dev);
   MPSE_HIP(ctx, hipGetLastError());
-  MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + 32, dev, size_t(w) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (w <= 1024) {
+    MPSE_TRY(publish_and_wait(ctx, reinterpret_cast<const double*>(dev), (int)w, 32));
+  } else {
+    MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + 32, dev, size_t(w) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   for (int64_t b = 0; b < w; ++b)
     if (ctx->pinned[32 + b] <= tol) {
       *unit_host = b + 1;

@@ -105,6 +105,8 @@ int mpse_ctx_create(int device, mpse_ctx** out) {
     delete ctx;
     return MPSE_ERR_HIP;
   }
+  if (hipHostGetDevicePointer((void**)&ctx->pinned_dev, ctx->pinned, 0) != hipSuccess) ctx->pinned_dev = nullptr;
+  ctx->pinned[4095] = 0.0;      // sequence slot of publish_and_wait
   ctx->stage_size = size_t(8) << 20;
   *out = ctx;
   return MPSE_OK;
@@ -255,3 +257,39 @@ int mpse_memset_zero(mpse_ctx* ctx, void* dst, size_t bytes) {
 }
 
 }  // extern "C"
+
+namespace {
+__global__ void k_publish(const double* __restrict__ src, double* dst, int count, volatile double* seq_slot, double seq) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *seq_slot = seq;
+    __threadfence_system();
+  }
+}
+}  // namespace
+
+int publish_and_wait(mpse_ctx* ctx, const double* dsrc, int count, int slot) {
+  if (count < 0 || count > 1024 || slot < 0 || slot + count > 4000) return mpse_fail(ctx, MPSE_ERR_ARG, "publish: range");
+  if (!ctx->pinned_dev) {  // no mapped view of the pinned buffer: plain copy + synchronise
+    MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + slot, dsrc, size_t(count) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MPSE_OK;
+  }
+  const double seq = double(++ctx->publish_seq);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, dsrc, ctx->pinned_dev + slot, count,
+                     (volatile double*)(ctx->pinned_dev + 4095), seq);
+  MPSE_HIP(ctx, hipGetLastError());
+  volatile double* flag = ctx->pinned + 4095;
+  for (long long spins = 0; *flag != seq; ++spins) {
+    if (spins > 2000000000LL || ((spins & 0xfffff) == 0xfffff && hipStreamQuery(ctx->stream) == hipSuccess && *flag != seq)) {
+      // the kernel is gone but the number never arrived: fall back to the ordinary path (also surfaces errors)
+      MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      MPSE_HIP(ctx, hipMemcpy(ctx->pinned + slot, dsrc, size_t(count) * sizeof(double), hipMemcpyDeviceToHost));
+      return MPSE_OK;
+    }
+  }
+  __sync_synchronize();
+  return MPSE_OK;
+}

@@ -317,8 +317,7 @@ int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, 
           hipLaunchKernelGGL((k_jacobi_step<CPLX>), dim3(N / 2), dim3(RED_THREADS), 0, ctx->stream, ws, vm, mm, nn, N,
                              step, tol, null2, CNT.as<int>());
         MPSE_HIP(ctx, hipGetLastError());
-        MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + 8, CNT.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MPSE_TRY(publish_and_wait(ctx, CNT.as<double>(), 1, 8));
         converged = (*reinterpret_cast<int*>(ctx->pinned + 8) == 0);
       }
       if (!converged) return mpse_fail(ctx, MPSE_ERR_NOCONV, "block_svd: Jacobi did not converge (block %d, %dx%d)", b, m, n);

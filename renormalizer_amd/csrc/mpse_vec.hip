@@ -306,8 +306,7 @@ void expm_coefs(int m, const std::vector<double>& alpha, const std::vector<doubl
 }
 
 int read_scalar2(mpse_ctx* ctx, const double* dsrc, double* a, double* b) {
-  MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned, dsrc, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MPSE_TRY(publish_and_wait(ctx, dsrc, 2, 0));
   if (ctx->prof_pending.size() > 2048) prof_drain(ctx);
   if (a) *a = ctx->pinned[0];
   if (b) *b = ctx->pinned[1];
@@ -483,9 +482,7 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
   // bring the scalars of iterations [alpha.size(), upto] to the host (one copy, one sync)
   auto fetch = [&](int upto) -> int {
     const int cnt = 4 + 4 * (upto + 1);
-    MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + 16, scal, size_t(cnt) * sizeof(double), hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MPSE_TRY(publish_and_wait(ctx, scal, cnt, 16));
     if (ctx->prof_pending.size() > 2048) prof_drain(ctx);
     const double* p = ctx->pinned + 16;
     nrmv = sqrt(p[0]);
@@ -509,8 +506,7 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
                          V.as<double>(), (long long)n, m, c, (const double*)prev, rtol, atol, dflag);
     MPSE_HIP(ctx, hipGetLastError());
     if (prev && flag_out) {
-      MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + 8, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-      MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      MPSE_TRY(publish_and_wait(ctx, reinterpret_cast<const double*>(dflag), 1, 8));
       *flag_out = *reinterpret_cast<int*>(ctx->pinned + 8);
     }
     return MPSE_OK;
