@@ -561,6 +561,12 @@ def gen_obs():
     out["bond_entropy"] = np.asarray(mps.calc_entropy("bond"))
     s1 = mps.calc_entropy("1site")
     out["site_entropy"] = np.array([s1[k] for k in range(len(mps))])
+    rdm2 = mps.calc_2site_rdm()
+    for (i, j) in ((0, 1), (0, 4), (2, 3), (3, 8), (7, 8)):
+        out[f"rdm2_{i}_{j}"] = np.asarray(rdm2[(i, j)])
+    s2 = mps.calc_entropy("2site")
+    out["pair_entropy"] = np.array([[i, j, s2[(i, j)]] for (i, j) in sorted(s2)])
+    out["mutual_entropy"] = np.asarray(mps.calc_entropy("mutual"))
     sv = mps.calc_bond_singular_values()
     width = max(len(x) for x in sv)
     out["bond_sv"] = np.array([np.pad(np.asarray(x), (0, width - len(x))) for x in sv])

@@ -83,3 +83,21 @@ def test_dense_round_trip():
     if hd is not None:
         v = dense.ravel()
         assert abs(v.conj() @ hd.reshape(32, 32) @ v - ref.expectation(h)) < 1e-12
+
+
+def test_two_site_rdm_and_mutual_entropy(state):
+    """mps/mps.py:1600-1655, 1734-1757 and mps/tests/test_mps.py:74-88"""
+    z, mps = state
+    rdm2 = mps.calc_2site_rdm()
+    n = len(mps)
+    assert len(rdm2) == n * (n - 1) // 2
+    for (i, j) in ((0, 1), (0, 4), (2, 3), (3, 8), (7, 8)):
+        ref = z[f"rdm2_{i}_{j}"]
+        assert rdm2[(i, j)].shape == ref.shape
+        assert np.abs(rdm2[(i, j)] - ref).max() < 1e-12
+    s2 = mps.calc_entropy("2site")
+    for i, j, v in z["pair_entropy"]:
+        assert abs(s2[(int(i), int(j))] - v) < 1e-9
+    assert np.abs(mps.calc_entropy("mutual") - z["mutual_entropy"]).max() < 1e-9
+    sb = mps.calc_entropy("bond")
+    assert abs(sb[1] - s2[(0, 1)]) < 1e-9 and abs(sb[-2] - s2[(n - 2, n - 1)]) < 1e-9
