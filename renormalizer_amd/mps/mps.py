@@ -769,6 +769,35 @@ class Mps:
     def is_right_canonical(self):
         return self.qnidx == 0
 
+    def _check_ortho(self, i, left: bool, rtol=None, atol=None) -> bool:
+        """A_i^+ A_i = 1 (left) or A_i A_i^+ = 1 (right) within the backend tolerances (mps/matrix.py:121-150); the
+        Gram matrix is formed on the device, only D x D numbers come back."""
+        from .backend import backend
+        rtol = backend.canonical_rtol if rtol is None else rtol
+        atol = backend.canonical_atol if atol is None else atol
+        eng = get_engine()
+        a = self[i]
+        m = a.reshape(-1, a.shape[-1]) if left else a.reshape(a.shape[0], -1)
+        g = (eng.matmul(m, m, trans_a=True, conj_a=True) if left else eng.matmul(m, m, trans_b=True, conj_b=True)).to_host()
+        return bool(np.allclose(g, np.eye(g.shape[0]), rtol=rtol, atol=atol))
+
+    def check_left_canonical(self, rtol: float = None, atol: float = None) -> bool:
+        """mps/mp.py:174-181"""
+        return all(self._check_ortho(i, True, rtol, atol) for i in range(len(self) - 1))
+
+    def check_right_canonical(self, rtol: float = None, atol: float = None) -> bool:
+        """mps/mp.py:183-190"""
+        return all(self._check_ortho(i, False, rtol, atol) for i in range(1, len(self)))
+
+    def angle(self, other) -> float:
+        """|<self|other>| (mps/mp.py:981-982)"""
+        return abs(self.dot(other, self_is_conj=False))
+
+    @property
+    def total_bytes(self) -> int:
+        """device memory held by the site tensors (mps/mp.py:1116-1117)"""
+        return int(sum(t.nbytes for t in self._mp))
+
     def ensure_left_canonical(self):
         """mps/mp.py:206-216.  The orthogonality check of the reference is replaced by always re-canonicalising
         (one QR sweep) - cheaper than downloading the sites to test them."""

@@ -101,3 +101,15 @@ def test_two_site_rdm_and_mutual_entropy(state):
     assert np.abs(mps.calc_entropy("mutual") - z["mutual_entropy"]).max() < 1e-9
     sb = mps.calc_entropy("bond")
     assert abs(sb[1] - s2[(0, 1)]) < 1e-9 and abs(sb[-2] - s2[(n - 2, n - 1)]) < 1e-9
+
+
+def test_canonical_checks_angle_and_size(state):
+    """mps/tests/test_mp.py: canonical-form predicates; angle; memory accounting"""
+    z, mps = state
+    m = mps.copy()
+    m.ensure_left_canonical()
+    assert m.check_left_canonical() and not m.check_right_canonical()
+    m.ensure_right_canonical()
+    assert m.check_right_canonical() and not m.check_left_canonical()
+    assert abs(m.angle(mps) - 1.0) < 1e-12
+    assert m.total_bytes == sum(int(np.prod(t.shape)) * 16 for t in m)
