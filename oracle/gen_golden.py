@@ -580,3 +580,63 @@ if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("mpo",)):
     gen_mpo()
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("ps2",)):
     gen_tdvp_ps2()
+
+
+def gen_pc_rk():
+    """Propagate & compress with Runge-Kutta propagators (mps.py:664-792): classical RK4 with a fixed step
+    (`prop_and_compress_tdrk4`), the general tableau driver with fixed (Kutta_RK3) and adaptive (RKF45 with its
+    embedded 4th-order error estimate) steps, and RK4 under a time-dependent Hamiltonian H(t) = (1 + 0.2 t / dt) H."""
+    from renormalizer.model import Phonon, Mol, HolsteinModel, Op
+    from renormalizer.mps import Mps, Mpo
+    from renormalizer.utils import Quantity, EvolveConfig, EvolveMethod, CompressConfig, CompressCriteria
+    nmol, pdim = 4, 4
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), pdim)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
+    gs = Mps.ground_state(model, max_entangled=False)
+    init = Mpo.onsite(model, r"a^\dagger", dof_set={nmol // 2}).apply(gs)
+    e0 = Quantity(init.expectation(Mpo(model)))
+    mpo = Mpo(model, offset=e0)
+    occ = [Mpo(model, Op(r"a^\dagger a", dof)) for dof in model.e_dofs]
+    out = {}
+    _dump_mpo(out, "mpo_", mpo)
+    for j, o in enumerate(occ):
+        _dump_mpo(out, f"obs{j}_", o)
+    out["nobs"] = np.array(len(occ))
+    for i, b in enumerate(model.basis):
+        out[f"sigmaqn_{i}"] = np.asarray(b.sigmaqn).reshape(b.nbas, -1).astype(np.int64)
+    _dump_mps(out, "init_", init)
+    dt = 15.0
+    out["dt"] = np.array(dt)
+
+    def run(tag, cfg, ham, nsteps=3):
+        mps = init.copy()
+        mps.evolve_config = cfg
+        mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=12)
+        vals, guess, norms, bdims = [], [], [], []
+        for _ in range(nsteps):
+            mps = mps.evolve(ham, dt)
+            vals.append([mps.expectation(o) for o in occ])
+            guess.append(mps.evolve_config.guess_dt)
+            norms.append(mps.mp_norm)
+            bdims.append(list(mps.bond_dims))
+        out[tag + "_obs"] = np.array(vals, dtype=complex).real
+        out[tag + "_guess_dt"] = np.array(guess, dtype=float)
+        out[tag + "_norms"] = np.array(norms)
+        out[tag + "_bond_dims"] = np.array(bdims)
+        out[tag + "_energy"] = np.array(mps.expectation(mpo))
+        print(tag, out[tag + "_obs"][-1], guess, bdims[-1])
+
+    run("rk4", EvolveConfig(EvolveMethod.prop_and_compress_tdrk4), mpo)
+    run("rk3", EvolveConfig(EvolveMethod.prop_and_compress_tdrk, rk_solver="Kutta_RK3"), mpo)
+    run("ck45", EvolveConfig(EvolveMethod.prop_and_compress_tdrk, rk_solver="Cash-Karp45", adaptive=True, guess_dt=6.0),
+        mpo)
+
+    def mpo_t(t, *args, **kwargs):
+        return mpo.scale(1.0 + 0.2 * t / dt)
+
+    run("rk4_td", EvolveConfig(EvolveMethod.prop_and_compress_tdrk4), mpo_t)
+    np.savez_compressed(os.path.join(GOLD, "pc_rk_holstein_small.npz"), **out)
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("pc_rk",)):
+    gen_pc_rk()

@@ -1081,6 +1081,10 @@ class Mps:
                 new_mps = step(self, mpo, evolve_dt)
         elif method is EvolveMethod.prop_and_compress:
             new_mps = self._evolve_prop_and_compress(mpo, evolve_dt)
+        elif method is EvolveMethod.prop_and_compress_tdrk4:
+            new_mps = self._evolve_prop_and_compress_tdrk4(mpo, evolve_dt)
+        elif method is EvolveMethod.prop_and_compress_tdrk:
+            new_mps = self._evolve_prop_and_compress_tdrk(mpo, evolve_dt)
         else:
             raise NotImplementedError(f"{method} is not implemented in the MI355X engine yet (TDVP-PS is)")
         if normalize:
@@ -1257,6 +1261,90 @@ def _evolve_prop_and_compress(self, mpo, evolve_dt) -> "Mps":
 
 
 Mps._evolve_prop_and_compress = _evolve_prop_and_compress
+
+
+def _as_mpo_of_t(mpo):
+    """A fixed MPO or a callable t -> MPO (t measured from the start of the step; the stage state is offered as the
+    keyword ``mps``), mps/mps.py:669-676"""
+    if callable(mpo):
+        return mpo
+    if not hasattr(mpo, "contract"):
+        raise TypeError(f"unsupported mpo type: {mpo}")
+    return lambda t, *args, **kwargs: mpo
+
+
+def _evolve_prop_and_compress_tdrk4(self, mpo, evolve_dt) -> "Mps":
+    """Classical fourth-order Runge-Kutta step of i dpsi/dt = H(t) psi with compression after every stage
+    (mps/mps.py:664-699): k_i = -i H(t_i) y_i by contract, stage states y + a k dt canonicalised and compressed,
+    and the final combination y + dt (k1 + 2 k2 + 2 k3 + k4) / 6 as one compressed sum."""
+    mpo_t = _as_mpo_of_t(mpo)
+
+    def stage(k, weight):
+        y = self.add(k.scale(weight * evolve_dt))
+        y.canonicalise().compress()
+        return y
+
+    k1 = mpo_t(0).contract(self).scale(-1j)
+    k2 = mpo_t(0.5 * evolve_dt).contract(stage(k1, 0.5)).scale(-1j)
+    k3 = mpo_t(0.5 * evolve_dt).contract(stage(k2, 0.5)).scale(-1j)
+    k4 = mpo_t(evolve_dt).contract(stage(k3, 1.0)).scale(-1j)
+    return compressed_sum([self, k1.scale(1 / 6 * evolve_dt), k2.scale(2 / 6 * evolve_dt), k3.scale(2 / 6 * evolve_dt),
+                           k4.scale(1 / 6 * evolve_dt)])
+
+
+def _evolve_prop_and_compress_tdrk(self, mpo, evolve_dt) -> "Mps":
+    """Explicit Runge-Kutta step with the tableau of ``evolve_config.rk_config`` for fixed or time-dependent H
+    (mps/mps.py:701-792).  Adaptive mode needs an embedded pair: the difference of the two weight rows applied to
+    the stage derivatives is the error estimate, p = (rtol / relative error)^(1/order) clipped to [0.1, 2] scales the
+    next sub-step and p < 0.5 repeats the current one."""
+    mpo_t = _as_mpo_of_t(mpo)
+    config = self.evolve_config
+    rk = config.rk_config
+    a, b, c = rk.tableau
+
+    def sub_step(y, tau, t0):
+        ks = []
+        for s in range(rk.stage):
+            ys = compressed_sum([y] + [ks[i].scale(a[s, i] * tau) for i in range(s) if a[s, i] != 0], batchsize=6)
+            ks.append(mpo_t(c[s] * tau + t0, mps=ys).contract(ys).scale(-1j))
+        new = compressed_sum([y] + [ks[s].scale(b[0, s] * tau) for s in range(rk.stage) if b[0, s] != 0], batchsize=6)
+        if not config.adaptive:
+            assert len(rk.order) == 1
+            return new, 0.0
+        assert len(rk.order) == 2 and rk.order[0] - rk.order[1] == 1
+        err = None
+        for s in range(rk.stage):
+            if np.allclose(b[0, s], b[1, s]):
+                continue
+            term = ks[s].scale((b[0, s] - b[1, s]) * tau)
+            err = term if err is None else err.add(term)
+        return new, err.mp_norm / new.mp_norm
+
+    config.check_valid_dt(evolve_dt)
+    if not config.adaptive:
+        return sub_step(self, evolve_dt, 0)[0]
+    p_restart, p_min, p_max = 0.5, 0.1, 2.0
+    evolved, new = 0, self
+    while True:
+        cfg = new.evolve_config
+        dt = _min_abs(cfg.guess_dt, evolve_dt - evolved)
+        cand, error = sub_step(new, dt, evolved)
+        p = (cand.evolve_config.adaptive_rtol / (error + 1e-30)) ** (1 / rk.order[0])
+        if p < p_restart:
+            # mps/mps.py:765-770: the rejected candidate replaces the state all the same; the next trial starts from it
+            new = cand
+            new.evolve_config.guess_dt = dt * max(p_min, p)
+            continue
+        new = cand
+        if np.allclose(dt + evolved, evolve_dt):
+            new.evolve_config.guess_dt = _min_abs(dt * p, new.evolve_config.guess_dt)
+            return new
+        new.evolve_config.guess_dt *= min(p, p_max)
+        evolved += dt
+
+
+Mps._evolve_prop_and_compress_tdrk4 = _evolve_prop_and_compress_tdrk4
+Mps._evolve_prop_and_compress_tdrk = _evolve_prop_and_compress_tdrk
 
 
 def _min_abs(t1, t2):

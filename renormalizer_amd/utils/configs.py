@@ -7,6 +7,8 @@ from enum import Enum
 
 import numpy as np
 
+from .rk import RungeKutta, TaylorExpansion
+
 
 class CompressCriteria(Enum):
     threshold = "threshold"
@@ -113,14 +115,18 @@ class EvolveMethod(Enum):
 
 class EvolveConfig:
     def __init__(self, method: EvolveMethod = EvolveMethod.prop_and_compress, adaptive=False, guess_dt=1e-1,
-                 adaptive_rtol=5e-4, taylor_order: int = None, reg_epsilon=1e-10, ivp_rtol=1e-5, ivp_atol=1e-8,
-                 ivp_solver="krylov", force_ovlp=True):
+                 adaptive_rtol=5e-4, taylor_order: int = None, rk_solver="C_RK4", reg_epsilon=1e-10, ivp_rtol=1e-5,
+                 ivp_atol=1e-8, ivp_solver="krylov", force_ovlp=True):
+        if isinstance(method, str):
+            method = EvolveMethod[method]
         self.method = method
+        self.rk_config = RungeKutta(rk_solver)
         self.adaptive = adaptive
         self.guess_dt = guess_dt
         self.adaptive_rtol = adaptive_rtol
         # utils/configs.py:364-368: one order more when the last Taylor term serves as the error estimate
         self.taylor_order = (5 if adaptive else 4) if taylor_order is None else taylor_order
+        self.taylor_config = TaylorExpansion(self.taylor_order)
         self.reg_epsilon = reg_epsilon
         self.ivp_rtol = ivp_rtol
         self.ivp_atol = ivp_atol

@@ -41,7 +41,7 @@ wrap(L, "contract_one_site", "env update")
 wrap(M, "hop_expr", "hop_expr setup")
 
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-model, mpo, mps = bench.build_workload(25, 16, D, 1234, "random")
+model, mpo, mps = bench.build_workload(25, 16, D, 1234, sys.argv[2] if len(sys.argv) > 2 else "random")
 mps = mps.evolve(mpo, 10.0)
 acc.clear(); cnt.clear()
 eng.sync()
