@@ -640,3 +640,49 @@ def gen_pc_rk():
 
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("pc_rk",)):
     gen_pc_rk()
+
+
+def gen_transport():
+    """`ChargeDiffusionDynamics` (transport/dynamics.py) on the model of transport/tests/test_dynamics.py::test_evolve
+    (5 molecules, J = 0.8 eV, one 1400 cm^-1 mode, 4 levels): relaxed initial state + default P&C, Franck-Condon
+    initial state + TDVP-PS with the reduced density matrix outputs, and a 3-molecule chain at 300 K (thermal
+    vibrational state from the exact local propagator, then P&C of the density operator)."""
+    from renormalizer.model import Phonon, Mol, HolsteinModel
+    from renormalizer.transport import ChargeDiffusionDynamics, InitElectron
+    from renormalizer.utils import Quantity, EvolveConfig, EvolveMethod, CompressConfig, CompressCriteria
+    out = {}
+
+    def model_of(nmol, pdim=4):
+        ph = Phonon.simple_phonon(Quantity(1400, "cm^{-1}"), Quantity(17, "a.u."), pdim)
+        return HolsteinModel([Mol(Quantity(3.87e-3, "a.u."), [ph])] * nmol, Quantity(0.8, "eV"))
+
+    def record(tag, ct):
+        out[tag + "_times"] = np.array(ct.evolve_times, dtype=float)
+        out[tag + "_energies"] = np.array(ct.energies, dtype=complex).real
+        out[tag + "_r_square"] = np.array(ct.r_square_array)
+        out[tag + "_e_occ"] = np.array(ct.e_occupations_array)
+        out[tag + "_ph_occ"] = np.array(ct.ph_occupations_array)
+        out[tag + "_bond_entropy"] = np.array(ct.bond_vn_entropy_array)
+        if ct.reduced_density_matrices:
+            out[tag + "_rdm"] = np.array(ct.reduced_density_matrices)
+            out[tag + "_k_occ"] = np.array(ct.k_occupations_array)
+            out[tag + "_eph_entropy"] = np.array(ct.eph_vn_entropy_array, dtype=complex).real
+            out[tag + "_coherent_length"] = np.array(ct.coherent_length_array)
+        print(tag, out[tag + "_e_occ"][-1], out[tag + "_r_square"][-1])
+
+    ct = ChargeDiffusionDynamics(model_of(5), stop_at_edge=False)
+    ct.evolve(2, 12)
+    record("pc_relaxed", ct)
+    ct = ChargeDiffusionDynamics(model_of(5), compress_config=CompressConfig(CompressCriteria.fixed, max_bonddim=16),
+                                 evolve_config=EvolveConfig(EvolveMethod.tdvp_ps), stop_at_edge=False,
+                                 init_electron=InitElectron.fc, rdm=True)
+    ct.evolve(2, 12)
+    record("tdvp_fc", ct)
+    ct = ChargeDiffusionDynamics(model_of(3), temperature=Quantity(300, "K"), stop_at_edge=False)
+    ct.evolve(2, 8)
+    record("thermal", ct)
+    np.savez_compressed(os.path.join(GOLD, "transport_dynamics.npz"), **out)
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("transport",)):
+    gen_transport()

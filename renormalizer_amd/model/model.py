@@ -83,6 +83,10 @@ class Model:
     def copy(self):
         return Model(list(self.basis), list(self.ham_terms), self.dipole, self.output_ordering)
 
+    def to_dict(self):
+        """Plain-type description for result dumps (model/model.py:213-228)"""
+        return {"Hamiltonian": [op.to_tuple() for op in self.ham_terms], "dipole": self.dipole}
+
 
 def construct_j_matrix(mol_num, j_constant, periodic=False):
     j = j_constant.as_au() if isinstance(j_constant, Quantity) else float(j_constant)
@@ -143,6 +147,24 @@ class HolsteinModel(Model):
     @property
     def gs_zpe(self):
         return sum(m.gs_zpe for m in self.mol_list)
+
+    def switch_scheme(self, scheme: int) -> "HolsteinModel":
+        """the same molecules and couplings laid out in another site ordering (model/model.py:349-363)"""
+        return HolsteinModel(self.mol_list, self.j_matrix, scheme)
+
+    def copy(self):
+        return HolsteinModel(self.mol_list, self.j_matrix, self.scheme)
+
+    @property
+    def j_constant(self):
+        """the single non-zero electronic coupling; ValueError when the couplings differ (model/model.py:372-391)"""
+        vals = set(np.asarray(self.j_matrix).ravel().tolist()) - {0.0}
+        if len(vals) != 1:
+            raise ValueError("J is not constant")
+        return vals.pop()
+
+    def __iter__(self):
+        return iter(self.mol_list)
 
     def __getitem__(self, i):
         return self.mol_list[i]

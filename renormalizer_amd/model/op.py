@@ -81,6 +81,10 @@ class Op:
     def is_identity(self):
         return all(s == "I" for s in self.split_symbol)
 
+    def to_tuple(self):
+        """(symbol, dofs, factor, quantum numbers) as nested tuples: hashable, used by result dumps (op.py:321-332)"""
+        return self.symbol, tuple(self.dofs), self.factor, tuple(tuple(np.atleast_1d(q).tolist()) for q in self.qn_list)
+
     def split_by_dof(self):
         """[(dof, Op restricted to that dof)] in order of first appearance; factor on the first."""
         groups = {}

@@ -64,6 +64,18 @@ class Phonon:
     def coupling_constant(self):
         return float(np.sqrt(self.reorganization_energy.as_au() / self.omega[0]))
 
+    @property
+    def term10(self):
+        """coefficient of (b^+ + b) in the excited-state potential (model/phonon.py:144-146)"""
+        return self.omega[1] ** 2 / np.sqrt(2.0 * self.omega[0]) * (-self.dis[1])
+
+    @property
+    def pbond(self):
+        return self.n_phys_dim
+
+    def to_dict(self):
+        return {"omega": self.omega, "displacement": self.dis, "num physical dimension": self.n_phys_dim}
+
 
 class Mol:
     def __init__(self, elocalex, ph_list, dipole=None):
@@ -81,3 +93,7 @@ class Mol:
     @property
     def reorganization_energy(self):
         return self.e0
+
+    def to_dict(self):
+        return {"elocalex": self.elocalex, "dipole": self.dipole, "reorganization energy in a.u.": self.e0,
+                "phonon list": [ph.to_dict() for ph in self.ph_list]}

@@ -302,6 +302,31 @@ class Mpo:
         return cls(model, [Op.identity(model.basis[0].dofs[0], model.qn_size)])
 
     @classmethod
+    def exact_propagator(cls, model, x, space="GS", shift=0.0):
+        """exp(x (H + shift)) for the electron-free ("GS") or the single-site excited ("EX") vibrational Hamiltonian of
+        a Holstein model, which is a sum of one-site terms, so the operator is a bond-dimension-1 product of local
+        exponentials (mps/mpo.py:33-101).  GS: exp(x omega n) on every mode; EX: exp(x (omega b^+ b + c (b^+ + b)))
+        with c = Phonon.term10.  The electronic sites carry the identity."""
+        assert space in ("GS", "EX")
+        arrays = []
+        for b in model.basis:
+            if not b.is_phonon:
+                arrays.append(np.eye(b.nbas).reshape(1, b.nbas, b.nbas, 1))
+                continue
+            imol, iph = b.dofs[0]
+            ph = model[imol].ph_list[iph]
+            n = ph.n_phys_dim
+            if space == "GS":
+                local = np.diag(np.exp(x * ph.omega[0] * np.arange(n)))
+            else:
+                off = ph.term10 * np.sqrt(np.arange(1, n))
+                h = np.diag(ph.omega[0] * np.arange(n, dtype=float)) + np.diag(off, 1) + np.diag(off, -1)
+                w, v = np.linalg.eigh(h)
+                local = (v * np.exp(x * w)) @ v.T
+            arrays.append(local.reshape(1, n, n, 1))
+        return cls.from_arrays(model, arrays).scale(np.exp(shift * x))
+
+    @classmethod
     def from_arrays(cls, model, arrays):
         """Operator from raw site tensors.  The bond quantum numbers are unknown and set to zero: fine wherever the
         operator is only contracted into environments (TDVP, DMRG, expectation values); ``apply / contract`` on a

@@ -198,7 +198,8 @@ class Mps:
         return self._mp[i]
 
     def __setitem__(self, i, t):
-        assert isinstance(t, DeviceTensor)
+        if not isinstance(t, DeviceTensor):
+            t = get_engine().asdevice(np.ascontiguousarray(t))      # host arrays are uploaded (mps/mp.py:1220-1236)
         self._mp[i] = t
 
     def __iter__(self):

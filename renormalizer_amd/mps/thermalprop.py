@@ -19,8 +19,6 @@ logger = logging.getLogger("renormalizer_amd")
 class ThermalProp(TdMpsJob):
     def __init__(self, init_mpdm: MpDm, h_mpo_model=None, exact=False, space="GS", evolve_config: EvolveConfig = None,
                  dump_mps=None, dump_dir=None, job_name=None, properties=None, auto_expand=True):
-        if exact:
-            raise NotImplementedError("exact propagation of a local Hamiltonian (Mpo.exact_propagator) is not implemented")
         if properties is not None:
             raise NotImplementedError("the Property interface is not implemented")
         self.init_mpdm = init_mpdm.canonicalise()
@@ -41,11 +39,22 @@ class ThermalProp(TdMpsJob):
 
     def process_mps(self, mps):
         self.energies.append(mps.expectation(self.h_mpo))
+        if self.exact:
+            return                                  # thermalprop.py:76-78: energies only
         self._e_occupations_array.append(np.asarray(mps.e_occupations))
         self._ph_occupations_array.append(np.asarray(mps.ph_occupations))
         self._vn_entropy_array.append(mps.calc_bond_entropy())
 
+    def evolve_exact(self, old_mpdm, evolve_dt):
+        """one application of the bond-dimension-1 propagator of a local Hamiltonian (thermalprop.py:95-103)"""
+        prop = Mpo.exact_propagator(old_mpdm.model, np.imag(evolve_dt), space=self.space, shift=-self.energies[-1])
+        new_mpdm = prop.apply(old_mpdm, canonicalise=True)
+        new_mpdm.normalize("mps_and_coeff")
+        return new_mpdm
+
     def evolve_single_step(self, evolve_dt):
+        if self.exact:
+            return self.evolve_exact(self.latest_mps, evolve_dt)
         h_mpo = Mpo(self.h_mpo.model, offset=Quantity(self.energies[-1]))
         return self.latest_mps.evolve(h_mpo, evolve_dt)
 
@@ -74,3 +83,11 @@ class ThermalProp(TdMpsJob):
                 "electron occupations array": self.e_occupations_array,
                 "phonon occupations array": self.ph_occupations_array,
                 "vn entropy array": np.array([np.asarray(v, dtype=float) for v in self._vn_entropy_array])}
+
+
+def load_thermal_state(model, path: str):
+    """A thermal state dumped by ``MpDm.dump``; None when the file does not exist (thermalprop.py:151-168)"""
+    try:
+        return MpDm.load(model, path)
+    except FileNotFoundError:
+        return None
