@@ -6,6 +6,7 @@ import numpy as np
 
 from ..utils import Quantity
 from .basis import BasisSet, BasisSHO, BasisSimpleElectron, BasisHalfSpin, BasisMultiElectronVac
+from .phonon import Phonon, Mol
 from .op import Op, OpSum
 
 
@@ -189,3 +190,23 @@ class SpinBosonModel(Model):
             ham += [Op("p^2", k, 0.5), Op("x^2", k, 0.5 * ph.omega[0] ** 2)]
             ham.append(Op("sigma_z", "spin") * Op("x", k) * (-ph.omega[1] ** 2 * ph.dis[1]))
         super().__init__(basis, ham, dipole={"spin": dipole or 0})
+
+
+def load_from_dict(param, scheme, lam: bool):
+    """(HolsteinModel, temperature) from the parameter dictionary of the transport examples (keys "mol num",
+    "j constant", "ph modes", "temperature", each quantity as [value, unit]); the phonon level counts are chosen by
+    ``Phonon.simplest_phonon`` at that temperature (model/model.py:523-533)."""
+    temperature = Quantity(*param["temperature"])
+    ph_list = [Phonon.simplest_phonon(Quantity(*omega), Quantity(*displacement), temperature=temperature, lam=lam)
+               for omega, displacement in param["ph modes"]]
+    model = HolsteinModel([Mol(Quantity(0), ph_list)] * param["mol num"], Quantity(*param["j constant"]), scheme)
+    return model, temperature
+
+
+def heisenberg_ops(nspin):
+    """terms of the spin-1/2 Heisenberg chain sum_i S_i . S_{i+1} in Pauli / ladder operators (model/model.py:536-543)"""
+    terms = []
+    for i in range(nspin - 1):
+        terms += [Op("sigma_z sigma_z", [i, i + 1], 1.0 / 4), Op("sigma_+ sigma_-", [i, i + 1], 1.0 / 2),
+                  Op("sigma_- sigma_+", [i, i + 1], 1.0 / 2)]
+    return terms
