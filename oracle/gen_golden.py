@@ -686,3 +686,44 @@ def gen_transport():
 
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("transport",)):
     gen_transport()
+
+
+def gen_spectral():
+    """`SpectralFunctionZT` on the thermofield Holstein ring of transport/tests/test_spectral_function.py (3 cells,
+    T = 0.2, omega = g = 1, 4 levels; the reference test compares with qutip, which is not installed here): G_ij(t)
+    and populations over five TDVP-PS steps, plus a T = 0 ring with P&C."""
+    from renormalizer.model import Op, TI1DModel
+    from renormalizer.model.basis import BasisSimpleElectron, BasisSHO
+    from renormalizer.transport.spectral_function import SpectralFunctionZT
+    from renormalizer.utils import Quantity, CompressConfig, EvolveMethod, EvolveConfig, CompressCriteria
+    out = {}
+    omega, g, nlevels, nsites = 1, 1, 4, 3
+    theta = np.arctanh(np.exp(-Quantity(0.2).to_beta() * omega / 2))
+    basis = [BasisSimpleElectron("e"), BasisSHO("ph0", omega, nlevels), BasisSHO("ph1", omega, nlevels)]
+    local = [Op(r"a^\dagger a", "e", g ** 2 * omega), Op(r"b^\dagger b", "ph0", omega), Op(r"b^\dagger b", "ph1", -omega),
+             - g * np.cosh(theta) * omega * Op(r"a^\dagger a", "e") * Op(r"b^\dagger + b", "ph0"),
+             - g * np.sinh(theta) * omega * Op(r"a^\dagger a", "e") * Op(r"b^\dagger + b", "ph1")]
+    hop = [Op(r"a^\dagger a", [(0, "e"), (1, "e")]), Op(r"a^\dagger a", [(1, "e"), (0, "e")])]
+    sf = SpectralFunctionZT(TI1DModel(basis, local, hop, nsites),
+                            compress_config=CompressConfig(CompressCriteria.fixed, max_bonddim=24),
+                            evolve_config=EvolveConfig(EvolveMethod.tdvp_ps))
+    sf.evolve(nsteps=5, evolve_time=2.5)
+    out["tf_theta"] = np.array(theta)
+    out["tf_times"] = np.array(sf.evolve_times, dtype=float)
+    out["tf_G"] = sf.G_array
+    out["tf_e_occ"] = np.array(sf.e_occupations_array)
+    out["tf_Gk"] = sf.get_dump_dict()["Gk array"]
+    basis = [BasisSimpleElectron("e"), BasisSHO("ph0", omega, nlevels)]
+    local = [Op(r"a^\dagger a", "e", g ** 2 * omega), Op(r"b^\dagger b", "ph0", omega),
+             - g * omega * Op(r"a^\dagger a", "e") * Op(r"b^\dagger + b", "ph0")]
+    sf = SpectralFunctionZT(TI1DModel(basis, local, hop, 4))
+    sf.evolve(nsteps=4, evolve_time=1.0)
+    out["zt_times"] = np.array(sf.evolve_times, dtype=float)
+    out["zt_G"] = sf.G_array
+    out["zt_e_occ"] = np.array(sf.e_occupations_array)
+    print(out["tf_G"][-1], out["zt_G"][-1])
+    np.savez_compressed(os.path.join(GOLD, "spectral_function.npz"), **out)
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("spectral",)):
+    gen_spectral()

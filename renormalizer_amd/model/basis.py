@@ -44,6 +44,16 @@ class BasisSet:
                 raise ValueError(f"op_symbol:{s} is not supported by {type(self).__name__}") from None
         return mat * op.factor
 
+    def copy(self, new_dof):
+        """the same local basis attached to another degree of freedom (basis.py:93-108)"""
+        import copy as _copy
+        new = _copy.copy(self)
+        new.dof = list(new_dof) if self.multi_dof else new_dof
+        if self.multi_dof:
+            shift = 1 if type(self).__name__ == "BasisMultiElectronVac" else 0
+            new.dof_name_map = {name: i + shift for i, name in enumerate(new.dof)}
+        return new
+
     def __repr__(self):
         return f"{type(self).__name__}(dof: {self.dof}, nbas: {self.nbas})"
 

@@ -192,6 +192,31 @@ class SpinBosonModel(Model):
         super().__init__(basis, ham, dipole={"spin": dipole or 0})
 
 
+class TI1DModel(Model):
+    """Translationally invariant chain with periodic boundary: ``basis`` and ``local_ham_terms`` describe one unit
+    cell (degrees of freedom renamed to ("cell<i>", dof) in the full model), ``nonlocal_ham_terms`` name their
+    degrees of freedom as (cell offset, dof) relative to the cell they are attached to (model/model.py:442-510)."""
+
+    def __init__(self, basis, local_ham_terms, nonlocal_ham_terms, ncell: int):
+        full_basis = []
+        for i in range(ncell):
+            for b in basis:
+                new_dofs = [(f"cell{i}", dof) for dof in b.dofs]
+                full_basis.append(b.copy(new_dofs if b.multi_dof else new_dofs[0]))
+        terms = []
+        for i in range(ncell):
+            for op in local_ham_terms:
+                terms.append(Op(op.symbol, [(f"cell{i}", dof) for dof in op.dofs], op.factor, op.qn_list))
+            for op in nonlocal_ham_terms:
+                dofs = []
+                for off, dof in op.dofs:
+                    assert isinstance(off, int)
+                    dofs.append((f"cell{(i + off) % ncell}", dof))
+                terms.append(Op(op.symbol, dofs, op.factor, op.qn_list))
+        super().__init__(full_basis, terms)
+        self.ncell = ncell
+
+
 def load_from_dict(param, scheme, lam: bool):
     """(HolsteinModel, temperature) from the parameter dictionary of the transport examples (keys "mol num",
     "j constant", "ph modes", "temperature", each quantity as [value, unit]); the phonon level counts are chosen by
