@@ -727,3 +727,63 @@ def gen_spectral():
 
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("spectral",)):
     gen_spectral()
+
+
+def gen_kubo():
+    """`TransportKubo` (transport/kubo.py) with fixed-step TDVP-PS in imaginary and real time on Holstein rings
+    (transport/tests/test_kubo.py: 50000 K, omega = J = 1; 3 molecules with a bond dimension that holds the full
+    one-exciton space, 5 molecules truncated to 24) and on Peierls rings (test_peierls_kubo's parameters:
+    phonon-assisted current, four-part decomposition; 3 sites untruncated, 4 sites truncated to 24), and with the
+    default P&C on the 3-molecule Holstein ring."""
+    from renormalizer.model import Phonon, Mol, HolsteinModel, Model
+    from renormalizer.model.basis import BasisSimpleElectron, BasisSHO
+    from renormalizer.model.op import Op
+    from renormalizer.transport.kubo import TransportKubo
+    from renormalizer.utils import Quantity, CompressConfig, EvolveConfig, EvolveMethod, CompressCriteria
+    out = {}
+
+    def tdvp():
+        return EvolveConfig(EvolveMethod.tdvp_ps)
+
+    def fixed(m):                       # a fresh object per job: max_dims is sized by the first model it meets
+        return CompressConfig(CompressCriteria.fixed, max_bonddim=m)
+
+    def holstein(nmol):
+        return HolsteinModel([Mol(Quantity(0), [Phonon.simple_phonon(Quantity(1), Quantity(1), 2)])] * nmol, Quantity(1), 3)
+
+    def peierls(n, nlevels=2, g=4):
+        v = -Quantity(120, "meV").as_au()
+        omega = Quantity(50, "cm-1").as_au()
+        ham, basis = [], []
+        for i in range(n):
+            i1, i2 = i, (i + 1) % n
+            ham += [Op(r"a^\dagger a", [i1, i2], v), Op(r"a a^\dagger", [i1, i2], v), Op(r"b^\dagger b", (i, 0), omega),
+                    Op(r"b^\dagger + b", (i, 0)) * Op(r"a^\dagger a", [i1, i2]) * g * omega,
+                    Op(r"b^\dagger + b", (i, 0)) * Op(r"a a^\dagger", [i1, i2]) * g * omega]
+            basis += [BasisSimpleElectron(i), BasisSHO((i, 0), omega, nlevels)]
+        return Model(basis, ham)
+
+    for nmol, m in ((3, 64), (5, 24)):
+        kubo = TransportKubo(holstein(nmol), Quantity(50000, "K"), insteps=4, compress_config=fixed(m),
+                             ievolve_config=tdvp(), evolve_config=tdvp())
+        kubo.evolve(nsteps=5, evolve_time=5)
+        out[f"holstein{nmol}_corr"] = kubo.auto_corr
+        out[f"holstein{nmol}_bond_dims"] = np.array(kubo.latest_mps.ket_mps.bond_dims)
+        print(nmol, kubo.auto_corr, kubo.latest_mps.ket_mps.bond_dims)
+    kubo = TransportKubo(holstein(3), Quantity(50000, "K"), insteps=20, compress_config=CompressConfig(threshold=1e-6))
+    kubo.evolve(nsteps=10, evolve_time=2)
+    out["holstein3_pc_corr"] = kubo.auto_corr
+    print("pc", kubo.auto_corr)
+    for n, m in ((3, 64), (4, 24)):
+        kubo = TransportKubo(peierls(n), Quantity(300, "K"), insteps=6, compress_config=fixed(m),
+                             ievolve_config=tdvp(), evolve_config=tdvp())
+        kubo.evolve(nsteps=5, evolve_time=1000)
+        out[f"peierls{n}_corr"] = kubo.auto_corr
+        out[f"peierls{n}_decomposition"] = kubo.auto_corr_decomposition
+        out[f"peierls{n}_j_bond_dims"] = np.array(list(kubo.j_oper.bond_dims) + list(kubo.j_oper2.bond_dims))
+        print(n, kubo.auto_corr)
+    np.savez_compressed(os.path.join(GOLD, "transport_kubo.npz"), **out)
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("kubo",)):
+    gen_kubo()

@@ -1380,6 +1380,30 @@ def _adaptive_tdvp(fun, cur_mps, mpo, evolve_target_t):
         cur_mps = half2
 
 
+class BraKetPair:
+    """A bra and a ket propagated side by side and their overlap <bra| O |ket> (O optional), including both
+    ``coeff`` factors (mps/mps.py:2061-2088); unpacks as (bra, ket)."""
+
+    def __init__(self, bra_mps, ket_mps, mpo=None):
+        self.bra_mps = bra_mps
+        self.ket_mps = ket_mps
+        self.mpo = mpo
+        self.ft = self.calc_ft()
+
+    def calc_ft(self):
+        if self.mpo is None:
+            dot = self.bra_mps.conj().dot(self.ket_mps)
+        else:
+            dot = self.ket_mps.expectation(self.mpo, self.bra_mps.conj())
+        return complex(dot * np.conjugate(self.bra_mps.coeff) * self.ket_mps.coeff)
+
+    def __iter__(self):
+        return iter((self.bra_mps, self.ket_mps))
+
+    def __str__(self):
+        return f"bra: {self.bra_mps}, ket: {self.ket_mps}, ft: {self.ft:g}"
+
+
 def compressed_sum(mps_list, batchsize=5, temp_m_trunc=None):
     """mps/lib.py:417-439"""
     from collections import deque

@@ -12,3 +12,5 @@ fs2au = 1.0e-15 / _c["atomic unit of time"][0]
 au2fs = 1.0 / fs2au
 K2au = _c["kelvin-hartree relationship"][0]
 au2K = _c["hartree-kelvin relationship"][0]
+# 1 cm^2 / (V s) in atomic units of mobility (e a0^2 / hbar)
+mobility2au = au2ev * _c["atomic unit of time"][0] / (_c["atomic unit of length"][0] * 100) ** 2
