@@ -787,3 +787,55 @@ def gen_kubo():
 
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("kubo",)):
     gen_kubo()
+
+
+def gen_vmf():
+    """TDVP-VMF (mps.py:887-1094) on the reduced headline model: the expanded initial state is stored, then three
+    evolve calls each with the matrix-unfolding regularisation (`tdvp_mu_vmf`, auto switch off), with the
+    density-matrix regularisation (`tdvp_vmf`, auto switch off), without the overlap corrections
+    (`force_ovlp=False`), with the automatic switch, and in imaginary time."""
+    from renormalizer.model import Phonon, Mol, HolsteinModel, Op
+    from renormalizer.mps import Mps, Mpo
+    from renormalizer.utils import Quantity, EvolveConfig, EvolveMethod, CompressConfig, CompressCriteria
+    nmol, pdim = 3, 4
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), pdim)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
+    gs = Mps.ground_state(model, max_entangled=False)
+    init = Mpo.onsite(model, r"a^\dagger", dof_set={nmol // 2}).apply(gs)
+    mpo = Mpo(model, offset=Quantity(init.expectation(Mpo(model))))
+    init.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=6)
+    init.evolve_config = EvolveConfig(EvolveMethod.tdvp_mu_vmf)
+    init = init.expand_bond_dimension(mpo)
+    init.canonicalise()
+    occ = [Mpo(model, Op(r"a^\dagger a", dof)) for dof in model.e_dofs]
+    out = {}
+    _dump_mps(out, "init_", init)
+    dt = 20.0
+    out["dt"] = np.array(dt)
+
+    def run(tag, method, step, auto=False, force_ovlp=True):
+        mps = init.copy()
+        mps.evolve_config = EvolveConfig(method, force_ovlp=force_ovlp)
+        mps.evolve_config.vmf_auto_switch = auto
+        vals, norms, methods = [], [], []
+        for _ in range(3):
+            mps = mps.evolve(mpo, step)
+            vals.append([mps.expectation(o) for o in occ])
+            norms.append(mps.mp_norm)
+            methods.append(mps.evolve_config.method.name)
+        out[tag + "_obs"] = np.array(vals, dtype=complex).real
+        out[tag + "_norms"] = np.array(norms)
+        out[tag + "_energy"] = np.array(complex(mps.expectation(mpo)).real)
+        out[tag + "_methods"] = np.array(methods)
+        print(tag, out[tag + "_obs"][-1], norms[-1], methods)
+
+    run("mu", EvolveMethod.tdvp_mu_vmf, dt)
+    run("vmf", EvolveMethod.tdvp_vmf, dt)
+    run("mu_noovlp", EvolveMethod.tdvp_mu_vmf, dt, force_ovlp=False)
+    run("auto", EvolveMethod.tdvp_mu_vmf, dt, auto=True)
+    run("imag", EvolveMethod.tdvp_mu_vmf, -20.0j)
+    np.savez_compressed(os.path.join(GOLD, "tdvp_vmf_holstein_small.npz"), **out)
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("vmf",)):
+    gen_vmf()

@@ -1086,6 +1086,9 @@ class Mps:
             new_mps = self._evolve_prop_and_compress_tdrk4(mpo, evolve_dt)
         elif method is EvolveMethod.prop_and_compress_tdrk:
             new_mps = self._evolve_prop_and_compress_tdrk(mpo, evolve_dt)
+        elif method in (EvolveMethod.tdvp_vmf, EvolveMethod.tdvp_mu_vmf):
+            from .tdvp_vmf import evolve_tdvp_mu_vmf
+            new_mps = evolve_tdvp_mu_vmf(self, mpo, evolve_dt)
         else:
             raise NotImplementedError(f"{method} is not implemented in the MI355X engine yet (TDVP-PS is)")
         if normalize:

@@ -132,6 +132,9 @@ class EvolveConfig:
         self.ivp_atol = ivp_atol
         self.ivp_solver = ivp_solver
         self.force_ovlp = force_ovlp
+        self.vmf_auto_switch = True          # tdvp_mu_vmf <-> tdvp_vmf by the smallest singular value (mps.py:1078-1090)
+        self.tdvp_cmf_midpoint = True
+        self.tdvp_cmf_c_trapz = False
         self.stat = None
 
     @property

@@ -456,3 +456,36 @@ def test_prop_and_compress_runge_kutta_matches_reference(golden_dir, tag):
             # the embedded error estimate is a difference of nearly equal fifth- and fourth-order results
             assert abs(mps.evolve_config.guess_dt / z[tag + "_guess_dt"][step] - 1) < 1e-3
     assert abs(mps.expectation(mpo) - float(z[tag + "_energy"].real)) < 1e-8
+
+
+@pytest.mark.parametrize("tag, method, force_ovlp, auto", [("mu", "tdvp_mu_vmf", True, False), ("vmf", "tdvp_vmf", True, False),
+                                                           ("mu_noovlp", "tdvp_mu_vmf", False, False),
+                                                           ("auto", "tdvp_mu_vmf", True, True), ("imag", "tdvp_mu_vmf", True, False)])
+def test_tdvp_vmf_matches_reference(golden_dir, tag, method, force_ovlp, auto):
+    """mps/mps.py:887-1094: the whole state integrated with RK45 (variable mean field) with the matrix-unfolding or
+    the density-matrix regularisation, with / without the overlap corrections, with the automatic switch between the
+    two, and in imaginary time; the state expanded by the reference is the starting point."""
+    from renormalizer_amd.mps.mps import Mps
+    z = np.load(os.path.join(golden_dir, "tdvp_vmf_holstein_small.npz"))
+    nmol = 3
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), 4)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
+    n = int(z["init_nsite"])
+    mps = Mps.from_arrays(model, [z[f"init_site_{i}"] for i in range(n)], [z[f"init_qn_{i}"] for i in range(n + 1)],
+                          int(z["init_qnidx"]), z["init_qntot"], bool(z["init_to_right"]), complex(z["init_coeff"]))
+    fc = Mpo.onsite(model, r"a^\dagger", dof_set={nmol // 2}).apply(Mps.ground_state(model, False))
+    mpo = Mpo(model, offset=Quantity(fc.expectation(Mpo(model))))
+    obs = [Mpo(model, Op(r"a^\dagger a", dof)) for dof in model.e_dofs]
+    mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=6)
+    mps.evolve_config = EvolveConfig(EvolveMethod[method], force_ovlp=force_ovlp)
+    mps.evolve_config.vmf_auto_switch = auto
+    step = -20.0j if tag == "imag" else float(z["dt"])
+    for k in range(3):
+        mps = mps.evolve(mpo, step)
+        vals = np.array([mps.expectation(o) for o in obs])
+        # RK45 runs at rtol 1e-5 / atol 1e-8 and the regularised inverses amplify rounding in the padded directions
+        # (weight 1e-10) by up to 1e5: the two codes agree to a few 1e-7, the north-star bar is 1e-6
+        assert np.abs(vals - z[tag + "_obs"][k]).max() < 1e-6, (k, vals - z[tag + "_obs"][k])
+        assert abs(mps.mp_norm - z[tag + "_norms"][k]) < 1e-6
+        assert mps.evolve_config.method.name == str(z[tag + "_methods"][k])
+    assert abs(mps.expectation(mpo) - float(z[tag + "_energy"])) < 1e-7
