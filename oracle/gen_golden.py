@@ -834,6 +834,29 @@ def gen_vmf():
     run("mu_noovlp", EvolveMethod.tdvp_mu_vmf, dt, force_ovlp=False)
     run("auto", EvolveMethod.tdvp_mu_vmf, dt, auto=True)
     run("imag", EvolveMethod.tdvp_mu_vmf, -20.0j)
+
+    # constant mean field (mps.py:1096-1265) from the same state; short steps: with the padded singular values the
+    # per-site equations are stiff and the explicit RK45 of the reference needs ~1e6 steps at dt = 5
+    def run_cmf(tag, midpoint=True, trapz=False, solver="krylov", step=0.5):
+        mps = init.copy()
+        mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_mu_cmf, ivp_solver=solver)
+        mps.evolve_config.tdvp_cmf_midpoint = midpoint
+        mps.evolve_config.tdvp_cmf_c_trapz = trapz
+        vals, norms = [], []
+        for _ in range(3):
+            mps = mps.evolve(mpo, step)
+            vals.append([mps.expectation(o) for o in occ])
+            norms.append(mps.mp_norm)
+        out[tag + "_obs"] = np.array(vals, dtype=complex).real
+        out[tag + "_norms"] = np.array(norms)
+        out[tag + "_energy"] = np.array(complex(mps.expectation(mpo)).real)
+        print(tag, out[tag + "_obs"][-1], norms[-1])
+
+    run_cmf("cmf")
+    run_cmf("cmf_trapz", trapz=True)
+    run_cmf("cmf_first", midpoint=False)
+    run_cmf("cmf_rk", solver="RK45")
+    run_cmf("cmf_imag", step=-0.5j)
     np.savez_compressed(os.path.join(GOLD, "tdvp_vmf_holstein_small.npz"), **out)
 
 

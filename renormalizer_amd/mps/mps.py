@@ -799,18 +799,23 @@ class Mps:
         """device memory held by the site tensors (mps/mp.py:1116-1117)"""
         return int(sum(t.nbytes for t in self._mp))
 
-    def ensure_left_canonical(self):
-        """mps/mp.py:206-216.  The orthogonality check of the reference is replaced by always re-canonicalising
-        (one QR sweep) - cheaper than downloading the sites to test them."""
-        self.move_qnidx(0)
-        self.to_right = True
-        return self.canonicalise()
+    def ensure_left_canonical(self, rtol: float = None, atol: float = None):
+        """mps/mp.py:206-216: canonicalise only when the direction flags or the site Gram matrices say it is needed -
+        a QR pass over an already canonical state would still rotate its weightless (padded) bond directions, which
+        the regularised inverses of TDVP-VMF / CMF are sensitive to"""
+        if self.to_right or self.qnidx != self.site_num - 1 or not self.check_left_canonical(rtol, atol):
+            self.move_qnidx(0)
+            self.to_right = True
+            return self.canonicalise()
+        return self
 
-    def ensure_right_canonical(self):
+    def ensure_right_canonical(self, rtol: float = None, atol: float = None):
         """mps/mp.py:218-228"""
-        self.move_qnidx(self.site_num - 1)
-        self.to_right = False
-        return self.canonicalise()
+        if (not self.to_right) or self.qnidx != 0 or not self.check_right_canonical(rtol, atol):
+            self.move_qnidx(self.site_num - 1)
+            self.to_right = False
+            return self.canonicalise()
+        return self
 
     def _update_mps(self, cstruct, cidx, qnbigl, qnbigr, percent=0):
         """Basis selection update after a DMRG / two-site step, mps/mp.py:651-888 for a single state:
@@ -1089,6 +1094,12 @@ class Mps:
         elif method in (EvolveMethod.tdvp_vmf, EvolveMethod.tdvp_mu_vmf):
             from .tdvp_vmf import evolve_tdvp_mu_vmf
             new_mps = evolve_tdvp_mu_vmf(self, mpo, evolve_dt)
+        elif method is EvolveMethod.tdvp_mu_cmf:
+            from .tdvp_vmf import evolve_tdvp_mu_cmf
+            if self.evolve_config.adaptive:
+                new_mps = _adaptive_tdvp(evolve_tdvp_mu_cmf, self, mpo, evolve_dt)
+            else:
+                new_mps = evolve_tdvp_mu_cmf(self, mpo, evolve_dt)
         else:
             raise NotImplementedError(f"{method} is not implemented in the MI355X engine yet (TDVP-PS is)")
         if normalize:
@@ -1104,8 +1115,7 @@ class Mps:
         tensor (Lanczos), QR/RQ by quantum-number block, one environment update, a backward
         step +i dt/2 of the bond factor (0-site Lanczos), absorbed into the next site; the last
         site of each half sweep is not split."""
-        if self.evolve_config.ivp_solver != "krylov":
-            raise NotImplementedError("only the Krylov (Lanczos) local propagator is implemented")
+        cfg = self.evolve_config
         eng = get_engine()
         if np.iscomplex(evolve_dt):
             mps = self.copy()
@@ -1126,7 +1136,7 @@ class Mps:
                 shape = list(mps[imps].shape)
                 w = mpo.device(imps, eng)
                 hop = hop_expr(l_array, r_array, [w], shape)
-                mps_t, j = expm_krylov(hop, -1j * evolve_dt / 2, mps[imps])
+                mps_t, j = _local_propagate(cfg, hop, -1j * evolve_dt / 2, mps[imps])
                 local_steps.append(j)
                 qnbigl, qnbigr, _ = mps._get_big_qn([imps], need_mat=False)
                 if (not mps.to_right and imps != 0) or (mps.to_right and imps != n - 1):
@@ -1139,7 +1149,7 @@ class Mps:
                     mps.qnidx = imps - 1
                     r_array = environ.GetLR("R", imps, mps, mpo, itensor=r_array, method="System")
                     hop_u = hop_expr(l_array, r_array, [], u.shape)
-                    b_t, j = expm_krylov(hop_u, 1j * evolve_dt / 2, u)
+                    b_t, j = _local_propagate(cfg, hop_u, 1j * evolve_dt / 2, u)
                     local_steps.append(j)
                     prv = mps[imps - 1]
                     mps[imps - 1] = eng.matmul(prv.reshape(-1, prv.shape[-1]), b_t.reshape(u.shape)) \
@@ -1150,7 +1160,7 @@ class Mps:
                     mps.qnidx = imps + 1
                     l_array = environ.GetLR("L", imps, mps, mpo, itensor=l_array, method="System")
                     hop_svt = hop_expr(l_array, r_array, [], vt.shape)
-                    b_t, j = expm_krylov(hop_svt, 1j * evolve_dt / 2, vt)
+                    b_t, j = _local_propagate(cfg, hop_svt, 1j * evolve_dt / 2, vt)
                     local_steps.append(j)
                     nxt = mps[imps + 1]
                     mps[imps + 1] = eng.matmul(b_t.reshape(vt.shape), nxt.reshape(nxt.shape[0], -1)) \
@@ -1164,12 +1174,37 @@ class Mps:
         return mps
 
 
+def _local_propagate(config, hop, factor, y):
+    """exp(factor * H_eff) y for one centre tensor: the engine's Lanczos exponential (``ivp_solver="krylov"``, the
+    default), or any explicit scheme of ``scipy.integrate.solve_ivp`` named by ``ivp_solver`` ("RK45", "RK23",
+    "DOP853") with ``ivp_rtol / ivp_atol`` as in mps/mps.py:1299-1315: dy/dt = (factor / |factor|) H y over
+    (0, |factor|); the step control runs on the host, every H y on the device.  Returns (tensor, number of H y)."""
+    if config.ivp_solver == "krylov":
+        return expm_krylov(hop, factor, y)
+    from scipy.integrate import solve_ivp
+    eng = get_engine()
+    span = abs(factor)
+    phase = complex(factor) / span
+    phase = phase.real if phase.imag == 0 else phase
+    y0 = y.to_host()
+    shape = y0.shape
+    if np.iscomplexobj(phase) or hop.operator_is_complex:
+        y0 = y0.astype(complex)
+
+    def rhs(t, v):
+        return hop(eng.asdevice(v.reshape(shape))).to_host().ravel() * phase
+
+    sol = solve_ivp(rhs, (0, span), y0.ravel(), method=config.ivp_solver, rtol=config.ivp_rtol, atol=config.ivp_atol)
+    if not sol.success:
+        raise RuntimeError(f"solve_ivp({config.ivp_solver}) failed on a local TDVP problem: {sol.message}")
+    return eng.asdevice(np.ascontiguousarray(sol.y[:, -1].reshape(shape))), sol.nfev
+
+
 def _evolve_tdvp_ps2(self, mpo, evolve_dt) -> "Mps":
     """Two-site TDVP with projector splitting, mps/mps.py:1406-1517: forward step -i dt/2 of the two-site
     centre, ``_update_mps`` (block SVD + truncation), environment update, backward step +i dt/2 of the
     next one-site centre, ``_push_cano``; the last pair of each half sweep is not stepped back."""
-    if self.evolve_config.ivp_solver != "krylov":
-        raise NotImplementedError("only the Krylov (Lanczos) local propagator is implemented")
+    cfg = self.evolve_config
     eng = get_engine()
     mps = self.copy() if np.iscomplex(evolve_dt) else self.to_complex()
     evolve_dt = complex(evolve_dt)
@@ -1189,7 +1224,7 @@ def _evolve_tdvp_ps2(self, mpo, evolve_dt) -> "Mps":
             a, b = mps[c0], mps[c1]
             ms2 = eng.matmul(a.reshape(-1, a.shape[-1]), b.reshape(b.shape[0], -1)).reshape(a.shape[:-1] + b.shape[1:])
             hop = hop_expr(l_array, r_array, [mpo.device(c0, eng), mpo.device(c1, eng)], ms2.shape)
-            mps_t, j = expm_krylov(hop, -1j * evolve_dt / 2, ms2)
+            mps_t, j = _local_propagate(cfg, hop, -1j * evolve_dt / 2, ms2)
             local_steps.append(j)
             qnbigl, qnbigr, _ = mps._get_big_qn([c0, c1], need_mat=False)
             mps._update_mps(mps_t.reshape(ms2.shape), [c0, c1], qnbigl, qnbigr)
@@ -1201,7 +1236,7 @@ def _evolve_tdvp_ps2(self, mpo, evolve_dt) -> "Mps":
                 r_array = environ.GetLR("R", ridx - 1, mps, mpo, itensor=r_array, method="System")
             ms1 = mps[c2]
             hop1 = hop_expr(l_array, r_array, [mpo.device(c2, eng)], ms1.shape)
-            mps_b, j = expm_krylov(hop1, 1j * evolve_dt / 2, ms1)
+            mps_b, j = _local_propagate(cfg, hop1, 1j * evolve_dt / 2, ms1)
             local_steps.append(j)
             mps[c2] = mps_b.reshape(ms1.shape)
             mps._push_cano(c2)

@@ -57,6 +57,11 @@ class SiteDerivative:
         self.s_inv, self.ovlp_inv1, self.ovlp_inv0, self.ovlp0, self.pre = map(up, (s_inv, ovlp_inv1, ovlp_inv0, ovlp0, pre))
 
     def __call__(self, y0):
+        """dy/dt on the host (the ODE drivers keep their vectors there)"""
+        return self.device(y0).to_host().reshape(self.shape) / self.coef
+
+    def device(self, y0):
+        """S_L0^-1 (1 - P) H y S^-1 as a device tensor, not yet divided by ``coef``"""
         eng = self.eng
         dl, dr = self.shape[0], self.shape[-1]
         rows = int(np.prod(self.shape[:-1]))
@@ -76,8 +81,7 @@ class SiteDerivative:
             eng._check(eng.lib.mpse_axpy(eng.ctx, hc.code, hc.ptr, bm.ptr, hc.size, -1.0, 0.0))
         if self.ovlp_inv0 is not None:
             hc = eng.matmul(self.ovlp_inv0, hc.reshape(dl, rows // dl * k)).reshape(rows, k)
-        out = eng.matmul(hc, self.s_inv)
-        return out.to_host().reshape(self.shape) / self.coef
+        return eng.matmul(hc, self.s_inv).reshape(self.shape)
 
 
 def evolve_tdvp_mu_vmf(self, mpo, evolve_dt):
@@ -196,3 +200,110 @@ def evolve_tdvp_mu_vmf(self, mpo, evolve_dt):
         elif sw_min < config.reg_epsilon and mps.evolve_config.method == EvolveMethod.tdvp_vmf:
             mps.evolve_config.method = EvolveMethod.tdvp_mu_vmf
     return mps.canonicalise()
+
+
+def evolve_tdvp_mu_cmf(self, mpo, evolve_dt):
+    """TDVP with constant mean field and matrix-unfolding regularisation (``Mps._evolve_tdvp_mu_cmf``,
+    mps/mps.py:1096-1265): the environments are frozen over the step - taken from the state at t (first order) or
+    at t + dt/2 from a first-order half step (``tdvp_cmf_midpoint``, default) - and every site is integrated on
+    its own with RK45, right to left, the coefficient site with the local propagator of ``ivp_solver``;
+    ``tdvp_cmf_c_trapz`` propagates the coefficient site in two halves around the update of the other sites.
+
+    One deviation from the reference: for the coefficient site with ``ivp_solver="krylov"`` it hands the operator
+    already divided by i to its Hermitian Lanczos routine, which overflows once dt |H| is of order one (measured in
+    the dev container); here the Hermitian operator and the factor -i dt go to the Lanczos exponential (identical
+    results where the reference's works).  Kept as in the reference: in imaginary time the midpoint environment comes
+    from a half step taken with the real number substituted for the step (mps.py:1113-1117, 1137).  With constant
+    regularised inverses (~1e5 on bond directions padded by ``expand_bond_dimension``) imaginary-time CMF is unstable
+    on freshly padded states - its first-order variant collapses within a step in the reference as well."""
+    from ..lib.krylov import expm_krylov
+    eng = get_engine()
+    config = self.evolve_config
+    if config.tdvp_cmf_c_trapz:
+        assert config.tdvp_cmf_midpoint
+    imag_time = bool(np.iscomplex(evolve_dt))
+    if imag_time:
+        evolve_dt = -np.imag(evolve_dt)
+        coef = -1
+    else:
+        coef = 1j
+    self.ensure_left_canonical()
+    mps = self.copy() if imag_time else self.to_complex()
+    n = mps.site_num
+    dtype = np.complex128 if mps.is_complex else np.float64
+    if config.tdvp_cmf_midpoint:
+        orig = self.evolve_config
+        first_order = orig.copy()
+        first_order.tdvp_cmf_midpoint = first_order.tdvp_cmf_c_trapz = first_order.adaptive = False
+        self.evolve_config = first_order
+        try:
+            environ_mps = self.evolve(mpo, evolve_dt / 2)
+        finally:
+            self.evolve_config = orig
+    else:
+        environ_mps = mps.copy()
+    if environ_mps.is_complex and not mps.is_complex:
+        mps = mps.to_complex()               # imaginary time with the (real-time) midpoint environment
+        dtype = np.complex128
+    loop = 1
+    if config.tdvp_cmf_c_trapz:
+        loop = 2
+        mps[n - 1] = environ_mps[n - 1]
+    ident_cache = {}
+    rk_steps = []
+    while loop > 0:
+        environ = Environ(environ_mps, mpo, "L")
+        if config.force_ovlp:
+            s_l = [np.ones((1, 1), dtype=dtype)]
+            for i in range(n):
+                s_l.append(transfer_matrix(eng, environ_mps[i], "L", s_l[i], ident_cache))
+            s_l_inv = []
+            for m in s_l:
+                w, u = scipy.linalg.eigh(m)
+                s_l_inv.append((u / w) @ u.T.conj())
+        else:
+            s_l = s_l_inv = [None] * (n + 1)
+        for i in mps.iter_idx_list(full=True):
+            shape = list(mps[i].shape)
+            ltensor = environ.read("L", i - 1)
+            if i == n - 1:
+                if loop == 1:
+                    hop = hop_expr(ltensor, environ.sentinel, [mpo.device(i, eng)], shape)
+                    f = SiteDerivative(eng, shape, hop, True, np.ones((1, 1), dtype=dtype), coef, s_l_inv[i + 1],
+                                       s_l_inv[i], s_l[i])
+                    if config.ivp_solver == "krylov":
+                        ms, nvec = expm_krylov(lambda v: f.device(v.reshape(shape)), evolve_dt / coef, mps[i])
+                        mps[i] = ms.reshape(shape)
+                    else:
+                        y0 = mps[i].to_host().astype(dtype)
+                        sol = solve_ivp(lambda t, y: f(eng.asdevice(y.reshape(shape))).ravel(), (0, evolve_dt), y0.ravel(),
+                                        method=config.ivp_solver, rtol=config.ivp_rtol, atol=config.ivp_atol)
+                        mps[i] = sol.y[:, -1].reshape(shape)
+                if loop == 1 and config.tdvp_cmf_c_trapz:
+                    break
+                continue
+            qnbigl, qnbigr, _ = environ_mps._get_big_qn([i + 1])
+            u, s, qnlset, v, s, qnrset = svd_qn.svd_qn(environ_mps[i + 1], qnbigl, qnbigr, environ_mps.qntot, system="R",
+                                                       full_matrices=False)
+            environ_mps[i + 1] = v.T.reshape((len(s),) + tuple(environ_mps[i + 1].shape[1:]))
+            rtensor = environ.GetLR("R", i + 1, environ_mps, mpo, itensor=None, method="System")
+            regular_s = mu_regularize(s, epsilon=config.reg_epsilon)
+            us = eng.asdevice(u.to_host() * s)
+            site = environ_mps[i]
+            rows = site.size // site.shape[-1]
+            environ_mps[i] = eng.matmul(site.reshape(rows, site.shape[-1]), us).reshape(tuple(site.shape[:-1]) + (len(s),))
+            environ_mps.qn[i + 1] = qnrset
+            environ_mps.qnidx = i
+            s_inv = (u.to_host().conj() / regular_s).T
+            hop = hop_expr(ltensor, rtensor, [mpo.device(i, eng)], shape[:-1] + [len(s)])
+            f = SiteDerivative(eng, shape, hop, False, s_inv, coef, s_l_inv[i + 1], s_l_inv[i], s_l[i], pre=us)
+            y0 = mps[i].to_host().astype(dtype)
+            sol = solve_ivp(lambda t, y: f(eng.asdevice(y.reshape(shape))).ravel(), (0, evolve_dt), y0.ravel(), method="RK45")
+            rk_steps.append(len(sol.t))
+            mps[i] = sol.y[:, -1].reshape(shape)
+        if loop == 2:
+            environ_mps = mps
+            evolve_dt /= 2.0
+        loop -= 1
+    mps.evolve_config.stat = {"rk_steps": rk_steps}
+    return mps

@@ -489,3 +489,80 @@ def test_tdvp_vmf_matches_reference(golden_dir, tag, method, force_ovlp, auto):
         assert abs(mps.mp_norm - z[tag + "_norms"][k]) < 1e-6
         assert mps.evolve_config.method.name == str(z[tag + "_methods"][k])
     assert abs(mps.expectation(mpo) - float(z[tag + "_energy"])) < 1e-7
+
+
+def _small_expanded_state(golden_dir):
+    from renormalizer_amd.mps.mps import Mps
+    z = np.load(os.path.join(golden_dir, "tdvp_vmf_holstein_small.npz"))
+    nmol = 3
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), 4)
+    model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
+    n = int(z["init_nsite"])
+    mps = Mps.from_arrays(model, [z[f"init_site_{i}"] for i in range(n)], [z[f"init_qn_{i}"] for i in range(n + 1)],
+                          int(z["init_qnidx"]), z["init_qntot"], bool(z["init_to_right"]), complex(z["init_coeff"]))
+    fc = Mpo.onsite(model, r"a^\dagger", dof_set={nmol // 2}).apply(Mps.ground_state(model, False))
+    mpo = Mpo(model, offset=Quantity(fc.expectation(Mpo(model))))
+    obs = [Mpo(model, Op(r"a^\dagger a", dof)) for dof in model.e_dofs]
+    mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=6)
+    return mps, mpo, obs
+
+
+@pytest.mark.parametrize("solver", ["RK45", "DOP853"])
+def test_tdvp_ps_with_ode_local_propagator(golden_dir, solver):
+    """`ivp_solver` other than "krylov" (mps/mps.py:1299-1315, 1342-1360, 1449-1510): the centre tensors are
+    propagated with scipy's explicit Runge-Kutta schemes (step control on the host, H y on the device); at tight
+    tolerances the result is the Lanczos one, for the one-site and the two-site integrator"""
+    mps0, mpo, obs = _small_expanded_state(golden_dir)
+    for method in (EvolveMethod.tdvp_ps, EvolveMethod.tdvp_ps2):
+        out = []
+        for s in ("krylov", solver):
+            mps = mps0.copy()
+            mps.evolve_config = EvolveConfig(method, ivp_solver=s, ivp_rtol=1e-10, ivp_atol=1e-12)
+            for _ in range(2):
+                mps = mps.evolve(mpo, 10.0)
+            out.append(np.array([mps.expectation(o) for o in obs]))
+            assert mps.evolve_config.stat["nobs"] > 0
+        assert np.abs(out[0] - out[1]).max() < 1e-7
+
+
+@pytest.mark.parametrize("solver", ["krylov", "RK45"])
+@pytest.mark.parametrize("c_trapz", [False, True])
+def test_tdvp_cmf_follows_tdvp_ps(golden_dir, solver, c_trapz):
+    """mps/mps.py:1096-1265 as tested in mps/tests/test_evolve.py::test_tdvp_cmf (5e-4 against the exact result):
+    constant-mean-field TDVP with the midpoint environment, both treatments of the coefficient site"""
+    mps0, mpo, obs = _small_expanded_state(golden_dir)
+    ref = mps0.copy()
+    ref.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    mps = mps0.copy()
+    mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_mu_cmf, ivp_solver=solver)
+    mps.evolve_config.tdvp_cmf_c_trapz = c_trapz
+    for _ in range(4):
+        ref = ref.evolve(mpo, 0.5)
+        mps = mps.evolve(mpo, 0.5)
+    a = np.array([ref.expectation(o) for o in obs])
+    b = np.array([mps.expectation(o) for o in obs])
+    assert np.abs(a - b).max() < 5e-4 and abs(mps.mp_norm - 1) < 1e-6
+
+
+@pytest.mark.parametrize("tag, midpoint, trapz, solver, tol", [("cmf", True, False, "krylov", 1e-6), ("cmf_trapz", True, True, "krylov", 1e-6),
+                                                               ("cmf_first", False, False, "krylov", 2e-5),
+                                                               ("cmf_rk", True, False, "RK45", 1e-6),
+                                                               ("cmf_imag", True, False, "krylov", 1e-5)])
+def test_tdvp_cmf_matches_reference(golden_dir, tag, midpoint, trapz, solver, tol):
+    """mps/mps.py:1096-1265 from the state the reference expanded: midpoint / first-order environments, the
+    trapezoid treatment of the coefficient site, Lanczos or RK45 on the coefficient site, imaginary time.  The
+    per-site RK45 runs at SciPy's default rtol 1e-3 / atol 1e-6 on equations made stiff by the regularised inverses,
+    so the two codes agree to ~1e-7 where the step sequences coincide and to a few 1e-6 otherwise (the method itself
+    is ~1e-5 from the converged result here, and the reference's own test allows 5e-4)."""
+    z = np.load(os.path.join(golden_dir, "tdvp_vmf_holstein_small.npz"))
+    mps, mpo, obs = _small_expanded_state(golden_dir)
+    mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_mu_cmf, ivp_solver=solver)
+    mps.evolve_config.tdvp_cmf_midpoint = midpoint
+    mps.evolve_config.tdvp_cmf_c_trapz = trapz
+    step = -0.5j if tag == "cmf_imag" else 0.5
+    for k in range(3):
+        mps = mps.evolve(mpo, step)
+        vals = np.array([mps.expectation(o) for o in obs])
+        assert np.abs(vals - z[tag + "_obs"][k]).max() < tol, (k, vals - z[tag + "_obs"][k])
+        assert abs(mps.mp_norm - z[tag + "_norms"][k]) < 1e-7
+    assert abs(mps.expectation(mpo) - float(z[tag + "_energy"])) < max(tol, 1e-7)
