@@ -1,12 +1,32 @@
-"""Spin-boson model construction: Ohmic spectral density, adiabatic renormalisation, bath discretisation.
+"""Spin-boson model: spectral densities, adiabatic renormalisation, bath discretisation and the dynamics job.
 
-Host-side counterpart of renormalizer/sbm/lib.py (SpectralDensityFunction :38-137, param2mollist :205-217)
-- the producer of the model for BASELINE config 2.  No arithmetic of the sweep lives here."""
+Counterpart of renormalizer/sbm (lib.py: ``SpectralDensityFunction`` / ``OhmicSDF`` :38-139, ``DebyeSDF`` :18-35,
+``ColeDavidsonSDF`` :142-202, ``param2mollist`` :205-217; sbm.py: ``SpinBosonDynamics``) - the producer and the driver
+of BASELINE config 2.  The model layer is host-side; ``SpinBosonDynamics`` steps the MPS on the device."""
+import logging
+
 import numpy as np
 import scipy.integrate
 
 from .model import Phonon, SpinBosonModel
-from .utils import Quantity
+from .utils import CompressConfig, Quantity
+from .utils.tdmps import TdMpsJob
+
+logger = logging.getLogger("renormalizer_amd")
+
+
+class DebyeSpectralDensityFunction:
+    r"""J(\omega) = 2 \lambda \omega \omega_c / (\omega^2 + \omega_c^2)"""
+
+    def __init__(self, lamb, omega_c):
+        self.lamb = lamb
+        self.omega_c = omega_c
+
+    def func(self, w):
+        return 2.0 * self.lamb * w * self.omega_c / (w ** 2 + self.omega_c ** 2)
+
+
+DebyeSDF = DebyeSpectralDensityFunction
 
 
 class SpectralDensityFunction:
@@ -19,6 +39,20 @@ class SpectralDensityFunction:
 
     def func(self, w):
         return np.pi / 2.0 * self.alpha * w ** self.s * self.omega_c ** (1 - self.s) * np.exp(-w / self.omega_c)
+
+    def reno(self, omega_l) -> float:
+        """tunnelling renormalisation factor exp(-2/pi int_{omega_l}^{30 omega_c} J(w)/w^2 dw) (lib.py:51-59)"""
+        val = scipy.integrate.quad(lambda x: self.func(x) / x ** 2, a=omega_l, b=self.omega_c * 30)[0]
+        return float(np.exp(-val * 2 / np.pi))
+
+    def _dos_wang1(self, nb, w):
+        return (nb + 1) / self.omega_c * np.exp(-w / self.omega_c)
+
+    def Wang1(self, nb):
+        """Wang's first discretisation: modes placed at equal weight of the density (nb + 1) / omega_c e^{-w/omega_c}
+        (lib.py:110-125)"""
+        omega = np.array([-np.log(1.0 - float(j) / (nb + 1)) * self.omega_c for j in range(1, nb + 1)])
+        return omega, 2.0 / np.pi * omega * self.func(omega) / self._dos_wang1(nb, omega)
 
     def adiabatic_renormalization(self, delta, p):
         """Self-consistent tunnelling renormalisation with cut-off omega_l = p*delta (lib.py:61-84)."""
@@ -46,6 +80,86 @@ class SpectralDensityFunction:
         dis = np.sqrt(c2) / omega ** 2
         idx = np.argsort(c2 / omega)[::-1] if ifsort else np.arange(len(omega))
         return [Quantity(omega[i]) for i in idx], [Quantity(dis[i]) for i in idx]
+
+
+OhmicSDF = SpectralDensityFunction
+
+
+class ColeDavidsonSDF:
+    r"""J(\omega) = \eta sin(\beta \theta) / (1 + \omega^2 / \omega_c^2)^{\beta / 2}, \theta = atan(\omega / \omega_c)
+    (lib.py:142-202)"""
+
+    def __init__(self, ita, omega_c, beta, omega_limit):
+        self.ita, self.omega_c, self.beta, self.omega_limit = ita, omega_c, beta, omega_limit
+
+    def func(self, w):
+        theta = np.arctan(w / self.omega_c)
+        return self.ita * np.sin(self.beta * theta) / (1 + w ** 2 / self.omega_c ** 2) ** (self.beta / 2)
+
+    def reno(self, omega_l):
+        val = scipy.integrate.quad(lambda x: self.func(x) / x ** 2, a=omega_l, b=omega_l * 1000)[0]
+        return float(np.exp(-val * 2 / np.pi))
+
+    def Wang1(self, nb, nsamples=int(1e7)):
+        """modes where the cumulated density A J(w)/w passes the integers, A normalising it to nb + 1 over
+        (0, omega_limit); located on a grid of ``nsamples`` points"""
+        a = (nb + 1) / scipy.integrate.quad(lambda x: self.func(x) / x, a=0, b=self.omega_limit)[0]
+        step = self.omega_limit / nsamples
+        grid = np.linspace(step, self.omega_limit, nsamples)
+        frac = (np.cumsum(a * self.func(grid) / grid) * step) % 1
+        omega = grid[np.where(frac[1:] - frac[:-1] < 0)[0]]
+        assert len(omega) == nb
+        return omega, 2.0 / np.pi * omega * self.func(omega) / (a * self.func(omega) / omega)
+
+
+def param2mollist(alpha: float, raw_delta: Quantity, omega_c: Quantity, renormalization_p: float, n_phonons: int):
+    """lib.py:205-217: Ohmic bath, adiabatic renormalisation, ``n_phonons`` equidistant modes up to the cut-off, level
+    counts picked per mode by ``Phonon.simplest_phonon``"""
+    sdf = SpectralDensityFunction(alpha, omega_c, s=1)
+    delta, max_omega = sdf.adiabatic_renormalization(raw_delta, renormalization_p)
+    omega_list, dis_list = sdf.post_process(*sdf.trapz(n_phonons, 0.0, max_omega))
+    ph_list = [Phonon.simplest_phonon(o, d) for o, d in zip(omega_list, dis_list)]
+    return SpinBosonModel(Quantity(0), Quantity(delta), ph_list)
+
+
+class SpinBosonDynamics(TdMpsJob):
+    """Spin up, all modes in their vacuum, then real-time propagation; per step the spin's reduced density matrix,
+    <sigma_z>, <sigma_x> and the bond entropies (sbm/sbm.py:13-92).  Finite temperature through thermofield-doubled
+    models."""
+
+    def __init__(self, model, auto_expand: bool = True, compress_config=None, evolve_config=None, dump_dir=None,
+                 dump_mps=None, job_name=None):
+        from .mps import Mpo
+        self.model = model
+        self.h_mpo = Mpo(model)
+        self.auto_expand = auto_expand
+        self.compress_config = CompressConfig() if compress_config is None else compress_config
+        self.sigma_x, self.sigma_z, self.rho, self.bond_entropy = [], [], [], []
+        super().__init__(evolve_config=evolve_config, dump_dir=dump_dir, dump_mps=dump_mps, job_name=job_name)
+
+    def init_mps(self):
+        from .mps import Mps
+        init_mps = Mps.ground_state(self.model, False)
+        init_mps.compress_config = self.compress_config
+        init_mps.evolve_config = self.evolve_config
+        if self.evolve_config.is_tdvp and self.auto_expand:
+            init_mps = init_mps.expand_bond_dimension(self.h_mpo, coef=1e-16, include_ex=False)
+        return init_mps
+
+    def process_mps(self, mps):
+        idx = next(i for i, b in enumerate(self.model.basis) if b.is_spin)
+        rho = mps.calc_1site_rdm(idx=idx)[idx]
+        self.rho.append(rho)
+        self.sigma_z.append(float((rho[0, 0] - rho[1, 1]).real))
+        self.sigma_x.append(float((rho[0, 1] + rho[1, 0]).real))
+        self.bond_entropy.append(mps.calc_entropy("bond"))
+
+    def evolve_single_step(self, evolve_dt):
+        return self.latest_mps.evolve(self.h_mpo, evolve_dt)
+
+    def get_dump_dict(self):
+        return {"time series": self.evolve_times, "sigma_x": self.sigma_x, "sigma_z": self.sigma_z, "rho": self.rho,
+                "bond_entropy": self.bond_entropy}
 
 
 def param2model(alpha, raw_delta, omega_c, renormalization_p, n_phonons, n_phys_dim):

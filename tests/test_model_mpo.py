@@ -118,3 +118,24 @@ def test_runge_kutta_tableaux_are_consistent():
     cfg = EvolveConfig("prop_and_compress_tdrk", rk_solver="RKF45", adaptive=True)
     assert cfg.method is EvolveMethod.prop_and_compress_tdrk and cfg.rk_config.order == (5, 4)
     assert cfg.taylor_config.order == 5 and not cfg.is_tdvp
+
+
+def test_sbm_spectral_densities_match_reference_values():
+    """renormalizer/sbm/lib.py helpers; expected numbers printed by the reference in the dev container
+    (OhmicSDF(0.05, 20): reno(1.0), Wang1(4); ColeDavidsonSDF(1, 2, 0.5, 50).reno(0.5); level counts of
+    param2mollist(0.05, 1, 20, 1, 6))"""
+    from renormalizer_amd import sbm
+    s = sbm.OhmicSDF(0.05, Quantity(20))
+    assert abs(s.reno(1.0) - 0.8839145141900421) < 1e-14
+    omega, c2 = s.Wang1(4)
+    assert np.allclose(omega, [4.46287103, 10.21651248, 18.32581464, 32.18875825], rtol=1e-9)
+    assert np.allclose(c2, [3.98344356, 20.87542543, 67.16709643, 207.22323152], rtol=1e-9)
+    cd = sbm.ColeDavidsonSDF(1.0, 2.0, 0.5, 50.0)
+    assert abs(cd.reno(0.5) - 0.7519293232952473) < 1e-13
+    omega, c2 = cd.Wang1(5, nsamples=200000)
+    assert len(omega) == 5 and np.all(np.diff(omega) > 0) and np.all(c2 > 0)
+    assert abs(sbm.DebyeSDF(0.3, 2.0).func(2.0) - 0.3) < 1e-15
+    model = sbm.param2mollist(0.05, Quantity(1), Quantity(20), 1, 6)
+    assert list(model.pbond_list) == [2, 4, 4, 4, 4, 4, 8]
+    delta, cut = s.adiabatic_renormalization(Quantity(1), 1)
+    assert abs(delta - 0.8784670041569083) < 1e-12 and abs(cut - delta) < 1e-15      # SURVEY section 8(c)
