@@ -159,3 +159,33 @@ def test_hubbard_two_component_qn_dmrg_and_imaginary_time():
     trace, _ = hub.imaginary_time(start, mpo, tol=1e-7)
     assert abs(trace[-1] - exact) < 1e-5 and len(trace) < 100
     assert all(b <= a + 1e-9 for a, b in zip(trace, trace[1:]))       # monotone cooling
+
+
+def test_optical_ssh_ground_state_and_correlations():
+    """example/ssh.py: hopping coupled to the difference of neighbouring oscillator coordinates (three-site operator
+    products in the MPO), two-site DMRG against the lowest eigenvalue of the dense one-electron Hamiltonian, and the
+    observables the example reports (operator products through ``Mpo @ Mpo``)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "examples", "ssh.py")
+    spec = importlib.util.spec_from_file_location("ssh_example", path)
+    ssh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ssh)
+    for nsites, periodic in ((2, True), (3, False)):
+        model = ssh.ssh_model(nsites, nboson_max=3, periodic=periodic)
+        dense = Mpo(model).todense()
+        # site order e0 ph0 e1 ph1 ...: one-electron sector
+        dims = list(model.pbond_list)
+        idx = np.indices(dims).reshape(len(dims), -1)
+        sector = idx[0::2].sum(axis=0) == 1
+        exact = np.linalg.eigvalsh(dense[np.ix_(sector, sector)])[0]
+        energy, mps = ssh.ground_state(model, 16, nsweeps=8)
+        assert abs(energy - exact) < 1e-9
+        obs = ssh.observables(model, mps)
+        rdm = obs["edof_rdm"]
+        assert abs(np.trace(rdm) - 1) < 1e-10 and np.allclose(rdm, rdm.conj().T, atol=1e-10)
+        assert np.allclose(obs["ni_nj"], np.diag(np.diag(rdm).real), atol=1e-9)      # one electron: n_i n_j = delta_ij n_i
+        assert np.all(obs["phonon_occupations"] > -1e-12)
+        if not periodic:
+            assert obs["phonon_occupations"].max() > 1e-3                            # the coupling dresses the electron
+        if periodic:
+            assert np.allclose(obs["phonon_displacement"], 0, atol=1e-6)              # inversion symmetric
