@@ -862,3 +862,47 @@ def gen_vmf():
 
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("vmf",)):
     gen_vmf()
+
+
+def gen_ofs():
+    """On-the-fly swapping (mp.py:696-757, mpo.py:427-454) with two-site TDVP on the reduced headline Hamiltonian
+    written as a general `Model` (the Holstein class refuses OFS), from a stored random one-exciton state of bond
+    dimension 5 - on product states the two site orders tie at zero entropy and rounding noise decides: site order
+    after every step, populations, energies."""
+    from renormalizer.model import Phonon, Mol, HolsteinModel, Model, Op
+    from renormalizer.mps import Mps, Mpo
+    from renormalizer.utils import Quantity, EvolveConfig, EvolveMethod, CompressConfig, CompressCriteria, OFS
+    nmol, pdim = 4, 4
+    ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), pdim)
+    hol = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
+    out = {}
+    np.random.seed(7)
+    model0 = Model(hol.basis, hol.ham_terms)
+    init = Mps.random(model0, 1, 5, percent=1.0)
+    init.canonicalise()
+    init.normalize("mps_and_coeff")
+    _dump_mps(out, "init_", init)
+    for tag, ofs in (("s", OFS.ofs_s), ("d", OFS.ofs_d), ("ds", OFS.ofs_ds)):
+        model = Model(hol.basis, hol.ham_terms)
+        mpo = Mpo(model)
+        mps = init.copy()
+        mps.model = model
+        mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps2)
+        mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=5, ofs=ofs)
+        orders, vals, energies = [], [], []
+        for _ in range(4):
+            mps = mps.evolve(mpo, 20.0)
+            orders.append([str(b.dofs[0]) for b in mps.model.basis])
+            vals.append([mps.expectation(Mpo(mps.model, Op(r"a^\dagger a", dof))) for dof in hol.e_dofs])
+            energies.append(mps.expectation(mpo))
+        out[f"tdvp_{tag}_orders"] = np.array(orders)
+        out[f"tdvp_{tag}_obs"] = np.array(vals, dtype=complex).real
+        out[f"tdvp_{tag}_energies"] = np.array(energies, dtype=complex).real
+        out[f"tdvp_{tag}_bond_dims"] = np.array(mps.bond_dims)
+        out[f"tdvp_{tag}_mpo_bond_dims"] = np.array(mpo.bond_dims)
+        print(tag, orders, out[f"tdvp_{tag}_obs"][-1], mpo.bond_dims)
+    np.savez_compressed(os.path.join(GOLD, "ofs_holstein_small.npz"), **out)
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("ofs",)):
+    gen_ofs()

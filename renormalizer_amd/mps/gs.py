@@ -133,6 +133,8 @@ def single_sweep(mps, mpo, environ, percent, last_opt_e_idx):
                 res_mps = mps.copy()
                 res_mps._update_mps(cstruct, cidx, qnbigl, qnbigr, percent)
             mps._update_mps(cstruct, cidx, qnbigl, qnbigr, percent)
+            if mps.compress_config.ofs is not None:
+                mpo.try_swap_site(mps.model, mps.compress_config.ofs_swap_jw)     # gs.py:300-301
         else:
             cstruct = [x.reshape(qn_mask.shape) for x in c]
             if cidx == last_opt_e_idx:

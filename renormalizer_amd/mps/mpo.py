@@ -377,6 +377,51 @@ class Mpo:
             self._dev[key] = eng.asdevice(self._mp[i])
         return self._dev[key]
 
+    def try_swap_site(self, new_model, swap_jw: bool = False, tol: float = 1e-13):
+        """Follow an on-the-fly exchange of two neighbouring sites of the state (mps/mpo.py:427-454): ``new_model`` is
+        the model with the new site order.  The reference re-derives the two sites from its symbolic MPO; here the
+        two-site operator W_i W_j is exchanged numerically and split again by quantum-number block (SVD per block,
+        rank revealed at ``tol``), which is exact and gives the bond the rank of the exchanged operator."""
+        diffs = [k for k, (b1, b2) in enumerate(zip(self.model.basis, new_model.basis)) if b1.dofs != b2.dofs]
+        if not diffs:
+            return
+        assert len(diffs) == 2 and diffs[1] - diffs[0] == 1
+        if swap_jw:
+            raise NotImplementedError("Jordan-Wigner sign handling when swapping fermionic sites (swap_jw)")
+        i, j = diffs
+        two = np.tensordot(self._mp[i], self._mp[j], axes=(3, 0)).transpose(0, 3, 4, 1, 2, 5)   # (wl, d2, d2, d1, d1, wr)
+        wl, d2, _, d1, _, wr = two.shape
+        sig2 = np.asarray(self.model.basis[j].sigmaqn).reshape(d2, -1)
+        # quantum number accumulated left of the new bond: left channel + charge transferred by the new first site
+        qrow = (np.asarray(self.qn[i])[:, None, None, :] + sig2[None, :, None, :] - sig2[None, None, :, :]).reshape(wl * d2 * d2, -1)
+        mat = two.reshape(wl * d2 * d2, d1 * d1 * wr)
+        scale = np.abs(mat).max()
+        left_cols, right_rows, chan_qn = [], [], []
+        for q in sorted(set(map(tuple, qrow.tolist()))):
+            rows = np.where((qrow == np.array(q)).all(axis=1))[0]
+            block = mat[rows]
+            cols = np.where(np.abs(block).max(axis=0) > 0)[0]
+            if len(cols) == 0:
+                continue
+            u, sv, vt = np.linalg.svd(block[:, cols], full_matrices=False)
+            keep = sv > tol * max(scale, 1e-300)
+            for k in np.where(keep)[0]:
+                col = np.zeros(mat.shape[0], dtype=mat.dtype)
+                col[rows] = u[:, k]
+                row = np.zeros(mat.shape[1], dtype=mat.dtype)
+                row[cols] = sv[k] * vt[k]
+                left_cols.append(col)
+                right_rows.append(row)
+                chan_qn.append(q)
+        k = len(chan_qn)
+        assert k > 0
+        self._mp[i] = np.ascontiguousarray(np.array(left_cols).T.reshape(wl, d2, d2, k))
+        self._mp[j] = np.ascontiguousarray(np.array(right_rows).reshape(k, d1, d1, wr))
+        self.qn[i + 1] = np.array(chan_qn, dtype=int).reshape(k, -1)
+        self._dev = {key: t for key, t in self._dev.items() if key[0] not in (i, j)}
+        new_model.mpos.clear()
+        self.model = new_model
+
     def apply(self, mp, canonicalise: bool = False):
         """Exact mpo @ mps, bond dimensions multiply (mpo.py:331-389): site = einsum("apqb,cqd->acpbd")."""
         from ..engine import get_engine, idx1, idx2

@@ -817,6 +817,55 @@ class Mps:
             return self.canonicalise()
         return self
 
+    def _ofs_try_swap(self, cstruct, cidx, s_keep, system):
+        """On-the-fly swapping of the two centre sites (mps/mp.py:696-757, J. Chem. Theory Comput. 18, 6437): the
+        two-site tensor is decomposed in the current and in the exchanged site order; the order with the smaller
+        discarded weight at the fixed bond dimension (OFS-D), the smaller entanglement entropy (OFS-S), or the
+        hybrid of the two (OFS-D/S) is kept.  On a swap the model's site order is exchanged; the caller swaps the
+        MPO sites (``Mpo.try_swap_site``).  Returns the decomposition in the new order, or None to keep the old."""
+        from ..model import HolsteinModel, Model
+        from ..utils import OFS, CompressCriteria
+        cfg = self.compress_config
+        if isinstance(self.model, HolsteinModel):
+            raise NotImplementedError("Can't perform OFS on Holstein model")      # its site order is part of the class
+        if cfg.ofs_swap_jw:
+            raise NotImplementedError("Jordan-Wigner sign handling when swapping fermionic sites (ofs_swap_jw)")
+        assert cfg.criteria is CompressCriteria.fixed
+        eng = get_engine()
+        c = eng.asdevice(cstruct)
+        dl, dr = c.shape[0], c.shape[-1]
+        half = (c.ndim - 2) // 2
+        p1, p2 = int(np.prod(c.shape[1:1 + half])), int(np.prod(c.shape[1 + half:-1]))
+        # (dl, p1, p2, dr) -> (dl, p2, p1, dr) with two inner transposes on the device
+        t1 = eng.empty((dl, p2 * dr, p1), c.dtype)
+        eng._check(eng.lib.mpse_transpose_inner(eng.ctx, c.code, t1.ptr, c.ptr, dl, p1, p2 * dr, 0))
+        c2 = eng.empty((dl * p2, p1, dr), c.dtype)
+        eng._check(eng.lib.mpse_transpose_inner(eng.ctx, c.code, c2.ptr, t1.ptr, dl * p2, dr, p1, 0))
+        c2 = c2.reshape((dl,) + tuple(c.shape[1 + half:-1]) + tuple(c.shape[1:1 + half]) + (dr,))
+        qnbigl2, qnbigr2, _ = self._get_big_qn(cidx, swap=True, need_mat=False)
+        U2, SU2, qnl2, V2, SV2, qnr2 = svd_qn.svd_qn(c2, qnbigl2, qnbigr2, self.qntot, system=system)
+        s1, s2 = np.asarray(s_keep, dtype=float), np.asarray(SU2, dtype=float)
+        ent1, ent2 = _vn_entropy(s1 ** 2), _vn_entropy(s2 ** 2)
+        mmax = cfg.bond_dim_max_value
+        loss1 = float((np.sort(s1)[::-1][mmax:] ** 2).sum())
+        loss2 = float((np.sort(s2)[::-1][mmax:] ** 2).sum())
+        if cfg.ofs is OFS.ofs_d:
+            retain = loss1 <= loss2
+        elif cfg.ofs is OFS.ofs_ds:
+            retain = (ent1 <= ent2) if (loss1 < 1e-10 and loss2 < 1e-10) else (loss1 <= loss2)
+        elif cfg.ofs is OFS.ofs_s:
+            retain = ent1 <= ent2
+        else:
+            assert cfg.ofs is OFS.ofs_debug
+            retain = True
+        logger.debug(f"OFS: sites {cidx}, swap: {not retain}, S: {ent1}, {ent2}, loss: {loss1}, {loss2}")
+        if retain:
+            return None
+        basis = list(self.model.basis)
+        basis[cidx[0]:cidx[1] + 1] = basis[cidx[0]:cidx[1] + 1][::-1]
+        self.model = Model(basis, self.model.ham_terms, self.model.dipole, self.model.output_ordering)
+        return U2, SU2, qnl2, V2, SV2, qnr2, qnbigl2, qnbigr2
+
     def _update_mps(self, cstruct, cidx, qnbigl, qnbigr, percent=0):
         """Basis selection update after a DMRG / two-site step, mps/mp.py:651-888 for a single state:
         full block SVD of the centre, m_trunc from the compress config, ``select_basis`` (equal quota per qn
@@ -856,6 +905,10 @@ class Mps:
             SU, SV = np.asarray(SU) ** 2, np.asarray(SV) ** 2
         else:
             U, SU, qnlnew, V, SV, qnrnew = svd_qn.svd_qn(cstruct, qnbigl, qnbigr, self.qntot, system=system)
+            if self.compress_config.ofs is not None and len(cidx) == 2:
+                swapped = self._ofs_try_swap(cstruct, cidx, SU, system)
+                if swapped is not None:
+                    U, SU, qnlnew, V, SV, qnrnew, qnbigl, qnbigr = swapped
         Vt = V.T
         if self.to_right:
             m_trunc = self.compress_config.compute_m_trunc(SU, cidx[0], self.to_right)
@@ -1228,6 +1281,8 @@ def _evolve_tdvp_ps2(self, mpo, evolve_dt) -> "Mps":
             local_steps.append(j)
             qnbigl, qnbigr, _ = mps._get_big_qn([c0, c1], need_mat=False)
             mps._update_mps(mps_t.reshape(ms2.shape), [c0, c1], qnbigl, qnbigr)
+            if mps.compress_config.ofs is not None:
+                mpo.try_swap_site(mps.model, mps.compress_config.ofs_swap_jw)
             if imps == last_idx:
                 continue
             if mps.to_right:

@@ -1,3 +1,3 @@
 from .quantity import Quantity
 from . import constant
-from .configs import CompressConfig, CompressCriteria, OptimizeConfig, EvolveConfig, EvolveMethod
+from .configs import CompressConfig, CompressCriteria, OptimizeConfig, EvolveConfig, EvolveMethod, OFS

@@ -16,9 +16,18 @@ class CompressCriteria(Enum):
     both = "both"
 
 
+class OFS(Enum):
+    """criterion for swapping the two centre sites of a two-site step on the fly (utils/configs.py:27-38)"""
+    ofs_s = "OFS-S"            # smaller entanglement entropy
+    ofs_ds = "OFS-D/S"         # discarded weight, entropy when nothing is discarded
+    ofs_d = "OFS-D"            # smaller discarded weight
+    ofs_debug = "OFS-Debug"    # evaluate both orders, never swap
+
+
 class CompressConfig:
     def __init__(self, criteria=CompressCriteria.threshold, threshold: float = 1e-3, max_bonddim: int = 32,
-                 vmethod: str = "2site", vprocedure=None, vrtol=1e-5, vguess_m=(5, 5)):
+                 vmethod: str = "2site", vprocedure=None, vrtol=1e-5, vguess_m=(5, 5), ofs: OFS = None,
+                 ofs_swap_jw: bool = False):
         if isinstance(criteria, str):
             criteria = getattr(CompressCriteria, criteria)
         if not isinstance(criteria, CompressCriteria):
@@ -36,6 +45,8 @@ class CompressConfig:
         self.vprocedure = vprocedure
         self.vrtol = vrtol
         self.vguess_m = vguess_m
+        self.ofs = ofs
+        self.ofs_swap_jw = ofs_swap_jw
 
     @property
     def threshold(self):

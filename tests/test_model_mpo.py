@@ -139,3 +139,37 @@ def test_sbm_spectral_densities_match_reference_values():
     assert list(model.pbond_list) == [2, 4, 4, 4, 4, 4, 8]
     delta, cut = s.adiabatic_renormalization(Quantity(1), 1)
     assert abs(delta - 0.8784670041569083) < 1e-12 and abs(cut - delta) < 1e-15
+
+
+def test_mpo_try_swap_site_is_exact():
+    """`Mpo.try_swap_site` (mps/mpo.py:427-454): exchanging two neighbouring sites numerically reproduces the MPO
+    built from scratch for the new site order, keeps the total operator (up to the permutation of the site axes) and
+    labels the new bond with quantum numbers"""
+    from renormalizer_amd.model import heisenberg_ops
+    basis = [BasisHalfSpin(i) for i in range(4)] + [BasisSHO("v", 1.0, 3)]
+    ham = heisenberg_ops(4) + [Op("sigma_z", 2) * Op(r"b^\dagger + b", "v") * 0.3, Op(r"b^\dagger b", "v", 1.0)]
+    model = Model(basis, ham)
+    mpo = Mpo(model)
+    for a, b in [(1, 2), (3, 4), (0, 1), (1, 2)]:
+        order = list(mpo.model.basis)
+        dims = [x.nbas for x in order]
+        n = len(dims)
+        before = mpo.todense().reshape(dims * 2)
+        order[a], order[b] = order[b], order[a]
+        new_model = Model(order, model.ham_terms)
+        mpo.try_swap_site(new_model)
+        perm = list(range(n))
+        perm[a], perm[b] = perm[b], perm[a]
+        got = mpo.todense().reshape([x.nbas for x in order] * 2)
+        assert np.abs(got - before.transpose(perm + [n + p for p in perm])).max() < 1e-13
+        assert np.abs(Mpo(new_model).todense().reshape(got.shape) - got).max() < 1e-13
+        assert mpo.model is new_model and len(mpo.qn[a + 1]) == mpo.bond_dims[a + 1]
+        assert mpo.bond_dims == Mpo(new_model).bond_dims
+    mpo.try_swap_site(mpo.model)                      # nothing to do
+    electron = Model([BasisSimpleElectron(0), BasisSimpleElectron(1), BasisSHO("v", 1.0, 2)],
+                     [Op(r"a^\dagger a", [0, 1], 0.5), Op(r"a^\dagger a", [1, 0], 0.5), Op(r"a^\dagger a", 1) * Op("x", "v")])
+    m2 = Mpo(electron)
+    swapped = Model([electron.basis[0], electron.basis[2], electron.basis[1]], electron.ham_terms)
+    m2.try_swap_site(swapped)
+    assert np.abs(m2.todense() - Mpo(swapped).todense()).max() < 1e-13
+    assert sorted(map(tuple, m2.qn[2].tolist())) == sorted(map(tuple, Mpo(swapped).qn[2].tolist()))
