@@ -147,13 +147,15 @@ int mpse_transpose_inner(mpse_ctx* ctx, int dtype, void* out, const void* in,
 
 /* Extents of a (one- or two-site) centre and its surroundings. */
 typedef struct {
-  int64_t Dl_bra, Dl_ket;   /* left bond of bra / ket (equal for an effective Hamiltonian) */
+  int64_t Dl_bra, Dl_ket;   /* left bond of bra / ket (equal for an effective Hamiltonian used by Lanczos / Davidson;
+                               mpse_heff_apply alone accepts bra != ket: H C projected onto another state's bonds) */
   int64_t Dr_bra, Dr_ket;
   int64_t d0, d1;           /* physical dims of the centre site(s); d1 unused for 0/1-site */
   int64_t danc;             /* ancilla dim of an MPDM site, 1 for an MPS */
   int64_t wl, wm, wr;       /* mpo bonds: left, middle (2-site only), right */
   int64_t env_unit;         /* mpse_env_update only: 1-based MPO-bond channel b with env[:, b, :] == identity
                                (see mpse_env_unit_channel); 0 = none / unknown */
+  int64_t danc1;            /* ancilla dim of the second site of a two-site MPDM centre; 0 = same as danc */
 } mpse_dims;
 
 /* Environment update, replaces mps/lib.py:169-250 contract_one_site
@@ -180,7 +182,7 @@ int mpse_env_unit_channel(mpse_ctx* ctx, int dtype, const void* env, int64_t D, 
 /* Effective Hamiltonian applied to the centre, replaces the closures built by
  * mps/hop_expr.py:57-115 (0-site abc,lbk,ck->al ; 1-site abc,bdef,lfk,cek->adl ;
  * 2-site abc,bdef,fghj,ljk,cehk->adgl ; ancilla variants), order (L.C).W.R.
- *   L (Dl,wl,Dl)  R (Dr,wr,Dr)  W0 (wl,d0,d0,wm|wr)  W1 (wm,d1,d1,wr)  C/out (Dl,d0[,danc][,d1[,danc]],Dr)
+ *   L (Dl,wl,Dl)  R (Dr,wr,Dr)  W0 (wl,d0,d0,wm|wr)  W1 (wm,d1,d1,wr)  C (Dl_ket,d0[,danc][,d1[,danc1]],Dr_ket), out the same with the bra bonds
  * nsite in {0,1,2}; for nsite==0 wl==wr is the shared mpo bond. */
 typedef struct {
   int nsite;

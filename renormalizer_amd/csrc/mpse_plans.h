@@ -134,61 +134,63 @@ inline void push_w(Plan& p, int wbuf, int w_dtype, int tin, int tout, int t_dtyp
        /*C=T_out[a]: (d,f), n*/ i1(d * wr, N), i1(N, 1), na, 0, d * N, d * wr * N);
 }
 
-// Effective Hamiltonian matvec, mps/hop_expr.py:57-115.
+// Effective Hamiltonian matvec, mps/hop_expr.py:57-115.  The bra-side bonds (rows of L / R, bonds of `out`) may
+// differ from the ket-side bonds (columns of L / R, bonds of C): that is the projection of H C onto another
+// state's bond spaces used by the variational compression (mps/mp.py:513-650); the Krylov / Davidson drivers
+// require them equal.
 inline Plan plan_heff(int dtype, const mpse_heff& h) {
   Plan p;
   const mpse_dims& s = h.dims;
   const int64_t Dl = s.Dl_ket, Dr = s.Dr_ket, wl = s.wl, wr = s.wr;
+  const int64_t Dlb = s.Dl_bra > 0 ? s.Dl_bra : Dl, Drb = s.Dr_bra > 0 ? s.Dr_bra : Dr;
   const int64_t anc = s.danc > 0 ? s.danc : 1;
-  if (s.Dl_bra != s.Dl_ket || s.Dr_bra != s.Dr_ket) {
-    p.error = "heff: bra/ket bonds must agree";
-    return p;
-  }
   if (h.nsite == 0) {
     // abc,lbk,ck->al (hop_expr.py:63-67): T[a,b,k] = L[(a,b),c] S[c,k] ; out[a,l] = T[a,(b,k)] R[l,(b,k)]
     if (wl != wr) {
       p.error = "heff(0-site): wl != wr";
       return p;
     }
-    p.tmp_elems[0] = Dl * wl * Dr;
-    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, Dr, h.l_unit, false);
-    push_times_env(p, B_T1, dtype, B_R, h.r_dtype, B_OUT, Dl, 1, wr, Dr, Dr, h.r_unit);
+    p.tmp_elems[0] = Dlb * wl * Dr;
+    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dlb, wl, Dl, Dr, h.l_unit, false);
+    push_times_env(p, B_T1, dtype, B_R, h.r_dtype, B_OUT, Dlb, 1, wr, Dr, Drb, h.r_unit);
     return p;
   }
   if (h.nsite == 1) {
     // abc,bdef,lfk,cek->adl (hop_expr.py:75-79); ancilla cegk->adgl (87-91)
     const int64_t d = s.d0, N = d * anc * Dr, Nb = anc * Dr;
-    p.tmp_elems[0] = Dl * wl * N;
-    p.tmp_elems[1] = Dl * d * wr * Nb;
+    p.tmp_elems[0] = Dlb * wl * N;
+    p.tmp_elems[1] = Dlb * d * wr * Nb;
     // T1[a,b,(e,g,k)] = sum_c L[(a,b),c] C[c,(e,g,k)]
-    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, N, h.l_unit, true);
+    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dlb, wl, Dl, N, h.l_unit, true);
     // T2[a,d,f,(g,k)] = sum_{b,e} W[b,d,e,f] T1[a,b,e,(g,k)]
-    push_w(p, B_W0, h.w_dtype, B_T1, B_T2, dtype, Dl, wl, d, wr, Nb);
+    push_w(p, B_W0, h.w_dtype, B_T1, B_T2, dtype, Dlb, wl, d, wr, Nb);
     // out[(a,d,g),l] = sum_{f,k} T2[a,d,f,g,k] R[l,f,k]
-    push_times_env(p, B_T2, dtype, B_R, h.r_dtype, B_OUT, Dl * d, anc, wr, Dr, Dr, h.r_unit);
+    push_times_env(p, B_T2, dtype, B_R, h.r_dtype, B_OUT, Dlb * d, anc, wr, Dr, Drb, h.r_unit);
     return p;
   }
   if (h.nsite == 2) {
-    // abc,bdef,fghj,ljk,cehk->adgl (hop_expr.py:99-103); ancilla cemhnk->admgnl (111-115)
+    // abc,bdef,fghj,ljk,cehk->adgl (hop_expr.py:99-103); ancilla cemhnk->admgnl (111-115): the two ancilla legs m, n
+    // have the sizes of their own sites (a0, a1)
     const int64_t d0 = s.d0, d1 = s.d1, wm = s.wm;
-    const int64_t n2 = anc * Dr;            // (n,k): trailing block after h
-    const int64_t n1 = anc * d1 * n2;       // (m,h,n,k): trailing block after e
+    const int64_t a0 = anc, a1 = s.danc1 > 0 ? s.danc1 : anc;
+    const int64_t n2 = a1 * Dr;             // (n,k): trailing block after h
+    const int64_t n1 = a0 * d1 * n2;        // (m,h,n,k): trailing block after e
     const int64_t N = d0 * n1;
-    p.tmp_elems[0] = Dl * wl * N;
-    p.tmp_elems[1] = Dl * d0 * wm * n1;
-    p.tmp_elems[2] = Dl * d0 * anc * d1 * wr * n2;
+    p.tmp_elems[0] = Dlb * wl * N;
+    p.tmp_elems[1] = Dlb * d0 * wm * n1;
+    p.tmp_elems[2] = Dlb * d0 * a0 * d1 * wr * n2;
     // T1[a,b,(e,m,h,n,k)]
-    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dl, wl, Dl, N, h.l_unit, true);
+    push_env_times(p, B_L, h.l_dtype, B_C, dtype, B_T1, Dlb, wl, Dl, N, h.l_unit, true);
     // T2[a,d,f,(m,h,n,k)]
-    push_w(p, B_W0, h.w_dtype, B_T1, B_T2, dtype, Dl, wl, d0, wm, n1);
+    push_w(p, B_W0, h.w_dtype, B_T1, B_T2, dtype, Dlb, wl, d0, wm, n1);
     // T3[(a,d),m,g,j,(n,k)] = sum_{f,h} W1[f,g,h,j] T2[(a,d),f,m,h,(n,k)]   batch (a,d); one step per m
-    for (int64_t m = 0; m < anc; ++m)
+    for (int64_t m = 0; m < a0; ++m)
       push(p, B_W1, 0, h.w_dtype, 0, B_T2, m * d1 * n2, dtype, 0, B_T3, m * d1 * wr * n2,
            i2(d1, wr, d1 * wr, 1), i2(wm, d1, d1 * d1 * wr, wr),
-           /*B: k=(f | h)*/ i2(wm, d1, anc * d1 * n2, n2), i1(n2, 1),
-           /*C: (g,j),(n,k)*/ i1(d1 * wr, n2), i1(n2, 1), Dl * d0, 0, wm * anc * d1 * n2, anc * d1 * wr * n2);
+           /*B: k=(f | h)*/ i2(wm, d1, a0 * d1 * n2, n2), i1(n2, 1),
+           /*C: (g,j),(n,k)*/ i1(d1 * wr, n2), i1(n2, 1), Dlb * d0, 0, wm * a0 * d1 * n2, a0 * d1 * wr * n2);
     // out[(a,d,m,g,n),l] = sum_{j,k} T3[a,d,m,g,j,n,k] R[l,j,k]
-    push_times_env(p, B_T3, dtype, B_R, h.r_dtype, B_OUT, Dl * d0 * anc * d1, anc, wr, Dr, Dr, h.r_unit);
+    push_times_env(p, B_T3, dtype, B_R, h.r_dtype, B_OUT, Dlb * d0 * a0 * d1, a1, wr, Dr, Drb, h.r_unit);
     return p;
   }
   p.error = "heff: nsite must be 0, 1 or 2";

@@ -436,10 +436,12 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
   if (!cplx && dt_im != 0.0)
     return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: complex time step needs a complex128 centre tensor");
   const mpse_dims& s = h->dims;
+  if ((s.Dl_bra > 0 && s.Dl_bra != s.Dl_ket) || (s.Dr_bra > 0 && s.Dr_bra != s.Dr_ket))
+    return mpse_fail(ctx, MPSE_ERR_SHAPE, "expm_lanczos: the effective Hamiltonian must be square (bra bonds == ket bonds)");
   const int64_t anc = s.danc > 0 ? s.danc : 1;
   int64_t n = s.Dl_ket * s.Dr_ket;
   if (h->nsite >= 1) n *= s.d0 * anc;
-  if (h->nsite == 2) n *= s.d1 * anc;
+  if (h->nsite == 2) n *= s.d1 * (s.danc1 > 0 ? s.danc1 : anc);
   if (n <= 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "expm_lanczos: empty centre tensor");
   if (max_dim <= 0 || max_dim > 128) max_dim = 128;
   const size_t es = dtype_size(dtype);

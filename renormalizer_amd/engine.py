@@ -46,7 +46,8 @@ class mpse_gemm_desc(C.Structure):
 class mpse_dims(C.Structure):
     _fields_ = [("Dl_bra", C.c_int64), ("Dl_ket", C.c_int64), ("Dr_bra", C.c_int64), ("Dr_ket", C.c_int64),
                 ("d0", C.c_int64), ("d1", C.c_int64), ("danc", C.c_int64),
-                ("wl", C.c_int64), ("wm", C.c_int64), ("wr", C.c_int64), ("env_unit", C.c_int64)]
+                ("wl", C.c_int64), ("wm", C.c_int64), ("wr", C.c_int64), ("env_unit", C.c_int64),
+                ("danc1", C.c_int64)]
 
 
 class mpse_heff(C.Structure):

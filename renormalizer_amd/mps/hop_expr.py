@@ -29,9 +29,15 @@ class Hop:
         h = mpse_heff()
         h.nsite = nsite
         d = h.dims
-        d.Dl_bra = d.Dl_ket = cshape[0]
-        d.Dr_bra = d.Dr_ket = cshape[-1]
+        d.Dl_ket, d.Dr_ket = cshape[0], cshape[-1]
+        # rows of the environments: equal to the ket bonds for H itself, the bonds of another state when H C is
+        # projected onto it (variational compression); the result then carries those bonds
+        d.Dl_bra, d.Dr_bra = self.l.shape[0], self.r.shape[0]
+        assert self.l.shape[2] == cshape[0] and self.r.shape[2] == cshape[-1], (self.l.shape, self.r.shape, cshape)
+        self.oshape = (self.l.shape[0],) + cshape[1:-1] + (self.r.shape[0],)
+        self.square = self.oshape == cshape
         d.danc = cshape[2] if ancilla else 1
+        d.danc1 = cshape[4] if (ancilla and nsite == 2) else 0          # neighbouring sites may differ in size
         d.wl, d.wr = self.l.shape[1], self.r.shape[1]
         d.d0 = self.cmo[0].shape[1] if nsite >= 1 else 1
         d.d1 = self.cmo[1].shape[1] if nsite == 2 else 1
@@ -51,7 +57,7 @@ class Hop:
         if self.operator_is_complex and not c.is_complex:
             c = c.to_complex()
         c = c.reshape(self.cshape)
-        out = eng.empty(self.cshape, c.dtype)
+        out = eng.empty(self.oshape, c.dtype)
         eng._check(eng.lib.mpse_heff_apply(eng.ctx, c.code, C.byref(self.heff), c.ptr, out.ptr))
         return out
 

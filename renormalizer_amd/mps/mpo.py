@@ -532,9 +532,12 @@ class Mpo:
         return self._like(arrays, qn, self.qntot + other.qntot)
 
     def contract(self, mps, algo="svd"):
-        """mpo @ mps followed by canonicalise + compress (mpo.py:391-425)."""
+        """mpo @ mps followed by canonicalise + compress, or by the variational compression of the product
+        (mpo.py:391-425)."""
+        if algo == "variational":
+            return mps.variational_compress(self)
         if algo != "svd":
-            raise NotImplementedError("only the svd contraction is implemented")
+            raise ValueError(f"unknown contraction algorithm {algo}")
         new = self.apply(mps)
         new.canonicalise()
         new.compress()

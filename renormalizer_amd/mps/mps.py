@@ -14,7 +14,7 @@ import numpy as np
 from ..engine import DeviceTensor, get_engine
 from ..lib.krylov import expm_krylov
 from ..model import Model, Op, OpSum
-from ..utils import CompressConfig, EvolveConfig, EvolveMethod, OptimizeConfig
+from ..utils import CompressConfig, CompressCriteria, EvolveConfig, EvolveMethod, OptimizeConfig
 from . import svd_qn
 from .hop_expr import hop_expr
 from .lib import Environ, contract_one_site
@@ -761,6 +761,78 @@ class Mps:
         return self, np.array([np.pad(s, (0, width - len(s))) for s in s_list])
 
     # ------------------------------------------------------------------ DMRG support
+    def variational_compress(self, mpo=None, guess=None):
+        """Approximation of ``mpo @ self`` at the bond dimensions of ``compress_config.vprocedure`` by sweeps that
+        maximise the overlap with the exact product (mps/mp.py:513-650): per step the effective operator
+        <guess| mpo |self> around the centre is applied to the centre of ``self`` - an effective-Hamiltonian product
+        whose bra bonds are those of the guess - and the result replaces the centre of the guess through the
+        basis-selection update (1-site or 2-site, ``vmethod``); converged when a sweep without forced basis
+        mixing moves the state by less than ``vrtol``.  ``self`` is not modified, ``guess`` is.
+
+        Without a guess the reference applies an SVD-compressed copy of the MPO (bond ``vguess_m[0]``) to an
+        SVD-compressed copy of the state (bond ``vguess_m[1]``); here the full MPO is applied to the compressed state
+        and the product is compressed to ``vguess_m[0] * vguess_m[1]``, the bond dimension that product would have."""
+        from ..utils import CompressConfig, CompressCriteria
+        if mpo is None:
+            raise NotImplementedError("Recommend to use svd to compress a single mps/mpo/mpdm.")
+        eng = get_engine()
+        if guess is None:
+            small = self.copy().canonicalise()
+            small.compress(temp_m_trunc=self.compress_config.vguess_m[1])
+            guess = mpo.apply(small).canonicalise()
+            guess.compress(temp_m_trunc=self.compress_config.vguess_m[0] * self.compress_config.vguess_m[1])
+            guess.compress_config = self.compress_config.copy()
+        mps = guess
+        mps.ensure_left_canonical()
+        procedure, method = mps.compress_config.vprocedure, mps.compress_config.vmethod
+        assert method in ("1site", "2site")
+        n = mps.site_num
+        environ = Environ(self, mpo, "L", mps_conj=mps.conj())
+        mps_old, converged = None, False
+        for isweep, (cc, percent) in enumerate(procedure):
+            if isinstance(cc, CompressConfig):
+                mps.compress_config = cc
+            else:
+                mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=int(cc))
+            for imps in mps.iter_idx_list(full=True):
+                if method == "2site" and ((mps.to_right and imps == n - 1) or (not mps.to_right and imps == 0)):
+                    break
+                lmethod, rmethod = ("System", "Enviro") if mps.to_right else ("Enviro", "System")
+                if method == "1site":
+                    lidx, cidx, ridx = imps - 1, [imps], imps + 1
+                elif mps.to_right:
+                    lidx, cidx, ridx = imps - 1, [imps, imps + 1], imps + 2
+                else:
+                    lidx, cidx, ridx = imps - 2, [imps - 1, imps], imps + 1
+                conj = mps.conj()
+                ltensor = environ.GetLR("L", lidx, self, mpo, itensor=None, method=lmethod, mps_conj=conj)
+                rtensor = environ.GetLR("R", ridx, self, mpo, itensor=None, method=rmethod, mps_conj=conj)
+                qnbigl, qnbigr, qnmat = mps._get_big_qn(cidx)
+                qn_mask = svd_qn.get_qn_mask(qnmat, mps.qntot)
+                if method == "1site":
+                    cms = self[cidx[0]]
+                else:
+                    a, b = self[cidx[0]], self[cidx[1]]
+                    cms = eng.matmul(a.reshape(-1, a.shape[-1]), b.reshape(b.shape[0], -1)).reshape(a.shape[:-1] + b.shape[1:])
+                hop = hop_expr(ltensor, rtensor, [mpo.device(i, eng) for i in cidx], cms.shape)
+                cout = hop(cms)
+                assert tuple(cout.shape) == qn_mask.shape, (cout.shape, qn_mask.shape)
+                mask = eng.asdevice(qn_mask.astype(np.float64))           # symmetry-forbidden entries are rounding noise
+                eng._check(eng.lib.mpse_mul_real(eng.ctx, cout.code, cout.ptr, mask.ptr, cout.size))
+                mps._update_mps(cout, cidx, qnbigl, qnbigr, percent)
+                if mps.compress_config.ofs is not None:
+                    raise NotImplementedError("OFS for variational compress not implemented")
+            mps._switch_direction()
+            if isweep > 0 and percent == 0:
+                error = mps.distance(mps_old) / np.sqrt(abs(mps.dot(mps, self_is_conj=False).real))
+                if error < mps.compress_config.vrtol:
+                    converged = True
+                    break
+            mps_old = mps.copy()
+        if not converged:
+            logger.warning("Variational compress is not converged! Please increase the procedure!")
+        return mps.canonicalise()
+
     @property
     def is_left_canonical(self):
         """mps/mp.py:192-197 (position of the qn centre only)"""

@@ -160,9 +160,10 @@ def make_heff(eng, l, r, cmo, cshape):
     h = E.mpse_heff()
     h.nsite = ns
     d = h.dims
-    d.Dl_bra = d.Dl_ket = cshape[0]
-    d.Dr_bra = d.Dr_ket = cshape[-1]
+    d.Dl_ket, d.Dr_ket = cshape[0], cshape[-1]
+    d.Dl_bra, d.Dr_bra = l.shape[0], r.shape[0]
     d.danc = cshape[2] if (ns >= 1 and len(cshape) == 2 * ns + 2) else 1
+    d.danc1 = cshape[4] if (ns == 2 and len(cshape) == 6) else 0
     d.wl, d.wr = l.shape[1], r.shape[1]
     d.d0 = cmo[0].shape[1] if ns >= 1 else 1
     d.d1 = cmo[1].shape[1] if ns == 2 else 1
@@ -179,7 +180,7 @@ def make_heff(eng, l, r, cmo, cshape):
 def dev_heff_apply(eng, l, r, cmo, c):
     h, keep = make_heff(eng, l, r, cmo, c.shape)
     Cd = eng.asdevice(c)
-    out = eng.empty(c.shape, c.dtype)
+    out = eng.empty((l.shape[0],) + c.shape[1:-1] + (r.shape[0],), c.dtype)
     eng._check(eng.lib.mpse_heff_apply(eng.ctx, Cd.code, C.byref(h), Cd.ptr, out.ptr))
     return out.to_host()
 
@@ -199,6 +200,35 @@ def test_heff_apply_golden(eng, golden_dir):
         g = lambda n: z[f"hop_{k}_{n}"]
         cmo = [g(f"w{j}") for j in range(int(g("nsite")))]
         assert _relerr(dev_heff_apply(eng, g("l"), g("r"), cmo, g("c")), g("out")) < 1e-12
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_heff_rectangular_and_unequal_ancillas(eng, cplx):
+    """bra bonds != ket bonds (H C projected onto another state's bond spaces, variational compression) and two-site
+    density-operator centres whose sites differ in size (ancilla legs of different dimension), against einsum;
+    the Krylov driver refuses a rectangular operator"""
+    rng = np.random.default_rng(19)
+    for (Dlb, Dlk, Drb, Drk, d0, a0, d1, a1, wl, wm, wr) in ((20, 8, 36, 10, 4, 4, 2, 2, 5, 4, 5), (7, 7, 9, 9, 2, 2, 4, 4, 3, 4, 3),
+                                                            (70, 33, 20, 65, 3, 1, 5, 1, 4, 3, 2)):
+        l, r = _rand(rng, (Dlb, wl, Dlk), cplx), _rand(rng, (Drb, wr, Drk), cplx)
+        w0, w1 = _rand(rng, (wl, d0, d0, wm), False), _rand(rng, (wm, d1, d1, wr), False)
+        if a0 == 1:
+            c = _rand(rng, (Dlk, d0, d1, Drk), cplx)
+            ref = np.einsum("abc,bdef,fghj,ljk,cehk->adgl", l, w0, w1, r, c, optimize=True)
+        else:
+            c = _rand(rng, (Dlk, d0, a0, d1, a1, Drk), cplx)
+            ref = np.einsum("abc,bdef,fghj,ljk,cemhnk->admgnl", l, w0, w1, r, c, optimize=True)
+        assert _relerr(dev_heff_apply(eng, l, r, [w0, w1], c), ref) < 1e-12
+        w = _rand(rng, (wl, d0, d0, wr), False)
+        c = _rand(rng, (Dlk, d0, Drk) if a0 == 1 else (Dlk, d0, a0, Drk), cplx)
+        ref = np.einsum("abc,bdef,lfk,cek->adl" if a0 == 1 else "abc,bdef,lfk,cegk->adgl", l, w, r, c, optimize=True)
+        assert _relerr(dev_heff_apply(eng, l, r, [w], c), ref) < 1e-12
+    h, keep = make_heff(eng, _rand(rng, (5, 2, 4), True), _rand(rng, (4, 2, 4), True), [_rand(rng, (2, 2, 2, 2), False)], (4, 2, 4))
+    v = eng.asdevice(_rand(rng, (4, 2, 4), True))
+    out = eng.empty((4, 2, 4), np.complex128)
+    nv = C.c_int()
+    st = eng.lib.mpse_expm_lanczos(eng.ctx, v.code, C.byref(h), 0.0, -0.1, v.ptr, out.ptr, 1e-5, 1e-8, 0, C.byref(nv))
+    assert st == E.MPSE_ERR_SHAPE if hasattr(E, "MPSE_ERR_SHAPE") else st != 0
 
 
 @pytest.mark.parametrize("cplx", [False, True])

@@ -48,9 +48,10 @@ def emu_heff(lib, l, r, cmo, c, l_unit=0, r_unit=0):
     if ns >= 1 and c.ndim == 2 * ns + 2:
         anc = c.shape[2]
     d = h.dims
-    d.Dl_bra = d.Dl_ket = c.shape[0]
-    d.Dr_bra = d.Dr_ket = c.shape[-1]
+    d.Dl_ket, d.Dr_ket = c.shape[0], c.shape[-1]
+    d.Dl_bra, d.Dr_bra = l.shape[0], r.shape[0]          # rows of the environments: the bonds of the result
     d.danc = anc
+    d.danc1 = c.shape[4] if (ns == 2 and c.ndim == 6) else 0
     d.wl, d.wr = l.shape[1], r.shape[1]
     d.d0 = cmo[0].shape[1] if ns >= 1 else 1
     d.d1 = cmo[1].shape[1] if ns == 2 else 1
@@ -63,7 +64,7 @@ def emu_heff(lib, l, r, cmo, c, l_unit=0, r_unit=0):
         h.w_dtype = E.dtype_code(keep[2].dtype)
     if ns == 2:
         h.W1 = keep[3].ctypes.data
-    out = np.full(c.shape, np.nan, dtype=c.dtype)
+    out = np.full((l.shape[0],) + c.shape[1:-1] + (r.shape[0],), np.nan, dtype=c.dtype)
     st = lib.emu_heff_apply(dt, C.byref(h), keep[-1].ctypes.data, out.ctypes.data)
     assert st == 0
     return out
@@ -160,6 +161,38 @@ def test_heff_plans_odd_shapes(emu):
             c = _rand(rng, (Dl, Dr), cplx)
             ref = orc.hop_apply(l, r0, [], c)
             assert np.abs(emu_heff(emu, l, r0, [], c) - ref).max() < 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_heff_plans_rectangular(emu, cplx):
+    """bra bonds != ket bonds: H C projected onto another state's bond spaces (variational compression,
+    mps/mp.py:513-650), all site counts, with and without the ancilla leg; unit channels must be ignored there"""
+    rng = np.random.default_rng(23)
+    for (Dlb, Dlk, Drb, Drk, d0, d1, wl, wm, wr, anc) in ((3, 5, 4, 2, 2, 3, 2, 3, 2, 1), (6, 2, 1, 5, 3, 2, 3, 2, 4, 2),
+                                                          (4, 4, 2, 6, 2, 2, 2, 2, 3, 1)):
+        l = _rand(rng, (Dlb, wl, Dlk), cplx)
+        r = _rand(rng, (Drb, wr, Drk), cplx)
+        w0 = _rand(rng, (wl, d0, d0, wr), False)
+        c = _rand(rng, (Dlk, d0, Drk) if anc == 1 else (Dlk, d0, anc, Drk), cplx)
+        ref = np.einsum("abc,bdef,lfk,cek->adl" if anc == 1 else "abc,bdef,lfk,cegk->adgl", l, w0, r, c)
+        # a unit-channel hint on a rectangular environment is meaningless and must be ignored
+        got = emu_heff(emu, l, r, [w0], c, l_unit=int(Dlb != Dlk), r_unit=int(Drb != Drk))
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-11 * np.abs(ref).max()
+        w0 = _rand(rng, (wl, d0, d0, wm), False)
+        w1 = _rand(rng, (wm, d1, d1, wr), False)
+        if anc == 1:
+            c = _rand(rng, (Dlk, d0, d1, Drk), cplx)
+            ref = np.einsum("abc,bdef,fghj,ljk,cehk->adgl", l, w0, w1, r, c)
+        else:
+            c = _rand(rng, (Dlk, d0, anc, d1, anc + 1, Drk), cplx)      # the two ancilla legs differ (sites of different size)
+            ref = np.einsum("abc,bdef,fghj,ljk,cemhnk->admgnl", l, w0, w1, r, c)
+        got = emu_heff(emu, l, r, [w0, w1], c)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-11 * np.abs(ref).max()
+        r0 = _rand(rng, (Drb, wl, Drk), cplx)
+        c = _rand(rng, (Dlk, Drk), cplx)
+        ref = np.einsum("abc,lbk,ck->al", l, r0, c)
+        got = emu_heff(emu, l, r0, [], c)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-11 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("cplx", [False, True])
