@@ -511,11 +511,13 @@ def gen_thermal():
     model = parameter.holstein_model
     beta = Quantity(298, "K").to_beta()
     out = {"beta": np.array(beta), "gs_zpe": np.array(model.gs_zpe)}
-    for tag, method, nsteps in (("pc", EvolveMethod.prop_and_compress, 10), ("ps", EvolveMethod.tdvp_ps, 10)):
+    for tag, method, nsteps in (("pc", EvolveMethod.prop_and_compress, 10), ("ps", EvolveMethod.tdvp_ps, 10),
+                                ("ps2", EvolveMethod.tdvp_ps2, 10)):
         init = MpDm.max_entangled_ex(model)
-        if tag == "ps":
+        if tag in ("ps", "ps2"):
             init.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=12)
-        tp = ThermalProp(init, evolve_config=EvolveConfig(method, adaptive=False, guess_dt=0.1 / 1j))
+        tp = ThermalProp(init, evolve_config=EvolveConfig(method, adaptive=False, guess_dt=0.1 / 1j),
+                         auto_expand=(tag != "ps2"))
         if tag == "ps":
             _dump_mps(out, "ps_init_", tp.latest_mps)      # the expanded D = 12 state the sweeps start from
         tp.evolve(evolve_dt=beta / 2j / nsteps, nsteps=nsteps)
