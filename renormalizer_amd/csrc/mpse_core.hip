@@ -105,6 +105,7 @@ int mpse_ctx_create(int device, mpse_ctx** out) {
     delete ctx;
     return MPSE_ERR_HIP;
   }
+  (void)hipMemset(ctx->dscratch + (size_t(1) << 16) - 8, 0, 8 * sizeof(double));
   if (hipHostGetDevicePointer((void**)&ctx->pinned_dev, ctx->pinned, 0) != hipSuccess) ctx->pinned_dev = nullptr;
   ctx->pinned[4095] = 0.0;      // sequence slot of publish_and_wait
   ctx->stage_size = size_t(8) << 20;

@@ -52,7 +52,8 @@ struct mpse_ctx {
   double* pinned = nullptr;     // 4096 doubles
   double* pinned_dev = nullptr; // the same buffer as the device sees it (mapped, host coherent)
   unsigned long long publish_seq = 0;
-  double* dscratch = nullptr;   // device scratch for reductions (1<<16 doubles)
+  double* dscratch = nullptr;   // device scratch for reductions (1<<16 doubles); the last 8 hold flag words
+  unsigned int flag_gen = 0;    // generation stamp of the Lanczos convergence flag (no per-check memset)
 };
 
 int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...);

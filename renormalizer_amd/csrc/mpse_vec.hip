@@ -208,10 +208,12 @@ struct Coefs {
   double im[128];
 };
 
-// res = sum_{i<m} coef_i V_i ; if prev != null also flag |res - prev| > atol + rtol |res| (numpy allclose)
+// res = sum_{i<m} coef_i V_i ; if prev != null also flag |res - prev| > atol + rtol |res| (numpy allclose): the flag
+// word is raised to this check's generation stamp, so it never has to be cleared between checks
 template <bool CPLX>
 __global__ void k_lincomb(double* __restrict__ res, const double* __restrict__ V, long long n, int m, Coefs c,
-                          const double* __restrict__ prev, double rtol, double atol, int* __restrict__ flag) {
+                          const double* __restrict__ prev, double rtol, double atol, unsigned int* __restrict__ flag,
+                          unsigned int gen) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   bool bad = false;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -237,7 +239,7 @@ __global__ void k_lincomb(double* __restrict__ res, const double* __restrict__ V
       res[i] = xr;
     }
   }
-  if (prev && bad) atomicOr(flag, 1);
+  if (prev && bad) atomicMax(flag, gen);
 }
 
 inline int ew_blocks(int64_t n) {
@@ -480,6 +482,7 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
   std::vector<double> alpha, beta;
   double nrmv = 0.0;
   bool have_res = false;
+  void* res_prev = nullptr;
   auto vec = [&](int j) { return V.as<char>() + size_t(j) * n * es; };
   // bring the scalars of iterations [alpha.size(), upto] to the host (one copy, one sync)
   auto fetch = [&](int upto) -> int {
@@ -494,22 +497,29 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
     }
     return MPSE_OK;
   };
-  auto finish = [&](int m, const void* prev, int* flag_out) -> int {
-    // out = V[:m]^T coef ; optional closeness test against prev (numpy allclose semantics)
+  auto finish = [&](int m, void* dst, const void* prev, int* flag_out) -> int {
+    // dst = V[:m]^T coef ; optional closeness test against prev (numpy allclose semantics)
     Coefs c;
     expm_coefs(m, alpha, beta, nrmv, dt, &c);
-    int* dflag = reinterpret_cast<int*>(scal + SC_FLAG);
-    if (prev) MPSE_HIP(ctx, hipMemsetAsync(dflag, 0, sizeof(int), ctx->stream));
+    unsigned int* dflag = reinterpret_cast<unsigned int*>(ctx->dscratch + (size_t(1) << 16) - 8);
+    unsigned int gen = 0;
+    if (prev) {
+      gen = ++ctx->flag_gen;
+      if (gen == 0) {  // wrapped: restart the stamps from a cleared word
+        MPSE_HIP(ctx, hipMemsetAsync(dflag, 0, sizeof(unsigned int), ctx->stream));
+        gen = ++ctx->flag_gen;
+      }
+    }
     if (cplx)
-      hipLaunchKernelGGL((k_lincomb<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)out,
-                         V.as<double>(), (long long)n, m, c, (const double*)prev, rtol, atol, dflag);
+      hipLaunchKernelGGL((k_lincomb<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst,
+                         V.as<double>(), (long long)n, m, c, (const double*)prev, rtol, atol, dflag, gen);
     else
-      hipLaunchKernelGGL((k_lincomb<false>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)out,
-                         V.as<double>(), (long long)n, m, c, (const double*)prev, rtol, atol, dflag);
+      hipLaunchKernelGGL((k_lincomb<false>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst,
+                         V.as<double>(), (long long)n, m, c, (const double*)prev, rtol, atol, dflag, gen);
     MPSE_HIP(ctx, hipGetLastError());
     if (prev && flag_out) {
       MPSE_TRY(publish_and_wait(ctx, reinterpret_cast<const double*>(dflag), 1, 8));
-      *flag_out = *reinterpret_cast<int*>(ctx->pinned + 8);
+      *flag_out = (*reinterpret_cast<unsigned int*>(ctx->pinned + 8) == gen) ? 1 : 0;
     }
     return MPSE_OK;
   };
@@ -530,7 +540,7 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
       if (!(nrmv > 0)) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: zero start vector");
       int bd = breakdown_at(j - 1);
       const int m = bd >= 0 ? bd + 1 : j + 1;
-      MPSE_TRY(finish(m, nullptr, nullptr));
+      MPSE_TRY(finish(m, out, nullptr, nullptr));
       if (nvec) *nvec = m;
       return MPSE_OK;
     }
@@ -552,29 +562,34 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
       if (bd >= 0) {
         // what the reference would have returned at iteration bd - unless one of its convergence tests
         // (even jj > 3, jj < bd) had fired earlier; those tests all ran here already and failed
-        MPSE_TRY(finish(bd + 1, nullptr, nullptr));
+        MPSE_TRY(finish(bd + 1, out, nullptr, nullptr));
         if (nvec) *nvec = bd + 1;
         return MPSE_OK;
       }
     }
     if (check) {
+      // successive estimates alternate between `out` and a spare buffer (no copies between checks); the typical
+      // solve converges on its third estimate, which lands in `out`
       if (!have_res) {
         MPSE_TRY(RES.alloc(size_t(n) * es));
-        MPSE_TRY(finish(j + 1, nullptr, nullptr));
-        MPSE_TRY(mpse_memcpy_d2d(ctx, RES.p, out, size_t(n) * es));
+        MPSE_TRY(finish(j + 1, out, nullptr, nullptr));
+        res_prev = out;
         have_res = true;
       } else {
+        void* dst = (res_prev == out) ? RES.p : out;
         int flag = 1;
-        MPSE_TRY(finish(j + 1, RES.p, &flag));
+        MPSE_TRY(finish(j + 1, dst, res_prev, &flag));
+        res_prev = dst;
         if (flag == 0) {
+          if (dst != out) MPSE_TRY(mpse_memcpy_d2d(ctx, out, dst, size_t(n) * es));
           if (nvec) *nvec = j + 1;
           return MPSE_OK;
         }
-        MPSE_TRY(mpse_memcpy_d2d(ctx, RES.p, out, size_t(n) * es));
       }
     }
     if (last) {
       if (nvec) *nvec = j + 1;
+      if (res_prev && res_prev != out) MPSE_TRY(mpse_memcpy_d2d(ctx, out, res_prev, size_t(n) * es));
       return mpse_fail(ctx, MPSE_ERR_NOCONV, "expm_lanczos: no convergence within %d Krylov vectors", max_dim);
     }
     if (j + 2 > cap) {  // grow the Krylov basis (krylov.py:63-68)
