@@ -42,6 +42,13 @@ void prof_drain(mpse_ctx* ctx) {
   ctx->prof_pending.clear();
 }
 
+namespace {
+__global__ void k_copy16(double2* __restrict__ dst, const double2* __restrict__ src, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
 extern "C" {
 
 int mpse_prof_enable(mpse_ctx* ctx, int on) {
@@ -238,6 +245,17 @@ int mpse_memcpy_d2h(mpse_ctx* ctx, void* dst_host, const void* src, size_t bytes
 int mpse_memcpy_d2d(mpse_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx || (bytes && (!dst || !src))) return MPSE_ERR_ARG;
   if (!bytes) return MPSE_OK;
+  // tensors are 16-byte aligned multiples of 8 bytes: a plain grid-stride kernel queues like any other launch, while
+  // the runtime's device-to-device copy leaves ~15 us of idle time behind it on the stream (rocprofv3 trace)
+  if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0 && (bytes & 15) == 0) {
+    const size_t n = bytes / 16;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(dst),
+                       reinterpret_cast<const double2*>(src), (long long)n);
+    MPSE_HIP(ctx, hipGetLastError());
+    return MPSE_OK;
+  }
   MPSE_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return MPSE_OK;
 }
