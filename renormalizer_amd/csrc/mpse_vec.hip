@@ -483,6 +483,7 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
   double nrmv = 0.0;
   bool have_res = false;
   void* res_prev = nullptr;
+  int pending_m = 0;   // Krylov dimension of a first estimate whose formation is postponed to the next check
   auto vec = [&](int j) { return V.as<char>() + size_t(j) * n * es; };
   // bring the scalars of iterations [alpha.size(), upto] to the host (one copy, one sync)
   auto fetch = [&](int upto) -> int {
@@ -552,24 +553,40 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
     // (every path that continues), the returning paths below read it through k_reduce_final
     const bool check = (j > 3 && j % 2 == 0);                      // krylov.py:76-81
     const bool last = (j + 1 >= max_dim);
-    if (check || last)
+    // The first estimate (j = 4) decides nothing - there is no earlier one to compare with - so it is not worth a
+    // host round trip: it is formed at the next check, from the same alpha / beta / vectors it would have used,
+    // right before the estimate it is compared with.  (A breakdown at j <= 4 is found at that next fetch and handled
+    // retroactively like any other.)
+    const bool defer = check && !have_res && pending_m == 0 && !last;
+    const bool sync_now = (check && !defer) || last;
+    if (sync_now)
       hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, part_b, nb, scal + 6 + 4 * j);
     MPSE_HIP(ctx, hipGetLastError());
-    if (check || last) {
+    if (sync_now) {
       MPSE_TRY(fetch(j));
       if (!(nrmv > 0)) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: zero start vector");
       const int bd = breakdown_at(j);
       if (bd >= 0) {
         // what the reference would have returned at iteration bd - unless one of its convergence tests
-        // (even jj > 3, jj < bd) had fired earlier; those tests all ran here already and failed
+        // (even jj > 3, jj < bd) had fired earlier: the deferred first estimate cannot fire (nothing to compare
+        // with), later ones all ran here already and failed
         MPSE_TRY(finish(bd + 1, out, nullptr, nullptr));
         if (nvec) *nvec = bd + 1;
         return MPSE_OK;
       }
     }
-    if (check) {
+    if (defer) {
+      pending_m = j + 1;
+    } else if (check) {
       // successive estimates alternate between `out` and a spare buffer (no copies between checks); the typical
       // solve converges on its third estimate, which lands in `out`
+      if (pending_m > 0) {
+        MPSE_TRY(RES.alloc(size_t(n) * es));
+        MPSE_TRY(finish(pending_m, out, nullptr, nullptr));
+        res_prev = out;
+        have_res = true;
+        pending_m = 0;
+      }
       if (!have_res) {
         MPSE_TRY(RES.alloc(size_t(n) * es));
         MPSE_TRY(finish(j + 1, out, nullptr, nullptr));
