@@ -2,9 +2,9 @@
 """Charge diffusion in a Holstein chain from a YAML parameter file - the workflow of the reference's
 example/dynamics.py on the MI355X engine (ChargeDiffusionDynamics, adaptive TDVP-PS, results in <fname>.npz).
 
-    python examples/dynamics.py examples/std.yaml [max_bonddim=16] [max_steps]
+    python examples/dynamics.py examples/holstein_chain.yaml [max_bonddim=16] [max_steps]
 
-std.yaml describes 21 molecules at 298 K: the thermal vibrational state is prepared as a purified density operator
+holstein_chain.yaml (the parameters of the reference's example/std.yaml) describes 21 molecules at 298 K: the thermal vibrational state is prepared as a purified density operator
 (every site carries an ancilla leg) and cached in <fname>_impdm.npz next to the results."""
 import logging
 import os

@@ -2,7 +2,7 @@
 """Mobility of a Holstein chain from the Green-Kubo current autocorrelation function - the workflow of the
 reference's example/transport_kubo.py on the MI355X engine (TransportKubo; results in <fname>_autocorr.npz).
 
-    python examples/transport_kubo.py examples/std.yaml [max_steps]"""
+    python examples/transport_kubo.py examples/holstein_chain.yaml [max_steps]"""
 import logging
 import os
 import sys
