@@ -8,7 +8,6 @@ test infrastructure only).
 import ctypes as C
 import os
 import threading
-import weakref
 
 import numpy as np
 

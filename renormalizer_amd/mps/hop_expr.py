@@ -5,8 +5,6 @@ the callable also carries the C-ABI descriptor (``mpse_heff``) so that the Lancz
 drivers can hand the whole solve to the engine without coming back to Python per matvec."""
 import ctypes as C
 
-import numpy as np
-
 from ..engine import DeviceTensor, get_engine, mpse_heff
 
 

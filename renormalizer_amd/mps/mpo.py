@@ -18,7 +18,7 @@ from collections import defaultdict
 import numpy as np
 import scipy.linalg
 
-from ..model import Op, OpSum
+from ..model import Op
 from ..utils import Quantity
 
 
