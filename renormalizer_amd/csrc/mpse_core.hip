@@ -112,7 +112,10 @@ int mpse_ctx_create(int device, mpse_ctx** out) {
     delete ctx;
     return MPSE_ERR_HIP;
   }
-  (void)hipMemset(ctx->dscratch + (size_t(1) << 16) - 8, 0, 8 * sizeof(double));
+  // on the context's own stream: touching the null stream would make the runtime open one more hardware queue,
+  // and with four trajectories per GPU (four streams) two of them would then share a queue and serialise
+  (void)hipMemsetAsync(ctx->dscratch + (size_t(1) << 16) - 8, 0, 8 * sizeof(double), ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
   if (hipHostGetDevicePointer((void**)&ctx->pinned_dev, ctx->pinned, 0) != hipSuccess) ctx->pinned_dev = nullptr;
   ctx->pinned[4095] = 0.0;      // sequence slot of publish_and_wait
   ctx->stage_size = size_t(8) << 20;
