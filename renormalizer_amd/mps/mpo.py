@@ -302,6 +302,22 @@ class Mpo:
         return cls(model, [Op.identity(model.basis[0].dofs[0], model.qn_size)])
 
     @classmethod
+    def ph_onsite(cls, model, opera: str, mol_idx: int, ph_idx=0):
+        """one vibrational operator of a Holstein model (mps/mpo.py:119-124)"""
+        from ..model import HolsteinModel
+        assert opera in ["b", r"b^\dagger", r"b^\dagger b"]
+        if not isinstance(model, HolsteinModel):
+            raise TypeError("ph_onsite only supports HolsteinModel")
+        return cls(model, Op(opera, (mol_idx, ph_idx)))
+
+    @classmethod
+    def intersite(cls, model, e_opera: dict, ph_opera: dict, scale: Quantity = Quantity(1.0)):
+        r"""product of electronic operators {molecule: symbol} and vibrational operators {(molecule, mode): symbol},
+        e.g. ``Mpo.intersite(model, {1: "a", 3: r"a^\dagger"}, {(0, 5): "b"})`` (mps/mpo.py:126-154)"""
+        ops = [Op(sym, key) for key, sym in e_opera.items()] + [Op(sym, key) for key, sym in ph_opera.items()]
+        return cls(model, scale.as_au() * Op.product(ops))
+
+    @classmethod
     def exact_propagator(cls, model, x, space="GS", shift=0.0):
         """exp(x (H + shift)) for the electron-free ("GS") or the single-site excited ("EX") vibrational Hamiltonian of
         a Holstein model, which is a sum of one-site terms, so the operator is a bond-dimension-1 product of local
@@ -542,6 +558,23 @@ class Mpo:
         new.canonicalise()
         new.compress()
         return new
+
+    def conj_trans(self):
+        """Hermitian conjugate: physical legs exchanged, entries conjugated, bond quantum numbers negated
+        (mps/mpo.py:456-461)"""
+        new = self._like([np.ascontiguousarray(np.moveaxis(w, (1, 2), (2, 1)).conj()) for w in self._mp],
+                         [-np.asarray(q) for q in self.qn], -np.asarray(self.qntot))
+        new.qnidx = self.qnidx
+        return new
+
+    def is_hermitian(self):
+        """dense check, small systems only (mps/mpo.py:475-477)"""
+        full = self.todense()
+        return bool(np.allclose(full.conj().T, full, atol=1e-7))
+
+    @property
+    def dummy_qn(self):
+        return [np.zeros((b, len(np.atleast_1d(self.qntot))), dtype=int) for b in self.bond_dims]
 
     def todense(self):
         """Full matrix (mpo.py:463-473); small systems only."""

@@ -761,6 +761,35 @@ class Mps:
         return self, np.array([np.pad(s, (0, width - len(s))) for s in s_list])
 
     # ------------------------------------------------------------------ DMRG support
+    @property
+    def threshold(self):
+        return self.compress_config.threshold
+
+    @threshold.setter
+    def threshold(self, v):
+        self.compress_config.threshold = v
+
+    def evolve_exact(self, h_mpo, evolve_dt, space):
+        """exp(-i H dt) for the local (purely vibrational) Hamiltonian of a Holstein model in the electron-free ("GS")
+        or the single-site excited ("EX") space: one application of the bond-dimension-1 propagator
+        (mps/mps.py:1519-1523, mps/mpdm.py:76-83); the energy offset of ``h_mpo`` goes into ``coeff`` as a phase."""
+        from .mpo import Mpo
+        offset = getattr(h_mpo, "offset", 0.0)
+        offset = offset.as_au() if hasattr(offset, "as_au") else float(offset)
+        prop = Mpo.exact_propagator(self.model, -1.0j * evolve_dt, space=space, shift=-offset)
+        new = prop.apply(self, canonicalise=True)
+        new.coeff = new.coeff * np.exp(-1.0j * offset * evolve_dt)
+        return new
+
+    @property
+    def digest(self):
+        """variance / mean / peak-to-peak of the dense state: a quick fingerprint for comparing two small pure states
+        (mps/mps.py:1525-1534); None for more than ten sites or density operators"""
+        if 10 < self.site_num or self.is_mpdm:
+            return None
+        dense = self.todense() / self.coeff
+        return {"var": dense.var(), "mean": dense.mean(), "ptp": np.ptp(dense)}
+
     def variational_compress(self, mpo=None, guess=None):
         """Approximation of ``mpo @ self`` at the bond dimensions of ``compress_config.vprocedure`` by sweeps that
         maximise the overlap with the exact product (mps/mp.py:513-650): per step the effective operator

@@ -173,3 +173,25 @@ def test_mpo_try_swap_site_is_exact():
     m2.try_swap_site(swapped)
     assert np.abs(m2.todense() - Mpo(swapped).todense()).max() < 1e-13
     assert sorted(map(tuple, m2.qn[2].tolist())) == sorted(map(tuple, Mpo(swapped).qn[2].tolist()))
+
+
+def test_mpo_small_constructors_and_conjugate():
+    """Mpo.ph_onsite / intersite / conj_trans / is_hermitian / dummy_qn (mps/mpo.py:119-154, 456-477)"""
+    ph = Phonon.simple_phonon(Quantity(0.01), Quantity(3.0), 3)
+    model = HolsteinModel([Mol(Quantity(0.1), [ph, ph])] * 2, Quantity(0.02), 3)
+    h = Mpo(model)
+    assert h.is_hermitian()
+    b = Mpo.ph_onsite(model, "b", 1, 1)
+    bd = Mpo.ph_onsite(model, r"b^\dagger", 1, 1)
+    assert not b.is_hermitian()
+    assert np.abs(b.conj_trans().todense() - bd.todense()).max() < 1e-14
+    assert np.abs(b.conj_trans().todense() - b.todense().conj().T).max() < 1e-14
+    hop = Mpo.intersite(model, {0: r"a^\dagger", 1: "a"}, {(0, 1): r"b^\dagger b"}, Quantity(2.0))
+    ref = 2.0 * (Mpo(model, Op(r"a^\dagger", 0) * Op("a", 1)).todense() @ Mpo(model, Op(r"b^\dagger b", (0, 1))).todense())
+    assert np.abs(hop.todense() - ref).max() < 1e-13
+    ct = hop.conj_trans()
+    assert np.abs(ct.todense() - hop.todense().conj().T).max() < 1e-13
+    assert all(np.array_equal(a, -np.asarray(q)) for a, q in zip(ct.qn, hop.qn))
+    assert [q.shape[0] for q in h.dummy_qn] == h.bond_dims and not any(q.any() for q in h.dummy_qn)
+    with pytest.raises(TypeError):
+        Mpo.ph_onsite(Model(model.basis, model.ham_terms), "b", 0)
