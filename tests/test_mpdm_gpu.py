@@ -201,3 +201,26 @@ def test_thermofield_agrees_with_purification():
     for _ in range(3):
         psi0, ref0 = psi0.evolve(hc, dt), ref0.evolve(h0, dt)
     assert np.abs(np.asarray(psi0.e_occupations) - np.asarray(ref0.e_occupations)).max() < 1e-8
+
+
+def test_mpdm_right_apply_and_evolve_exact():
+    """MpDm.apply (rho @ O, mpdm.py:130-165) against dense matrices for an operator with bond dimension > 1, and
+    MpDm.evolve_exact = rho exp(-i H_vib dt) (mpdm.py:76-83)"""
+    import scipy.linalg
+    from renormalizer_amd.mps import MpDm, Mps
+    ph = [Phonon.simple_phonon(Quantity(0.01), Quantity(3.0), 3)]
+    model = HolsteinModel([Mol(Quantity(0.1), ph)] * 2, Quantity(0.02), 3)
+    psi = Mps.random(model, 1, 4, rng=np.random.default_rng(11)).to_complex()
+    psi.canonicalise().normalize("mps_and_coeff")
+    h = Mpo(model)
+    rho = h.apply(MpDm.from_mps(psi))                        # some operator with structure: H diag(psi)
+    dense_rho = rho.todense()
+    assert np.abs(dense_rho - h.todense() @ np.diag(psi.todense().ravel())).max() < 1e-12
+    out = rho.apply(h)
+    assert np.abs(out.todense() - dense_rho @ h.todense()).max() < 1e-12
+    assert list(out.bond_dims) == [a * b for a, b in zip(rho.bond_dims, h.bond_dims)]
+    gs = MpDm.max_entangled_gs(model).to_complex()
+    dt = 5.0
+    ev = gs.evolve_exact(h, dt, "GS")
+    dense_h = h.todense() - model.gs_zpe * np.eye(h.todense().shape[0])
+    assert np.abs(ev.todense() - gs.todense() @ scipy.linalg.expm(-1j * dt * dense_h)).max() < 1e-12
