@@ -19,11 +19,10 @@ logger = logging.getLogger("renormalizer_amd")
 class ThermalProp(TdMpsJob):
     def __init__(self, init_mpdm: MpDm, h_mpo_model=None, exact=False, space="GS", evolve_config: EvolveConfig = None,
                  dump_mps=None, dump_dir=None, job_name=None, properties=None, auto_expand=True):
-        if properties is not None:
-            raise NotImplementedError("the Property interface is not implemented")
         self.init_mpdm = init_mpdm.canonicalise()
         self.h_mpo = Mpo(self.init_mpdm.model if h_mpo_model is None else h_mpo_model)
         self.exact, self.space = exact, space
+        self.properties = properties
         self.auto_expand = auto_expand
         self.energies = []
         self._e_occupations_array = []
@@ -44,6 +43,8 @@ class ThermalProp(TdMpsJob):
         self._e_occupations_array.append(np.asarray(mps.e_occupations))
         self._ph_occupations_array.append(np.asarray(mps.ph_occupations))
         self._vn_entropy_array.append(mps.calc_bond_entropy())
+        if self.properties is not None:
+            self.properties.calc_properties(mps)
 
     def evolve_exact(self, old_mpdm, evolve_dt):
         """one application of the bond-dimension-1 propagator of a local Hamiltonian (thermalprop.py:95-103)"""
@@ -82,7 +83,8 @@ class ThermalProp(TdMpsJob):
                 "energies": np.array(self.energies),
                 "electron occupations array": self.e_occupations_array,
                 "phonon occupations array": self.ph_occupations_array,
-                "vn entropy array": np.array([np.asarray(v, dtype=float) for v in self._vn_entropy_array])}
+                "vn entropy array": np.array([np.asarray(v, dtype=float) for v in self._vn_entropy_array]),
+                **({} if self.properties is None else dict(self.properties.prop_res))}
 
 
 def load_thermal_state(model, path: str):

@@ -26,8 +26,6 @@ class TransportKubo(TdMpsJob):
     def __init__(self, model, temperature: Quantity, distance_matrix: np.ndarray = None, insteps: int = 1,
                  ievolve_config=None, compress_config=None, evolve_config=None, dump_dir: str = None,
                  job_name: str = None, thermal_dump_path: str = None, properties=None):
-        if properties is not None:
-            raise NotImplementedError("the Property interface is not implemented")
         self.model = model
         self.distance_matrix = distance_matrix
         self.h_mpo = Mpo(model)
@@ -51,6 +49,7 @@ class TransportKubo(TdMpsJob):
             self.thermal_dump_path = os.path.join(dump_dir, job_name + "_impdm.npz")
         else:
             self.thermal_dump_path = None
+        self.properties = properties
         self._auto_corr = []
         self._auto_corr_decomposition = []
         super().__init__(evolve_config=evolve_config, dump_dir=dump_dir, job_name=job_name)
@@ -114,6 +113,8 @@ class TransportKubo(TdMpsJob):
     def process_mps(self, mps):
         if self.j_oper2 is None:
             self._auto_corr.append(-mps.ft)
+            if self.properties is not None:
+                self.properties.calc_properties_braketpair(mps)
             return
         (bra, ket), (_, ket2) = mps
         parts = [-BraKetPair(bra, k, j).ft for j in (self.j_oper, self.j_oper2) for k in (ket, ket2)]
@@ -153,7 +154,8 @@ class TransportKubo(TdMpsJob):
     def get_dump_dict(self):
         return {"mol list": self.model.to_dict(), "temperature": self.temperature.as_au(),
                 "time series": self.evolve_times, "auto correlation": self.auto_corr,
-                "auto correlation decomposition": self.auto_corr_decomposition, "mobility": self.calc_mobility()[1]}
+                "auto correlation decomposition": self.auto_corr_decomposition, "mobility": self.calc_mobility()[1],
+                **({} if self.properties is None else dict(self.properties.prop_res))}
 
     def calc_mobility(self):
         """(mobility in a.u., in cm^2 / V s): trapezoid integral of Re C(t) over kT"""
