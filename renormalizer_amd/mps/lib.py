@@ -47,12 +47,16 @@ def contract_one_site(environ, ms, mo, domain, ms_conj=None):
     eng._check(eng.lib.mpse_env_update(
         eng.ctx, out.code, DOMAIN_L if domain == "L" else DOMAIN_R, C.byref(d), environ.ptr, environ.code,
         ket.ptr, bra.ptr, 1 if ms_conj is None else 0, mo.ptr, mo.code, out.ptr))
-    if ms_conj is None and oshape[0] == oshape[2]:
+    if ms_conj is None and oshape[0] == oshape[2] and oshape[0] >= UNIT_MIN_BOND:
         out.unit = find_unit_channel(out)
     return out
 
 
 UNIT_TOL = 1e-12
+# The contraction plans use a unit channel only when the product it saves has at least 2^27 multiply-adds
+# (mpse_plans.h unit_pays: D^2 x d D for a one-site matvec): below D = 128 no physical dimension reaches that, and the
+# detection - a small kernel plus a host round trip per environment update - would be pure latency.
+UNIT_MIN_BOND = 128
 
 
 def find_unit_channel(env):
