@@ -26,15 +26,22 @@ __global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const double* __res
                                                              long long n, double* __restrict__ partial) {
   double re = 0, im = 0;
   const long long stride = (long long)gridDim.x * RED_THREADS;
-  for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += stride) {
-    if (CPLX) {
-      const double2 a = reinterpret_cast<const double2*>(x)[i];
-      const double2 b = reinterpret_cast<const double2*>(y)[i];
-      re += a.x * b.x + a.y * b.y;
-      im += a.x * b.y - a.y * b.x;
-    } else {
-      re += x[i] * y[i];
+  if (CPLX) {
+    // two 16-byte loads per operand in flight per thread (the loop is HBM-latency bound otherwise)
+    const double2* x2 = reinterpret_cast<const double2*>(x);
+    const double2* y2 = reinterpret_cast<const double2*>(y);
+    for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += 2 * stride) {
+      const long long i1 = i + stride;
+      const bool h1 = i1 < n;
+      const double2 a0 = x2[i], b0 = y2[i];
+      const double2 a1 = h1 ? x2[i1] : make_double2(0.0, 0.0), b1 = h1 ? y2[i1] : make_double2(0.0, 0.0);
+      re += a0.x * b0.x + a0.y * b0.y;
+      im += a0.x * b0.y - a0.y * b0.x;
+      re += a1.x * b1.x + a1.y * b1.y;
+      im += a1.x * b1.y - a1.y * b1.x;
     }
+  } else {
+    for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += stride) re += x[i] * y[i];
   }
   block_allsum2(re, im);
   if (threadIdx.x == 0) {
@@ -117,7 +124,10 @@ __global__ void k_scale_into(double* dst, const double* __restrict__ src, long l
 }
 
 // dst = src / sqrt(b2) where b2 = sum of the nb partials of the preceding norm kernel; block 0 also stores b2
-// (and the unused imaginary slot) to b2_out for the host and for the next recurrence step
+// (and the unused imaginary slot) to b2_out for the host and for the next recurrence step.
+// VEC: 16-byte accesses, two per operand in flight per thread (needs 16-byte aligned vectors of even length - always
+// the case for complex128); the plain path serves odd-length real vectors.
+template <bool VEC>
 __global__ __launch_bounds__(RED_THREADS) void k_scale_into_dev(double* dst, const double* __restrict__ src,
                                                                 long long n_doubles,
                                                                 const double* __restrict__ partial, int nb,
@@ -130,12 +140,27 @@ __global__ __launch_bounds__(RED_THREADS) void k_scale_into_dev(double* dst, con
   }
   const double s = 1.0 / sqrt(b2);
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_doubles; i += stride) dst[i] = src[i] * s;
+  if (VEC) {
+    const long long n2 = n_doubles >> 1;
+    double2* d2 = reinterpret_cast<double2*>(dst);
+    const double2* s2 = reinterpret_cast<const double2*>(src);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += 2 * stride) {
+      const long long i1 = i + stride;
+      const bool h1 = i1 < n2;
+      const double2 a0 = s2[i];
+      const double2 a1 = h1 ? s2[i1] : make_double2(0.0, 0.0);
+      d2[i] = make_double2(a0.x * s, a0.y * s);
+      if (h1) d2[i1] = make_double2(a1.x * s, a1.y * s);
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_doubles; i += stride) dst[i] = src[i] * s;
+  }
 }
 
 // Lanczos three-term update fused with the norm: w -= a*v1 + b*v0 ; partial = sum |w|^2
 // (lib/krylov/krylov.py:70-71).  a = *ap and b = sqrt(*b2p) are read from device memory so that the
-// recurrence never waits for the host.
+// recurrence never waits for the host.  VEC as above.
+template <bool VEC>
 __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update(double* __restrict__ w, const double* __restrict__ v1,
                                                                 const double* __restrict__ v0, long long n_doubles,
                                                                 const double* __restrict__ a_partial, int a_nb,
@@ -152,12 +177,34 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update(double* __restri
   const double b = v0 ? sqrt(*b2p) : 0.0;
   double s = 0, zero = 0;
   const long long stride = (long long)gridDim.x * RED_THREADS;
-  for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n_doubles; i += stride) {
-    double t = a * v1[i];
-    if (v0) t += b * v0[i];
-    const double x = w[i] - t;
-    w[i] = x;
-    s += x * x;
+  if (VEC) {
+    const long long n2 = n_doubles >> 1;
+    double2* w2 = reinterpret_cast<double2*>(w);
+    const double2* p1 = reinterpret_cast<const double2*>(v1);
+    const double2* p0 = reinterpret_cast<const double2*>(v0);
+    const double2 z = make_double2(0.0, 0.0);
+    for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n2; i += 2 * stride) {
+      const long long i1 = i + stride;
+      const bool h1 = i1 < n2;
+      const double2 wa = w2[i], va = p1[i], ua = v0 ? p0[i] : z;
+      const double2 wb = h1 ? w2[i1] : z, vb = h1 ? p1[i1] : z, ub = (h1 && v0) ? p0[i1] : z;
+      const double2 xa = make_double2(wa.x - (a * va.x + b * ua.x), wa.y - (a * va.y + b * ua.y));
+      const double2 xb = make_double2(wb.x - (a * vb.x + b * ub.x), wb.y - (a * vb.y + b * ub.y));
+      w2[i] = xa;
+      s += xa.x * xa.x + xa.y * xa.y;
+      if (h1) {
+        w2[i1] = xb;
+        s += xb.x * xb.x + xb.y * xb.y;
+      }
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n_doubles; i += stride) {
+      double t = a * v1[i];
+      if (v0) t += b * v0[i];
+      const double x = w[i] - t;
+      w[i] = x;
+      s += x * x;
+    }
   }
   block_allsum2(s, zero);
   if (threadIdx.x == 0) {
@@ -475,8 +522,14 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
 
   // v0 = C / |C|
   dot_partials(Cin, Cin, part_b);
-  hipLaunchKernelGGL(k_scale_into_dev, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, V.as<double>(),
-                     (const double*)Cin, (long long)nd, (const double*)part_b, nb, scal);
+  // 16-byte vector accesses whenever every Krylov vector starts on a 16-byte boundary (always for complex128)
+  const bool vec16 = (cplx || n % 2 == 0) && (reinterpret_cast<uintptr_t>(Cin) & 15) == 0;
+  if (vec16)
+    hipLaunchKernelGGL(k_scale_into_dev<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, V.as<double>(),
+                       (const double*)Cin, (long long)nd, (const double*)part_b, nb, scal);
+  else
+    hipLaunchKernelGGL(k_scale_into_dev<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, V.as<double>(),
+                       (const double*)Cin, (long long)nd, (const double*)part_b, nb, scal);
   MPSE_HIP(ctx, hipGetLastError());
 
   std::vector<double> alpha, beta;
@@ -545,10 +598,16 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
       if (nvec) *nvec = m;
       return MPSE_OK;
     }
-    hipLaunchKernelGGL(k_lanczos_update, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
-                       (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
-                       (long long)nd, (const double*)part_a, nb, scal + 4 + 4 * j,
-                       (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b);
+    if (vec16)
+      hipLaunchKernelGGL(k_lanczos_update<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
+                         (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
+                         (long long)nd, (const double*)part_a, nb, scal + 4 + 4 * j,
+                         (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b);
+    else
+      hipLaunchKernelGGL(k_lanczos_update<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
+                         (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
+                         (long long)nd, (const double*)part_a, nb, scal + 4 + 4 * j,
+                         (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b);
     // beta_j^2: needed by the host at a check and by the next update; k_scale_into_dev stores it when it runs
     // (every path that continues), the returning paths below read it through k_reduce_final
     const bool check = (j > 3 && j % 2 == 0);                      // krylov.py:76-81
@@ -617,8 +676,12 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
       std::swap(V.p, V2.p);
       cap = ncap;
     }
-    hipLaunchKernelGGL(k_scale_into_dev, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
-                       W.as<const double>(), (long long)nd, (const double*)part_b, nb, scal + 6 + 4 * j);
+    if (vec16)
+      hipLaunchKernelGGL(k_scale_into_dev<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
+                         W.as<const double>(), (long long)nd, (const double*)part_b, nb, scal + 6 + 4 * j);
+    else
+      hipLaunchKernelGGL(k_scale_into_dev<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
+                         W.as<const double>(), (long long)nd, (const double*)part_b, nb, scal + 6 + 4 * j);
   }
 }
 
