@@ -466,7 +466,32 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs g, int bat
     for (int j = blockIdx.x * 256 + threadIdx.x; j < g.N; j += gridDim.x * 256) {
       const double* w = wrow + (long long)j * EC;
       double xr = 0, xi = 0;
-      for (int s = 0; s < g.ksplit; ++s) {
+      int s = 0;
+      // four slices in flight per thread (the loads are independent, the additions keep their fixed order)
+      for (; s + 4 <= g.ksplit; s += 4) {
+        if constexpr (CC) {
+          const double2 v0 = *reinterpret_cast<const double2*>(w + (long long)s * mn * EC);
+          const double2 v1 = *reinterpret_cast<const double2*>(w + (long long)(s + 1) * mn * EC);
+          const double2 v2 = *reinterpret_cast<const double2*>(w + (long long)(s + 2) * mn * EC);
+          const double2 v3 = *reinterpret_cast<const double2*>(w + (long long)(s + 3) * mn * EC);
+          xr += v0.x;
+          xi += v0.y;
+          xr += v1.x;
+          xi += v1.y;
+          xr += v2.x;
+          xi += v2.y;
+          xr += v3.x;
+          xi += v3.y;
+        } else {
+          const double v0 = w[(long long)s * mn], v1 = w[(long long)(s + 1) * mn];
+          const double v2 = w[(long long)(s + 2) * mn], v3 = w[(long long)(s + 3) * mn];
+          xr += v0;
+          xr += v1;
+          xr += v2;
+          xr += v3;
+        }
+      }
+      for (; s < g.ksplit; ++s) {
         if constexpr (CC) {
           const double2 v = *reinterpret_cast<const double2*>(w + (long long)s * mn * EC);
           xr += v.x;
