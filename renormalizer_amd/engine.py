@@ -16,6 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RENO_MPSENGINE") or os.path.join(_HERE, "csrc", "libmpsengine.so")
 
 F64, C128 = 0, 1
+# status codes of include/mpsengine.h
+MPSE_OK, MPSE_ERR_OOM, MPSE_ERR_SHAPE, MPSE_ERR_NOCONV, MPSE_ERR_HIP, MPSE_ERR_ARG = 0, 1, 2, 3, 4, 5
 DOMAIN_L, DOMAIN_R = 0, 1
 
 STATUS = {0: "OK", 1: "OOM", 2: "SHAPE", 3: "NOCONV", 4: "HIP", 5: "ARG"}

@@ -156,3 +156,42 @@ def test_block_qr_columns_with_denormal_squared_norms(eng):
     err = np.abs(q @ r - a).max(axis=0)
     scale = np.abs(a).max(axis=0)
     assert np.all(err <= 1e-12 * scale + 1e-139)
+
+
+def _raw_lanczos(eng, hop, dt, c, max_dim):
+    v = eng.asdevice(c)
+    out = eng.empty(v.shape, v.dtype)
+    nv = C.c_int()
+    st = eng.lib.mpse_expm_lanczos(eng.ctx, v.code, C.byref(hop.heff), dt.real, dt.imag, v.ptr, out.ptr, 1e-5, 1e-8,
+                                   max_dim, C.byref(nv))
+    return st, out, nv.value
+
+
+def test_krylov_dimension_limit_and_estimate_schedule(eng):
+    """The first convergence estimate (j = 4) is formed at the second check (j = 6); every way the recurrence can end
+    around those two checks must still behave like the reference: Krylov dimension limits that fall on / between the
+    checks report MPSE_ERR_NOCONV without crashing, and for time steps that need 5 ... 15 vectors the result and the
+    number of vectors are the oracle's."""
+    rng = np.random.default_rng(5)
+    D, d, w = 6, 4, 3
+    l, r = _herm_env(rng, D, w), _herm_env(rng, D, w)
+    wm = rng.standard_normal((w, d, d, w))
+    wm = (wm + wm.transpose(0, 2, 1, 3)) / 2
+    c = rng.standard_normal((D, d, D)) + 1j * rng.standard_normal((D, d, D))
+    hop = hop_expr(eng.asdevice(l), eng.asdevice(r), [eng.asdevice(wm)], c.shape)
+    scale = np.abs(np.linalg.eigvalsh((lambda h: (h + h.conj().T) / 2)(orc.hop_dense(l, r, [wm])))).max()
+    seen = set()
+    for x in (0.02, 0.2, 0.6, 1.5, 3.0, 6.0):
+        dt = -1j * x / scale
+        ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(l, r, [wm], y.reshape(c.shape)).ravel(), dt, c.ravel())
+        out, nv = expm_krylov(hop, dt, eng.asdevice(c))
+        assert nv == nref, (x, nv, nref)
+        assert np.abs(out.to_host().ravel() - ref).max() < 1e-10 * np.abs(ref).max()
+        seen.add(nv)
+    assert len(seen) >= 3 and min(seen) <= 7 and max(seen) >= 11          # several estimate schedules exercised
+    dt = -1j * 6.0 / scale
+    for max_dim in (3, 5, 6, 7, 8):
+        st, out, nv = _raw_lanczos(eng, hop, dt, c, max_dim)
+        assert st == E.MPSE_ERR_NOCONV and nv == max_dim, (max_dim, st, nv)
+    st, out, nv = _raw_lanczos(eng, hop, dt, c, 64)
+    assert st == 0 and nv == max(seen)
