@@ -488,3 +488,21 @@ def test_gemm_skip_zero_tiles_equals_dense(eng, ca, cb):
     eng.gemm(eng.asdevice(A), eng.asdevice(B), out, i1(200, 400), i1(400, 1), i1(400, 300), i1(300, 1), i1(200, 300),
              i1(300, 1), beta=2.0, skip_zero_tiles=3)
     assert np.array_equal(out.to_host(), 2.0 * C0)
+
+
+def test_device_copies_all_alignments(eng):
+    """device-to-device copies: the 16-byte kernel path (complex, even-length real) and the runtime path (odd-length
+    real, views that start 8 bytes into an allocation) must both be exact"""
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 255, 256, 257, 70001):
+        a = rng.standard_normal(n)
+        t = eng.asdevice(a)
+        assert np.array_equal(t.copy().to_host(), a)
+        z = a + 1j * rng.standard_normal(n)
+        tz = eng.asdevice(z)
+        assert np.array_equal(tz.copy().to_host(), z)
+        if n > 2:
+            shifted = t.shifted(1)                       # starts 8 bytes into the buffer
+            dst = eng.empty((n - 1,), np.float64)
+            eng._check(eng.lib.mpse_memcpy_d2d(eng.ctx, dst.ptr, shifted.ptr, (n - 1) * 8))
+            assert np.array_equal(dst.to_host(), a[1:])
