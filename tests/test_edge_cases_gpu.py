@@ -195,3 +195,23 @@ def test_krylov_dimension_limit_and_estimate_schedule(eng):
         assert st == E.MPSE_ERR_NOCONV and nv == max_dim, (max_dim, st, nv)
     st, out, nv = _raw_lanczos(eng, hop, dt, c, 64)
     assert st == 0 and nv == max(seen)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 3), (4, 3, 2), (5, 2, 7), (1, 3, 1)])
+def test_real_lanczos_odd_and_even_lengths(eng, shape):
+    """real-dtype (imaginary-time) Lanczos: odd-length vectors take the 8-byte kernels, even-length ones the 16-byte
+    kernels; both against the oracle"""
+    rng = np.random.default_rng(sum(shape))
+    Dl, d, Dr = shape
+    w = 2
+    l, r = _herm_env(rng, Dl, w).real.copy(), _herm_env(rng, Dr, w).real.copy()
+    l, r = (l + l.transpose(2, 1, 0)) / 2, (r + r.transpose(2, 1, 0)) / 2
+    wm = rng.standard_normal((w, d, d, w))
+    wm = (wm + wm.transpose(0, 2, 1, 3)) / 2
+    c = rng.standard_normal(shape)
+    hop = hop_expr(eng.asdevice(l), eng.asdevice(r), [eng.asdevice(wm)], c.shape)
+    out, nv = expm_krylov(hop, -0.4, eng.asdevice(c))
+    assert not out.is_complex
+    ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(l, r, [wm], y.reshape(c.shape)).ravel(), -0.4, c.ravel())
+    assert nv == nref
+    assert np.abs(out.to_host().ravel() - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
