@@ -726,17 +726,75 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     // tile occupancy of both operands (one small scan launch), then only K tiles with data on both sides are visited
     g.nkw = (nkt_all + 7) / 8;
     const size_t wa = size_t(d->batch) * g.tiles_m * g.nkw, wb = size_t(d->batch) * g.tiles_n * g.nkw;
-    MPSE_TRY(MSK.alloc((wa + wb) * sizeof(unsigned long long)));
-    unsigned long long* am = MSK.as<unsigned long long>();
-    unsigned long long* bmk = am + wa;
-    // (flag bytes past the last k tile stay unwritten: next_kt never looks beyond kt_end)
     // skip_zero bit 0: scan A, bit 1: scan B (an operand that is as large as the product itself is not worth a pass)
     const bool sa = skip_zero & 1, sb_ = skip_zero & 2;
-    OccOperand oa{g.A, g.mA, g.kA, g.M, sa ? g.tiles_m : 0, ca ? 1 : 0, g.a_kfast, g.sbA, reinterpret_cast<unsigned char*>(am)};
-    OccOperand ob{g.B, g.nB, g.kB, g.N, sb_ ? g.tiles_n : 0, cb ? 1 : 0, g.b_kfast, g.sbB, reinterpret_cast<unsigned char*>(bmk)};
-    const int tmax = (sa ? g.tiles_m : 0) > (sb_ ? g.tiles_n : 0) ? (sa ? g.tiles_m : 0) : (sb_ ? g.tiles_n : 0);
-    const dim3 og((nkt_all + 3) / 4, tmax, (unsigned)(2 * d->batch));
-    hipLaunchKernelGGL(k_tile_occ, og, dim3(256), 0, ctx->stream, oa, ob, g.K, g.nkw, (int)d->batch);
+    // Inside a Krylov solve the environments do not change: their masks are computed once and kept (mpse_internal.h)
+    auto cacheable = [&](const void* p) {
+      if (!ctx->occ_cache_on) return false;
+      const char* c = reinterpret_cast<const char*>(p);
+      return (c >= ctx->occ_lo[0] && c < ctx->occ_hi[0]) || (c >= ctx->occ_lo[1] && c < ctx->occ_hi[1]);
+    };
+    auto make_key = [&](const void* p, const IdxMap& rm, const IdxMap& km, long long sb, int nrows, int tiles, int cplx) {
+      mpse_ctx::OccKey k;
+      memset(&k, 0, sizeof(k));
+      k.ptr = p;
+      k.r_ext = rm.ext, k.r_lo = rm.lo, k.r_shi = rm.s_hi, k.r_slo = rm.s_lo;
+      k.k_ext = km.ext, k.k_lo = km.lo, k.k_shi = km.s_hi, k.k_slo = km.s_lo;
+      k.sb = sb, k.nrows = nrows, k.tiles = tiles, k.nkw = g.nkw, k.batch = (int)d->batch, k.K = g.K, k.cplx = cplx;
+      return k;
+    };
+    auto find = [&](const mpse_ctx::OccKey& k) -> void* {
+      for (const auto& e : ctx->occ_cache)
+        if (memcmp(&e.key, &k, sizeof(k)) == 0) return e.mask;
+      return nullptr;
+    };
+    unsigned long long *am = nullptr, *bmk = nullptr;
+    bool scan_a = sa, scan_b = sb_;
+    mpse_ctx::OccKey ka, kb;
+    const bool ca_ok = sa && cacheable(g.A), cb_ok = sb_ && cacheable(g.B);
+    if (ca_ok) {
+      ka = make_key(g.A, g.mA, g.kA, g.sbA, g.M, g.tiles_m, ca ? 1 : 0);
+      if (void* hit = find(ka)) am = static_cast<unsigned long long*>(hit), scan_a = false;
+    }
+    if (cb_ok) {
+      kb = make_key(g.B, g.nB, g.kB, g.sbB, g.N, g.tiles_n, cb ? 1 : 0);
+      if (void* hit = find(kb)) bmk = static_cast<unsigned long long*>(hit), scan_b = false;
+    }
+    // storage: cached masks live until the solve ends, the others in a temporary of this call
+    size_t tmp_words = 0;
+    if (scan_a && !ca_ok) tmp_words += wa;
+    if (scan_b && !cb_ok) tmp_words += wb;
+    if (tmp_words) MPSE_TRY(MSK.alloc(tmp_words * sizeof(unsigned long long)));
+    unsigned long long* tmp = MSK.as<unsigned long long>();
+    if (scan_a) {
+      if (ca_ok) {
+        void* pm = nullptr;
+        MPSE_TRY(mpse_malloc(ctx, wa * sizeof(unsigned long long), &pm));
+        ctx->occ_cache.push_back({ka, pm});
+        am = static_cast<unsigned long long*>(pm);
+      } else {
+        am = tmp;
+        tmp += wa;
+      }
+    }
+    if (scan_b) {
+      if (cb_ok) {
+        void* pm = nullptr;
+        MPSE_TRY(mpse_malloc(ctx, wb * sizeof(unsigned long long), &pm));
+        ctx->occ_cache.push_back({kb, pm});
+        bmk = static_cast<unsigned long long*>(pm);
+      } else {
+        bmk = tmp;
+      }
+    }
+    // (flag bytes past the last k tile stay unwritten: next_kt never looks beyond kt_end)
+    if (scan_a || scan_b) {
+      OccOperand oa{g.A, g.mA, g.kA, g.M, scan_a ? g.tiles_m : 0, ca ? 1 : 0, g.a_kfast, g.sbA, reinterpret_cast<unsigned char*>(am)};
+      OccOperand ob{g.B, g.nB, g.kB, g.N, scan_b ? g.tiles_n : 0, cb ? 1 : 0, g.b_kfast, g.sbB, reinterpret_cast<unsigned char*>(bmk)};
+      const int tmax = (scan_a ? g.tiles_m : 0) > (scan_b ? g.tiles_n : 0) ? (scan_a ? g.tiles_m : 0) : (scan_b ? g.tiles_n : 0);
+      const dim3 og((nkt_all + 3) / 4, tmax, (unsigned)(2 * d->batch));
+      hipLaunchKernelGGL(k_tile_occ, og, dim3(256), 0, ctx->stream, oa, ob, g.K, g.nkw, (int)d->batch);
+    }
     g.amask = sa ? am : nullptr;
     g.bmask = sb_ ? bmk : nullptr;
   }

@@ -54,6 +54,22 @@ struct mpse_ctx {
   unsigned long long publish_seq = 0;
   double* dscratch = nullptr;   // device scratch for reductions (1<<16 doubles); the last 8 hold flag words
   unsigned int flag_gen = 0;    // generation stamp of the Lanczos convergence flag (no per-check memset)
+  // Tile-occupancy masks of operands that stay constant over one Krylov solve (the two environments): computed by
+  // the first matvec, reused by the others.  Active only inside mpse_expm_lanczos, for operands inside the ranges
+  // registered there.
+  struct OccKey {
+    const void* ptr;
+    long long r_ext, r_lo, r_shi, r_slo, k_ext, k_lo, k_shi, k_slo, sb;
+    int nrows, tiles, nkw, batch, K, cplx;
+  };
+  struct OccEntry {
+    OccKey key;
+    void* mask;
+  };
+  bool occ_cache_on = false;
+  const char* occ_lo[2] = {nullptr, nullptr};
+  const char* occ_hi[2] = {nullptr, nullptr};
+  std::vector<OccEntry> occ_cache;
 };
 
 int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...);

@@ -585,6 +585,23 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
     return -1;
   };
 
+  // the environments are constant over the solve: their tile-occupancy masks are scanned once (mpse_gemm.hip)
+  struct OccScope {
+    mpse_ctx* c;
+    OccScope(mpse_ctx* ctx, const mpse_heff* h) : c(ctx) {
+      const mpse_dims& s = h->dims;
+      const size_t lb = size_t(s.Dl_ket) * s.wl * s.Dl_ket * (h->l_dtype == MPSE_C128 ? 16 : 8);
+      const size_t rb = size_t(s.Dr_ket) * s.wr * s.Dr_ket * (h->r_dtype == MPSE_C128 ? 16 : 8);
+      c->occ_lo[0] = static_cast<const char*>(h->L), c->occ_hi[0] = c->occ_lo[0] + lb;
+      c->occ_lo[1] = static_cast<const char*>(h->R), c->occ_hi[1] = c->occ_lo[1] + rb;
+      c->occ_cache_on = true;
+    }
+    ~OccScope() {
+      c->occ_cache_on = false;
+      for (auto& e : c->occ_cache) mpse_free(c, e.mask);
+      c->occ_cache.clear();
+    }
+  } occ_scope(ctx, h);
   for (int j = 0;; ++j) {
     MPSE_TRY(mpse_heff_apply(ctx, dtype, h, vec(j), W.p));
     dot_partials(W.p, vec(j), part_a);                             // alpha_j = Re <w, v_j> (partials)
