@@ -9,7 +9,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from renormalizer_amd import HolsteinModel, Mol, Phonon, Quantity  # noqa: E402
-from renormalizer_amd.mps import MpDm, ThermalProp  # noqa: E402
+from renormalizer_amd import Mpo  # noqa: E402
+from renormalizer_amd.mps import MpDm, thermal_state  # noqa: E402
 from renormalizer_amd.utils import CompressConfig, CompressCriteria, EvolveConfig, EvolveMethod, constant  # noqa: E402
 
 ph_list = [Phonon.simple_phonon(Quantity(106.51, "cm^{-1}"), Quantity(30.1370), 4),
@@ -19,7 +20,8 @@ model = HolsteinModel([Mol(Quantity(2.67, "eV"), ph_list, 15.45)] * 3, j, 3)
 rho = MpDm.max_entangled_ex(model)
 rho.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=16)
 beta = Quantity(298, "K").to_beta()
-job = ThermalProp(rho, evolve_config=EvolveConfig(EvolveMethod.tdvp_ps, guess_dt=0.1 / 1j))
-job.evolve(evolve_dt=beta / 2j / 20, nsteps=20)
-print("populations :", job.e_occupations_array[-1], " exact 0.20896541 0.35240030 0.43863429")
-print("energy      :", job.energies[-1], " exact", 0.0853388 + model.gs_zpe)
+rho.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps, guess_dt=0.1 / 1j)
+h = Mpo(model)
+rho, energies = thermal_state(rho, h, beta / 2j / 20, 20)
+print("populations :", rho.e_occupations, " exact 0.20896541 0.35240030 0.43863429")
+print("energy      :", energies[-1], " exact", 0.0853388 + model.gs_zpe)

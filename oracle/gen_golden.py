@@ -7,7 +7,7 @@ third-party packages), runs the reference's own functions at the seams of the
 hot path and stores inputs + outputs as small .npz files
 under tests/golden/.  Only data is written - no reference source.
 
-    cd /tmp && python /root/repo/oracle/gen_golden.py [seams|tdvp|dmrg|mpo|all]
+    cd /tmp && python /root/repo/oracle/gen_golden.py [seams|tdvp|mpo|ps2|adaptive|pc_adaptive|fmo|thermal|obs|pc_rk|vmf|ofs|thermofield|dmrg|all]
 
 The GPU box never runs this (no /root/reference there); tests read the .npz.
 """
@@ -642,153 +642,6 @@ def gen_pc_rk():
 
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("pc_rk",)):
     gen_pc_rk()
-
-
-def gen_transport():
-    """`ChargeDiffusionDynamics` (transport/dynamics.py) on the model of transport/tests/test_dynamics.py::test_evolve
-    (5 molecules, J = 0.8 eV, one 1400 cm^-1 mode, 4 levels): relaxed initial state + default P&C, Franck-Condon
-    initial state + TDVP-PS with the reduced density matrix outputs, and a 3-molecule chain at 300 K (thermal
-    vibrational state from the exact local propagator, then P&C of the density operator)."""
-    from renormalizer.model import Phonon, Mol, HolsteinModel
-    from renormalizer.transport import ChargeDiffusionDynamics, InitElectron
-    from renormalizer.utils import Quantity, EvolveConfig, EvolveMethod, CompressConfig, CompressCriteria
-    out = {}
-
-    def model_of(nmol, pdim=4):
-        ph = Phonon.simple_phonon(Quantity(1400, "cm^{-1}"), Quantity(17, "a.u."), pdim)
-        return HolsteinModel([Mol(Quantity(3.87e-3, "a.u."), [ph])] * nmol, Quantity(0.8, "eV"))
-
-    def record(tag, ct):
-        out[tag + "_times"] = np.array(ct.evolve_times, dtype=float)
-        out[tag + "_energies"] = np.array(ct.energies, dtype=complex).real
-        out[tag + "_r_square"] = np.array(ct.r_square_array)
-        out[tag + "_e_occ"] = np.array(ct.e_occupations_array)
-        out[tag + "_ph_occ"] = np.array(ct.ph_occupations_array)
-        out[tag + "_bond_entropy"] = np.array(ct.bond_vn_entropy_array)
-        if ct.reduced_density_matrices:
-            out[tag + "_rdm"] = np.array(ct.reduced_density_matrices)
-            out[tag + "_k_occ"] = np.array(ct.k_occupations_array)
-            out[tag + "_eph_entropy"] = np.array(ct.eph_vn_entropy_array, dtype=complex).real
-            out[tag + "_coherent_length"] = np.array(ct.coherent_length_array)
-        print(tag, out[tag + "_e_occ"][-1], out[tag + "_r_square"][-1])
-
-    ct = ChargeDiffusionDynamics(model_of(5), stop_at_edge=False)
-    ct.evolve(2, 12)
-    record("pc_relaxed", ct)
-    ct = ChargeDiffusionDynamics(model_of(5), compress_config=CompressConfig(CompressCriteria.fixed, max_bonddim=16),
-                                 evolve_config=EvolveConfig(EvolveMethod.tdvp_ps), stop_at_edge=False,
-                                 init_electron=InitElectron.fc, rdm=True)
-    ct.evolve(2, 12)
-    record("tdvp_fc", ct)
-    ct = ChargeDiffusionDynamics(model_of(3), temperature=Quantity(300, "K"), stop_at_edge=False)
-    ct.evolve(2, 8)
-    record("thermal", ct)
-    np.savez_compressed(os.path.join(GOLD, "transport_dynamics.npz"), **out)
-
-
-if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("transport",)):
-    gen_transport()
-
-
-def gen_spectral():
-    """`SpectralFunctionZT` on the thermofield Holstein ring of transport/tests/test_spectral_function.py (3 cells,
-    T = 0.2, omega = g = 1, 4 levels; the reference test compares with qutip, which is not installed here): G_ij(t)
-    and populations over five TDVP-PS steps, plus a T = 0 ring with P&C."""
-    from renormalizer.model import Op, TI1DModel
-    from renormalizer.model.basis import BasisSimpleElectron, BasisSHO
-    from renormalizer.transport.spectral_function import SpectralFunctionZT
-    from renormalizer.utils import Quantity, CompressConfig, EvolveMethod, EvolveConfig, CompressCriteria
-    out = {}
-    omega, g, nlevels, nsites = 1, 1, 4, 3
-    theta = np.arctanh(np.exp(-Quantity(0.2).to_beta() * omega / 2))
-    basis = [BasisSimpleElectron("e"), BasisSHO("ph0", omega, nlevels), BasisSHO("ph1", omega, nlevels)]
-    local = [Op(r"a^\dagger a", "e", g ** 2 * omega), Op(r"b^\dagger b", "ph0", omega), Op(r"b^\dagger b", "ph1", -omega),
-             - g * np.cosh(theta) * omega * Op(r"a^\dagger a", "e") * Op(r"b^\dagger + b", "ph0"),
-             - g * np.sinh(theta) * omega * Op(r"a^\dagger a", "e") * Op(r"b^\dagger + b", "ph1")]
-    hop = [Op(r"a^\dagger a", [(0, "e"), (1, "e")]), Op(r"a^\dagger a", [(1, "e"), (0, "e")])]
-    sf = SpectralFunctionZT(TI1DModel(basis, local, hop, nsites),
-                            compress_config=CompressConfig(CompressCriteria.fixed, max_bonddim=24),
-                            evolve_config=EvolveConfig(EvolveMethod.tdvp_ps))
-    sf.evolve(nsteps=5, evolve_time=2.5)
-    out["tf_theta"] = np.array(theta)
-    out["tf_times"] = np.array(sf.evolve_times, dtype=float)
-    out["tf_G"] = sf.G_array
-    out["tf_e_occ"] = np.array(sf.e_occupations_array)
-    out["tf_Gk"] = sf.get_dump_dict()["Gk array"]
-    basis = [BasisSimpleElectron("e"), BasisSHO("ph0", omega, nlevels)]
-    local = [Op(r"a^\dagger a", "e", g ** 2 * omega), Op(r"b^\dagger b", "ph0", omega),
-             - g * omega * Op(r"a^\dagger a", "e") * Op(r"b^\dagger + b", "ph0")]
-    sf = SpectralFunctionZT(TI1DModel(basis, local, hop, 4))
-    sf.evolve(nsteps=4, evolve_time=1.0)
-    out["zt_times"] = np.array(sf.evolve_times, dtype=float)
-    out["zt_G"] = sf.G_array
-    out["zt_e_occ"] = np.array(sf.e_occupations_array)
-    print(out["tf_G"][-1], out["zt_G"][-1])
-    np.savez_compressed(os.path.join(GOLD, "spectral_function.npz"), **out)
-
-
-if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("spectral",)):
-    gen_spectral()
-
-
-def gen_kubo():
-    """`TransportKubo` (transport/kubo.py) with fixed-step TDVP-PS in imaginary and real time on Holstein rings
-    (transport/tests/test_kubo.py: 50000 K, omega = J = 1; 3 molecules with a bond dimension that holds the full
-    one-exciton space, 5 molecules truncated to 24) and on Peierls rings (test_peierls_kubo's parameters:
-    phonon-assisted current, four-part decomposition; 3 sites untruncated, 4 sites truncated to 24), and with the
-    default P&C on the 3-molecule Holstein ring."""
-    from renormalizer.model import Phonon, Mol, HolsteinModel, Model
-    from renormalizer.model.basis import BasisSimpleElectron, BasisSHO
-    from renormalizer.model.op import Op
-    from renormalizer.transport.kubo import TransportKubo
-    from renormalizer.utils import Quantity, CompressConfig, EvolveConfig, EvolveMethod, CompressCriteria
-    out = {}
-
-    def tdvp():
-        return EvolveConfig(EvolveMethod.tdvp_ps)
-
-    def fixed(m):                       # a fresh object per job: max_dims is sized by the first model it meets
-        return CompressConfig(CompressCriteria.fixed, max_bonddim=m)
-
-    def holstein(nmol):
-        return HolsteinModel([Mol(Quantity(0), [Phonon.simple_phonon(Quantity(1), Quantity(1), 2)])] * nmol, Quantity(1), 3)
-
-    def peierls(n, nlevels=2, g=4):
-        v = -Quantity(120, "meV").as_au()
-        omega = Quantity(50, "cm-1").as_au()
-        ham, basis = [], []
-        for i in range(n):
-            i1, i2 = i, (i + 1) % n
-            ham += [Op(r"a^\dagger a", [i1, i2], v), Op(r"a a^\dagger", [i1, i2], v), Op(r"b^\dagger b", (i, 0), omega),
-                    Op(r"b^\dagger + b", (i, 0)) * Op(r"a^\dagger a", [i1, i2]) * g * omega,
-                    Op(r"b^\dagger + b", (i, 0)) * Op(r"a a^\dagger", [i1, i2]) * g * omega]
-            basis += [BasisSimpleElectron(i), BasisSHO((i, 0), omega, nlevels)]
-        return Model(basis, ham)
-
-    for nmol, m in ((3, 64), (5, 24)):
-        kubo = TransportKubo(holstein(nmol), Quantity(50000, "K"), insteps=4, compress_config=fixed(m),
-                             ievolve_config=tdvp(), evolve_config=tdvp())
-        kubo.evolve(nsteps=5, evolve_time=5)
-        out[f"holstein{nmol}_corr"] = kubo.auto_corr
-        out[f"holstein{nmol}_bond_dims"] = np.array(kubo.latest_mps.ket_mps.bond_dims)
-        print(nmol, kubo.auto_corr, kubo.latest_mps.ket_mps.bond_dims)
-    kubo = TransportKubo(holstein(3), Quantity(50000, "K"), insteps=20, compress_config=CompressConfig(threshold=1e-6))
-    kubo.evolve(nsteps=10, evolve_time=2)
-    out["holstein3_pc_corr"] = kubo.auto_corr
-    print("pc", kubo.auto_corr)
-    for n, m in ((3, 64), (4, 24)):
-        kubo = TransportKubo(peierls(n), Quantity(300, "K"), insteps=6, compress_config=fixed(m),
-                             ievolve_config=tdvp(), evolve_config=tdvp())
-        kubo.evolve(nsteps=5, evolve_time=1000)
-        out[f"peierls{n}_corr"] = kubo.auto_corr
-        out[f"peierls{n}_decomposition"] = kubo.auto_corr_decomposition
-        out[f"peierls{n}_j_bond_dims"] = np.array(list(kubo.j_oper.bond_dims) + list(kubo.j_oper2.bond_dims))
-        print(n, kubo.auto_corr)
-    np.savez_compressed(os.path.join(GOLD, "transport_kubo.npz"), **out)
-
-
-if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("kubo",)):
-    gen_kubo()
 
 
 def gen_vmf():

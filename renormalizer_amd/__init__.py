@@ -21,7 +21,7 @@ def __getattr__(name):
     if name == "optimize_mps":
         from .mps.gs import optimize_mps
         return optimize_mps
-    if name in ("MpDm", "ThermalProp"):
+    if name in ("MpDm", "thermal_state"):
         from . import mps as _mps
         return getattr(_mps, name)
     if name == "backend":

@@ -112,6 +112,7 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
 
 extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, void* out) {
   if (!ctx || !h || !C || !out || !h->L || !h->R) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (dtype != MPSE_C128 && (h->l_dtype == MPSE_C128 || h->r_dtype == MPSE_C128 || h->w_dtype == MPSE_C128))
     return mpse_fail(ctx, MPSE_ERR_ARG, "heff_apply: real centre with complex operator parts");
   Plan p = plan_heff(dtype, *h);
@@ -129,6 +130,7 @@ extern "C" int mpse_env_update(mpse_ctx* ctx, int dtype, int domain, const mpse_
                                int env_dtype, const void* ket, const void* bra, int bra_conj, const void* W,
                                int w_dtype, void* out) {
   if (!ctx || !dims || !env || !ket || !W || !out) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (dtype != MPSE_C128 && (env_dtype == MPSE_C128 || w_dtype == MPSE_C128))
     return mpse_fail(ctx, MPSE_ERR_ARG, "env_update: real sites with complex env/mpo");
   if (!bra) {
@@ -149,6 +151,7 @@ extern "C" int mpse_env_update(mpse_ctx* ctx, int dtype, int domain, const mpse_
 extern "C" int mpse_env_unit_channel(mpse_ctx* ctx, int dtype, const void* env, int64_t D, int64_t w, double tol,
                                      int64_t* unit_host) {
   if (!ctx || !env || !unit_host) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   *unit_host = 0;
   if (D <= 0 || w <= 0 || w > 2048) return MPSE_OK;
   unsigned long long* dev = reinterpret_cast<unsigned long long*>(ctx->dscratch);

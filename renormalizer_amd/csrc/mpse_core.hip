@@ -123,9 +123,7 @@ int mpse_ctx_create(int device, mpse_ctx** out) {
   return MPSE_OK;
 }
 
-int mpse_pool_trim(mpse_ctx* ctx) {
-  if (!ctx) return MPSE_ERR_ARG;
-  MPSE_HIP(ctx, hipSetDevice(ctx->device));
+static int pool_trim_locked(mpse_ctx* ctx) {
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (auto& kv : ctx->free_blocks) {
     (void)hipFree(kv.second);
@@ -133,6 +131,13 @@ int mpse_pool_trim(mpse_ctx* ctx) {
   }
   ctx->free_blocks.clear();
   return MPSE_OK;
+}
+
+int mpse_pool_trim(mpse_ctx* ctx) {
+  if (!ctx) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
+  return pool_trim_locked(ctx);
 }
 
 int mpse_ctx_destroy(mpse_ctx* ctx) {
@@ -153,6 +158,7 @@ int mpse_ctx_destroy(mpse_ctx* ctx) {
 
 int mpse_sync(mpse_ctx* ctx) {
   if (!ctx) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (!ctx->prof_pending.empty()) prof_drain(ctx);
   return MPSE_OK;
@@ -178,6 +184,8 @@ static size_t bucket_of(size_t bytes) {
 
 int mpse_malloc(mpse_ctx* ctx, size_t bytes, void** dptr) {
   if (!ctx || !dptr) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
   size_t b = bucket_of(bytes);
   auto it = ctx->free_blocks.find(b);
   void* p = nullptr;
@@ -189,7 +197,7 @@ int mpse_malloc(mpse_ctx* ctx, size_t bytes, void** dptr) {
     if (e != hipSuccess) {
       // give cached blocks back to the driver and retry once
       (void)hipGetLastError();  // the failed call leaves a sticky error that later hipGetLastError() checks would see
-      mpse_pool_trim(ctx);
+      pool_trim_locked(ctx);
       e = hipMalloc(&p, b);
       if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -209,6 +217,7 @@ int mpse_malloc(mpse_ctx* ctx, size_t bytes, void** dptr) {
 int mpse_free(mpse_ctx* ctx, void* dptr) {
   if (!ctx) return MPSE_ERR_ARG;
   if (!dptr) return MPSE_OK;
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
   auto it = ctx->live.find(dptr);
   if (it == ctx->live.end()) return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_free: unknown pointer %p", dptr);
   ctx->free_blocks.emplace(it->second, dptr);
@@ -220,6 +229,7 @@ int mpse_free(mpse_ctx* ctx, void* dptr) {
 int mpse_mem_info(mpse_ctx* ctx, size_t* pool_bytes, size_t* in_use_bytes, size_t* device_free,
                   size_t* device_total) {
   if (!ctx) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (pool_bytes) *pool_bytes = ctx->pool_bytes;
   if (in_use_bytes) *in_use_bytes = ctx->in_use_bytes;
   size_t f = 0, t = 0;
@@ -231,6 +241,7 @@ int mpse_mem_info(mpse_ctx* ctx, size_t* pool_bytes, size_t* in_use_bytes, size_
 
 int mpse_memcpy_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes) {
   if (!ctx || (bytes && (!dst || !src_host))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (!bytes) return MPSE_OK;
   MPSE_HIP(ctx, hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -239,6 +250,7 @@ int mpse_memcpy_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes
 
 int mpse_memcpy_d2h(mpse_ctx* ctx, void* dst_host, const void* src, size_t bytes) {
   if (!ctx || (bytes && (!dst_host || !src))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (!bytes) return MPSE_OK;
   MPSE_HIP(ctx, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -247,6 +259,7 @@ int mpse_memcpy_d2h(mpse_ctx* ctx, void* dst_host, const void* src, size_t bytes
 
 int mpse_memcpy_d2d(mpse_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx || (bytes && (!dst || !src))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (!bytes) return MPSE_OK;
   // tensors are 16-byte aligned multiples of 8 bytes: a plain grid-stride kernel queues like any other launch, while
   // the runtime's device-to-device copy leaves ~15 us of idle time behind it on the stream (rocprofv3 trace)
@@ -266,6 +279,7 @@ int mpse_memcpy_d2d(mpse_ctx* ctx, void* dst, const void* src, size_t bytes) {
 int mpse_memcpy_2d(mpse_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
                    size_t height) {
   if (!ctx || ((width_bytes && height) && (!dst || !src))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (!width_bytes || !height) return MPSE_OK;
   MPSE_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDeviceToDevice, ctx->stream));
   return MPSE_OK;
@@ -273,6 +287,7 @@ int mpse_memcpy_2d(mpse_ctx* ctx, void* dst, size_t dpitch, const void* src, siz
 
 int mpse_memset_zero(mpse_ctx* ctx, void* dst, size_t bytes) {
   if (!ctx || (bytes && !dst)) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (!bytes) return MPSE_OK;
   MPSE_HIP(ctx, hipMemsetAsync(dst, 0, bytes, ctx->stream));
   return MPSE_OK;

@@ -639,6 +639,7 @@ __global__ __launch_bounds__(256) void k_transpose_inner(double* out, const doub
 
 static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C, int skip_zero) {
   if (!ctx || !d) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if ((d->dtype_a != MPSE_F64 && d->dtype_a != MPSE_C128) || (d->dtype_b != MPSE_F64 && d->dtype_b != MPSE_C128))
     return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_gemm: unknown dtype");
   if (d->m_a.ext != d->m_c.ext || d->n_b.ext != d->n_c.ext || d->k_a.ext != d->k_b.ext)
@@ -864,6 +865,7 @@ int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index 
 extern "C" int mpse_transpose_inner(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t d0, int64_t d1,
                                     int64_t d2, int conj) {
   if (!ctx) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (d0 <= 0 || d1 <= 0 || d2 <= 0) return MPSE_OK;
   if (!out || !in) return MPSE_ERR_ARG;
   long long nblk = d0 * ((d1 + 31) / 32) * ((d2 + 31) / 32);

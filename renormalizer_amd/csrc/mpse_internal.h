@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -23,6 +24,7 @@ struct mpse_ctx {
   // size-bucketed caching allocator: hipMalloc/hipFree synchronise the device, the
   // sweep allocates per site.  Single in-order stream => a freed block may be handed
   // out again immediately.
+  std::mutex pool_mu;                       // mpse_malloc / mpse_free may be called from a GC pass on another thread
   std::multimap<size_t, void*> free_blocks;
   std::unordered_map<void*, size_t> live;   // ptr -> bucket size
   size_t pool_bytes = 0;
@@ -73,6 +75,14 @@ struct mpse_ctx {
 };
 
 int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...);
+// Makes ctx->device the calling thread's current HIP device (a new thread starts on device 0; allocations and
+// launches follow the CURRENT device, not the stream's).  Every entry point that allocates or launches calls it.
+inline int mpse_bind(mpse_ctx* ctx) {
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur == ctx->device) return MPSE_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess) return mpse_fail(ctx, MPSE_ERR_HIP, "hipSetDevice(%d) failed", ctx->device);
+  return MPSE_OK;
+}
 // asynchronous upload of a small host array through the pinned ring (the host buffer may be reused at once)
 int stage_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes);
 // fold finished profiling records into the totals; call only when the stream is idle
@@ -91,6 +101,8 @@ void prof_drain(mpse_ctx* ctx);
     int _s = (call);              \
     if (_s != MPSE_OK) return _s; \
   } while (0)
+
+#define MPSE_BIND(ctx) MPSE_TRY(mpse_bind(ctx))
 
 // RAII temporary from the pool
 struct TmpBuf {

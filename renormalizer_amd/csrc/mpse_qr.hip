@@ -379,6 +379,7 @@ int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int6
                   const int64_t* col_off_host, int system_is_R, void* U, void* Vt, int64_t K) {
   if (!ctx || !coef || !U || !Vt || !row_idx_host || !row_off_host || !col_idx_host || !col_off_host)
     return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (nblocks <= 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
   if (dtype == MPSE_C128)
     return block_qr_impl<true>(ctx, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host, col_off_host,
@@ -392,6 +393,7 @@ int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int6
 int mpse_gather_cols(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t nrow, int64_t ncol_in,
                      const int64_t* cols_host, const double* scale_host, int64_t ncol_out) {
   if (!ctx || !cols_host || (nrow * ncol_out && (!out || !in))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (nrow * ncol_out <= 0) return MPSE_OK;
   TmpBuf IDX(ctx);
   MPSE_TRY(IDX.alloc(size_t(ncol_out) * 16));
@@ -417,6 +419,7 @@ int mpse_gather_cols(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_
 int mpse_gather_rows(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t ncol, const int64_t* rows_host,
                      const double* scale_host, int64_t nrow_out) {
   if (!ctx || !rows_host || (nrow_out * ncol && (!out || !in))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (nrow_out * ncol <= 0) return MPSE_OK;
   TmpBuf IDX(ctx);
   MPSE_TRY(IDX.alloc(size_t(nrow_out) * 16));

@@ -366,6 +366,7 @@ extern "C" int mpse_block_svd_full(mpse_ctx* ctx, int dtype, const void* coef, i
                                    double* S_host, int64_t K) {
   if (!ctx || !coef || !U || !Vt || !S_host || !row_idx_host || !row_off_host || !col_idx_host || !col_off_host)
     return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (nblocks <= 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
   if (dtype == MPSE_C128)
     return block_svd_impl<true>(ctx, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host,

@@ -384,6 +384,7 @@ extern "C" {
 
 int mpse_cast_f64_to_c128(mpse_ctx* ctx, void* dst, const void* src, int64_t n) {
   if (!ctx || (n && (!dst || !src))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (n <= 0) return MPSE_OK;
   hipLaunchKernelGGL(k_cast, dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst, (const double*)src,
                      (long long)n);
@@ -393,6 +394,7 @@ int mpse_cast_f64_to_c128(mpse_ctx* ctx, void* dst, const void* src, int64_t n) 
 
 int mpse_conj_inplace(mpse_ctx* ctx, void* x, int64_t n) {
   if (!ctx || (n && !x)) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (n <= 0) return MPSE_OK;
   hipLaunchKernelGGL(k_conj, dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)x, (long long)n);
   MPSE_HIP(ctx, hipGetLastError());
@@ -401,6 +403,7 @@ int mpse_conj_inplace(mpse_ctx* ctx, void* x, int64_t n) {
 
 int mpse_scal(mpse_ctx* ctx, int dtype, void* x, int64_t n, double a_re, double a_im) {
   if (!ctx || (n && !x)) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (n <= 0) return MPSE_OK;
   if (dtype == MPSE_C128)
     hipLaunchKernelGGL((k_scal<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)x, (long long)n, a_re,
@@ -414,6 +417,7 @@ int mpse_scal(mpse_ctx* ctx, int dtype, void* x, int64_t n, double a_re, double 
 
 int mpse_axpy(mpse_ctx* ctx, int dtype, void* y, const void* x, int64_t n, double a_re, double a_im) {
   if (!ctx || (n && (!x || !y))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (n <= 0) return MPSE_OK;
   if (dtype == MPSE_C128)
     hipLaunchKernelGGL((k_axpy<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)y, (const double*)x,
@@ -427,6 +431,7 @@ int mpse_axpy(mpse_ctx* ctx, int dtype, void* y, const void* x, int64_t n, doubl
 
 int mpse_mul_real(mpse_ctx* ctx, int dtype, void* x, const void* m_f64, int64_t n) {
   if (!ctx || (n && (!x || !m_f64))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (n <= 0) return MPSE_OK;
   if (dtype == MPSE_C128)
     hipLaunchKernelGGL((k_mul_real<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)x,
@@ -441,6 +446,7 @@ int mpse_mul_real(mpse_ctx* ctx, int dtype, void* x, const void* m_f64, int64_t 
 int mpse_davidson_precond(mpse_ctx* ctx, int dtype, void* out, const void* r, const void* hdiag_f64,
                           const void* mask_f64, int64_t n, double e, double shift) {
   if (!ctx || (n && (!out || !r || !hdiag_f64))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (n <= 0) return MPSE_OK;
   if (dtype == MPSE_C128)
     hipLaunchKernelGGL((k_precond<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)out,
@@ -454,6 +460,7 @@ int mpse_davidson_precond(mpse_ctx* ctx, int dtype, void* out, const void* r, co
 
 int mpse_real_part(mpse_ctx* ctx, void* out_f64, const void* z_c128, int64_t n) {
   if (!ctx || (n && (!out_f64 || !z_c128))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   if (n <= 0) return MPSE_OK;
   hipLaunchKernelGGL(k_real_part, dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)out_f64,
                      (const double*)z_c128, (long long)n);
@@ -463,6 +470,7 @@ int mpse_real_part(mpse_ctx* ctx, void* out_f64, const void* z_c128, int64_t n) 
 
 int mpse_dotc(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n, double* out_host) {
   if (!ctx || !out_host || (n && (!x || !y))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   out_host[0] = out_host[1] = 0.0;
   if (n <= 0) return MPSE_OK;
   return dotc_sync(ctx, dtype, x, y, n, &out_host[0], &out_host[1]);
@@ -470,6 +478,7 @@ int mpse_dotc(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n,
 
 int mpse_nrm2(mpse_ctx* ctx, int dtype, const void* x, int64_t n, double* out_host) {
   if (!ctx || !out_host || (n && !x)) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   out_host[0] = 0.0;
   if (n <= 0) return MPSE_OK;
   double re = 0, im = 0;
@@ -481,6 +490,7 @@ int mpse_nrm2(mpse_ctx* ctx, int dtype, const void* x, int64_t n, double* out_ho
 int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re, double dt_im, const void* Cin,
                       void* out, double rtol, double atol, int max_dim, int* nvec) {
   if (!ctx || !h || !Cin || !out) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
   const bool cplx = dtype == MPSE_C128;
   if (!cplx && dt_im != 0.0)
     return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: complex time step needs a complex128 centre tensor");

@@ -70,6 +70,10 @@ def eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, cguess):
     hdiag = _hdiag(eng, hop.l, hop.r, hop.cmo)
     mask = eng.asdevice(qn_mask.astype(np.float64))
     nroots = mps.optimize_config.nroots
+    if hop.operator_is_complex:
+        # complex MPO / environments with a real centre: the iteration runs in complex128 (NumPy promotes silently
+        # in the reference, gs.py:520-538)
+        cguess = cguess.to_complex() if nroots == 1 else [g.to_complex() for g in cguess]
     if nroots == 1:
         e, c, ncyc = davidson(lambda x: hop(x), cguess.reshape(cshape), hdiag, mask=mask, tol=1e-12, max_cycle=100,
                               max_space=12, lindep=1e-14)

@@ -78,6 +78,8 @@ class MpDm(Mps):
         assert not getattr(mp, "is_mps", False) and len(mp) == len(self)
         new = self.metacopy()
         cplx = self.is_complex or mp.is_complex
+        if cplx:
+            new.dtype = np.dtype(np.complex128)     # mpdm.py:140-141 to_complex(inplace=True)
         for i, ms in enumerate(self):
             w = mp.device(i, eng)
             if cplx:

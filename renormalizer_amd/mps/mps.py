@@ -304,6 +304,7 @@ class Mps:
     def conj(self):
         new = self.metacopy()
         new._mp = [t.conj() if t.is_complex else t for t in self._mp]
+        new.coeff = np.conjugate(self.coeff)          # mps/mps.py:415-418
         return new
 
     def to_complex(self, inplace=False):
@@ -1134,6 +1135,11 @@ class Mps:
         eng = get_engine()
         assert np.all(self.qntot == other.qntot)
         assert self.site_num == other.site_num
+        if not np.allclose(self.coeff, other.coeff):
+            # mps/mps.py:1802-1808: different prefactors are folded into the states before the sum
+            a, b = self.scale(self.coeff), other.scale(other.coeff)
+            a.coeff = b.coeff = 1
+            return a.add(b)
         new = self.metacopy()
         cplx = self.is_complex or other.is_complex
         dt = np.dtype(np.complex128 if cplx else np.float64)
@@ -1572,30 +1578,6 @@ def _adaptive_tdvp(fun, cur_mps, mpo, evolve_target_t):
             return half2
         config.guess_dt *= p
         cur_mps = half2
-
-
-class BraKetPair:
-    """A bra and a ket propagated side by side and their overlap <bra| O |ket> (O optional), including both
-    ``coeff`` factors (mps/mps.py:2061-2088); unpacks as (bra, ket)."""
-
-    def __init__(self, bra_mps, ket_mps, mpo=None):
-        self.bra_mps = bra_mps
-        self.ket_mps = ket_mps
-        self.mpo = mpo
-        self.ft = self.calc_ft()
-
-    def calc_ft(self):
-        if self.mpo is None:
-            dot = self.bra_mps.conj().dot(self.ket_mps)
-        else:
-            dot = self.ket_mps.expectation(self.mpo, self.bra_mps.conj())
-        return complex(dot * np.conjugate(self.bra_mps.coeff) * self.ket_mps.coeff)
-
-    def __iter__(self):
-        return iter((self.bra_mps, self.ket_mps))
-
-    def __str__(self):
-        return f"bra: {self.bra_mps}, ket: {self.ket_mps}, ft: {self.ft:g}"
 
 
 def compressed_sum(mps_list, batchsize=5, temp_m_trunc=None):

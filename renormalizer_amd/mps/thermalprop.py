@@ -1,95 +1,25 @@
-"""Imaginary-time propagation of a matrix product density operator to a finite temperature.
-
-Counterpart of renormalizer/mps/thermalprop.py (``ThermalProp``): rho(beta/2) = exp(-beta H / 2) rho(0) is reached
-by ``nsteps`` calls of ``MpDm.evolve`` with an imaginary step; after every step the energy, the electronic and
-vibrational occupations and the bond entropies are recorded.  The Hamiltonian is re-referenced to the latest
-energy before every step (thermalprop.py:105-107) so the norm stays O(1)."""
-import logging
-
+"""Purified thermal state by imaginary-time propagation (the preparer behind the reference's finite-temperature
+runs, mps/thermalprop.py:95-133): rho(beta/2) = exp(-beta H / 2) rho(0), ``nsteps`` calls of ``MpDm.evolve`` with an
+imaginary step, the Hamiltonian re-referenced to the latest energy before every step so the norm stays O(1)."""
 import numpy as np
 
-from ..utils import EvolveConfig, Quantity
-from ..utils.tdmps import TdMpsJob
-from .mpdm import MpDm
+from ..utils import Quantity
 from .mpo import Mpo
 
-logger = logging.getLogger("renormalizer_amd")
 
-
-class ThermalProp(TdMpsJob):
-    def __init__(self, init_mpdm: MpDm, h_mpo_model=None, exact=False, space="GS", evolve_config: EvolveConfig = None,
-                 dump_mps=None, dump_dir=None, job_name=None, properties=None, auto_expand=True):
-        self.init_mpdm = init_mpdm.canonicalise()
-        self.h_mpo = Mpo(self.init_mpdm.model if h_mpo_model is None else h_mpo_model)
-        self.exact, self.space = exact, space
-        self.properties = properties
-        self.auto_expand = auto_expand
-        self.energies = []
-        self._e_occupations_array = []
-        self._ph_occupations_array = []
-        self._vn_entropy_array = []
-        super().__init__(evolve_config=evolve_config, dump_mps=dump_mps, dump_dir=dump_dir, job_name=job_name)
-
-    def init_mps(self):
-        self.init_mpdm.evolve_config = self.evolve_config
-        if self.evolve_config.is_tdvp and self.auto_expand:
-            self.init_mpdm = self.init_mpdm.expand_bond_dimension(self.h_mpo)
-        return self.init_mpdm
-
-    def process_mps(self, mps):
-        self.energies.append(mps.expectation(self.h_mpo))
-        if self.exact:
-            return                                  # thermalprop.py:76-78: energies only
-        self._e_occupations_array.append(np.asarray(mps.e_occupations))
-        self._ph_occupations_array.append(np.asarray(mps.ph_occupations))
-        self._vn_entropy_array.append(mps.calc_bond_entropy())
-        if self.properties is not None:
-            self.properties.calc_properties(mps)
-
-    def evolve_exact(self, old_mpdm, evolve_dt):
-        """one application of the bond-dimension-1 propagator of a local Hamiltonian (thermalprop.py:95-103)"""
-        prop = Mpo.exact_propagator(old_mpdm.model, np.imag(evolve_dt), space=self.space, shift=-self.energies[-1])
-        new_mpdm = prop.apply(old_mpdm, canonicalise=True)
-        new_mpdm.normalize("mps_and_coeff")
-        return new_mpdm
-
-    def evolve_single_step(self, evolve_dt):
-        if self.exact:
-            return self.evolve_exact(self.latest_mps, evolve_dt)
-        h_mpo = Mpo(self.h_mpo.model, offset=Quantity(self.energies[-1]))
-        return self.latest_mps.evolve(h_mpo, evolve_dt)
-
-    def evolve(self, evolve_dt=None, nsteps=None, evolve_time=None):
-        for t in (evolve_dt, evolve_time):
-            if t is not None:
-                assert np.iscomplex(t) and np.imag(t) < 0
-        return super().evolve(evolve_dt, nsteps, evolve_time)
-
-    @property
-    def e_occupations_array(self):
-        return np.array(self._e_occupations_array)
-
-    @property
-    def ph_occupations_array(self):
-        return np.array(self._ph_occupations_array)
-
-    @property
-    def vn_entropy_array(self):
-        return np.array(self._vn_entropy_array)
-
-    def get_dump_dict(self):
-        # same keys as thermalprop.py:136-148
-        return {"time series": np.array([-np.imag(t) for t in self.evolve_times]),
-                "energies": np.array(self.energies),
-                "electron occupations array": self.e_occupations_array,
-                "phonon occupations array": self.ph_occupations_array,
-                "vn entropy array": np.array([np.asarray(v, dtype=float) for v in self._vn_entropy_array]),
-                **({} if self.properties is None else dict(self.properties.prop_res))}
-
-
-def load_thermal_state(model, path: str):
-    """A thermal state dumped by ``MpDm.dump``; None when the file does not exist (thermalprop.py:151-168)"""
-    try:
-        return MpDm.load(model, path)
-    except FileNotFoundError:
-        return None
+def thermal_state(init_mpdm, h_mpo, evolve_dt, nsteps, auto_expand=True, on_step=None):
+    """Returns (rho(beta / 2), energies).  ``evolve_dt`` = beta / 2j / nsteps (negative imaginary); ``on_step(rho)`` is
+    called on the initial state and after every step."""
+    assert np.iscomplex(evolve_dt) and np.imag(evolve_dt) < 0
+    rho = init_mpdm.canonicalise()
+    if rho.evolve_config.is_tdvp and auto_expand:
+        rho = rho.expand_bond_dimension(h_mpo)
+    energies = [rho.expectation(h_mpo)]
+    if on_step is not None:
+        on_step(rho)
+    for _ in range(nsteps):
+        rho = rho.evolve(Mpo(h_mpo.model, offset=Quantity(energies[-1])), evolve_dt)
+        energies.append(rho.expectation(h_mpo))
+        if on_step is not None:
+            on_step(rho)
+    return rho, energies

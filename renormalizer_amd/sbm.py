@@ -1,16 +1,15 @@
-"""Spin-boson model: spectral densities, adiabatic renormalisation, bath discretisation and the dynamics job.
+"""Spin-boson model construction: spectral densities, adiabatic renormalisation, bath discretisation.
 
-Counterpart of renormalizer/sbm (lib.py: ``SpectralDensityFunction`` / ``OhmicSDF`` :38-139, ``DebyeSDF`` :18-35,
-``ColeDavidsonSDF`` :142-202, ``param2mollist`` :205-217; sbm.py: ``SpinBosonDynamics``) - the producer and the driver
-of BASELINE config 2.  The model layer is host-side; ``SpinBosonDynamics`` steps the MPS on the device."""
+Counterpart of renormalizer/sbm/lib.py (``SpectralDensityFunction`` / ``OhmicSDF`` :38-139, ``DebyeSDF`` :18-35,
+``ColeDavidsonSDF`` :142-202, ``param2mollist`` :205-217) - the producer of BASELINE config 2's model.  Host-side
+only; the dynamics are plain ``Mps.evolve`` calls (examples/sbm.py)."""
 import logging
 
 import numpy as np
 import scipy.integrate
 
 from .model import Phonon, SpinBosonModel
-from .utils import CompressConfig, Quantity
-from .utils.tdmps import TdMpsJob
+from .utils import Quantity
 
 logger = logging.getLogger("renormalizer_amd")
 
@@ -120,46 +119,6 @@ def param2mollist(alpha: float, raw_delta: Quantity, omega_c: Quantity, renormal
     omega_list, dis_list = sdf.post_process(*sdf.trapz(n_phonons, 0.0, max_omega))
     ph_list = [Phonon.simplest_phonon(o, d) for o, d in zip(omega_list, dis_list)]
     return SpinBosonModel(Quantity(0), Quantity(delta), ph_list)
-
-
-class SpinBosonDynamics(TdMpsJob):
-    """Spin up, all modes in their vacuum, then real-time propagation; per step the spin's reduced density matrix,
-    <sigma_z>, <sigma_x> and the bond entropies (sbm/sbm.py:13-92).  Finite temperature through thermofield-doubled
-    models."""
-
-    def __init__(self, model, auto_expand: bool = True, compress_config=None, evolve_config=None, dump_dir=None,
-                 dump_mps=None, job_name=None):
-        from .mps import Mpo
-        self.model = model
-        self.h_mpo = Mpo(model)
-        self.auto_expand = auto_expand
-        self.compress_config = CompressConfig() if compress_config is None else compress_config
-        self.sigma_x, self.sigma_z, self.rho, self.bond_entropy = [], [], [], []
-        super().__init__(evolve_config=evolve_config, dump_dir=dump_dir, dump_mps=dump_mps, job_name=job_name)
-
-    def init_mps(self):
-        from .mps import Mps
-        init_mps = Mps.ground_state(self.model, False)
-        init_mps.compress_config = self.compress_config
-        init_mps.evolve_config = self.evolve_config
-        if self.evolve_config.is_tdvp and self.auto_expand:
-            init_mps = init_mps.expand_bond_dimension(self.h_mpo, coef=1e-16, include_ex=False)
-        return init_mps
-
-    def process_mps(self, mps):
-        idx = next(i for i, b in enumerate(self.model.basis) if b.is_spin)
-        rho = mps.calc_1site_rdm(idx=idx)[idx]
-        self.rho.append(rho)
-        self.sigma_z.append(float((rho[0, 0] - rho[1, 1]).real))
-        self.sigma_x.append(float((rho[0, 1] + rho[1, 0]).real))
-        self.bond_entropy.append(mps.calc_entropy("bond"))
-
-    def evolve_single_step(self, evolve_dt):
-        return self.latest_mps.evolve(self.h_mpo, evolve_dt)
-
-    def get_dump_dict(self):
-        return {"time series": self.evolve_times, "sigma_x": self.sigma_x, "sigma_z": self.sigma_z, "rho": self.rho,
-                "bond_entropy": self.bond_entropy}
 
 
 def param2model(alpha, raw_delta, omega_c, renormalization_p, n_phonons, n_phys_dim):

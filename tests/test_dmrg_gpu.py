@@ -134,61 +134,36 @@ def test_mpo_algebra_dense():
     assert abs(psi.expectation(h2) - hpsi.conj().dot(hpsi)) < 1e-10
 
 
-def test_hubbard_two_component_qn_dmrg_and_imaginary_time():
-    """example/hubbard.py at 4 sites: Jordan-Wigner Hubbard chain with (N_up, N_down) conservation; the two-site
-    DMRG energy and the imaginary-time TDVP-PS limit (adaptive steps) both reach the lowest eigenvalue of the dense
-    Hamiltonian in the (2, 2) sector."""
-    import importlib.util
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "examples", "hubbard.py")
-    spec = importlib.util.spec_from_file_location("hubbard_example", path)
-    hub = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(hub)
-    ns = 4
-    model = hub.hubbard_model(ns)
-    mpo = Mpo(model)
-    dense = mpo.todense()
-    # basis index = spins in site order, state 1 of spin orbital i = occupied; even orbitals up, odd down
-    bits = (np.arange(2 ** (2 * ns))[:, None] >> np.arange(2 * ns - 1, -1, -1)[None, :]) & 1
-    sector = (bits[:, 0::2].sum(1) == 2) & (bits[:, 1::2].sum(1) == 2)
-    exact = np.linalg.eigvalsh(dense[np.ix_(sector, sector)])[0]
-    e_dmrg, gs = hub.dmrg(model, mpo, [2, 2], 32)
-    assert abs(e_dmrg - exact) < 1e-9
-    assert sorted(map(tuple, np.asarray(gs.qntot).reshape(1, -1).tolist())) == [(2, 2)]
+def test_complex_hopping_ring_ground_state():
+    """A real random guess with a complex effective Hamiltonian (Peierls phases on a 4-site ring threaded by a flux):
+    the Davidson iteration must promote its vectors (the NumPy reference does so silently, gs.py:520-538)."""
+    from renormalizer_amd import BasisSimpleElectron, Op
+    from renormalizer_amd.mps.gs import optimize_mps
     from renormalizer_amd.mps.mps import Mps
-    start = Mps.random(model, [2, 2], 32, percent=1.0, rng=np.random.default_rng(1))
-    trace, _ = hub.imaginary_time(start, mpo, tol=1e-7)
-    assert abs(trace[-1] - exact) < 1e-5 and len(trace) < 100
-    assert all(b <= a + 1e-9 for a, b in zip(trace, trace[1:]))       # monotone cooling
-
-
-def test_optical_ssh_ground_state_and_correlations():
-    """example/ssh.py: hopping coupled to the difference of neighbouring oscillator coordinates (three-site operator
-    products in the MPO), two-site DMRG against the lowest eigenvalue of the dense one-electron Hamiltonian, and the
-    observables the example reports (operator products through ``Mpo @ Mpo``)."""
-    import importlib.util
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "examples", "ssh.py")
-    spec = importlib.util.spec_from_file_location("ssh_example", path)
-    ssh = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(ssh)
-    for nsites, periodic in ((2, True), (3, False)):
-        model = ssh.ssh_model(nsites, nboson_max=3, periodic=periodic)
-        dense = Mpo(model).todense()
-        # site order e0 ph0 e1 ph1 ...: one-electron sector
-        dims = list(model.pbond_list)
-        idx = np.indices(dims).reshape(len(dims), -1)
-        sector = idx[0::2].sum(axis=0) == 1
-        exact = np.linalg.eigvalsh(dense[np.ix_(sector, sector)])[0]
-        energy, mps = ssh.ground_state(model, 16, nsweeps=8)
-        assert abs(energy - exact) < 1e-9
-        obs = ssh.observables(model, mps)
-        rdm = obs["edof_rdm"]
-        assert abs(np.trace(rdm) - 1) < 1e-10 and np.allclose(rdm, rdm.conj().T, atol=1e-10)
-        assert np.allclose(obs["ni_nj"], np.diag(np.diag(rdm).real), atol=1e-9)      # one electron: n_i n_j = delta_ij n_i
-        assert np.all(obs["phonon_occupations"] > -1e-12)
-        if not periodic:
-            assert obs["phonon_occupations"].max() > 1e-3                            # the coupling dresses the electron
-        if periodic:
-            assert np.allclose(obs["phonon_displacement"], 0, atol=1e-6)              # inversion symmetric
+    n, phi = 4, 0.37
+    basis = [BasisSimpleElectron(i) for i in range(n)]
+    terms = []
+    for i in range(n):
+        j = (i + 1) % n
+        terms.append(Op(r"a^\dagger a", [i, j], -1.0 * np.exp(1j * phi)))
+        terms.append(Op(r"a^\dagger a", [j, i], -1.0 * np.exp(-1j * phi)))
+        terms.append(Op(r"a^\dagger a", [i, i], 0.1 * i))
+    model = Model(basis, terms)
+    mpo = Mpo(model)
+    assert mpo.is_complex
+    dense = mpo.todense()
+    assert np.abs(dense - dense.conj().T).max() < 1e-14
+    bits = (np.arange(2 ** n)[:, None] >> np.arange(n - 1, -1, -1)[None, :]) & 1
+    sector = bits.sum(1) == 1
+    exact = np.linalg.eigvalsh(dense[np.ix_(sector, sector)])[0]
+    for method in ("1site", "2site"):
+        mps = Mps.random(model, 1, 4, rng=np.random.default_rng(3))
+        assert not mps.is_complex
+        mps.optimize_config.procedure = [[4, 0.2], [4, 0], [4, 0], [4, 0]]
+        mps.optimize_config.method = method
+        energies, opt = optimize_mps(mps.copy(), mpo)
+        assert abs(min(energies) - exact) < 1e-10, (method, energies, exact)
+        assert abs(opt.expectation(mpo) - exact) < 1e-9
 
 
 def test_two_site_dmrg_with_on_the_fly_swapping():

@@ -215,3 +215,64 @@ def test_real_lanczos_odd_and_even_lengths(eng, shape):
     ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(l, r, [wm], y.reshape(c.shape)).ravel(), -0.4, c.ravel())
     assert nv == nref
     assert np.abs(out.to_host().ravel() - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_engine_used_from_a_worker_thread():
+    """A second context driven entirely from another thread (a new thread's current HIP device is 0, so every entry
+    point binds the context's device itself), while buffers of the main engine are released concurrently."""
+    import threading
+    res = {}
+
+    def work():
+        e2 = E.Engine(0)
+        E.use_engine(e2)
+        try:
+            rng = np.random.default_rng(5)
+            a, b = rng.standard_normal((70, 33)), rng.standard_normal((33, 45))
+            for _ in range(20):
+                out = e2.matmul(e2.asdevice(a), e2.asdevice(b)).to_host()
+            res["err"] = float(np.abs(out - a @ b).max())
+        finally:
+            E.use_engine(None)
+            e2.close()
+
+    t = threading.Thread(target=work)
+    t.start()
+    main = E.get_engine()
+    for _ in range(200):                      # allocator traffic on the main context while the worker runs
+        main.zeros((64, 64))
+    t.join()
+    assert res["err"] < 1e-12
+
+
+def test_mpdm_complex_promotion_after_apply():
+    """A real density operator times a complex operator is complex - in its tensors AND in its dtype flag (the
+    reference calls to_complex(inplace=True), mpdm.py:140-141): later sums / products must allocate complex results."""
+    from renormalizer_amd import HolsteinModel, Mol, Phonon, Quantity
+    from renormalizer_amd.mps import MpDm
+    ph = [Phonon.simple_phonon(Quantity(0.01), Quantity(3.0), 3)]
+    model = HolsteinModel([Mol(Quantity(0.1), ph)] * 2, Quantity(0.02), 3)
+    h = Mpo(model)
+    gs = MpDm.max_entangled_gs(model)
+    assert not gs.is_complex
+    ev = gs.evolve_exact(h, 5.0, "GS")
+    assert ev.is_complex and all(t.is_complex for t in ev)
+    twice = h.contract(ev)
+    assert twice.is_complex
+    dense = ev.todense()
+    assert np.abs((ev + ev).todense() - 2 * dense).max() < 1e-12
+    c = ev.conj()
+    assert abs(c.coeff - np.conjugate(ev.coeff)) < 1e-15
+
+
+def test_mps_add_with_different_coeff():
+    """mps/mps.py:1802-1808: prefactors that differ are folded into the states before the direct sum"""
+    from renormalizer_amd import HolsteinModel, Mol, Phonon, Quantity
+    from renormalizer_amd.mps.mps import Mps
+    ph = [Phonon.simple_phonon(Quantity(0.01), Quantity(3.0), 3)]
+    model = HolsteinModel([Mol(Quantity(0.1), ph)] * 2, Quantity(0.02), 3)
+    a = Mps.random(model, 1, 4, rng=np.random.default_rng(1))
+    b = Mps.random(model, 1, 4, rng=np.random.default_rng(2))
+    a.coeff = 0.5j
+    b.coeff = 2.0
+    assert np.abs((a + b).todense() - (a.todense() + b.todense())).max() < 1e-13

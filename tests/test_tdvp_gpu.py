@@ -568,21 +568,31 @@ def test_tdvp_cmf_matches_reference(golden_dir, tag, midpoint, trapz, solver, to
     assert abs(mps.expectation(mpo) - float(z[tag + "_energy"])) < max(tol, 1e-7)
 
 
-def test_spin_boson_dynamics_job_reproduces_reference_sigma_z(tmp_path):
-    """`sbm.SpinBosonDynamics` (renormalizer/sbm/sbm.py) on BASELINE config 2's stand-in: alpha = 0.05, Delta = 1
-    (adiabatically renormalised), omega_c = 20, 20 modes with 8 levels, D = 64, TDVP-PS, dt = 0.1.  <sigma_z(t)> as
-    measured with the reference (insensitive to the random expander at 5e-15)."""
+def test_spin_boson_sigma_z_reproduces_reference():
+    """BASELINE config 2's stand-in (renormalizer/sbm): alpha = 0.05, Delta = 1 (adiabatically renormalised),
+    omega_c = 20, 20 modes with 8 levels, D = 64, TDVP-PS, dt = 0.1.  <sigma_z(t)> as measured with the reference
+    (insensitive to the random expander at 5e-15)."""
     from renormalizer_amd import sbm
+    from renormalizer_amd.mps.mps import Mps
     ref = [1.0, 0.9846060563460243, 0.9389039214679588, 0.8643177094118863, 0.7631714975081663, 0.6386167803697902,
            0.49453409941361465, 0.33541192144804705, 0.16620655032362253, -0.00781255235784125, -0.18122720641516832]
     model, delta = sbm.param2model(0.05, Quantity(1), Quantity(20), 1, 20, 8)
-    job = sbm.SpinBosonDynamics(model, compress_config=CompressConfig(CompressCriteria.fixed, max_bonddim=64),
-                                evolve_config=EvolveConfig(EvolveMethod.tdvp_ps), dump_dir=str(tmp_path), job_name="sbm")
-    job.evolve(evolve_dt=0.1, nsteps=10)
-    assert np.abs(np.array(job.sigma_z) - ref).max() < 1e-6
-    assert abs(job.sigma_x[0]) < 1e-12 and len(job.bond_entropy) == 11 and job.rho[0].shape == (2, 2)
-    z = np.load(tmp_path / "sbm.npz", allow_pickle=True)
-    assert np.allclose(z["sigma_z"], job.sigma_z) and "bond_entropy" in z.files
+    mpo = Mpo(model)
+    mps = Mps.ground_state(model, False)
+    mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=64)
+    mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    mps = mps.expand_bond_dimension(mpo, coef=1e-16, include_ex=False)
+    spin = next(i for i, b in enumerate(model.basis) if b.is_spin)
+    sz = []
+    for k in range(11):
+        if k:
+            mps = mps.evolve(mpo, 0.1)
+        rho = mps.calc_1site_rdm(idx=spin)[spin]
+        sz.append(float((rho[0, 0] - rho[1, 1]).real))
+        if k == 0:
+            assert abs((rho[0, 1] + rho[1, 0]).real) < 1e-12 and rho.shape == (2, 2)
+    assert np.abs(np.array(sz) - ref).max() < 1e-6
+    assert len(mps.calc_entropy("bond")) == len(mps) - 1
 
 
 @pytest.mark.parametrize("tag", ["s", "d", "ds"])
