@@ -171,6 +171,14 @@ int mpse_env_update(mpse_ctx* ctx, int dtype, int domain, const mpse_dims* dims,
                     const void* env, int env_dtype, const void* ket, const void* bra, int bra_conj,
                     const void* W, int w_dtype, void* out);
 
+/* Environment update through a stack of n_mpo MPO sites, replaces mps/lib.py:121-166 contract_one_site_multi_mpo
+ * (used by optimize_mps(omega=...), mps/gs.py:106-112, for the (H - omega)^2 functional: Environ(mps, [mpo, mpo])).
+ *   env : (D_bra, w_1, .., w_n, D_ket) - layer 1 touches the bra, layer n the ket;  W[i] : (wl[i], d0, d0, wr[i]), device
+ *   out : (D'_bra, w'_1, .., w'_n, D'_ket);  dims->wl / wr / wm / env_unit are ignored.  1 <= n_mpo <= 4. */
+int mpse_env_update_multi(mpse_ctx* ctx, int dtype, int domain, const mpse_dims* dims, int n_mpo,
+                          const int64_t* wl, const int64_t* wr, const void* env, int env_dtype,
+                          const void* ket, const void* bra, int bra_conj, const void* const* W, int w_dtype, void* out);
+
 /* Finds an MPO-bond channel b of a square environment env (D, w, D) with max|env[:, b, :] - 1| <= tol: the
  * channel in which no operator has acted yet is the identity matrix when the sites behind it are canonical
  * (the reference contracts it like any other, mps/lib.py:200-205).  *unit_host = b + 1, or 0 if there is none.
@@ -196,6 +204,12 @@ typedef struct {
 
 int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, void* out);
 
+/* Two-layer effective Hamiltonian of the (H - omega)^2 functional, replaces the twolayer=True closures of
+ * mps/hop_expr.py:24-52 (1-site abcd,befg,cfhi,jgik,aej->dhk ; 2-site abcd,befg,cfhi,gjkl,ikmn,olnp,aejo->dhmp).
+ *   L (Dl, wl, wl, Dl), R (Dr, wr, wr, Dr); W0 / W1 serve both layers; no ancilla; nsite in {1, 2}; the unit-channel
+ *   fields are ignored. */
+int mpse_heff_apply2(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, void* out);
+
 /* Lanczos exponential out = expm(dt*Heff) C, replaces lib/krylov/krylov.py:27-82
  * expm_krylov as called at mps/mps.py:1300-1303, 1343-1346, 1377-1380 (same
  * recurrence without re-orthogonalisation, same stopping rule: successive
@@ -203,6 +217,29 @@ int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
  * Synchronous; *nvec receives the Krylov dimension. */
 int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re, double dt_im,
                       const void* C, void* out, double rtol, double atol, int max_dim, int* nvec);
+
+/* Davidson eigensolver for the lowest nroots eigenpairs of the effective Hamiltonian, replaces
+ * lib/davidson/davidson.py:154-441 as called at mps/gs.py:533-538 (diagonal preconditioner r / (hdiag - e + shift),
+ * Gram-Schmidt twice, restart from the Ritz vectors when max_space vectors are held, convergence of a root when
+ * |de| < tol and |r| < sqrt(tol), new directions dropped when their squared norm falls under lindep).
+ *   h         : the projected operator (mpse_heff_apply; twolayer != 0: mpse_heff_apply2, the (H - omega)^2 form)
+ *   hdiag_f64 : its diagonal (n doubles, device);  mask_f64: 0/1 weights of the symmetry-allowed entries or NULL
+ *               (the reference compresses vectors to those entries on the host, mps/gs.py:260, 520-523)
+ *   guess     : nguess start vectors of n elements each, contiguous (device);  x_out: nroots vectors (device)
+ *   e_host    : nroots eigenvalues;  max_space <= 0 selects 12 + 3 (nroots - 1), max_cycle <= 0 selects 100
+ * The subspace matrix grows by one batched reduction per new vector; subspace eigenproblems run on the host.
+ * Synchronous. */
+int mpse_davidson(mpse_ctx* ctx, int dtype, const mpse_heff* h, int twolayer, const void* hdiag_f64,
+                  const void* mask_f64, int nroots, int nguess, const void* guess, double tol, int max_cycle,
+                  int max_space, double lindep, double shift, double* e_host, void* x_out, int* ncycle, int* nmatvec);
+
+/* Which renormalised basis states to keep, replaces select_basis of mps/lib.py:253-322 (the index selection; the
+ * column copies are mpse_gather_cols / mpse_gather_rows): an equal quota int(m_max * percent / nblocks) per
+ * quantum-number block (ascending block id, descending weight inside a block), the remaining slots by descending
+ * weight; stable on ties.  block_id_host[i] = rank of state i's quantum number among the distinct ones (may be NULL
+ * when percent == 0).  picked_host receives min(count, m_max) indices.  Host-side integer logic, no device work. */
+int mpse_truncate_select(const double* sigma_host, const int64_t* block_id_host, int64_t count, int64_t m_max,
+                         double percent, int64_t* picked_host, int64_t* npicked);
 
 /* ------------------------------------------------ block decompositions */
 

@@ -761,3 +761,239 @@ def gen_ofs():
 
 if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("ofs",)):
     gen_ofs()
+
+
+def gen_thermofield():
+    """Finite temperature through thermofield-doubled baths (BASELINE config 4): the Hamiltonian is written term by
+    term with the reference's Model / Op exactly like transport/tests/test_spectral_function.py:16-48 (physical mode
+    omega b^+b, tilde mode -omega b~^+b~, couplings -g omega cosh(theta) / sinh(theta) a^+a (b^+ + b),
+    theta = arctanh(exp(-beta omega / 2)), on-site energy eps + sum g^2 omega), then propagated with the reference's
+    TDVP-PS.  Two cases: a Holstein trimer with two modes per molecule, and the FMO model of example/fmo.py with
+    three modes per site at 77 K (35 sites).  Stored: parameters, dense Hamiltonian (trimer, small ladders), bond
+    dimensions, populations / energy per step."""
+    import json
+    from renormalizer.model import Op, Model
+    from renormalizer.model.basis import BasisSimpleElectron, BasisSHO
+    from renormalizer.mps import Mps, Mpo
+    from renormalizer.utils import Quantity, CompressConfig, CompressCriteria, EvolveConfig, EvolveMethod
+    from renormalizer.utils.constant import cm2au
+    from renormalizer.model import Phonon
+
+    out = {}
+
+    def tf_model(eps, jmat, omegas, gs, nlevels, beta):
+        """eps[i], jmat[i, j], per molecule the modes (omega_k, g_k) with nlevels[k] levels (physical and tilde)"""
+        nmol = len(eps)
+        basis, ham = [], []
+        for i in range(nmol):
+            basis.append(BasisSimpleElectron(f"e{i}"))
+            for k, (w, nl) in enumerate(zip(omegas, nlevels)):
+                basis.append(BasisSHO(f"v{i}_{k}", w, int(nl)))
+                basis.append(BasisSHO(f"t{i}_{k}", w, int(nl)))
+        for i in range(nmol):
+            ham.append(Op(r"a^\dagger a", f"e{i}", eps[i] + sum(g ** 2 * w for w, g in zip(omegas, gs))))
+            for j in range(nmol):
+                if i != j and jmat[i, j] != 0:
+                    ham.append(Op(r"a^\dagger a", [f"e{i}", f"e{j}"], jmat[i, j]))
+            for k, (w, g) in enumerate(zip(omegas, gs)):
+                theta = np.arctanh(np.exp(-beta * w / 2))
+                ham.append(Op(r"b^\dagger b", f"v{i}_{k}", w))
+                ham.append(Op(r"b^\dagger b", f"t{i}_{k}", -w))
+                ham.append(-g * np.cosh(theta) * w * Op(r"a^\dagger a", f"e{i}") * Op(r"b^\dagger + b", f"v{i}_{k}"))
+                ham.append(-g * np.sinh(theta) * w * Op(r"a^\dagger a", f"e{i}") * Op(r"b^\dagger + b", f"t{i}_{k}"))
+        return Model(basis, ham)
+
+    def run(model, nmol, start, D, nsteps, dt, seed, pre):
+        gs = Mps.ground_state(model, max_entangled=False)
+        init = Mpo(model, Op(r"a^\dagger", f"e{start}")).apply(gs)
+        e0 = init.expectation(Mpo(model))
+        mpo = Mpo(model, offset=Quantity(e0))
+        occ_ops = [Mpo(model, Op(r"a^\dagger a", f"e{i}")) for i in range(nmol)]
+        init.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=D)
+        init.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+        np.random.seed(seed)
+        mps = init.expand_bond_dimension(mpo)
+        mps.canonicalise()
+        # fixed-bond TDVP follows the 1e-10 padding of expand_bond_dimension, which no two codes reproduce beyond
+        # ~1e-6 relative: the expanded state itself is part of the fixture
+        _dump_mps(out, pre + "init_", mps)
+        occ = [np.array([mps.expectation(o) for o in occ_ops])]
+        ener = [mps.expectation(mpo)]
+        for _ in range(nsteps):
+            mps = mps.evolve(mpo, dt)
+            occ.append(np.array([mps.expectation(o) for o in occ_ops]))
+            ener.append(mps.expectation(mpo))
+        return e0, np.array(mpo.bond_dims), np.array(mps.bond_dims), np.array(occ), np.array(ener)
+
+    # ---- Holstein trimer, two modes, k T ~ omega_0
+    omegas = np.array([0.005, 0.012])
+    gs_ = np.array([0.9, 0.4])
+    temperature = Quantity(1500, "K")
+    beta = temperature.to_beta()
+    eps = np.array([0.0, 0.002, -0.001])
+    jmat = np.array([[0, 0.003, 0.001], [0.003, 0, 0.002], [0.001, 0.002, 0]])
+    out.update(tri_omega=omegas, tri_g=gs_, tri_beta=np.array(beta), tri_eps=eps, tri_j=jmat)
+    small = tf_model(eps[:2], jmat[:2, :2], omegas[:1], gs_[:1], [3], beta)
+    out["dimer_dense"] = Mpo(small).todense()
+    model = tf_model(eps, jmat, omegas, gs_, [8, 5], beta)
+    e0, wb, mb, occ, ener = run(model, 3, 0, 16, 6, 40.0, 77, "tri_")
+    out.update(tri_levels=np.array([8, 5]), tri_e0=np.array(e0), tri_mpo_bond=wb, tri_bond=mb, tri_occ=occ,
+               tri_energy=ener, tri_dt=np.array(40.0))
+    print("trimer occ", occ[-1], "mpo bonds", wb)
+    # ---- FMO at 77 K, three modes per site (example/fmo.py parameters)
+    nph = 3
+    sdf = np.array(json.load(open(os.path.join(GOLD, "fmo_sdf.json"))))
+    j_cm = np.array([[310, -98, 6, -6, 7, -12, -10, 38], [-98, 230, 30, 7, 2, 12, 5, 8], [6, 30, 0, -59, -2, -10, 5, 2],
+                     [-6, 7, -59, 180, -65, -17, -65, -2], [7, 2, -2, -65, 405, 89, -6, 5], [-12, 11, -10, -17, 89, 320, 32, -10],
+                     [-10, 5, 5, -64, -6, 32, 270, -11], [38, 8, 2, -2, 5, -10, -11, 505]], dtype=float)
+    om_cm = np.linspace(2, 300, nph)
+    om = om_cm * cm2au
+    hr = np.interp(om_cm, sdf[:, 0], sdf[:, 1])
+    hr *= 0.42 / hr.sum()
+    phonons = [Phonon.simplest_phonon(Quantity(o), Quantity(l), lam=True) for o, l in zip(om, hr * om)]
+    levels = [ph.n_phys_dim for ph in phonons]
+    g = np.sqrt(hr)                                       # Huang-Rhys factor S = g^2
+    arr = np.array([7, 5, 3, 1, 2, 4, 6]) - 1
+    j = (j_cm * cm2au)[arr][:, arr]
+    beta77 = Quantity(77, "K").to_beta()
+    model = tf_model(np.diag(j).copy(), j - np.diag(np.diag(j)), om, g, levels, beta77)
+    e0, wb, mb, occ, ener = run(model, 7, 3, 12, 4, 160.0, 78, "fmo_")
+    out.update(fmo_nph=np.array(nph), fmo_levels=np.array(levels), fmo_beta=np.array(beta77), fmo_e0=np.array(e0),
+               fmo_mpo_bond=wb, fmo_bond=mb, fmo_occ=occ, fmo_energy=ener)
+    print("fmo levels", levels, "occ", occ[-1], "mpo bonds", wb[:8])
+    np.savez_compressed(os.path.join(GOLD, "thermofield.npz"), **out)
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("thermofield",)):
+    gen_thermofield()
+
+
+def gen_dmrg():
+    """Seams and runs of the DMRG path:
+      * contract_one_site_multi_mpo (mps/lib.py:121-166) and the two-layer hop_expr (mps/hop_expr.py:24-52) on random
+        inputs;
+      * eigh_iterative / eigh_direct (mps/gs.py:383-407, 486-576) captured inside real sweeps of the Holstein test
+        model (one-layer and (H - omega)^2): (ltensor, rtensor, cmo, qn_mask, cguess) -> (e, c);
+      * H2O / STO-3G (example/h2o_qc.py): a seeded random start at M = 50, the energy after every sweep for the
+        M = 50 and the M = 512 procedure (same start; the bonds saturate below 50 - SURVEY 8d item 5), final bonds.
+    -> tests/golden/dmrg_seams.npz, tests/golden/h2o_dmrg.npz"""
+    from renormalizer.mps import lib as ref_lib, gs as ref_gs
+    from renormalizer.mps.hop_expr import hop_expr
+    from renormalizer.mps import Mps, Mpo
+    from renormalizer.model import Model, Phonon, Mol, HolsteinModel, h_qc
+    from renormalizer.utils import Quantity, constant
+    rng = np.random.default_rng(20260929)
+    out = {}
+    # ---- multi-MPO environment update, two MPO layers
+    k = 0
+    for cplx in (False, True):
+        for anc in (False, True):
+            for dom in ("L", "R"):
+                Dl, Dr, d, da, w1l, w1r, w2l, w2r = 4, 5, 3, 2, 3, 2, 2, 4
+                shp = (Dl, d, da, Dr) if anc else (Dl, d, Dr)
+                ms = _rand(rng, shp, cplx)
+                mo1 = _rand(rng, (w1l, d, d, w1r), False)
+                mo2 = _rand(rng, (w2l, d, d, w2r), False)
+                env = _rand(rng, (Dl, w1l, w2l, Dl) if dom == "L" else (Dr, w1r, w2r, Dr), cplx)
+                res = ref_lib.contract_one_site_multi_mpo(env, ms, [mo1, mo2], dom)
+                out.update({f"menv{k}_env": env, f"menv{k}_ms": ms, f"menv{k}_mo1": mo1, f"menv{k}_mo2": mo2,
+                            f"menv{k}_dom": np.array(dom), f"menv{k}_out": np.asarray(res)})
+                k += 1
+    out["menv_n"] = np.array(k)
+    # ---- two-layer effective Hamiltonian
+    k = 0
+    for cplx in (False, True):
+        for nsite in (1, 2):
+            Dl, Dr, d0, d1, wl, wm, wr = 4, 5, 3, 2, 3, 2, 4
+            l = _rand(rng, (Dl, wl, wl, Dl), cplx)
+            if nsite == 1:
+                cmo = [_rand(rng, (wl, d0, d0, wr), False)]
+                cshape = (Dl, d0, Dr)
+            else:
+                cmo = [_rand(rng, (wl, d0, d0, wm), False), _rand(rng, (wm, d1, d1, wr), False)]
+                cshape = (Dl, d0, d1, Dr)
+            r = _rand(rng, (Dr, wr, wr, Dr), cplx)
+            c = _rand(rng, cshape, cplx)
+            hc = hop_expr(l, r, [m.copy() for m in cmo], cshape, True)(c)
+            out.update({f"hop2_{k}_l": l, f"hop2_{k}_r": r, f"hop2_{k}_c": c, f"hop2_{k}_out": np.asarray(hc),
+                        f"hop2_{k}_nsite": np.array(nsite)})
+            for i, m in enumerate(cmo):
+                out[f"hop2_{k}_w{i}"] = m
+            k += 1
+    out["hop2_n"] = np.array(k)
+
+    # ---- eigensolver seams inside real sweeps (renormalizer/tests/parameter.py model)
+    omega = [Quantity(106.51, "cm^{-1}"), Quantity(1555.55, "cm^{-1}")]
+    dis = [Quantity(30.1370), Quantity(8.7729)]
+    ph_list = [Phonon.simple_phonon(o, d, 4) for o, d in zip(omega, dis)]
+    j = np.array([[0.0, -0.1, -0.2], [-0.1, 0.0, -0.3], [-0.2, -0.3, 0.0]]) / constant.au2ev
+    model = HolsteinModel([Mol(Quantity(2.67, "eV"), ph_list, 15.45)] * 3, j, 3)
+    mpo = Mpo(model)
+    records = []
+    orig_it, orig_di = ref_gs.eigh_iterative, ref_gs.eigh_direct
+
+    def rec(kind, orig, wanted):
+        def wrapped(mps, qn_mask, ltensor, rtensor, cmo, omega_, *rest):
+            e, c = orig(mps, qn_mask, ltensor, rtensor, cmo, omega_, *rest)
+            tag = (kind, omega_ is not None, mps.optimize_config.method)
+            if wanted.get(tag, 0) > 0 and np.sum(qn_mask) > 8:
+                wanted[tag] -= 1
+                records.append(dict(kind=kind, twolayer=omega_ is not None, l=np.asarray(ltensor), r=np.asarray(rtensor),
+                                    cmo=[np.asarray(m) for m in cmo], mask=qn_mask.copy(),
+                                    guess=None if not rest else np.asarray(rest[0][0]), e=float(e), c=np.asarray(c)))
+            return e, c
+        return wrapped
+
+    wanted = {("it", False, "2site"): 2, ("it", False, "1site"): 1, ("di", False, "2site"): 1, ("di", False, "1site"): 1,
+              ("it", True, "2site"): 1, ("it", True, "1site"): 1, ("di", True, "1site"): 1}
+    ref_gs.eigh_iterative = rec("it", orig_it, wanted)
+    ref_gs.eigh_direct = rec("di", orig_di, wanted)
+    try:
+        for method in ("2site", "1site"):
+            for om in (None, 0.09):
+                np.random.seed(2019)
+                mps = Mps.random(model, 1, 12, percent=1.0)
+                mps.optimize_config.procedure = [[12, 0.4], [16, 0.2], [20, 0]]
+                mps.optimize_config.method = method
+                energies, _ = ref_gs.optimize_mps(mps.copy(), mpo, omega=om)
+                out[f"holstein_{method}_{'omega' if om else 'gs'}_energies"] = np.array(energies)
+                print(method, om, energies)
+    finally:
+        ref_gs.eigh_iterative, ref_gs.eigh_direct = orig_it, orig_di
+    for k, r in enumerate(records):
+        pre = f"eig{k}_"
+        out.update({pre + "kind": np.array(r["kind"]), pre + "twolayer": np.array(r["twolayer"]), pre + "l": r["l"],
+                    pre + "r": r["r"], pre + "mask": r["mask"], pre + "e": np.array(r["e"]), pre + "c": r["c"],
+                    pre + "nsite": np.array(len(r["cmo"]))})
+        for i, m in enumerate(r["cmo"]):
+            out[pre + f"w{i}"] = m
+        if r["guess"] is not None:
+            out[pre + "guess"] = r["guess"]
+    out["eig_n"] = np.array(len(records))
+    out["eig_omega"] = np.array(0.09)
+    print("eigensolver seams:", [(r["kind"], r["twolayer"], len(r["cmo"]), r["mask"].shape, r["e"]) for r in records])
+    np.savez_compressed(os.path.join(GOLD, "dmrg_seams.npz"), **out)
+
+    # ---- H2O
+    sh, aseri, nuc = h_qc.read_fcidump(os.path.join(GOLD, "h2o_fcidump.txt"), 7)
+    basis, terms = h_qc.qc_model(sh, aseri)
+    model = Model(basis, terms)
+    mpo = Mpo(model)
+    np.random.seed(512)
+    start = Mps.random(model, [5, 5], 50, percent=1.0)
+    h2o = {"nuc": np.array(nuc), "mpo_bond_dims": np.array(mpo.bond_dims)}
+    _dump_mps(h2o, "init_", start)
+    for M in (50, 512):
+        mps = start.copy()
+        mps.optimize_config.procedure = [[M, 0.4], [M, 0.2], [M, 0.1], [M, 0], [M, 0], [M, 0], [M, 0]]
+        mps.optimize_config.method = "2site"
+        energies, gs = ref_gs.optimize_mps(mps, mpo)
+        h2o[f"energies_M{M}"] = np.array(energies)
+        h2o[f"bond_dims_M{M}"] = np.array(gs.bond_dims)
+        h2o[f"sweep_bond_dims_M{M}"] = np.array(mps.bond_dims)
+        print("H2O M", M, energies, gs.bond_dims, mps.bond_dims)
+    np.savez_compressed(os.path.join(GOLD, "h2o_dmrg.npz"), **h2o)
+
+
+if __name__ == "__main__" and (len(sys.argv) > 1 and sys.argv[1] in ("dmrg",)):
+    gen_dmrg()

@@ -148,6 +148,49 @@ extern "C" int mpse_env_update(mpse_ctx* ctx, int dtype, int domain, const mpse_
   return run_plan(ctx, dtype, p, bufs);
 }
 
+extern "C" int mpse_env_update_multi(mpse_ctx* ctx, int dtype, int domain, const mpse_dims* dims, int n_mpo,
+                                     const int64_t* wl, const int64_t* wr, const void* env, int env_dtype,
+                                     const void* ket, const void* bra, int bra_conj, const void* const* W, int w_dtype,
+                                     void* out) {
+  if (!ctx || !dims || !env || !ket || !W || !wl || !wr || !out) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
+  if (n_mpo < 1 || n_mpo > 4) return mpse_fail(ctx, MPSE_ERR_ARG, "env_update_multi: 1 to 4 MPO layers, got %d", n_mpo);
+  if (dtype != MPSE_C128 && (env_dtype == MPSE_C128 || w_dtype == MPSE_C128))
+    return mpse_fail(ctx, MPSE_ERR_ARG, "env_update_multi: real sites with complex env/mpo");
+  if (!bra) {
+    bra = ket;
+    if (dims->Dl_bra != dims->Dl_ket || dims->Dr_bra != dims->Dr_ket)
+      return mpse_fail(ctx, MPSE_ERR_SHAPE, "env_update_multi: bra==NULL needs equal bonds");
+  }
+  Plan p = plan_env_multi(dtype, domain, *dims, n_mpo, wl, wr, env_dtype, w_dtype, bra_conj);
+  const void* bufs[B_COUNT] = {nullptr};
+  bufs[B_L] = env;
+  for (int i = 0; i < n_mpo; ++i) {
+    if (!W[i]) return MPSE_ERR_ARG;
+    bufs[w_buf(i)] = W[i];
+  }
+  bufs[B_C] = ket;
+  bufs[B_BRA] = bra;
+  bufs[B_OUT] = out;
+  return run_plan(ctx, dtype, p, bufs);
+}
+
+extern "C" int mpse_heff_apply2(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, void* out) {
+  if (!ctx || !h || !C || !out || !h->L || !h->R || !h->W0) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
+  if (dtype != MPSE_C128 && (h->l_dtype == MPSE_C128 || h->r_dtype == MPSE_C128 || h->w_dtype == MPSE_C128))
+    return mpse_fail(ctx, MPSE_ERR_ARG, "heff_apply2: real centre with complex operator parts");
+  Plan p = plan_heff2(dtype, *h);
+  const void* bufs[B_COUNT] = {nullptr};
+  bufs[B_L] = h->L;
+  bufs[B_R] = h->R;
+  bufs[B_W0] = h->W0;
+  bufs[B_W1] = h->W1;
+  bufs[B_C] = C;
+  bufs[B_OUT] = out;
+  return run_plan(ctx, dtype, p, bufs);
+}
+
 extern "C" int mpse_env_unit_channel(mpse_ctx* ctx, int dtype, const void* env, int64_t D, int64_t w, double tol,
                                      int64_t* unit_host) {
   if (!ctx || !env || !unit_host) return MPSE_ERR_ARG;

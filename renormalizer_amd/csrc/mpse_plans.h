@@ -10,13 +10,18 @@
 // All index permutations are absorbed in operand strides; nothing is transposed in memory.
 #pragma once
 #include <cstdint>
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mpsengine.h"
 
 namespace mpse_plan {
 
-enum Buf { B_L = 0, B_R, B_W0, B_W1, B_C, B_BRA, B_OUT, B_T1, B_T2, B_T3, B_COUNT };
+enum Buf { B_L = 0, B_R, B_W0, B_W1, B_C, B_BRA, B_OUT, B_T1, B_T2, B_T3, B_W2, B_W3, B_COUNT };
+inline int w_buf(int layer) { return layer == 0 ? B_W0 : layer == 1 ? B_W1 : layer == 2 ? B_W2 : B_W3; }
 
 enum Kind { K_GEMM = 0, K_COPY = 1 };
 
@@ -253,6 +258,275 @@ inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, i
     return p;
   }
   p.error = "env: bad domain";
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Labelled views: the plans for stacked MPO layers (mps/lib.py:121-166, mps/hop_expr.py:24-52) are written as
+// pairwise contractions of tensors whose dimensions carry one-letter labels; `contract` turns one contraction into
+// strided-GEMM steps (labels listed outer -> inner; adjacent labels are merged when their strides are contiguous;
+// an index may have at most two levels per operand, everything else goes to `loops`, one step per value).
+struct View {
+  int buf = 0, dt = MPSE_F64;
+  int64_t off = 0;
+  std::vector<std::pair<char, int64_t>> dims;   // memory order, row major
+  View() {}
+  View(int b, int d, std::initializer_list<std::pair<char, int64_t>> l) : buf(b), dt(d), dims(l) {}
+  int64_t ext(char c) const {
+    for (auto& p : dims)
+      if (p.first == c) return p.second;
+    return -1;
+  }
+  int64_t stride(char c) const {   // 0 if the label is absent
+    int64_t s = 1;
+    for (size_t i = dims.size(); i-- > 0;) {
+      if (dims[i].first == c) return s;
+      s *= dims[i].second;
+    }
+    return 0;
+  }
+  int64_t size() const {
+    int64_t s = 1;
+    for (auto& p : dims) s *= p.second;
+    return s;
+  }
+};
+
+inline bool labels_index(const View& v, const std::string& labels, mpse_index* out) {
+  std::vector<std::pair<int64_t, int64_t>> lv;  // (ext, stride), outer -> inner, merged
+  int64_t total = 1;
+  for (char c : labels) {
+    const int64_t e = v.ext(c), st = v.stride(c);
+    if (e < 0) return false;
+    total *= e;
+    if (e == 1) continue;
+    if (!lv.empty() && lv.back().second == e * st)
+      lv.back().first *= e, lv.back().second = st;
+    else
+      lv.push_back({e, st});
+  }
+  if (lv.empty()) {
+    *out = i1(total, 1);
+    return true;
+  }
+  if (lv.size() == 1) {
+    *out = i1(lv[0].first, lv[0].second);
+    return true;
+  }
+  if (lv.size() == 2) {
+    *out = i2(lv[0].first, lv[1].first, lv[0].second, lv[1].second);
+    return true;
+  }
+  return false;
+}
+
+// C[batch][m, n] = sum_k A[batch][m, k] B[batch][k, n] for every value of the `loops` labels
+inline void contract(Plan& p, const View& A, const View& B, const View& C, const std::string& m, const std::string& k,
+                     const std::string& n, const std::string& batch = "", const std::string& loops = "",
+                     int conja = 0) {
+  if (p.error) return;
+  mpse_index ma, ka, kb, nb, mc, nc, ba, bb, bc;
+  if (!labels_index(A, m, &ma) || !labels_index(A, k, &ka) || !labels_index(B, k, &kb) || !labels_index(B, n, &nb) ||
+      !labels_index(C, m, &mc) || !labels_index(C, n, &nc)) {
+    p.error = "plan: an index of a stacked-MPO contraction needs more than two stride levels";
+    return;
+  }
+  int64_t nbatch = 1, sba = 0, sbb = 0, sbc = 0;
+  if (!batch.empty()) {
+    // a batch label may be absent from A or B (stride 0) but must be a single level where present
+    auto one = [&](const View& v, int64_t* st) {
+      std::string present;
+      for (char c : batch)
+        if (v.ext(c) >= 0) present.push_back(c);
+      if (present.empty()) {
+        *st = 0;
+        return true;
+      }
+      if (present.size() != batch.size()) return false;
+      mpse_index ix;
+      if (!labels_index(v, batch, &ix) || (ix.lo_ext < ix.ext && ix.ext > 1)) return false;
+      *st = ix.s_lo;
+      return true;
+    };
+    if (!one(A, &sba) || !one(B, &sbb) || !one(C, &sbc)) {
+      p.error = "plan: batch labels of a stacked-MPO contraction do not form one level";
+      return;
+    }
+    for (char c : batch) nbatch *= C.ext(c);
+  }
+  std::vector<int64_t> ext, cnt(loops.size(), 0);
+  int64_t nloop = 1;
+  for (char c : loops) {
+    const int64_t e = C.ext(c) >= 0 ? C.ext(c) : (A.ext(c) >= 0 ? A.ext(c) : B.ext(c));
+    ext.push_back(e);
+    nloop *= e;
+  }
+  for (int64_t it = 0; it < nloop; ++it) {
+    int64_t oa = A.off, ob = B.off, oc = C.off;
+    for (size_t l = 0; l < loops.size(); ++l) {
+      oa += cnt[l] * A.stride(loops[l]);
+      ob += cnt[l] * B.stride(loops[l]);
+      oc += cnt[l] * C.stride(loops[l]);
+    }
+    push(p, A.buf, oa, A.dt, conja, B.buf, ob, B.dt, 0, C.buf, oc, ma, ka, kb, nb, mc, nc, nbatch, sba, sbb, sbc);
+    for (size_t l = loops.size(); l-- > 0;) {
+      if (++cnt[l] < ext[l]) break;
+      cnt[l] = 0;
+    }
+  }
+}
+
+// Environment update with a stack of n MPO sites (mps/lib.py:121-166 contract_one_site_multi_mpo), n >= 1:
+//   L: env E[a, b_1..b_n, c], bra[a, x_0, g, p], W_i[b_i, x_{i-1}, x_i, f_i], ket[c, x_n, g, h] -> out[p, f_1..f_n, h]
+//   R: env E[a, b_1..b_n, c], bra[p, x_0, g, a], W_i[q_i, x_{i-1}, x_i, b_i], ket[h, x_n, g, c] -> out[p, q_1..q_n, h]
+// (layer 1 touches the bra, layer n the ket; g = traced ancilla).  Buffers: B_L env, B_C ket, B_BRA bra, B_OUT out,
+// MPO sites w_buf(layer) = B_W0, B_W1, B_W2, B_W3; intermediates alternate between B_T1 and B_T2.
+inline Plan plan_env_multi(int dtype, int domain, const mpse_dims& s, int n, const int64_t* wl, const int64_t* wr,
+                           int env_dtype, int w_dtype, int bra_conj) {
+  Plan p;
+  if (n < 1 || n > 4) {
+    p.error = "env_multi: 1 to 4 MPO layers";
+    return p;
+  }
+  const int64_t d = s.d0, anc = s.danc > 0 ? s.danc : 1;
+  const int64_t Dlb = s.Dl_bra, Dlk = s.Dl_ket, Drb = s.Dr_bra, Drk = s.Dr_ket;
+  int64_t WL = 1, WR = 1;
+  for (int i = 0; i < n; ++i) WL *= wl[i], WR *= wr[i];
+  const bool left = domain == MPSE_DOMAIN_L;
+  if (!left && domain != MPSE_DOMAIN_R) {
+    p.error = "env: bad domain";
+    return p;
+  }
+  // sizes of the intermediates: after the first GEMM the channels still carry the incoming bonds; layer by layer
+  // (ket side first) they are replaced by the outgoing ones
+  int64_t win[4], wout[4];
+  for (int i = 0; i < n; ++i) win[i] = left ? wl[i] : wr[i], wout[i] = left ? wr[i] : wl[i];
+  const int64_t Da = left ? Dlb : Drb;      // bond of the environment row that stays open until the last step
+  const int64_t Dh = left ? Drk : Dlk;      // open ket bond
+  const int64_t Din = left ? Dlk : Drk;     // contracted ket bond
+  int64_t cur = Da * d * anc * Dh;
+  for (int i = 0; i < n; ++i) cur *= win[i];
+  int64_t maxsz = cur;
+  {
+    int64_t t = cur;
+    for (int i = n - 1; i >= 0; --i) {
+      t = t / win[i] * wout[i];
+      if (t > maxsz) maxsz = t;
+    }
+  }
+  p.tmp_elems[0] = p.tmp_elems[1] = maxsz;
+  int tb = B_T1;
+  if (left) {
+    // T_n[(b_1..b_n), a, x, g, h] = sum_c E[a, (b), c] ket[c, (x, g, h)]   (channel-outer layout)
+    push_env_times(p, B_L, env_dtype, B_C, dtype, tb, Dlb, WL, Dlk, d * anc * Drk, 0, true);
+    // layer i = n..1: T_{i-1}[P, a, y, f_i, F, g, h] = sum_{b_i, x} W_i[b_i, y, x, f_i] T_i[P, b_i, a, x, F, g, h]
+    int64_t P = WL, F = 1;
+    for (int i = n - 1; i >= 0; --i) {
+      P /= wl[i];
+      View W(w_buf(i), w_dtype, {{'b', wl[i]}, {'y', d}, {'x', d}, {'f', wr[i]}});
+      View Tin(tb, dtype, {{'P', P}, {'b', wl[i]}, {'a', Dlb}, {'x', d}, {'N', F * anc * Drk}});
+      const int to = tb == B_T1 ? B_T2 : B_T1;
+      View Tout(to, dtype, {{'P', P}, {'a', Dlb}, {'y', d}, {'f', wr[i]}, {'N', F * anc * Drk}});
+      contract(p, W, Tin, Tout, "yf", "bx", "N", "a", "P");
+      tb = to;
+      F *= wr[i];
+    }
+    // out[p, (F, h)] = sum_{a, y, g} bra*[(a, y, g), p] T_0[(a, y), F, g, h]
+    push(p, B_BRA, 0, dtype, bra_conj, tb, 0, dtype, 0, B_OUT, 0, i1(Drb, 1), i1(Dlb * d * anc, Drb),
+         i2(Dlb * d, anc, WR * anc * Drk, Drk), i2(WR, Drk, anc * Drk, 1), i1(Drb, WR * Drk), i1(WR * Drk, 1));
+    return p;
+  }
+  // R: T_n[h, x, g, (b_1..b_n), a] = sum_c ket[(h, x, g), c] E[a, (b), c]
+  push(p, B_C, 0, dtype, 0, B_L, 0, env_dtype, 0, tb, 0, i1(Dlk * d * anc, Drk), i1(Drk, 1), i1(Drk, 1),
+       i2(WR, Drb, Drk, WR * Drk), i1(Dlk * d * anc, WR * Drb), i1(WR * Drb, 1));
+  // layer i = n..1: T_{i-1}[h, q_i, Q, y, g, P, a] = sum_{x, b_i} W_i[q_i, y, x, b_i] T_i[h, Q, x, g, P, b_i, a]
+  int64_t P = WR, Q = 1;
+  for (int i = n - 1; i >= 0; --i) {
+    P /= wr[i];
+    View W(w_buf(i), w_dtype, {{'q', wl[i]}, {'y', d}, {'x', d}, {'b', wr[i]}});
+    View Tin(tb, dtype, {{'h', Dlk}, {'Q', Q}, {'x', d}, {'g', anc}, {'P', P}, {'b', wr[i]}, {'a', Drb}});
+    const int to = tb == B_T1 ? B_T2 : B_T1;
+    View Tout(to, dtype, {{'h', Dlk}, {'q', wl[i]}, {'Q', Q}, {'y', d}, {'g', anc}, {'P', P}, {'a', Drb}});
+    contract(p, W, Tin, Tout, "qy", "xb", "Pa", "h", "Qg");
+    tb = to;
+    Q *= wl[i];
+  }
+  // out[p, (Q, h)] = sum_{y, g, a} bra*[p, (y, g, a)] T_0[h, Q, (y, g, a)]
+  push(p, B_BRA, 0, dtype, bra_conj, tb, 0, dtype, 0, B_OUT, 0, i1(Dlb, d * anc * Drb), i1(d * anc * Drb, 1),
+       i1(d * anc * Drb, 1), i2(WL, Dlk, d * anc * Drb, WL * d * anc * Drb), i1(Dlb, WL * Dlk), i1(WL * Dlk, 1));
+  return p;
+}
+
+// Two-layer effective Hamiltonian of the (H - omega)^2 functional, mps/hop_expr.py:24-52 (same MPO sites in both
+// layers, no ancilla):
+//   1-site  abcd, befg, cfhi, jgik, aej -> dhk          L (Dl, wl, wl, Dl), R (Dr, wr, wr, Dr), W0 (wl, d0, d0, wr)
+//   2-site  abcd, befg, cfhi, gjkl, ikmn, olnp, aejo -> dhmp         W0 (wl, d0, d0, wm), W1 (wm, d1, d1, wr)
+// The centre enters through the FIRST bond index of L / R and the upper physical legs, the result leaves through
+// the last one - exactly the reference's index placement.
+inline Plan plan_heff2(int dtype, const mpse_heff& h) {
+  Plan p;
+  const mpse_dims& s = h.dims;
+  const int64_t Dl = s.Dl_ket, Dr = s.Dr_ket, wl = s.wl, wr = s.wr, d0 = s.d0;
+  if (h.nsite != 1 && h.nsite != 2) {
+    p.error = "heff (two layers): one- or two-site centres only";
+    return p;
+  }
+  if ((s.Dl_bra > 0 && s.Dl_bra != Dl) || (s.Dr_bra > 0 && s.Dr_bra != Dr)) {
+    p.error = "heff (two layers): bra bonds must equal ket bonds";
+    return p;
+  }
+  // z: a pure batch index next to the right bond (several centres at once - the columns of the identity when the
+  // dense projected operator is wanted, mps/gs.py:307-369); 1-site: C (Dl, d0, z, Dr) with z = danc,
+  // 2-site: C (Dl, d0, d1, z, Dr) with z = danc1 (danc must be 1)
+  if (h.nsite == 1) {
+    const int64_t nz = s.danc > 0 ? s.danc : 1;
+    const int64_t big = std::max(wl * wl, std::max(wl * wr, wr * wr)) * Dl * d0 * nz * Dr;
+    p.tmp_elems[0] = p.tmp_elems[1] = p.tmp_elems[2] = big;
+    View L(B_L, h.l_dtype, {{'a', Dl}, {'b', wl}, {'c', wl}, {'d', Dl}});
+    View R(B_R, h.r_dtype, {{'j', Dr}, {'g', wr}, {'i', wr}, {'k', Dr}});
+    View W(B_W0, h.w_dtype, {{'b', wl}, {'e', d0}, {'f', d0}, {'g', wr}});       // layer 1 labels
+    View W2(B_W0, h.w_dtype, {{'c', wl}, {'f', d0}, {'h', d0}, {'i', wr}});      // layer 2 labels
+    View C(B_C, dtype, {{'a', Dl}, {'e', d0}, {'z', nz}, {'j', Dr}});
+    View T1(B_T1, dtype, {{'b', wl}, {'c', wl}, {'d', Dl}, {'e', d0}, {'z', nz}, {'j', Dr}});
+    contract(p, L, C, T1, "bcd", "a", "ezj");
+    View T2(B_T2, dtype, {{'c', wl}, {'d', Dl}, {'f', d0}, {'g', wr}, {'z', nz}, {'j', Dr}});
+    contract(p, W, T1, T2, "fg", "be", "zj", "cd");
+    View T3(B_T3, dtype, {{'d', Dl}, {'h', d0}, {'z', nz}, {'j', Dr}, {'g', wr}, {'i', wr}});
+    contract(p, W2, T2, T3, "hi", "cf", "zjg", "d");
+    View O(B_OUT, dtype, {{'d', Dl}, {'h', d0}, {'z', nz}, {'k', Dr}});
+    contract(p, T3, R, O, "dhz", "jgi", "k");
+    return p;
+  }
+  if (s.danc > 1) {
+    p.error = "heff (two layers, 2-site): the batch index is danc1, danc must be 1";
+    return p;
+  }
+  const int64_t d1 = s.d1, wm = s.wm, nz = s.danc1 > 0 ? s.danc1 : 1;
+  {
+    int64_t big = 0;
+    const int64_t cand[5] = {wl * wl, wl * wm, wm * wm, wm * wr, wr * wr};
+    for (int64_t c : cand) big = c > big ? c : big;
+    p.tmp_elems[0] = p.tmp_elems[1] = p.tmp_elems[2] = big * d0 * d1 * nz * Dl * Dr;
+  }
+  View L(B_L, h.l_dtype, {{'a', Dl}, {'b', wl}, {'c', wl}, {'d', Dl}});
+  View R(B_R, h.r_dtype, {{'o', Dr}, {'l', wr}, {'n', wr}, {'p', Dr}});
+  View C(B_C, dtype, {{'a', Dl}, {'e', d0}, {'j', d1}, {'z', nz}, {'o', Dr}});
+  View Wa(B_W0, h.w_dtype, {{'b', wl}, {'e', d0}, {'f', d0}, {'g', wm}});
+  View Wb(B_W0, h.w_dtype, {{'c', wl}, {'f', d0}, {'h', d0}, {'i', wm}});
+  View Wc(B_W1, h.w_dtype, {{'g', wm}, {'j', d1}, {'k', d1}, {'l', wr}});
+  View Wd(B_W1, h.w_dtype, {{'i', wm}, {'k', d1}, {'m', d1}, {'n', wr}});
+  View T1(B_T1, dtype, {{'b', wl}, {'c', wl}, {'d', Dl}, {'e', d0}, {'j', d1}, {'z', nz}, {'o', Dr}});
+  contract(p, L, C, T1, "bcd", "a", "ejzo");
+  View T2(B_T2, dtype, {{'c', wl}, {'d', Dl}, {'f', d0}, {'g', wm}, {'j', d1}, {'z', nz}, {'o', Dr}});
+  contract(p, Wa, T1, T2, "fg", "be", "jzo", "cd");
+  View T3(B_T3, dtype, {{'d', Dl}, {'h', d0}, {'i', wm}, {'g', wm}, {'j', d1}, {'z', nz}, {'o', Dr}});
+  contract(p, Wb, T2, T3, "hi", "cf", "gjzo", "d");
+  View T4(B_T1, dtype, {{'d', Dl}, {'h', d0}, {'i', wm}, {'k', d1}, {'l', wr}, {'z', nz}, {'o', Dr}});
+  contract(p, Wc, T3, T4, "kl", "gj", "zo", "dhi");
+  View T5(B_T2, dtype, {{'d', Dl}, {'h', d0}, {'m', d1}, {'z', nz}, {'o', Dr}, {'l', wr}, {'n', wr}});
+  contract(p, Wd, T4, T5, "mn", "ik", "zol", "dh");
+  View O(B_OUT, dtype, {{'d', Dl}, {'h', d0}, {'m', d1}, {'z', nz}, {'p', Dr}});
+  contract(p, T5, R, O, "dhmz", "oln", "p");
   return p;
 }
 

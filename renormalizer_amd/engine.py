@@ -111,9 +111,16 @@ _SIGNATURES = {
     "mpse_env_update": [C.c_void_p, C.c_int, C.c_int, C.POINTER(mpse_dims), C.c_void_p, C.c_int, C.c_void_p,
                         C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p],
     "mpse_heff_apply": [C.c_void_p, C.c_int, C.POINTER(mpse_heff), C.c_void_p, C.c_void_p],
+    "mpse_heff_apply2": [C.c_void_p, C.c_int, C.POINTER(mpse_heff), C.c_void_p, C.c_void_p],
+    "mpse_env_update_multi": [C.c_void_p, C.c_int, C.c_int, C.POINTER(mpse_dims), C.c_int, _i64p, _i64p, C.c_void_p,
+                              C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_void_p],
     "mpse_env_unit_channel": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_double, _i64p],
     "mpse_expm_lanczos": [C.c_void_p, C.c_int, C.POINTER(mpse_heff), C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                           C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int)],
+    "mpse_davidson": [C.c_void_p, C.c_int, C.POINTER(mpse_heff), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                      C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, _dblp, C.c_void_p,
+                      C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "mpse_truncate_select": [_dblp, _i64p, C.c_int64, C.c_int64, C.c_double, _i64p, _i64p],
     "mpse_block_qr": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _i64p, _i64p, _i64p, _i64p,
                       C.c_int, C.c_void_p, C.c_void_p, C.c_int64],
     "mpse_block_svd": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int, _i64p, _i64p, _i64p, _i64p,

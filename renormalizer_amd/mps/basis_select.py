@@ -1,30 +1,34 @@
-"""Host-side integer / bookkeeping helpers for choosing which renormalised basis states to keep.
+"""Which renormalised basis states to keep (counterpart of ``select_basis`` in renormalizer/mps/lib.py:253-322): an
+optional equal quota per quantum-number block, then the remaining slots by descending singular value (stable on
+ties).  The index selection is ``mpse_truncate_select`` of the engine library (host-side integer logic, no device
+work); the column copies are done on the device (mpse_gather_cols)."""
+import ctypes as C
 
-Counterpart of ``select_basis`` in renormalizer/mps/lib.py:253-322: an optional equal quota per
-quantum-number block, then the remaining slots by descending singular value (stable on ties).
-Only the index selection happens here; the column copies are done on the device
-(mpse_gather_cols)."""
 import numpy as np
+
+from ..engine import load_library
+
+_LIB = None
 
 
 def select_basis_indices(sset, qnlist, Mmax, percent=0.0):
-    sset = np.asarray(sset, dtype=float)
-    qn_t = [tuple(int(x) for x in np.atleast_1d(qn)) for qn in qnlist]
-    remaining = list(range(len(qn_t)))
-    nbasis = min(len(remaining), int(Mmax))
-    picked = []
+    global _LIB
+    if _LIB is None:
+        _LIB = load_library()
+    sset = np.ascontiguousarray(sset, dtype=np.float64)
+    n = len(sset)
+    ids = None
     if percent != 0:
-        blocks = sorted(set(qn_t))
-        per_block = int(nbasis * percent / len(blocks))
-        for b in blocks:
-            members = [i for i in remaining if qn_t[i] == b]
-            members.sort(key=lambda i: -sset[i])
-            take = members[: min(per_block, len(members))]
-            picked += take
-            taken = set(take)
-            remaining = [i for i in remaining if i not in taken]
-    rest = nbasis - len(picked)
-    remaining.sort(key=lambda i: -sset[i])
-    picked += remaining[:rest]
-    assert len(set(picked)) == len(picked)
-    return picked
+        qn_t = [tuple(int(x) for x in np.atleast_1d(qn)) for qn in qnlist]
+        rank = {b: i for i, b in enumerate(sorted(set(qn_t)))}
+        ids = np.ascontiguousarray([rank[q] for q in qn_t], dtype=np.int64)
+    picked = np.empty(max(n, 1), dtype=np.int64)
+    npicked = C.c_int64(0)
+    st = _LIB.mpse_truncate_select(sset.ctypes.data_as(C.POINTER(C.c_double)),
+                                   None if ids is None else ids.ctypes.data_as(C.POINTER(C.c_int64)), n, int(Mmax),
+                                   float(percent), picked.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(npicked))
+    if st != 0:
+        raise ValueError(f"mpse_truncate_select failed with status {st}")
+    out = [int(i) for i in picked[:npicked.value]]
+    assert len(set(out)) == len(out)
+    return out

@@ -1,19 +1,19 @@
 """DMRG ground-state optimisation on the device.
 
 Counterpart of renormalizer/mps/gs.py: ``optimize_mps`` (:54-171) macro loop over the ``procedure`` of
-``OptimizeConfig``, ``single_sweep`` (:174-304) over the sites, the iterative eigensolver set-up
-``get_ham_iterative`` / ``eigh_iterative`` (:410-576).  Differences by design: the quantum-number mask is kept
-as a dense 0/1 weight vector on the device (the reference compresses vectors to the allowed entries on the
-host, gs.py:260, 520-523 - same iterates, no host round trip), every centre is solved with the Davidson
-iteration (the reference diagonalises centres below 1000 elements densely with SciPy, gs.py:245-247).
-``nroots > 1`` (state-averaged DMRG) uses the block Davidson of lib/davidson.py and the averaged-density-matrix
-update of ``Mps._update_mps``.  ``omega`` (excited states through the (H - omega)^2 functional, gs.py:106-112)
-runs the same sweeps on the product MPO (H - omega).(H - omega) rather than on two-layer environments."""
+``OptimizeConfig``, ``single_sweep`` (:174-304) over the sites, the dense solver for small centres
+``get_ham_direct`` / ``eigh_direct`` (:307-407) and the iterative set-up ``get_ham_iterative`` / ``eigh_iterative``
+(:410-576).  One difference by design: the quantum-number mask is kept as a dense 0/1 weight vector on the device
+(the reference compresses vectors to the allowed entries on the host, gs.py:260, 520-523 - same iterates, no host
+round trip).  ``nroots > 1`` (state-averaged DMRG) uses the block Davidson of the engine and the
+averaged-density-matrix update of ``Mps._update_mps``.  ``omega`` (excited states through the (H - omega)^2
+functional, gs.py:106-112) stacks H - omega twice between bra and ket: two-layer environments
+(``contract_one_site_multi_mpo``) and two-layer centre problems (``hop_expr(twolayer=True)``)."""
 import logging
 
 import numpy as np
 
-from ..engine import get_engine, idx1, idx2
+from ..engine import get_engine, idx1
 from ..lib.davidson import davidson, davidson_multi
 from ..utils import CompressConfig, CompressCriteria
 from .hop_expr import hop_expr
@@ -23,18 +23,30 @@ from .svd_qn import get_qn_mask
 logger = logging.getLogger("renormalizer_amd")
 
 
-def _hdiag(eng, l, r, cmo):
-    """Diagonal of the effective Hamiltonian (gs.py:423-445) from strided diagonal views of L, W, R:
-    1-site ba,bcg,gf->acf ; 2-site ba,bce,edg,gf->acdf.  Returns a float64 device tensor."""
+def _hdiag(eng, l, r, cmo, twolayer=False):
+    """Diagonal of the effective Hamiltonian (gs.py:423-477) from strided diagonal views of L and R and the
+    physical-diagonal parts of the MPO sites: one layer  ba,bcg,gf->acf / ba,bce,edg,gf->acdf ; two layers
+    abca,bdef,cedg,hfgh->adh / abca,bdef,cedg,fhij,gihk,ljkl->adhl, where the pair of stacked MPO bonds is treated as
+    one channel and the per-site factor sum_e W[b,d,e,f] W[c,e,d,g] (KBs) is formed on the host.  Returns a float64
+    device tensor."""
     cplx = l.is_complex or r.is_complex or any(w.is_complex for w in cmo)
     dt = np.complex128 if cplx else np.float64
-    Dl, wl = l.shape[0], l.shape[1]
-    Dr, wr = r.shape[0], r.shape[1]
-    w0 = cmo[0]
-    d0, w0r = w0.shape[1], w0.shape[3]
-    # X1[a,(c,g)] = sum_b L[a,b,a] W0[b,c,c,g]
+    Dl, Dr = l.shape[0], r.shape[0]
+    wl = int(np.prod(l.shape[1:-1]))           # w or w * w
+    wr = int(np.prod(r.shape[1:-1]))
+    wd = []                                    # per site: (channels in, d, channels out), diagonal in the physical leg
+    for w in cmo:
+        wh = w.to_host()
+        if twolayer:
+            x = np.einsum("bdef,cedg->bcdfg", wh, wh)
+            wd.append(x.reshape(wh.shape[0] ** 2, wh.shape[1], wh.shape[3] ** 2))
+        else:
+            wd.append(np.einsum("bddf->bdf", wh))
+    wdev = [eng.asdevice(np.ascontiguousarray(x)) for x in wd]
+    d0, w0r = wd[0].shape[1], wd[0].shape[2]
+    # X1[a,(c,g)] = sum_b L[a,b,a] wd0[b,c,g]
     x1 = eng.empty((Dl, d0 * w0r), dt)
-    eng.gemm(l, w0, x1, idx1(Dl, wl * Dl + 1), idx1(wl, Dl), idx1(wl, d0 * d0 * w0r), idx2(d0, w0r, d0 * w0r + w0r, 1),
+    eng.gemm(l, wdev[0], x1, idx1(Dl, wl * Dl + 1), idx1(wl, Dl), idx1(wl, d0 * w0r), idx1(d0 * w0r, 1),
              idx1(Dl, d0 * w0r), idx1(d0 * w0r, 1))
     if len(cmo) == 1:
         # hd[(a,c),f] = sum_g X1[(a,c),g] R[f,g,f]
@@ -42,11 +54,10 @@ def _hdiag(eng, l, r, cmo):
         eng.gemm(x1, r, out, idx1(Dl * d0, wr), idx1(wr, 1), idx1(wr, Dr), idx1(Dr, wr * Dr + 1),
                  idx1(Dl * d0, Dr), idx1(Dr, 1))
     else:
-        w1 = cmo[1]
-        wm, d1 = w1.shape[0], w1.shape[1]
-        # X2[(e,d),f] = sum_g W1[e,d,d,g] R[f,g,f]
+        wm, d1 = wd[1].shape[0], wd[1].shape[1]
+        # X2[(e,d),f] = sum_g wd1[e,d,g] R[f,g,f]
         x2 = eng.empty((wm * d1, Dr), dt)
-        eng.gemm(w1, r, x2, idx2(wm, d1, d1 * d1 * wr, d1 * wr + wr), idx1(wr, 1), idx1(wr, Dr), idx1(Dr, wr * Dr + 1),
+        eng.gemm(wdev[1], r, x2, idx1(wm * d1, wr), idx1(wr, 1), idx1(wr, Dr), idx1(Dr, wr * Dr + 1),
                  idx1(wm * d1, Dr), idx1(Dr, 1))
         # hd[(a,c),(d,f)] = sum_e X1[(a,c),e] X2[e,(d,f)]
         out = eng.empty((Dl, d0, d1, Dr), dt)
@@ -59,15 +70,47 @@ def _hdiag(eng, l, r, cmo):
     return out
 
 
-def eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, cguess):
-    """gs.py:486-576 with algo == "davidson" and nroots == 1."""
+def _sign_fix(c):
+    """gs.py:372-380"""
+    return c / np.sign(c[np.abs(c).argmax()])
+
+
+def eigh_direct(mps, qn_mask, ltensor, rtensor, cmo, twolayer=False):
+    """gs.py:307-407: dense projected operator (one engine call, ``Hop.dense``), restricted to the symmetry-allowed
+    entries, diagonalised on the host with LAPACK like the reference.  Returns (e, c) with c as device tensor(s) of the
+    centre's shape."""
+    eng = get_engine()
+    if mps.optimize_config.inverse != 1.0:
+        raise NotImplementedError("optimize_config.inverse != 1")
+    cshape = qn_mask.shape
+    hop = hop_expr(ltensor, rtensor, cmo, cshape, twolayer)
+    ham = hop.dense()
+    flat = qn_mask.ravel()
+    ham = ham[flat][:, flat]
+    ham = (ham + ham.conj().T) / 2
+    w, v = np.linalg.eigh(ham)
+    nroots = mps.optimize_config.nroots
+
+    def expand(col):
+        full = np.zeros(flat.shape, dtype=v.dtype)
+        full[flat] = _sign_fix(col)
+        return eng.asdevice(full.reshape(cshape))
+
+    if nroots == 1:
+        return float(w[0]), expand(v[:, 0]), 0
+    k = min(nroots, v.shape[1])
+    return [float(x) for x in w[:k]], [expand(v[:, i]) for i in range(k)], 0
+
+
+def eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, cguess, twolayer=False):
+    """gs.py:486-576 with algo == "davidson"."""
     eng = get_engine()
     inverse = mps.optimize_config.inverse
     if inverse != 1.0:
         raise NotImplementedError("optimize_config.inverse != 1")
     cshape = qn_mask.shape
-    hop = hop_expr(ltensor, rtensor, cmo, cshape)
-    hdiag = _hdiag(eng, hop.l, hop.r, hop.cmo)
+    hop = hop_expr(ltensor, rtensor, cmo, cshape, twolayer)
+    hdiag = _hdiag(eng, hop.l, hop.r, hop.cmo, twolayer)
     mask = eng.asdevice(qn_mask.astype(np.float64))
     nroots = mps.optimize_config.nroots
     if hop.operator_is_complex:
@@ -75,17 +118,16 @@ def eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, cguess):
         # in the reference, gs.py:520-538)
         cguess = cguess.to_complex() if nroots == 1 else [g.to_complex() for g in cguess]
     if nroots == 1:
-        e, c, ncyc = davidson(lambda x: hop(x), cguess.reshape(cshape), hdiag, mask=mask, tol=1e-12, max_cycle=100,
+        e, c, ncyc = davidson(hop, cguess.reshape(cshape), hdiag, mask=mask, tol=1e-12, max_cycle=100,
                               max_space=12, lindep=1e-14)
         return e, c, ncyc
     guesses = [g.reshape(cshape) for g in cguess]
-    e, c, ncyc = davidson_multi(lambda x: hop(x), guesses, hdiag, nroots, mask=mask, tol=1e-12, max_cycle=100,
-                                lindep=1e-14)
+    e, c, ncyc = davidson_multi(hop, guesses, hdiag, nroots, mask=mask, tol=1e-12, max_cycle=100, lindep=1e-14)
     return e, c, ncyc
 
 
-def single_sweep(mps, mpo, environ, percent, last_opt_e_idx):
-    """gs.py:174-304 (nroots == 1, no omega, no site swapping)."""
+def single_sweep(mps, mpo, environ, percent, last_opt_e_idx, omega=None):
+    """gs.py:174-304; ``omega``: the centre problems are those of (H - omega)^2 on two-layer environments."""
     eng = get_engine()
     method = mps.optimize_config.method
     nroots = mps.optimize_config.nroots
@@ -104,8 +146,9 @@ def single_sweep(mps, mpo, environ, percent, last_opt_e_idx):
             lidx, cidx, ridx = imps - 1, [imps, imps + 1], imps + 2
         else:
             lidx, cidx, ridx = imps - 2, [imps - 1, imps], imps + 1
-        ltensor = environ.GetLR("L", lidx, mps, mpo, itensor=None, method=lmethod)
-        rtensor = environ.GetLR("R", ridx, mps, mpo, itensor=None, method=rmethod)
+        operator = mpo if omega is None else [mpo, mpo]
+        ltensor = environ.GetLR("L", lidx, mps, operator, itensor=None, method=lmethod)
+        rtensor = environ.GetLR("R", ridx, mps, operator, itensor=None, method=rmethod)
         qnbigl, qnbigr, qnmat = mps._get_big_qn(cidx)
         qn_mask = get_qn_mask(qnmat, mps.qntot)
         cmo = [mpo.device(i, eng) for i in cidx]
@@ -128,7 +171,15 @@ def single_sweep(mps, mpo, environ, percent, last_opt_e_idx):
                     guess.append(two_site(mps[cidx[0]], ms))
             while len(guess) < nroots:
                 guess.append(eng.asdevice((rng.random(qn_mask.shape) - 0.5) * qn_mask))
-        e, c, ncyc = eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, guess)
+        # gs.py:245-247: small centres are diagonalised densely
+        if int(np.prod(qn_mask.shape)) < 1000 or mps.optimize_config.algo == "direct":
+            e, c, ncyc = eigh_direct(mps, qn_mask, ltensor, rtensor, cmo, omega is not None)
+            if nroots > 1:
+                while len(c) < nroots:              # fewer allowed states than roots: pad like the random guesses
+                    c.append(eng.asdevice((rng.random(qn_mask.shape) - 0.5) * qn_mask))
+                    e.append(e[-1])
+        else:
+            e, c, ncyc = eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, guess, omega is not None)
         hops.append(ncyc)
         micro.append((e, cidx))
         if nroots == 1:
@@ -155,12 +206,9 @@ def optimize_mps(mps, mpo, omega: float = None):
     """DMRG ground state (gs.py:54-171).  Returns (list of the lowest energy of every macro sweep, optimised mps).
     The input mps is overwritten, as in the reference."""
     if omega is not None:
-        # gs.py:106-112 builds two-layer environments for (H - omega)^2.  P (H - omega)^2 P is the projected
-        # operator of the product MPO (H - omega).(H - omega), so the ordinary one-layer kernels are run on that
-        # operator (bond dimension (w + 1)^2) instead of adding a second MPO leg to every kernel.
+        # gs.py:106-112: H - omega, stacked twice between bra and ket (two-layer environments and centre problems)
         from .mpo import Mpo
-        shifted = mpo.add(Mpo.identity(mpo.model).scale(-omega))
-        mpo = shifted.product(shifted)
+        mpo = mpo.add(Mpo.identity(mpo.model).scale(-omega))
     nroots = mps.optimize_config.nroots
     assert mps.optimize_config.method in ["2site", "1site"]
     if mps.is_left_canonical:
@@ -170,7 +218,7 @@ def optimize_mps(mps, mpo, omega: float = None):
         mps.ensure_left_canonical()
         env = "L"
     compress_config_bk = mps.compress_config
-    environ = Environ(mps, mpo, env)
+    environ = Environ(mps, mpo if omega is None else [mpo, mpo], env)
     macro = []
     opt_e_idx = None
     res_mps = None
@@ -181,7 +229,7 @@ def optimize_mps(mps, mpo, omega: float = None):
             mps.compress_config = CompressConfig(criteria=CompressCriteria.fixed, max_bonddim=int(cfg))
         else:
             raise TypeError(cfg)
-        micro, res, = single_sweep(mps, mpo, environ, percent, opt_e_idx)
+        micro, res, = single_sweep(mps, mpo, environ, percent, opt_e_idx, omega)
         if res is not None:
             res_mps = res
         # gs.py:136-160: the centre with the lowest (summed, for several roots) energy marks the optimal position

@@ -5,12 +5,15 @@ the callable also carries the C-ABI descriptor (``mpse_heff``) so that the Lancz
 drivers can hand the whole solve to the engine without coming back to Python per matvec."""
 import ctypes as C
 
+import numpy as np
+
 from ..engine import DeviceTensor, get_engine, mpse_heff
 
 
 class Hop:
-    def __init__(self, ltensor, rtensor, cmo, cshape):
+    def __init__(self, ltensor, rtensor, cmo, cshape, twolayer=False):
         self.eng = get_engine()
+        self.twolayer = bool(twolayer)
         eng = self.eng
         nsite = len(cmo)
         cshape = tuple(int(s) for s in cshape)
@@ -21,6 +24,11 @@ class Hop:
         self.cshape = cshape
         self.l = eng.asdevice(ltensor)
         self.r = eng.asdevice(rtensor)
+        if self.twolayer:
+            # (H - omega)^2: L (Dl, wl, wl, Dl), R (Dr, wr, wr, Dr), the same MPO sites in both layers, no ancilla
+            # (hop_expr.py:24-52); the engine's batch index next to the right bond serves the dense direct solver
+            assert nsite in (1, 2) and self.l.ndim == 4 and self.r.ndim == 4
+            assert self.l.shape[1] == self.l.shape[2] and self.r.shape[1] == self.r.shape[2]
         self.cmo = [eng.asdevice(w) for w in cmo]
         if nsite == 2 and self.cmo[0].is_complex != self.cmo[1].is_complex:
             self.cmo = [w.to_complex() for w in self.cmo]
@@ -31,7 +39,7 @@ class Hop:
         # rows of the environments: equal to the ket bonds for H itself, the bonds of another state when H C is
         # projected onto it (variational compression); the result then carries those bonds
         d.Dl_bra, d.Dr_bra = self.l.shape[0], self.r.shape[0]
-        assert self.l.shape[2] == cshape[0] and self.r.shape[2] == cshape[-1], (self.l.shape, self.r.shape, cshape)
+        assert self.l.shape[-1] == cshape[0] and self.r.shape[-1] == cshape[-1], (self.l.shape, self.r.shape, cshape)
         self.oshape = (self.l.shape[0],) + cshape[1:-1] + (self.r.shape[0],)
         self.square = self.oshape == cshape
         d.danc = cshape[2] if ancilla else 1
@@ -56,11 +64,35 @@ class Hop:
             c = c.to_complex()
         c = c.reshape(self.cshape)
         out = eng.empty(self.oshape, c.dtype)
-        eng._check(eng.lib.mpse_heff_apply(eng.ctx, c.code, C.byref(self.heff), c.ptr, out.ptr))
+        apply = eng.lib.mpse_heff_apply2 if self.twolayer else eng.lib.mpse_heff_apply
+        eng._check(apply(eng.ctx, c.code, C.byref(self.heff), c.ptr, out.ptr))
         return out
+
+    def dense(self):
+        """The projected operator as a matrix H[(out indices), (in indices)] on the host (get_ham_direct,
+        mps/gs.py:307-369): applied to all columns of the identity in ONE call - the unit vectors ride on the batch
+        index next to the right bond (the ancilla slot of the contraction plans)."""
+        assert self.square and (self.heff.dims.danc == 1 or self.nsite == 0)
+        eng = self.eng
+        n = int(np.prod(self.cshape))
+        dt = np.complex128 if self.operator_is_complex else np.float64
+        eye = np.eye(n, dtype=dt).reshape(self.cshape + self.cshape)          # [in indices..., column]
+        # columns -> batch index placed before the right bond: (Dl, d.., z, Dr)
+        nd = len(self.cshape)
+        x = np.moveaxis(eye.reshape(self.cshape + (n,)), -1, nd - 1)
+        h = mpse_heff()
+        C.memmove(C.byref(h), C.byref(self.heff), C.sizeof(mpse_heff))
+        if self.nsite == 1:
+            h.dims.danc = n
+        else:
+            h.dims.danc, h.dims.danc1 = 1, n
+        xin = eng.asdevice(np.ascontiguousarray(x))
+        out = eng.empty(xin.shape, dt)
+        apply = eng.lib.mpse_heff_apply2 if self.twolayer else eng.lib.mpse_heff_apply
+        eng._check(apply(eng.ctx, xin.code, C.byref(h), xin.ptr, out.ptr))
+        res = np.moveaxis(out.to_host(), nd - 1, -1)
+        return res.reshape(n, n)
 
 
 def hop_expr(ltensor, rtensor, cmo, cshape, twolayer: bool = False):
-    if twolayer:
-        raise NotImplementedError("two-layer (H - omega)^2 effective Hamiltonians are not implemented")
-    return Hop(ltensor, rtensor, list(cmo), cshape)
+    return Hop(ltensor, rtensor, list(cmo), cshape, twolayer)

@@ -52,6 +52,46 @@ def contract_one_site(environ, ms, mo, domain, ms_conj=None):
     return out
 
 
+def contract_one_site_multi_mpo(environ, ms, mos, domain, ms_conj=None):
+    """Environment update through a stack of MPO sites (mps/lib.py:121-166): ``environ`` has one leg per MPO between
+    its bra and ket legs, layer 0 touches the bra.  One C-ABI call (mpse_env_update_multi)."""
+    assert domain in ["L", "R"]
+    eng = ms.eng
+    mos = [_as_w(eng, mo) for mo in mos]
+    n = len(mos)
+    bra = ms if ms_conj is None else ms_conj
+    if ms.ndim not in (3, 4):
+        raise ValueError(f"MPS ndim is not 3 or 4, got {ms.ndim}")
+    if environ.ndim != n + 2:
+        raise ValueError(f"environment with {environ.ndim - 2} MPO legs for {n} MPO sites")
+    wcplx = any(mo.is_complex for mo in mos)
+    cplx = ms.is_complex or environ.is_complex or bra.is_complex or wcplx
+    dt = np.complex128 if cplx else np.float64
+    ket = ms.to_complex() if cplx else ms
+    bra = bra.to_complex() if cplx else bra
+    if wcplx:
+        mos = [mo.to_complex() for mo in mos]
+    d = mpse_dims()
+    d.Dl_ket, d.Dr_ket = ket.shape[0], ket.shape[-1]
+    d.Dl_bra, d.Dr_bra = bra.shape[0], bra.shape[-1]
+    d.d0, d.d1 = ket.shape[1], 1
+    d.danc = ket.shape[2] if ket.ndim == 4 else 1
+    wl = (C.c_int64 * n)(*[mo.shape[0] for mo in mos])
+    wr = (C.c_int64 * n)(*[mo.shape[3] for mo in mos])
+    ptrs = (C.c_void_p * n)(*[mo.ptr for mo in mos])
+    if domain == "L":
+        assert environ.shape == (d.Dl_bra,) + tuple(wl) + (d.Dl_ket,), (environ.shape, tuple(wl))
+        oshape = (d.Dr_bra,) + tuple(wr) + (d.Dr_ket,)
+    else:
+        assert environ.shape == (d.Dr_bra,) + tuple(wr) + (d.Dr_ket,), (environ.shape, tuple(wr))
+        oshape = (d.Dl_bra,) + tuple(wl) + (d.Dl_ket,)
+    out = eng.empty(oshape, dt)
+    eng._check(eng.lib.mpse_env_update_multi(
+        eng.ctx, out.code, DOMAIN_L if domain == "L" else DOMAIN_R, C.byref(d), n, wl, wr, environ.ptr, environ.code,
+        ket.ptr, bra.ptr, 1 if ms_conj is None else 0, ptrs, mos[0].code, out.ptr))
+    return out
+
+
 UNIT_TOL = 1e-12
 # The contraction plans use a unit channel only when the product it saves has at least 2^27 multiply-adds
 # (mpse_plans.h unit_pays: D^2 x d D for a one-site matvec): below D = 128 no physical dimension reaches that, and the
@@ -78,12 +118,24 @@ class Environ:
     def __init__(self, mps, mpo, domain=None, mps_conj=None):
         self.eng = get_engine()
         self._virtual_disk = {}
-        self.sentinel = self.eng.ones((1, 1, 1), np.float64)
-        self.sentinel.unit = 1
+        # a list of MPOs stacks their sites between bra and ket (lib.py:24-28, used for (H - omega)^2)
+        self.multi = isinstance(mpo, (list, tuple))
+        if self.multi:
+            self.sentinel = self.eng.ones((1,) * (len(mpo) + 2), np.float64)
+        else:
+            self.sentinel = self.eng.ones((1, 1, 1), np.float64)
+            self.sentinel.unit = 1
         self._construct(mps, mpo, domain, mps_conj)
 
     def _mo(self, mpo, idx):
+        if isinstance(mpo, (list, tuple)):
+            return [self._mo(m, idx) for m in mpo]
         return mpo.device(idx, self.eng) if hasattr(mpo, "device") else _as_w(self.eng, mpo[idx])
+
+    def _step(self, tensor, ms, mo, domain, ms_conj):
+        if isinstance(mo, list):
+            return contract_one_site_multi_mpo(tensor, ms, mo, domain, ms_conj=ms_conj)
+        return contract_one_site(tensor, ms, mo, domain, ms_conj=ms_conj)
 
     def _construct(self, mps, mpo, domain=None, mps_conj=None):
         assert domain in ["L", "R", None]
@@ -98,7 +150,7 @@ class Environ:
         tensor = self.sentinel
         for idx in rng:
             cj = None if mps_conj is None else mps_conj[idx]
-            tensor = contract_one_site(tensor, mps[idx], self._mo(mpo, idx), domain, ms_conj=cj)
+            tensor = self._step(tensor, mps[idx], self._mo(mpo, idx), domain, cj)
             self.write(domain, idx, tensor)
 
     def GetLR(self, domain, siteidx, mps, mpo, itensor=None, method="Scratch", mps_conj=None):
@@ -112,13 +164,13 @@ class Environ:
             itensor = self.sentinel
             sites = range(siteidx + 1) if domain == "L" else range(len(mps) - 1, siteidx - 1, -1)
             for i in sites:
-                itensor = contract_one_site(itensor, mps[i], self._mo(mpo, i), domain, ms_conj=mps_conj[i])
+                itensor = self._step(itensor, mps[i], self._mo(mpo, i), domain, mps_conj[i])
         elif method == "Enviro":
             itensor = self.read(domain, siteidx)
         else:
             if itensor is None:
                 itensor = self.read(domain, siteidx + (-1 if domain == "L" else 1))
-            itensor = contract_one_site(itensor, mps[siteidx], self._mo(mpo, siteidx), domain, mps_conj[siteidx])
+            itensor = self._step(itensor, mps[siteidx], self._mo(mpo, siteidx), domain, mps_conj[siteidx])
             self.write(domain, siteidx, itensor)
         return itensor
 

@@ -102,4 +102,30 @@ extern "C" int emu_env_update(int dtype, int domain, const mpse_dims* dims, cons
   return run(dtype, p, bufs);
 }
 
+extern "C" int emu_env_update_multi(int dtype, int domain, const mpse_dims* dims, int n, const int64_t* wl,
+                                    const int64_t* wr, const void* env, int env_dtype, const void* ket, const void* bra,
+                                    int bra_conj, const void* const* W, int w_dtype, void* out) {
+  if (!bra) bra = ket;
+  Plan p = plan_env_multi(dtype, domain, *dims, n, wl, wr, env_dtype, w_dtype, bra_conj);
+  const void* bufs[B_COUNT] = {nullptr};
+  bufs[B_L] = env;
+  for (int i = 0; i < n; ++i) bufs[w_buf(i)] = W[i];
+  bufs[B_C] = ket;
+  bufs[B_BRA] = bra;
+  bufs[B_OUT] = out;
+  return run(dtype, p, bufs);
+}
+
+extern "C" int emu_heff_apply2(int dtype, const mpse_heff* h, const void* C, void* out) {
+  Plan p = plan_heff2(dtype, *h);
+  const void* bufs[B_COUNT] = {nullptr};
+  bufs[B_L] = h->L;
+  bufs[B_R] = h->R;
+  bufs[B_W0] = h->W0;
+  bufs[B_W1] = h->W1;
+  bufs[B_C] = C;
+  bufs[B_OUT] = out;
+  return run(dtype, p, bufs);
+}
+
 extern "C" void emu_set_unit_threshold(long long macs) { unit_threshold() = macs; }

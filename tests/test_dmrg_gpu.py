@@ -191,3 +191,116 @@ def test_two_site_dmrg_with_on_the_fly_swapping():
     exact = 0.0953734687866298
     assert results[OFS.ofs_d] >= exact - 1e-9
     assert results[OFS.ofs_d] <= results[None] + 1e-6
+
+
+def test_stacked_mpo_seams_match_reference(golden_dir):
+    """contract_one_site_multi_mpo (mps/lib.py:121-166) and the two-layer hop_expr (mps/hop_expr.py:24-52) through the
+    C ABI against reference-captured inputs / outputs (tests/golden/dmrg_seams.npz): real / complex, L / R, with and
+    without ancilla, one- and two-site centres."""
+    from renormalizer_amd.engine import get_engine
+    from renormalizer_amd.mps.hop_expr import hop_expr
+    from renormalizer_amd.mps.lib import contract_one_site_multi_mpo
+    eng = get_engine()
+    z = np.load(os.path.join(golden_dir, "dmrg_seams.npz"))
+    for k in range(int(z["menv_n"])):
+        g = lambda n: z[f"menv{k}_{n}"]
+        out = contract_one_site_multi_mpo(eng.asdevice(g("env")), eng.asdevice(g("ms")),
+                                          [eng.asdevice(g("mo1")), eng.asdevice(g("mo2"))], str(g("dom"))).to_host()
+        assert out.shape == g("out").shape
+        assert np.abs(out - g("out")).max() < 1e-12 * max(1, np.abs(g("out")).max()), k
+    for k in range(int(z["hop2_n"])):
+        g = lambda n: z[f"hop2_{k}_{n}"]
+        ns = int(g("nsite"))
+        hop = hop_expr(g("l"), g("r"), [g(f"w{j}") for j in range(ns)], g("c").shape, True)
+        out = hop(eng.asdevice(g("c"))).to_host()
+        assert np.abs(out - g("out")).max() < 1e-12 * max(1, np.abs(g("out")).max()), k
+        # the dense form used by the direct solver reproduces the action
+        dense = hop.dense()
+        assert np.abs(dense @ g("c").ravel() - g("out").ravel()).max() < 1e-11 * max(1, np.abs(g("out")).max())
+
+
+def test_eigensolver_seams_match_reference(golden_dir):
+    """eigh_iterative (Davidson in the engine, gs.py:486-576) and eigh_direct (gs.py:383-407) on centre problems
+    captured inside the reference's sweeps - (L, W, R, qn_mask, guess) -> (e, c) - for one-layer and (H - omega)^2
+    problems, one- and two-site centres.  Eigenvectors agree up to the sign the reference fixes (gs.py:372-380)."""
+    import types
+    from renormalizer_amd.engine import get_engine
+    from renormalizer_amd.mps import gs
+    from renormalizer_amd.utils import OptimizeConfig
+    eng = get_engine()
+    z = np.load(os.path.join(golden_dir, "dmrg_seams.npz"))
+    seen = set()
+    for k in range(int(z["eig_n"])):
+        g = lambda n: z[f"eig{k}_{n}"]
+        kind, two, ns = str(g("kind")), bool(g("twolayer")), int(g("nsite"))
+        seen.add((kind, two, ns))
+        mask = g("mask")
+        cmo = [eng.asdevice(g(f"w{j}")) for j in range(ns)]
+        mps = types.SimpleNamespace(optimize_config=OptimizeConfig())
+        l, r = eng.asdevice(g("l")), eng.asdevice(g("r"))
+        if kind == "it":
+            guess = np.zeros(mask.shape)
+            guess[mask] = g("guess")
+            e, c, ncyc = gs.eigh_iterative(mps, mask, l, r, cmo, eng.asdevice(guess), two)
+            assert 0 < ncyc < 100
+        else:
+            e, c, _ = gs.eigh_direct(mps, mask, l, r, cmo, two)
+        assert abs(e - float(g("e"))) < 1e-10 * max(1.0, abs(float(g("e")))), (k, kind, two, e, float(g("e")))
+        cvec = c.to_host()[mask]
+        assert np.abs(c.to_host()[~mask]).max() == 0.0
+        ref = g("c")
+        assert abs(abs(np.vdot(ref, cvec)) / np.linalg.norm(cvec) - 1.0) < 1e-8, (k, kind, two)
+        if kind == "di":
+            assert np.abs(cvec - ref).max() < 1e-7                        # same sign convention
+    assert {("it", False, 2), ("it", False, 1), ("di", False, 2), ("di", False, 1), ("it", True, 2), ("it", True, 1),
+            ("di", True, 1)} <= seen
+    # the converged sweep energies of those runs (random starts differ, the fixed points do not)
+    for method in ("2site", "1site"):
+        assert abs(z[f"holstein_{method}_gs_energies"][-1] - 0.0953734687866) < 2e-9
+
+
+@pytest.mark.parametrize("method", ["2site", "1site"])
+def test_holstein_omega_two_layer_matches_reference(golden_dir, method):
+    """optimize_mps(omega=0.09) (gs.py:106-112: two-layer environments) converges to the reference's value of the
+    (H - omega)^2 functional for the Holstein test model."""
+    from renormalizer_amd.mps.gs import optimize_mps
+    from renormalizer_amd.mps.mps import Mps
+    z = np.load(os.path.join(golden_dir, "dmrg_seams.npz"))
+    model = _holstein_test_model()
+    mpo = Mpo(model)
+    mps = Mps.random(model, 1, 12, rng=np.random.default_rng(2019))
+    mps.optimize_config.procedure = [[12, 0.4], [16, 0.2], [20, 0], [20, 0]]
+    mps.optimize_config.method = method
+    energies, opt = optimize_mps(mps.copy(), mpo, omega=float(z["eig_omega"]))
+    ref = float(z[f"holstein_{method}_omega_energies"][-1])
+    assert abs(min(energies) - ref) < 1e-9, (energies, ref)
+    e = opt.expectation(mpo)
+    assert abs((e - 0.09) ** 2 - ref) < 1e-7
+
+
+def test_h2o_sweep_energies_and_saturated_bonds_match_reference(golden_dir):
+    """BASELINE config 5 at its stated size: example/h2o_qc.py from the reference's own seeded random start
+    (tests/golden/h2o_dmrg.npz), procedure [[M, .4], [M, .2], [M, .1], [M, 0] x 4] at M = 50 and at M = 512 - the
+    exact bond dimensions of 14 spin orbitals with (5, 5) electrons saturate at 37, so both run the same workload
+    (SURVEY.md section 8d item 5).  The energy after EVERY sweep and the final bond dimensions are the reference's."""
+    from renormalizer_amd.mps.gs import optimize_mps
+    from renormalizer_amd.mps.mps import Mps
+    z = np.load(os.path.join(golden_dir, "h2o_dmrg.npz"))
+    sh, aseri, nuc = h_qc.read_fcidump(os.path.join(golden_dir, "h2o_fcidump.txt"), 7)
+    model = Model(*h_qc.qc_model(sh, aseri))
+    mpo = Mpo(model)
+    assert mpo.bond_dims == z["mpo_bond_dims"].tolist()
+    n = int(z["init_nsite"])
+    for M in (50, 512):
+        mps = Mps.from_arrays(model, [z[f"init_site_{i}"] for i in range(n)], [z[f"init_qn_{i}"] for i in range(n + 1)],
+                              int(z["init_qnidx"]), z["init_qntot"], bool(z["init_to_right"]), complex(z["init_coeff"]).real)
+        mps.optimize_config.procedure = [[M, 0.4], [M, 0.2], [M, 0.1], [M, 0], [M, 0], [M, 0], [M, 0]]
+        mps.optimize_config.method = "2site"
+        energies, gs_mps = optimize_mps(mps, mpo)
+        ref = z[f"energies_M{M}"]
+        assert len(energies) == len(ref), (energies, ref)               # same convergence decision (4 sweeps)
+        assert np.abs(np.array(energies) - ref).max() < 1e-8, (M, energies, ref)
+        assert abs(min(energies) + nuc - (-75.008697516450)) < 1e-8
+        assert list(gs_mps.bond_dims) == z[f"bond_dims_M{M}"].tolist()
+        assert list(mps.bond_dims) == z[f"sweep_bond_dims_M{M}"].tolist()
+        assert max(gs_mps.bond_dims) == 37

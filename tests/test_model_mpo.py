@@ -195,3 +195,22 @@ def test_mpo_small_constructors_and_conjugate():
     assert [q.shape[0] for q in h.dummy_qn] == h.bond_dims and not any(q.any() for q in h.dummy_qn)
     with pytest.raises(TypeError):
         Mpo.ph_onsite(Model(model.basis, model.ham_terms), "b", 0)
+
+
+def test_thermofield_hamiltonian_matches_reference_dense(golden_dir=None):
+    """model/thermofield.py against the Hamiltonian the reference writes term by term
+    (transport/tests/test_spectral_function.py:16-48; tests/golden/thermofield.npz, oracle/gen_golden.py thermofield):
+    dense matrix of a dimer with one doubled mode."""
+    import os
+    from renormalizer_amd import Mol, Mpo, Phonon, Quantity
+    from renormalizer_amd.model import thermofield_holstein
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "thermofield.npz"))
+    w, g, beta = float(z["tri_omega"][0]), float(z["tri_g"][0]), float(z["tri_beta"])
+    temperature = Quantity(1.0 / beta)                   # k_B T in atomic units
+    assert abs(temperature.to_beta() - beta) < 1e-9 * beta
+    mols = [Mol(Quantity(float(e)), [Phonon.simple_phonon(Quantity(w), Quantity(g * np.sqrt(2.0 / w)), 3)])
+            for e in z["tri_eps"][:2]]
+    model = thermofield_holstein(mols, z["tri_j"][:2, :2], temperature)
+    dense = Mpo(model).todense()
+    assert dense.shape == z["dimer_dense"].shape
+    assert np.abs(dense - z["dimer_dense"]).max() < 1e-13

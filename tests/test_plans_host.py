@@ -278,3 +278,89 @@ def test_plans_random_shapes_property(emu):
             assert np.abs(out - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
 
     check()
+
+
+def test_stacked_mpo_plans_vs_golden(emu, golden_dir):
+    """plan_env_multi / plan_heff2 (mps/lib.py:121-166, mps/hop_expr.py:24-52) against reference-captured seams
+    (tests/golden/dmrg_seams.npz), and with three layers against einsum."""
+    emu.emu_env_update_multi.argtypes = [C.c_int, C.c_int, C.POINTER(E.mpse_dims), C.c_int, C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_int64), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+    emu.emu_heff_apply2.argtypes = [C.c_int, C.POINTER(E.mpse_heff), C.c_void_p, C.c_void_p]
+    z = np.load(os.path.join(golden_dir, "dmrg_seams.npz"))
+
+    def env_multi(env, ms, mos, dom):
+        cplx = np.iscomplexobj(ms) or np.iscomplexobj(env)
+        wdt = complex if cplx else float
+        ket = _c(ms.astype(wdt))
+        env = _c(env)
+        mos = [_c(m) for m in mos]
+        n = len(mos)
+        d = E.mpse_dims()
+        d.Dl_ket = d.Dl_bra = ket.shape[0]
+        d.Dr_ket = d.Dr_bra = ket.shape[-1]
+        d.d0 = ket.shape[1]
+        d.danc = ket.shape[2] if ket.ndim == 4 else 1
+        wl = (C.c_int64 * n)(*[m.shape[0] for m in mos])
+        wr = (C.c_int64 * n)(*[m.shape[3] for m in mos])
+        ws = (C.c_void_p * n)(*[m.ctypes.data for m in mos])
+        if dom == "L":
+            oshape = (ket.shape[-1],) + tuple(m.shape[3] for m in mos) + (ket.shape[-1],)
+        else:
+            oshape = (ket.shape[0],) + tuple(m.shape[0] for m in mos) + (ket.shape[0],)
+        out = np.full(oshape, np.nan, dtype=wdt)
+        st = emu.emu_env_update_multi(E.C128 if cplx else E.F64, 0 if dom == "L" else 1, C.byref(d), n, wl, wr,
+                                      env.ctypes.data, E.dtype_code(env.dtype), ket.ctypes.data, None, 1, ws,
+                                      E.dtype_code(mos[0].dtype), out.ctypes.data)
+        assert st == 0
+        return out
+
+    for k in range(int(z["menv_n"])):
+        g = lambda n: z[f"menv{k}_{n}"]
+        out = env_multi(g("env"), g("ms"), [g("mo1"), g("mo2")], str(g("dom")))
+        assert out.shape == g("out").shape
+        assert np.abs(out - g("out")).max() < 1e-11 * max(1, np.abs(g("out")).max()), k
+    rng = np.random.default_rng(3)
+    ms = _rand(rng, (4, 3, 5), True)
+    mos = [_rand(rng, s, False) for s in ((2, 3, 3, 3), (3, 3, 3, 2), (2, 3, 3, 4))]
+    envl = _rand(rng, (4, 2, 3, 2, 4), True)
+    ref = np.einsum("abcde,axp,bxyf,cyzg,dzuh,euq->pfghq", envl, ms.conj(), *mos, ms)
+    assert np.abs(env_multi(envl, ms, mos, "L") - ref).max() < 1e-11 * np.abs(ref).max()
+    envr = _rand(rng, (5, 3, 2, 4, 5), True)
+    ref = np.einsum("abcde,pxa,fxyb,gyzc,hzud,que->pfghq", envr, ms.conj(), *mos, ms)
+    assert np.abs(env_multi(envr, ms, mos, "R") - ref).max() < 1e-11 * np.abs(ref).max()
+    one = env_multi(envl[:, :, 0, 0, :], ms, mos[:1], "L")               # a single layer is the ordinary update
+    assert np.abs(one - orc.contract_one_site(envl[:, :, 0, 0, :], ms, mos[0], "L")).max() < 1e-11
+
+    for k in range(int(z["hop2_n"])):
+        g = lambda n: z[f"hop2_{k}_{n}"]
+        ns = int(g("nsite"))
+        l, r, c = _c(g("l")), _c(g("r")), _c(g("c"))
+        cmo = [_c(g(f"w{j}")) for j in range(ns)]
+        h = E.mpse_heff()
+        h.nsite = ns
+        d = h.dims
+        d.Dl_ket = d.Dl_bra = c.shape[0]
+        d.Dr_ket = d.Dr_bra = c.shape[-1]
+        d.danc = 1
+        d.wl, d.wr = l.shape[1], r.shape[1]
+        d.d0 = cmo[0].shape[1]
+        d.d1 = cmo[1].shape[1] if ns == 2 else 1
+        d.wm = cmo[0].shape[3] if ns == 2 else 1
+        h.L, h.l_dtype, h.R, h.r_dtype = l.ctypes.data, E.dtype_code(l.dtype), r.ctypes.data, E.dtype_code(r.dtype)
+        h.W0, h.w_dtype = cmo[0].ctypes.data, E.dtype_code(cmo[0].dtype)
+        if ns == 2:
+            h.W1 = cmo[1].ctypes.data
+        out = np.full(c.shape, np.nan, dtype=c.dtype)
+        assert emu.emu_heff_apply2(E.dtype_code(c.dtype), C.byref(h), c.ctypes.data, out.ctypes.data) == 0
+        assert np.abs(out - g("out")).max() < 1e-11 * max(1, np.abs(g("out")).max()), k
+        # three centres at once through the batch index next to the right bond
+        cz = _c(np.stack([c, 2 * c, -c[::-1]], axis=-2))
+        if ns == 1:
+            d.danc = 3
+        else:
+            d.danc1 = 3
+        outz = np.full(cz.shape, np.nan, dtype=c.dtype)
+        assert emu.emu_heff_apply2(E.dtype_code(c.dtype), C.byref(h), cz.ctypes.data, outz.ctypes.data) == 0
+        assert np.abs(outz[..., 0, :] - g("out")).max() < 1e-11 * max(1, np.abs(g("out")).max())
+        assert np.abs(outz[..., 1, :] - 2 * g("out")).max() < 1e-10 * max(1, np.abs(g("out")).max())

@@ -419,6 +419,65 @@ def test_fmo_model_matches_reference(golden_dir):
     assert np.abs(occ - z["e_occ"]).max() < 1e-6
 
 
+def _thermofield_run(model, start, D, nsteps, dt, z, pre):
+    """electron created on molecule ``start`` of the doubled vacuum; the bond-expanded start state is the reference's
+    (fixed-bond TDVP follows the 1e-10 padding of expand_bond_dimension, which is reproducible to ~1e-6 only)"""
+    from renormalizer_amd.mps.mps import Mps
+    psi = Mpo.onsite(model, r"a^\dagger", dof_set={start}).apply(Mps.ground_state(model, False))
+    e0 = psi.expectation(Mpo(model))
+    mpo = Mpo(model, offset=Quantity(e0))
+    own = psi.copy()
+    own.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=D)
+    own = own.expand_bond_dimension(mpo).canonicalise()
+    n = int(z[pre + "init_nsite"])
+    psi = Mps.from_arrays(model, [z[pre + f"init_site_{i}"] for i in range(n)], [z[pre + f"init_qn_{i}"] for i in range(n + 1)],
+                          int(z[pre + "init_qnidx"]), z[pre + "init_qntot"], bool(z[pre + "init_to_right"]),
+                          complex(z[pre + "init_coeff"]))
+    assert list(own.bond_dims) == list(psi.bond_dims)                  # the own expansion reaches the same bonds
+    psi.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=D)
+    psi.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    occ, ener = [np.asarray(psi.e_occupations)], [psi.expectation(mpo)]
+    for _ in range(nsteps):
+        psi = psi.evolve(mpo, dt)
+        occ.append(np.asarray(psi.e_occupations))
+        ener.append(psi.expectation(mpo))
+    return e0, mpo, psi, np.array(occ), np.array(ener)
+
+
+def test_thermofield_tdvp_matches_reference(golden_dir):
+    """BASELINE config 4's finite-temperature route, pinned to the reference: the thermofield Hamiltonian that the
+    reference writes by hand (transport/tests/test_spectral_function.py:16-48: tilde modes of frequency -omega,
+    cosh / sinh couplings) propagated by the reference's TDVP-PS (tests/golden/thermofield.npz) against
+    model/thermofield.py + the engine - a Holstein trimer with two doubled modes per molecule at k T ~ omega, and the
+    FMO model of example/fmo.py with three doubled modes per site at 77 K (35 sites)."""
+    import importlib.util
+    from renormalizer_amd.model import thermofield_holstein
+    z = np.load(os.path.join(golden_dir, "thermofield.npz"))
+    beta = float(z["tri_beta"])
+    phs = [Phonon.simple_phonon(Quantity(float(w)), Quantity(float(g * np.sqrt(2.0 / w))), int(n))
+           for w, g, n in zip(z["tri_omega"], z["tri_g"], z["tri_levels"])]
+    mols = [Mol(Quantity(float(e)), phs) for e in z["tri_eps"]]
+    model = thermofield_holstein(mols, z["tri_j"], Quantity(1.0 / beta))
+    e0, mpo, psi, occ, ener = _thermofield_run(model, 0, 16, 6, float(z["tri_dt"]), z, "tri_")
+    assert abs(e0 - float(z["tri_e0"])) < 1e-12
+    assert mpo.bond_dims == z["tri_mpo_bond"].tolist()
+    assert list(psi.bond_dims) == z["tri_bond"].tolist()
+    assert np.abs(occ - z["tri_occ"]).max() < 1e-6, np.abs(occ - z["tri_occ"]).max()
+    assert np.abs(ener - z["tri_energy"]).max() < 1e-8
+    spec = importlib.util.spec_from_file_location("fmo_example", os.path.join(os.path.dirname(golden_dir), "..", "examples", "fmo.py"))
+    fmo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fmo)
+    model = fmo.fmo_model(int(z["fmo_nph"]), temperature_k=77.0)
+    assert len(model.basis) == 7 * (1 + 2 * int(z["fmo_nph"]))
+    assert [b.nbas for b in model.basis[1:7:2]] == z["fmo_levels"].tolist()
+    e0, mpo, psi, occ, ener = _thermofield_run(model, 3, 12, 4, 160.0, z, "fmo_")
+    assert abs(e0 - float(z["fmo_e0"])) < 1e-12
+    assert mpo.bond_dims == z["fmo_mpo_bond"].tolist()
+    assert list(psi.bond_dims) == z["fmo_bond"].tolist()
+    assert np.abs(occ - z["fmo_occ"]).max() < 1e-6, np.abs(occ - z["fmo_occ"]).max()
+    assert np.abs(ener - z["fmo_energy"]).max() < 1e-8
+
+
 def _pc_rk_setup(golden_dir):
     from renormalizer_amd.mps.mps import Mps
     z = np.load(os.path.join(golden_dir, "pc_rk_holstein_small.npz"))
