@@ -2,14 +2,21 @@
 """Headline benchmark: TDVP-PS sweep throughput on the 50-site Holstein chain (BASELINE.json
 configs[2]: 25 molecules x 1 mode, dphys = 2/16 alternating, Dbond = 256, complex128, dt = 10 a.u.).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one process per GPU, e.g. launched by
+                                                            python -m torch.distributed.run; RANK / LOCAL_RANK /
+                                                            WORLD_SIZE / MASTER_PORT are read from the environment)
 
 A "step" is one ``Mps.evolve(mpo, dt)`` = two half sweeps = 2*Nsite site updates (forward solves)
 plus 2*(Nsite-1) bond back-steps, on one independent trajectory per GPU.  The MPS, the MPO and all
 environments are resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line:
     value      = site updates per second, all ranks together (weak scaling: one trajectory per GPU)
     roofline   = FP64-MFMA roofline of the dominant kernel (complex x complex contraction), measured
-                 with HIP events on the engine's stream over the timed region
+                 with HIP events on the engine's stream over the timed region: `achieved` counts the MFMA
+                 work actually issued (visited K tiles x 6 real flops per complex multiply-add of the 3M
+                 scheme), `achieved_dense_equiv` the algorithmic 8 M N K of SURVEY.md 8(d); `classes` adds the
+                 HBM-bound Lanczos vector kernels and the block QR
+No PyTorch: ranks talk through librccl.so bound with ctypes (renormalizer_amd/parallel.py), only for the barrier,
+the max of the elapsed time and ONE all-gather of the observables.
     cpu_baseline = the NumPy/SciPy restatement of the reference path (oracle/) timed on the host on a
                  bounded sample of the same workload (4 BLAS threads, like RENO_NUM_THREADS=4)
 """
@@ -32,6 +39,7 @@ sys.path.insert(0, REPO)
 
 PROF_STRIDE = 7                   # HIP-event timing of every 7th contraction launch inside the timed region
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (AMD datasheet)
+HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (MI355X_MICROARCH.md)
 
 
 def _roctx():
@@ -48,13 +56,22 @@ def _roctx():
         return None
 
 
-def build_workload(nmol, pdim, bond_dim, seed, init):
+DISORDER_AU = 50.0 * 4.556335e-6   # static diagonal disorder of the trajectories beyond the first: sigma = 50 cm^-1
+
+
+def build_workload(nmol, pdim, bond_dim, seed, init, unit=0):
     from renormalizer_amd import (HolsteinModel, Phonon, Mol, Quantity, Mpo, CompressConfig, CompressCriteria,
                                   EvolveConfig, EvolveMethod)
     from renormalizer_amd.mps.mps import Mps
-    # example/std.yaml parameters, T = 0, fixed phonon levels
+    from renormalizer_amd.parallel import trajectory_seed
+    # example/std.yaml parameters, T = 0, fixed phonon levels.  Trajectory 0 is the
+    # clean chain; every further independent trajectory (other ranks, other streams of a GPU) is a static-disorder
+    # realisation of it with its own seed - same sizes, different numbers
     ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), pdim)
-    model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
+    eps = np.zeros(nmol)
+    if unit > 0:
+        eps = np.random.default_rng(trajectory_seed(2024, unit)).normal(0.0, DISORDER_AU, size=nmol)
+    model = HolsteinModel([Mol(Quantity(float(e)), [ph]) for e in eps], Quantity(3.0e-2), 3)
     fc = Mps.hartree_product_state(model, {nmol // 2: 1})          # electron created on the centre molecule
     e0 = fc.expectation(Mpo(model))
     mpo = Mpo(model, offset=Quantity(e0))
@@ -124,7 +141,7 @@ def main():
     ap.add_argument("--traj-per-gpu", type=int, default=1,
                     help="independent trajectories sharing each GPU (threads with their own stream); 1 = headline")
     ap.add_argument("--cpu-updates", type=int, default=9, help="site updates in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+    ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "gloo"],
                     help="gloo + --share-gpu exercises the multi-rank flow on a single GPU (testing only)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use GPU 0 (testing only)")
     args = ap.parse_args()
@@ -137,30 +154,24 @@ def main():
         local_rank = 0
     os.environ["RENO_GPU"] = str(local_rank)
 
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.dist_backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend="gloo")
-
     from renormalizer_amd.engine import Engine, get_engine, use_engine
+    from renormalizer_amd.parallel import gather_observables, make_collective, max_over_ranks
     T = max(1, args.traj_per_gpu)
     engines = [get_engine()] + [Engine(local_rank) for _ in range(T - 1)]
     eng = engines[0]
     nsite = 2 * args.nmol
+    # one communicator per process (ctypes RCCL on the engine's device and stream); serial for a single process
+    coll = make_collective(eng, backend="gloo" if (world > 1 and args.dist_backend == "gloo") else None)
+    if world > 1:
+        print(f"[rank {rank}] device {local_rank}: {eng.device_name}; {coll.kind} communicator of {coll.world} ranks",
+              file=sys.stderr, flush=True)
 
     def barrier():
         for e in engines:
             e.sync()
-        if dist is not None:
-            dist.barrier()
-            if args.dist_backend == "nccl":
-                import torch
-                torch.cuda.synchronize()
+        coll.barrier()
+        for e in engines:
+            e.sync()
 
     import threading
     sync = threading.Barrier(T + 1)
@@ -171,7 +182,7 @@ def main():
         try:
             use_engine(engines[t])
             model, mpo, mps = build_workload(args.nmol, args.pdim, args.bond_dim, seed=1234 + rank * T + t,
-                                             init=args.init)
+                                             init=args.init, unit=rank * T + t)
             for _ in range(args.warmup):
                 mps = mps.evolve(mpo, args.dt)
             engines[t].prof_reset()
@@ -223,13 +234,13 @@ def main():
                 acc[f] += v[f]
     use_engine(None)
 
-    if dist is not None:
-        from renormalizer_amd.parallel import gather_observables, max_over_ranks
-        dev = f"cuda:{local_rank}" if args.dist_backend == "nccl" else "cpu"
-        elapsed = max_over_ranks(elapsed, device=dev)
-        # the only collective of the whole job: all_gather of the per-trajectory observables (KBs)
-        occ_table = gather_observables(np.asarray(mps.e_occupations)[None, :], [rank], world, device=dev)
-        assert occ_table.shape[0] == world
+    elapsed = max_over_ranks(coll, elapsed)
+    # the only collective of the whole job besides the barriers: all-gather of the per-trajectory observables (KBs)
+    occ_table = gather_observables(coll, np.asarray(mps.e_occupations)[None, :], [rank], world)
+    assert occ_table.shape[0] == world
+    if world > 1 and rank == 0:
+        distinct = len({tuple(np.round(r, 10)) for r in occ_table})
+        print(f"[rank 0] gathered populations of {world} trajectories, {distinct} distinct", file=sys.stderr, flush=True)
 
     if rank == 0:
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
@@ -237,14 +248,38 @@ def main():
         # collected from inside this process
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as fh:
+            with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as fh:
                 traffic = json.load(fh)["kernels"]["void k_gemm<true, true, true>"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --init random)"
+            traffic_src = ("profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                           "command, bench.py --init physical; counters cannot be read from inside the process)")
         except (OSError, KeyError, ValueError):
             pass
         zz = prof["c128xc128"]
-        achieved = zz["flops"] / (zz["ms"] * 1e-3) / 1e12 if zz["ms"] > 0 else 0.0
+        sec = zz["ms"] * 1e-3
+        dense = zz["flops"] / sec / 1e12 if sec > 0 else 0.0
+        issued = zz["issued_flops"] / sec / 1e12 if sec > 0 else 0.0
         total_ms = sum(v["ms"] for v in prof.values())
+        classes = []
+        vv, qq = prof["lanczos_vec"], prof["block_qr"]
+        if vv["ms"] > 0:
+            gbs = vv["bytes"] / (vv["ms"] * 1e-3) / 1e9
+            classes.append({"kernel": "Lanczos vector kernels (dot / three-term update + norm / normalise)", "bound": "hbm",
+                            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "timed_launches": vv["launches"], "avg_launch_ms": vv["ms"] / max(1, vv["launches"]),
+                            "alg_bytes_per_launch": vv["bytes"] / max(1, vv["launches"])})
+        if qq["ms"] > 0:
+            tf = qq["flops"] / (qq["ms"] * 1e-3) / 1e12
+            classes.append({"kernel": "block QR / RQ (Householder panels, whole mpse_block_qr calls)", "bound": "latency (FP64 vector)",
+                            "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                            "timed_calls": qq["launches"], "avg_call_ms": qq["ms"] / max(1, qq["launches"]),
+                            "alg_flops_per_call": qq["flops"] / max(1, qq["launches"])})
+        for nm in ("c128xf64", "f64xc128"):
+            v = prof[nm]
+            if v["ms"] > 0:
+                classes.append({"kernel": f"k_gemm<{nm}> (MPO step)", "bound": "hbm",
+                                "achieved": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "timed_launches": v["launches"],
+                                "avg_launch_ms": v["ms"] / max(1, v["launches"])})
         out = {
             "metric": "TDVP-PS sweep site-updates/sec at (Nsite=%d, Dbond=%d, dphys=2/%d)" % (nsite, args.bond_dim, args.pdim),
             "value": world * T * args.steps * 2 * nsite / elapsed,
@@ -258,28 +293,34 @@ def main():
             "vs_baseline": None,
             "dtype": "c128",
             "data": ("synthetic (std.yaml Holstein parameters; electron created on the centre molecule of the phonon "
-                     "vacuum, bonds expanded to Dbond with expand_bond_dimension, as transport/dynamics.py:173-199)"
+                     "vacuum, bonds expanded to Dbond with expand_bond_dimension, as transport/dynamics.py:173-199; "
+                     "trajectories beyond the first carry static diagonal disorder, sigma = 50 cm^-1, own seed)"
                      if args.init == "physical" else
                      "synthetic (random quantum-number-conserving MPS, 1 exciton; std.yaml Holstein parameters)"),
             "config": {"workload": "configs[2]: %d-site Holstein chain TDVP-PS, %d independent trajector%s per GPU"
                                    % (nsite, T, "y" if T == 1 else "ies"),
                        "nsite": nsite, "bond_dim": args.bond_dim, "dphys": [2, args.pdim], "mpo_bond": max(mpo.bond_dims),
                        "dt": args.dt, "init": args.init, "mean_krylov_dim": float(np.mean(kry)),
-                       "device": eng.device_name},
-            "roofline": {"bound": "mfma", "kernel": "k_gemm<c128,c128> (FP64 MFMA strided contraction)",
-                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                       "device": eng.device_name, "collective": coll.kind},
+            "roofline": {"bound": "mfma", "kernel": "k_gemm<c128,c128> (FP64 MFMA strided contraction, 3M complex products)",
+                         "achieved": issued, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": issued / FP64_MFMA_PEAK_TFLOPS,
+                         "achieved_note": "issued MFMA work: K tiles visited (device counters) x 65536 MACs x 6 real flops",
+                         "achieved_dense_equiv": dense, "frac_dense_equiv": dense / FP64_MFMA_PEAK_TFLOPS,
+                         "visited_ktile_share": (zz["ktiles"] * 65536.0 * 8.0 / zz["flops"]) if zz["flops"] else None,
+                         "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "compulsory_bytes_per_launch": zz["bytes"] / max(1, zz["launches"]),
                          "timed_launches": zz["launches"], "sampling_stride": PROF_STRIDE, "avg_launch_ms": zz["ms"] / max(1, zz["launches"]),
                          "alg_flops_per_launch": zz["flops"] / max(1, zz["launches"]),
-                         "contraction_time_share_of_wall_est": PROF_STRIDE * 1e-3 * total_ms / elapsed / T},
+                         "issued_flops_per_launch": zz["issued_flops"] / max(1, zz["launches"]),
+                         "sampled_time_share_of_wall_est": PROF_STRIDE * 1e-3 * total_ms / elapsed / T,
+                         "classes": classes},
         }
         if world == 1 and args.cpu_updates > 0:
             out["cpu_baseline"] = cpu_baseline(model, mpo, mps, args.dt, args.cpu_updates)
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    coll.close()
 
 
 if __name__ == "__main__":

@@ -7,8 +7,9 @@ the tabulated spectral density, T = 0, TDVP-PS at fixed bond dimension.
 A temperature > 0 switches to the thermofield form (BASELINE config 4): every mode is doubled, 7 + 2 x 7 x modes sites.
 
 With more than one trajectory, static disorder (Gaussian, 50 cm^-1) is added to the site energies with a seed per
-trajectory; under ``python -m torch.distributed.run --nproc-per-node N examples/fmo.py ...`` the trajectories are dealt
-to the ranks (one GPU each) and only the population tables are gathered at the end."""
+trajectory; with one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT in the environment, e.g. from
+``python -m torch.distributed.run --nproc-per-node N examples/fmo.py ...``) the trajectories are dealt to the ranks and
+only the population tables are gathered at the end - one RCCL all-gather bound through ctypes, no PyTorch."""
 import json
 import os
 import sys
@@ -20,7 +21,7 @@ sys.path.insert(0, REPO)
 
 from renormalizer_amd import (CompressConfig, CompressCriteria, EvolveConfig, EvolveMethod, HolsteinModel, Mol, Mpo, Mps,  # noqa: E402
                               Phonon, Quantity)
-from renormalizer_amd.parallel import gather_observables, trajectory_seed, units_of_rank  # noqa: E402
+from renormalizer_amd.parallel import gather_observables, make_collective, trajectory_seed, units_of_rank  # noqa: E402
 from renormalizer_amd.utils.constant import cm2au  # noqa: E402
 
 J_CM = np.array([[310, -98, 6, -6, 7, -12, -10, 38], [-98, 230, 30, 7, 2, 12, 5, 8], [6, 30, 0, -59, -2, -10, 5, 2],
@@ -65,19 +66,15 @@ if __name__ == "__main__":
     temperature_k = float(sys.argv[5]) if len(sys.argv) > 5 else 0.0
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     os.environ.setdefault("RENO_GPU", os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
-        dist.init_process_group(backend="nccl")
+    coll = make_collective()
     mine = units_of_rank(ntraj, rank, world)
     rows = []
     for u in mine:
         rng = np.random.default_rng(trajectory_seed(2024, u))
         model = fmo_model(nph, disorder_cm=50.0 if ntraj > 1 else 0.0, rng=rng, temperature_k=temperature_k)
         rows.append(run(model, D, nsteps).ravel())
-    table = gather_observables(np.array(rows), mine, ntraj,
-                               device=f"cuda:{os.environ.get('LOCAL_RANK', 0)}" if world > 1 else "cpu")
+    table = gather_observables(coll, np.array(rows), mine, ntraj)
+    coll.close()
     if rank == 0:
         pops = table.reshape(ntraj, nsteps + 1, -1).mean(axis=0)
         for i, p in enumerate(pops):

@@ -65,6 +65,12 @@ int mpse_device_info(mpse_ctx* ctx, char* name, size_t name_len, int* n_cu, void
  * Totals cover the TIMED launches since the last reset; algorithmic flops use 2/4/4/8 per MAC.
  * on == 1 times every launch, on == N > 1 every N-th launch (sampling: two HIP events per timed launch
  * cost a few microseconds of stream time each). */
+/* variants 4 and 5 of mpse_prof_get: 4 = the HBM-bound Lanczos vector kernels inside mpse_expm_lanczos (algorithmic
+ * bytes in total_bytes), 5 = whole mpse_block_qr calls (Householder flops in total_flops).  The sampling counter is
+ * shared by all variants.  mpse_prof_get_ktiles: 64 x 64 x 16 multiply-add blocks the timed contraction launches of a
+ * variant (0-3) actually multiplied - with structural-zero skipping fewer than the dense count; the MFMA work issued
+ * is ktiles x 65536 MACs x {2, 4, 4, 6} real flops (complex x complex uses three real products per complex one). */
+int mpse_prof_get_ktiles(mpse_ctx* ctx, int variant, int64_t* ktiles);
 int mpse_prof_enable(mpse_ctx* ctx, int on);
 int mpse_prof_reset(mpse_ctx* ctx);
 int mpse_prof_get(mpse_ctx* ctx, int variant, double* total_ms, double* total_flops, double* total_bytes,

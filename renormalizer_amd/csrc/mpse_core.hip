@@ -42,6 +42,37 @@ void prof_drain(mpse_ctx* ctx) {
   ctx->prof_pending.clear();
 }
 
+bool prof_begin(mpse_ctx* ctx, int variant, double flops, double bytes, mpse_ctx::ProfRec* rec) {
+  if (!ctx->prof_on || (ctx->prof_counter++ % ctx->prof_stride != 0)) return false;
+  auto get_event = [&](hipEvent_t* e) {
+    if (!ctx->prof_free_events.empty()) {
+      *e = ctx->prof_free_events.back();
+      ctx->prof_free_events.pop_back();
+      return true;
+    }
+    return hipEventCreate(e) == hipSuccess;
+  };
+  if (!get_event(&rec->e0)) return false;
+  if (!get_event(&rec->e1)) {
+    ctx->prof_free_events.push_back(rec->e0);
+    return false;
+  }
+  rec->variant = variant;
+  rec->flops = flops;
+  rec->bytes = bytes;
+  if (hipEventRecord(rec->e0, ctx->stream) != hipSuccess) {
+    ctx->prof_free_events.push_back(rec->e0);
+    ctx->prof_free_events.push_back(rec->e1);
+    return false;
+  }
+  return true;
+}
+
+void prof_end(mpse_ctx* ctx, const mpse_ctx::ProfRec& rec) {
+  (void)hipEventRecord(rec.e1, ctx->stream);
+  ctx->prof_pending.push_back(rec);
+}
+
 namespace {
 __global__ void k_copy16(double2* __restrict__ dst, const double2* __restrict__ src, long long n) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -65,16 +96,32 @@ int mpse_prof_reset(mpse_ctx* ctx) {
   if (!ctx) return MPSE_ERR_ARG;
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   prof_drain(ctx);
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < mpse_ctx::PROF_NVAR; ++i) {
     ctx->prof_ms[i] = ctx->prof_flops[i] = ctx->prof_bytes[i] = 0;
     ctx->prof_launches[i] = 0;
   }
+  if (ctx->prof_ktiles) {
+    MPSE_HIP(ctx, hipMemsetAsync(ctx->prof_ktiles, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return MPSE_OK;
+}
+
+int mpse_prof_get_ktiles(mpse_ctx* ctx, int variant, int64_t* ktiles) {
+  if (!ctx || !ktiles || variant < 0 || variant > 3) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
+  *ktiles = 0;
+  if (!ctx->prof_ktiles) return MPSE_OK;
+  unsigned long long v[4];
+  MPSE_HIP(ctx, hipMemcpyAsync(v, ctx->prof_ktiles, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+  MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *ktiles = (int64_t)v[variant];
   return MPSE_OK;
 }
 
 int mpse_prof_get(mpse_ctx* ctx, int variant, double* total_ms, double* total_flops, double* total_bytes,
                   int64_t* launches) {
-  if (!ctx || variant < 0 || variant > 3) return MPSE_ERR_ARG;
+  if (!ctx || variant < 0 || variant >= mpse_ctx::PROF_NVAR) return MPSE_ERR_ARG;
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   prof_drain(ctx);
   if (total_ms) *total_ms = ctx->prof_ms[variant];
@@ -108,6 +155,7 @@ int mpse_ctx_create(int device, mpse_ctx** out) {
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void**)&ctx->pinned, 4096 * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&ctx->dscratch, (size_t(1) << 16) * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&ctx->prof_ktiles, 4 * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc((void**)&ctx->stage, size_t(8) << 20) != hipSuccess) {
     delete ctx;
     return MPSE_ERR_HIP;
@@ -115,6 +163,7 @@ int mpse_ctx_create(int device, mpse_ctx** out) {
   // on the context's own stream: touching the null stream would make the runtime open one more hardware queue,
   // and with four trajectories per GPU (four streams) two of them would then share a queue and serialise
   (void)hipMemsetAsync(ctx->dscratch + (size_t(1) << 16) - 8, 0, 8 * sizeof(double), ctx->stream);
+  (void)hipMemsetAsync(ctx->prof_ktiles, 0, 4 * sizeof(unsigned long long), ctx->stream);
   (void)hipStreamSynchronize(ctx->stream);
   if (hipHostGetDevicePointer((void**)&ctx->pinned_dev, ctx->pinned, 0) != hipSuccess) ctx->pinned_dev = nullptr;
   ctx->pinned[4095] = 0.0;      // sequence slot of publish_and_wait
@@ -151,6 +200,7 @@ int mpse_ctx_destroy(mpse_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->dscratch) (void)hipFree(ctx->dscratch);
+  if (ctx->prof_ktiles) (void)hipFree(ctx->prof_ktiles);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return MPSE_OK;

@@ -53,6 +53,7 @@ struct GemmArgs {
   const unsigned long long* amask;
   const unsigned long long* bmask;
   int nkw;
+  unsigned long long* kt_counter;   // profiling only: every workgroup adds the number of K tiles it multiplied
 };
 
 __device__ __forceinline__ long long idx_off(const IdxMap& m, int i) {
@@ -321,7 +322,9 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
     }
   };
 
+  int kt_done = 0;
   while (kt < kt_end) {
+    ++kt_done;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
     }
   }
 
+  if (g.kt_counter && tid == 0 && kt_done) atomicAdd(g.kt_counter, (unsigned long long)kt_done);
   if constexpr (M3) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -703,26 +707,15 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
 
   dim3 grid((unsigned)nblk), block(256);
   mpse_ctx::ProfRec rec;
-  const bool prof_this = ctx->prof_on && (ctx->prof_counter++ % ctx->prof_stride == 0);
-  if (prof_this) {
-    auto get_event = [&](hipEvent_t* e) {
-      if (!ctx->prof_free_events.empty()) {
-        *e = ctx->prof_free_events.back();
-        ctx->prof_free_events.pop_back();
-        return hipSuccess;
-      }
-      return hipEventCreate(e);
-    };
-    MPSE_HIP(ctx, get_event(&rec.e0));
-    MPSE_HIP(ctx, get_event(&rec.e1));
-    rec.variant = (ca ? 1 : 0) + (cb ? 2 : 0);
-    const double mnk = double(g.M) * double(g.N) * double(g.K) * double(d->batch);
-    rec.flops = mnk * ((ca && cb) ? 8.0 : (ca || cb) ? 4.0 : 2.0);
-    // compulsory traffic: read A and B once, write C once (+ read C when beta != 0)
-    rec.bytes = double(d->batch) * (double(g.M) * g.K * (ca ? 16 : 8) + double(g.K) * g.N * (cb ? 16 : 8) +
-                                    double(g.M) * g.N * ((ca || cb) ? 16 : 8) * (g.use_beta ? 2 : 1));
-    MPSE_HIP(ctx, hipEventRecord(rec.e0, ctx->stream));
-  }
+  const int variant = (ca ? 1 : 0) + (cb ? 2 : 0);
+  const double mnk = double(g.M) * double(g.N) * double(g.K) * double(d->batch);
+  // algorithmic (dense-equivalent) flops; compulsory traffic: read A and B once, write C once (+ read C when beta != 0)
+  const bool prof_this = prof_begin(
+      ctx, variant, mnk * ((ca && cb) ? 8.0 : (ca || cb) ? 4.0 : 2.0),
+      double(d->batch) * (double(g.M) * g.K * (ca ? 16 : 8) + double(g.K) * g.N * (cb ? 16 : 8) +
+                          double(g.M) * g.N * ((ca || cb) ? 16 : 8) * (g.use_beta ? 2 : 1)),
+      &rec);
+  g.kt_counter = prof_this && ctx->prof_ktiles ? ctx->prof_ktiles + variant : nullptr;
   if (skip_zero && is_single(g.kA) && is_single(g.kB) && nkt_all >= 2 && d->batch <= 16384) {
     // tile occupancy of both operands (one small scan launch), then only K tiles with data on both sides are visited
     g.nkw = (nkt_all + 7) / 8;
@@ -824,10 +817,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     else
       hipLaunchKernelGGL((k_splitk_reduce<false>), rgrid, dim3(256), 0, ctx->stream, g, (int)d->batch);
   }
-  if (prof_this) {
-    MPSE_HIP(ctx, hipEventRecord(rec.e1, ctx->stream));
-    ctx->prof_pending.push_back(rec);
-  }
+  if (prof_this) prof_end(ctx, rec);
   MPSE_HIP(ctx, hipGetLastError());
   return MPSE_OK;
 }

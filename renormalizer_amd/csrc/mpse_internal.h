@@ -41,10 +41,14 @@ struct mpse_ctx {
   long long prof_counter = 0;
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_free_events;
-  double prof_ms[4] = {0, 0, 0, 0};
-  double prof_flops[4] = {0, 0, 0, 0};
-  double prof_bytes[4] = {0, 0, 0, 0};
-  int64_t prof_launches[4] = {0, 0, 0, 0};
+  static constexpr int PROF_NVAR = 6;     // 0-3: contraction kernel by operand types, 4: Lanczos vector kernels, 5: block QR
+  double prof_ms[PROF_NVAR] = {0};
+  double prof_flops[PROF_NVAR] = {0};
+  double prof_bytes[PROF_NVAR] = {0};
+  int64_t prof_launches[PROF_NVAR] = {0};
+  // K tiles (64 x 64 x 16 multiply-add blocks) actually multiplied by the timed contraction launches, per variant:
+  // structural-zero skipping makes this smaller than the dense count (device counters, one atomic per workgroup)
+  unsigned long long* prof_ktiles = nullptr;
 
   // pinned ring for small host->device uploads that must not stall the stream (index lists, descriptors)
   char* stage = nullptr;
@@ -87,6 +91,10 @@ inline int mpse_bind(mpse_ctx* ctx) {
 int stage_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes);
 // fold finished profiling records into the totals; call only when the stream is idle
 void prof_drain(mpse_ctx* ctx);
+// HIP-event bracket around a group of launches on the context stream; begin returns false when this call is not
+// sampled (profiling off or not the N-th call) or no event could be had
+bool prof_begin(mpse_ctx* ctx, int variant, double flops, double bytes, mpse_ctx::ProfRec* rec);
+void prof_end(mpse_ctx* ctx, const mpse_ctx::ProfRec& rec);
 
 #define MPSE_HIP(ctx, call)                                                              \
   do {                                                                                   \

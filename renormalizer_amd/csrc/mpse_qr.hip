@@ -295,6 +295,16 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   MPSE_TRY(mpse_memset_zero(ctx, Vt, size_t(K * ncol) * es));
   const int64_t nri = row_off[nblocks], nci = col_off[nblocks];
   TmpBuf IDX(ctx), WS(ctx), Q(ctx), PRM(ctx);
+  // optional HIP-event sampling of the whole decomposition (mpse_prof_*, variant 5): Householder factorisation +
+  // explicit economic Q, F = (c/2) (4 m n^2 - 4 n^3 / 3) per block with c = 8 complex / 2 real
+  double qr_flops = 0.0, qr_bytes = 0.0;
+  for (const QrBlk& B : blks) {
+    const double m = B.mm, n = B.k;
+    qr_flops += (CPLX ? 4.0 : 1.0) * (4.0 * m * n * n - 4.0 * n * n * n / 3.0);
+    qr_bytes += double(es) * (2.0 * B.mm * B.nn + double(B.mm) * B.k);
+  }
+  mpse_ctx::ProfRec qrec;
+  const bool qpt = prof_begin(ctx, 5, qr_flops, qr_bytes, &qrec);
   MPSE_TRY(IDX.alloc(size_t(nri + nci) * sizeof(int64_t)));
   MPSE_TRY(WS.alloc(size_t(ws_tot) * es));
   MPSE_TRY(Q.alloc(size_t(q_tot) * es));
@@ -334,6 +344,7 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
                        (double*)U, (double*)Vt, (const double*)(ws + B.ws_off * E), (long long)K, (long long)ncol, rows,
                        cols, B.mm, B.nn, B.k, (long long)B.prm_off, herm);
   }
+  if (qpt) prof_end(ctx, qrec);
   MPSE_HIP(ctx, hipGetLastError());
   return MPSE_OK;
 }

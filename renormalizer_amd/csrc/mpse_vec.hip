@@ -521,7 +521,18 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
   double* part_a = ctx->dscratch;                          // <w, v_j> partials
   double* part_b = ctx->dscratch + 4 * RED_MAX_BLOCKS;     // |.|^2 partials
 
+  // optional HIP-event sampling of the HBM-bound vector kernels (mpse_prof_*, variant 4): algorithmic bytes
+  const double vbytes = double(n) * double(es);
   auto dot_partials = [&](const void* x, const void* y, double* dst_partial) {
+    mpse_ctx::ProfRec rec;
+    const bool pt = prof_begin(ctx, 4, 0.0, 2.0 * vbytes, &rec);
+    struct End {
+      mpse_ctx* c;
+      const mpse_ctx::ProfRec* r;
+      ~End() {
+        if (r) prof_end(c, *r);
+      }
+    } end{ctx, pt ? &rec : nullptr};
     if (cplx)
       hipLaunchKernelGGL((k_dot_partial<true>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
                          (const double*)y, (long long)n, dst_partial);
@@ -625,6 +636,8 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
       if (nvec) *nvec = m;
       return MPSE_OK;
     }
+    mpse_ctx::ProfRec urec;
+    const bool upt = prof_begin(ctx, 4, 0.0, (j > 0 ? 4.0 : 3.0) * vbytes, &urec);
     if (vec16)
       hipLaunchKernelGGL(k_lanczos_update<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
                          (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
@@ -635,6 +648,7 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
                          (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
                          (long long)nd, (const double*)part_a, nb, scal + 4 + 4 * j,
                          (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b);
+    if (upt) prof_end(ctx, urec);
     // beta_j^2: needed by the host at a check and by the next update; k_scale_into_dev stores it when it runs
     // (every path that continues), the returning paths below read it through k_reduce_final
     const bool check = (j > 3 && j % 2 == 0);                      // krylov.py:76-81
@@ -703,12 +717,15 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
       std::swap(V.p, V2.p);
       cap = ncap;
     }
+    mpse_ctx::ProfRec srec;
+    const bool spt = prof_begin(ctx, 4, 0.0, 2.0 * vbytes, &srec);
     if (vec16)
       hipLaunchKernelGGL(k_scale_into_dev<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
                          W.as<const double>(), (long long)nd, (const double*)part_b, nb, scal + 6 + 4 * j);
     else
       hipLaunchKernelGGL(k_scale_into_dev<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
                          W.as<const double>(), (long long)nd, (const double*)part_b, nb, scal + 6 + 4 * j);
+    if (spt) prof_end(ctx, srec);
   }
 }
 

@@ -87,6 +87,7 @@ _SIGNATURES = {
     "mpse_prof_enable": [C.c_void_p, C.c_int],
     "mpse_prof_reset": [C.c_void_p],
     "mpse_prof_get": [C.c_void_p, C.c_int, _dblp, _dblp, _dblp, C.POINTER(C.c_int64)],
+    "mpse_prof_get_ktiles": [C.c_void_p, C.c_int, C.POINTER(C.c_int64)],
     "mpse_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
     "mpse_free": [C.c_void_p, C.c_void_p],
     "mpse_pool_trim": [C.c_void_p],
@@ -354,12 +355,18 @@ class Engine:
 
     def prof_get(self):
         """{variant: dict(ms, flops, bytes, launches)} for the contraction kernel variants."""
-        names = {0: "f64xf64", 1: "c128xf64", 2: "f64xc128", 3: "c128xc128"}
+        names = {0: "f64xf64", 1: "c128xf64", 2: "f64xc128", 3: "c128xc128", 4: "lanczos_vec", 5: "block_qr"}
+        issued_per_mac = {0: 2.0, 1: 4.0, 2: 4.0, 3: 6.0}     # real flops the MFMA units execute per multiply-add
         out = {}
         for v, nm in names.items():
             ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
             self._check(self.lib.mpse_prof_get(self.ctx, v, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)))
             out[nm] = dict(ms=ms.value, flops=fl.value, bytes=by.value, launches=n.value)
+            if v < 4:
+                kt = C.c_int64()
+                self._check(self.lib.mpse_prof_get_ktiles(self.ctx, v, C.byref(kt)))
+                out[nm]["ktiles"] = kt.value
+                out[nm]["issued_flops"] = kt.value * 65536.0 * issued_per_mac[v]
         return out
 
     # -- tensor factories

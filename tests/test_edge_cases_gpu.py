@@ -1,6 +1,7 @@
 """Edge cases of the hot path on the GPU: Krylov breakdown / zero vectors / tiny spaces, invalid quantum numbers,
 degenerate shapes (bond dimension 1, empty blocks, two-site chains), error reporting of the C ABI."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -276,3 +277,21 @@ def test_mps_add_with_different_coeff():
     a.coeff = 0.5j
     b.coeff = 2.0
     assert np.abs((a + b).todense() - (a.todense() + b.todense())).max() < 1e-13
+
+
+def test_rccl_collective_through_ctypes(tmp_path, monkeypatch):
+    """parallel.RcclCollective (librccl.so bound with ctypes, communicator on the engine's device and stream): a
+    one-rank communicator on this box's GPU - unique-id rendezvous file, all-reduce(max), all-gather, teardown.  The
+    N-rank flow is the same code; its bookkeeping is covered by tests/test_sharding_gloo.py."""
+    from renormalizer_amd import parallel
+    monkeypatch.setenv("MPSE_RENDEZVOUS_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "29655")
+    coll = parallel.RcclCollective(E.get_engine(), 0, 1)
+    assert coll.kind == "rccl" and coll.world == 1
+    assert os.path.exists(parallel._rendezvous_path())
+    assert coll.allreduce_max(2.75) == 2.75
+    coll.barrier()
+    rows = parallel.gather_observables(coll, np.array([[0.25, 0.5, 0.125]]), [0], 1)
+    assert rows.tolist() == [[0.25, 0.5, 0.125]]
+    coll.close()
+    assert not os.path.exists(parallel._rendezvous_path())

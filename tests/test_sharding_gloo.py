@@ -1,6 +1,7 @@
 """Trajectory sharding across ranks: one independent trajectory per rank, no data-path
 collective, one all_gather of the observables at the end.  Exercised here with world_size 2 on the gloo
-backend (CPU) through the same helper bench.py uses on RCCL."""
+backend (CPU): ``GlooCollective`` is the stand-in of the ctypes ``RcclCollective`` that bench.py and
+examples/fmo.py use on the GPUs (same three operations: barrier, max, all-gather)."""
 import os
 import socket
 import subprocess
@@ -24,23 +25,23 @@ def test_two_rank_gather(tmp_path):
         import os, sys
         sys.path.insert(0, {REPO!r})
         import numpy as np
-        import torch
-        import torch.distributed as dist
-        from renormalizer_amd.parallel import trajectory_seed, gather_observables, max_over_ranks
-        dist.init_process_group(backend="gloo")
-        rank, world = dist.get_rank(), dist.get_world_size()
+        from renormalizer_amd.parallel import (trajectory_seed, gather_observables, max_over_ranks, make_collective,
+                                               units_of_rank)
+        coll = make_collective(backend="gloo")          # CPU stand-in of the RCCL collective (same interface)
+        rank, world = coll.rank, coll.world
         # unit u -> rank u mod world; every rank works on its own trajectories only
-        units = [u for u in range(5) if u % world == rank]
+        units = units_of_rank(5, rank, world)
         obs = np.array([[trajectory_seed(1234, u), u * 0.5] for u in units], dtype=np.float64)
-        allobs = gather_observables(obs, units, 5, device="cpu")
-        t = max_over_ranks(float(rank + 1), device="cpu")
+        allobs = gather_observables(coll, obs, units, 5)
+        coll.barrier()
+        t = max_over_ranks(coll, float(rank + 1))
         if rank == 0:
             assert allobs.shape == (5, 2), allobs.shape
             assert np.array_equal(allobs[:, 1], np.arange(5) * 0.5)
             assert len(set(allobs[:, 0].tolist())) == 5           # distinct seeds per trajectory
             assert t == float(world)
             print("OK")
-        dist.destroy_process_group()
+        coll.close()
     """))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
@@ -48,3 +49,18 @@ def test_two_rank_gather(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "OK" in out.stdout
+
+
+def test_rendezvous_file_and_serial_collective(tmp_path, monkeypatch):
+    """The unique-id rendezvous is keyed by the launcher's pid and port; one process needs no communicator."""
+    import numpy as np
+    from renormalizer_amd import parallel
+    monkeypatch.setenv("MPSE_RENDEZVOUS_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "29517")
+    p = parallel._rendezvous_path()
+    assert p.startswith(str(tmp_path)) and str(os.getppid()) in p and p.endswith("_29517.id")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    coll = parallel.make_collective()
+    assert coll.kind == "serial" and coll.allreduce_max(3.5) == 3.5
+    tab = parallel.gather_observables(coll, np.array([[1.0, 2.0], [3.0, 4.0]]), [0, 1], 2)
+    assert tab.tolist() == [[1.0, 2.0], [3.0, 4.0]]
