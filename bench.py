@@ -229,8 +229,8 @@ def main():
     prof = {}
     for r in results:
         for k, v in r["prof"].items():
-            acc = prof.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-            for f in acc:
+            acc = prof.setdefault(k, {f: 0 * x for f, x in v.items()})
+            for f in v:
                 acc[f] += v[f]
     use_engine(None)
 

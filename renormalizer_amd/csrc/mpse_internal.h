@@ -162,6 +162,7 @@ struct QrBlk {
   long long q_off;   // element offset of its mm x k Q inside the Q buffer
   int mm, nn, k;
   int prm_off;       // offset of its reflector parameters
+  int nq = 0;        // columns of Q to form (0 -> k); columns beyond k complete the basis (full_matrices SVD)
 };
 constexpr int HH_BATCH_MAX_ROWS = 4096;
 int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm, const QrBlk* blks_host, int nblk,

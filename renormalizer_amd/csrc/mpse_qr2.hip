@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_hh_formq_b(double* q_base, const double
   __shared__ double s_head[2];
   const QrBlk B = blks[blockIdx.y];
   const int c = blockIdx.x;
-  if (c >= B.k) return;
+  if (c >= (B.nq > B.k ? B.nq : B.k)) return;
   const int mm = B.mm;
   const double* a = ws_base + B.ws_off * E;
   const HhParam* prm = prm_base + B.prm_off;
@@ -327,7 +327,8 @@ __global__ __launch_bounds__(256) void k_hh_formq_b(double* q_base, const double
   double2 x[RPT];
 #pragma unroll
   for (int q = 0; q < RPT; ++q) x[q] = make_double2((tid + 256 * q) == c ? 1.0 : 0.0, 0.0);
-  for (int j = c; j >= 0; --j) {
+  // columns c >= k (orthogonal complement) receive all reflectors
+  for (int j = (c < B.k ? c : B.k - 1); j >= 0; --j) {
     const HhParam p = prm[j];
     const double2 tau = make_double2(p.tau_re, p.tau_im), scale = make_double2(p.scale_re, p.scale_im);
     if (tau.x == 0.0 && tau.y == 0.0) continue;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void k_hh_formq_b(double* q_base, const double
 
 template <bool CPLX>
 int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk* dblk, int nblk, int max_mm,
-                int max_nn, int max_k, bool form_q) {
+                int max_nn, int max_k, int max_q, bool form_q) {
   // Register-resident configurations by block height: 256 threads x 4 rows, 512 x 4, 512 x 8 (4 panel columns
   // each).  Per column the kernel pays one reduction round (eight values through the halving butterfly), the
   // scalar reflector set-up in wave 0 and the branch-free update; the waves of one SIMD serialise on the VALU, so
@@ -406,8 +407,8 @@ int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk*
       }
     }
   }
-  if (form_q && max_k > 0) {
-    dim3 grid(max_k, nblk);
+  if (form_q && max_q > 0) {
+    dim3 grid(max_q, nblk);
     switch (cfg) {
       case 0:
         hipLaunchKernelGGL((k_hh_formq_b<CPLX, 4>), grid, dim3(256), 0, ctx->stream, q, ws, dblk, prm);
@@ -430,16 +431,18 @@ int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk*
 int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm, const QrBlk* blks_host, int nblk,
                   bool form_q) {
   if (nblk <= 0) return MPSE_OK;
-  int max_mm = 0, max_nn = 0, max_k = 0;
+  int max_mm = 0, max_nn = 0, max_k = 0, max_q = 0;
   for (int b = 0; b < nblk; ++b) {
     max_mm = blks_host[b].mm > max_mm ? blks_host[b].mm : max_mm;
     max_nn = blks_host[b].nn > max_nn ? blks_host[b].nn : max_nn;
     max_k = blks_host[b].k > max_k ? blks_host[b].k : max_k;
+    const int nq = blks_host[b].nq > blks_host[b].k ? blks_host[b].nq : blks_host[b].k;
+    max_q = nq > max_q ? nq : max_q;
   }
   if (max_mm > HH_BATCH_MAX_ROWS) return mpse_fail(ctx, MPSE_ERR_SHAPE, "hh_qr_batched: block too tall");
   TmpBuf DB(ctx);
   MPSE_TRY(DB.alloc(size_t(nblk) * sizeof(QrBlk)));
   MPSE_TRY(stage_h2d(ctx, DB.p, blks_host, size_t(nblk) * sizeof(QrBlk)));
-  if (cplx) return run_batched<true>(ctx, ws, q, prm, DB.as<QrBlk>(), nblk, max_mm, max_nn, max_k, form_q);
-  return run_batched<false>(ctx, ws, q, prm, DB.as<QrBlk>(), nblk, max_mm, max_nn, max_k, form_q);
+  if (cplx) return run_batched<true>(ctx, ws, q, prm, DB.as<QrBlk>(), nblk, max_mm, max_nn, max_k, max_q, form_q);
+  return run_batched<false>(ctx, ws, q, prm, DB.as<QrBlk>(), nblk, max_mm, max_nn, max_k, max_q, form_q);
 }

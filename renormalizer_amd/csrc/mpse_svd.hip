@@ -243,15 +243,21 @@ __global__ void k_scatter_null(double* U, double* Vt, const double* __restrict__
 }
 
 template <bool CPLX>
+int block_svd_batched(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, int nblocks, const int64_t* row_idx,
+                      const int64_t* row_off, const int64_t* col_idx, const int64_t* col_off, void* U, void* Vt,
+                      double* S_host, int64_t K, const int64_t* extra_host, int64_t KU, int64_t KV);
+
+template <bool CPLX>
 int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, int nblocks, const int64_t* row_idx,
                    const int64_t* row_off, const int64_t* col_idx, const int64_t* col_off, void* U, void* Vt,
                    double* S_host, int64_t K, const int64_t* extra_host, int64_t KU, int64_t KV) {
   constexpr size_t es = CPLX ? 16 : 8;
-  int64_t ktot = 0, maxws = 0, maxk = 0, maxq = 0, nu = 0, nv = 0;
+  int64_t ktot = 0, maxws = 0, maxk = 0, maxq = 0, nu = 0, nv = 0, maxrows = 0;
   for (int b = 0; b < nblocks; ++b) {
     const int64_t m = row_off[b + 1] - row_off[b], n = col_off[b + 1] - col_off[b];
     if (m < 0 || n < 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_svd: negative block extent");
     const int64_t k = std::min(m, n);
+    if (k > 0) maxrows = std::max(maxrows, std::max(m, n));
     ktot += k;
     maxws = std::max(maxws, m * n);
     maxk = std::max(maxk, k);
@@ -266,6 +272,9 @@ int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, 
                      (long long)KU, (long long)KV, (long long)(ktot + nu), (long long)(ktot + nv));
   if (ktot != K) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_svd: K=%lld but blocks give %lld", (long long)K, (long long)ktot);
   if (ktot == 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
+  if (maxrows <= HH_BATCH_MAX_ROWS)   // every block fits the register-resident Householder kernels: batched path
+    return block_svd_batched<CPLX>(ctx, coef, nrow, ncol, nblocks, row_idx, row_off, col_idx, col_off, U, Vt, S_host, K,
+                                   extra_host, KU, KV);
   MPSE_TRY(mpse_memset_zero(ctx, U, size_t(nrow * KU) * es));
   MPSE_TRY(mpse_memset_zero(ctx, Vt, size_t(KV * ncol) * es));
   const int64_t nri = row_off[nblocks], nci = col_off[nblocks];
@@ -354,6 +363,400 @@ int block_svd_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, 
     // PERM / SIG are rewritten for the next block only after this block's scatter: same stream, in order
     koff += k;
   }
+  return MPSE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Batched variant: all quantum-number blocks of a decomposition share every launch (blockIdx.y = block), the
+// convergence of a sweep is read once for all blocks, column norms once for all blocks.  Same algorithm and
+// thresholds as above.
+struct SvdBlk {
+  long long ws_off, v_off, q_off;   // element offsets: column-major block (mm x nn), V (nn x nn), completed Q (mm x nq)
+  long long row_off, col_off;       // into the concatenated row / column index lists
+  long long koff, null_off;         // where its singular triplets / null vectors go in U / Vt
+  int mm, nn, N, herm, extra, sig_off;
+  double tol;
+};
+
+template <bool CPLX>
+__global__ void k_gather_blocks(double* ws, const double* __restrict__ coef, long long ncol,
+                                const long long* __restrict__ rows_all, const long long* __restrict__ cols_all,
+                                const SvdBlk* __restrict__ blks) {
+  const SvdBlk B = blks[blockIdx.y];
+  const long long* rows = rows_all + B.row_off;
+  const long long* cols = cols_all + B.col_off;
+  double* w = ws + B.ws_off * Cx<CPLX>::E;
+  const int mm = B.mm, nn = B.nn;
+  const long long total = (long long)mm * nn;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    if (!B.herm) {
+      const int c = (int)(t % nn), r = (int)(t / nn);
+      Cx<CPLX>::st(w, r + (long long)c * mm, Cx<CPLX>::ld(coef, rows[r] * ncol + cols[c]));
+    } else {
+      const int r = (int)(t % mm), c = (int)(t / mm);
+      double2 v = Cx<CPLX>::ld(coef, rows[c] * ncol + cols[r]);
+      v.y = -v.y;
+      Cx<CPLX>::st(w, r + (long long)c * mm, v);
+    }
+  }
+}
+
+template <bool CPLX>
+__global__ void k_identity_blocks(double* vbase, const SvdBlk* __restrict__ blks) {
+  const SvdBlk B = blks[blockIdx.y];
+  double* v = vbase + B.v_off * Cx<CPLX>::E;
+  const long long total = (long long)B.nn * B.nn;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride)
+    Cx<CPLX>::st(v, t, make_double2((t % B.nn) == (t / B.nn) ? 1.0 : 0.0, 0.0));
+}
+
+template <bool CPLX>
+__global__ __launch_bounds__(RED_THREADS) void k_col_norms_b(const double* __restrict__ ws,
+                                                             const SvdBlk* __restrict__ blks, double* sig) {
+  const SvdBlk B = blks[blockIdx.y];
+  if ((int)blockIdx.x >= B.nn) return;
+  const double* col = ws + (B.ws_off + (long long)blockIdx.x * B.mm) * Cx<CPLX>::E;
+  double s = 0, z = 0;
+  for (int r = threadIdx.x; r < B.mm; r += RED_THREADS) {
+    const double2 x = Cx<CPLX>::ld(col, r);
+    s += x.x * x.x + x.y * x.y;
+  }
+  block_allsum2(s, z);
+  if (threadIdx.x == 0) sig[B.sig_off + blockIdx.x] = sqrt(s);
+}
+
+// null2[b] = (largest column norm * eps * mm)^2 ; also resets the sweep state of the block
+__global__ void k_null2(const SvdBlk* __restrict__ blks, const double* __restrict__ sig, double* null2, int* nrot,
+                        int* done) {
+  const SvdBlk B = blks[blockIdx.x];
+  double m = 0.0;
+  for (int j = threadIdx.x; j < B.nn; j += 64) m = fmax(m, sig[B.sig_off + j]);
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if (threadIdx.x == 0) {
+    const double nn = m * 2.220446049250313e-16 * (double)B.mm;
+    null2[blockIdx.x] = nn * nn;
+    nrot[blockIdx.x] = 0;
+    done[blockIdx.x] = B.nn > 1 ? 0 : 1;
+  }
+}
+
+// after a sweep: a block without rotations is converged; counters restart
+__global__ void k_sweep_end(int nblk, int* nrot, int* done) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblk) return;
+  if (nrot[b] == 0) done[b] = 1;
+  nrot[b] = 0;
+}
+
+template <bool CPLX>
+__global__ __launch_bounds__(RED_THREADS) void k_jacobi_step_b(double* ws, double* vbase,
+                                                               const SvdBlk* __restrict__ blks, int step,
+                                                               const double* __restrict__ null2v, int* nrot,
+                                                               const int* __restrict__ done) {
+  constexpr int E = Cx<CPLX>::E;
+  const int b = blockIdx.y;
+  if (done[b]) return;
+  const SvdBlk B = blks[b];
+  const int N = B.N, nn = B.nn, mm = B.mm;
+  const int kk = blockIdx.x;
+  if (step >= N - 1 || kk >= N / 2) return;
+  int p, q;
+  if (kk == 0) {
+    p = step % (N - 1);
+    q = N - 1;
+  } else {
+    p = (step + kk) % (N - 1);
+    q = (step - kk + (N - 1)) % (N - 1);
+  }
+  if (p > q) {
+    const int t = p;
+    p = q;
+    q = t;
+  }
+  if (q >= nn) return;
+  double* a = ws + B.ws_off * E;
+  double* v = vbase + B.v_off * E;
+  double* ap = a + (long long)p * mm * E;
+  double* aq = a + (long long)q * mm * E;
+  double alpha = 0, beta = 0, gr = 0, gi = 0;
+  for (int r = threadIdx.x; r < mm; r += RED_THREADS) {
+    const double2 x = Cx<CPLX>::ld(ap, r), y = Cx<CPLX>::ld(aq, r);
+    alpha += x.x * x.x + x.y * x.y;
+    beta += y.x * y.x + y.y * y.y;
+    gr += x.x * y.x + x.y * y.y;
+    gi += x.x * y.y - x.y * y.x;
+  }
+  block_allsum2(alpha, beta);
+  block_allsum2(gr, gi);
+  const double g = sqrt(gr * gr + gi * gi);
+  const double null2 = null2v[b];
+  if (g == 0.0 || alpha <= null2 || beta <= null2) return;
+  if (!(g > B.tol * sqrt(alpha) * sqrt(beta))) return;
+  const double pr = gr / g, pi = gi / g;
+  const double zeta = (beta - alpha) / (2.0 * g);
+  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+  for (int r = threadIdx.x; r < mm; r += RED_THREADS) {
+    const double2 x = Cx<CPLX>::ld(ap, r), y0 = Cx<CPLX>::ld(aq, r);
+    const double2 y = make_double2(y0.x * pr + y0.y * pi, y0.y * pr - y0.x * pi);
+    Cx<CPLX>::st(ap, r, make_double2(c * x.x - s * y.x, c * x.y - s * y.y));
+    Cx<CPLX>::st(aq, r, make_double2(s * x.x + c * y.x, s * x.y + c * y.y));
+  }
+  double* vp = v + (long long)p * nn * E;
+  double* vq = v + (long long)q * nn * E;
+  for (int r = threadIdx.x; r < nn; r += RED_THREADS) {
+    const double2 x = Cx<CPLX>::ld(vp, r), y0 = Cx<CPLX>::ld(vq, r);
+    const double2 y = make_double2(y0.x * pr + y0.y * pi, y0.y * pr - y0.x * pi);
+    Cx<CPLX>::st(vp, r, make_double2(c * x.x - s * y.x, c * x.y - s * y.y));
+    Cx<CPLX>::st(vq, r, make_double2(s * x.x + c * y.x, s * x.y + c * y.y));
+  }
+  if (threadIdx.x == 0) atomicAdd(nrot + b, 1);
+}
+
+template <bool CPLX>
+__global__ void k_normalise_perm_b(double* un_base, const double* __restrict__ ws, const SvdBlk* __restrict__ blks,
+                                   const double* __restrict__ sig, const long long* __restrict__ perm,
+                                   const double* __restrict__ thresh) {
+  const SvdBlk B = blks[blockIdx.y];
+  const int mm = B.mm, nn = B.nn;
+  double* dst = un_base + B.ws_off * Cx<CPLX>::E;
+  const double* src = ws + B.ws_off * Cx<CPLX>::E;
+  const double th = thresh[blockIdx.y];
+  const long long total = (long long)mm * nn;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int j = (int)(t / mm), r = (int)(t % mm);
+    const int pj = (int)perm[B.sig_off + j];
+    const double sg = sig[B.sig_off + pj];
+    double2 x = Cx<CPLX>::ld(src, r + (long long)pj * mm);
+    if (sg > th) {
+      x.x /= sg;
+      x.y /= sg;
+    } else {
+      x = make_double2(0.0, 0.0);
+    }
+    Cx<CPLX>::st(dst, t, x);
+  }
+}
+
+template <bool CPLX>
+__global__ void k_scatter_svd_b(double* U, double* Vt, const double* __restrict__ un_base,
+                                const double* __restrict__ q_base, const double* __restrict__ v_base,
+                                const long long* __restrict__ perm_all, long long K, long long ncol,
+                                const long long* __restrict__ rows_all, const long long* __restrict__ cols_all,
+                                const SvdBlk* __restrict__ blks) {
+  constexpr int E = Cx<CPLX>::E;
+  const SvdBlk B = blks[blockIdx.y];
+  const int mm = B.mm, nn = B.nn, herm = B.herm;
+  const double* un = un_base + B.ws_off * E;
+  const double* q = q_base + B.q_off * E;
+  const double* vm = v_base + B.v_off * E;
+  const long long* perm = perm_all + B.sig_off;
+  const long long* rows = rows_all + B.row_off;
+  const long long* cols = cols_all + B.col_off;
+  const long long koff = B.koff;
+  const long long totq = (long long)mm * nn, totv = (long long)nn * nn;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < totq + totv; t += stride) {
+    if (t < totq) {
+      int j, r;
+      if (!herm) {
+        j = (int)(t % nn);
+        r = (int)(t / nn);
+      } else {
+        r = (int)(t % mm);
+        j = (int)(t / mm);
+      }
+      double2 d = Cx<CPLX>::ld(un, j + (long long)j * mm);
+      if (d.x == 0.0 && d.y == 0.0) d = make_double2(1.0, 0.0);
+      const double2 x = Cx<CPLX>::ld(q, r + (long long)j * mm);
+      double2 y = make_double2(x.x * d.x - x.y * d.y, x.x * d.y + x.y * d.x);
+      if (!herm) {
+        Cx<CPLX>::st(U, rows[r] * K + koff + j, y);
+      } else {
+        y.y = -y.y;
+        Cx<CPLX>::st(Vt, (koff + j) * ncol + cols[r], y);
+      }
+    } else {
+      const long long t2 = t - totq;
+      int j, c;
+      if (!herm) {
+        c = (int)(t2 % nn);
+        j = (int)(t2 / nn);
+      } else {
+        j = (int)(t2 % nn);
+        c = (int)(t2 / nn);
+      }
+      const int pj = (int)perm[j];
+      double2 x = Cx<CPLX>::ld(vm, c + (long long)pj * nn);
+      if (!herm) {
+        x.y = -x.y;
+        Cx<CPLX>::st(Vt, (koff + j) * ncol + cols[c], x);
+      } else {
+        Cx<CPLX>::st(U, rows[c] * K + koff + j, x);
+      }
+    }
+  }
+}
+
+template <bool CPLX>
+__global__ void k_scatter_null_b(double* U, double* Vt, const double* __restrict__ q_base, long long ldU,
+                                 long long ncol, const long long* __restrict__ rows_all,
+                                 const long long* __restrict__ cols_all, const SvdBlk* __restrict__ blks) {
+  const SvdBlk B = blks[blockIdx.y];
+  if (B.extra <= 0) return;
+  const int mm = B.mm, nn = B.nn, extra = B.extra;
+  const double* q = q_base + B.q_off * Cx<CPLX>::E;
+  const long long* rows = rows_all + B.row_off;
+  const long long* cols = cols_all + B.col_off;
+  const long long total = (long long)mm * extra;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    if (!B.herm) {
+      const int e = (int)(t % extra), r = (int)(t / extra);
+      Cx<CPLX>::st(U, rows[r] * ldU + B.null_off + e, Cx<CPLX>::ld(q, r + (long long)(nn + e) * mm));
+    } else {
+      const int r = (int)(t % mm), e = (int)(t / mm);
+      double2 x = Cx<CPLX>::ld(q, r + (long long)(nn + e) * mm);
+      x.y = -x.y;
+      Cx<CPLX>::st(Vt, (B.null_off + e) * ncol + cols[r], x);
+    }
+  }
+}
+
+template <bool CPLX>
+int block_svd_batched(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, int nblocks, const int64_t* row_idx,
+                      const int64_t* row_off, const int64_t* col_idx, const int64_t* col_off, void* U, void* Vt,
+                      double* S_host, int64_t K, const int64_t* extra_host, int64_t KU, int64_t KV) {
+  constexpr size_t es = CPLX ? 16 : 8;
+  constexpr int E = CPLX ? 2 : 1;
+  std::vector<SvdBlk> blks;
+  long long ws_tot = 0, v_tot = 0, q_tot = 0, sig_tot = 0, koff = 0, uoff = K, voff = K;
+  int maxN = 0, maxnn = 0;
+  long long max_elems = 1;
+  for (int b = 0; b < nblocks; ++b) {
+    const int m = (int)(row_off[b + 1] - row_off[b]), n = (int)(col_off[b + 1] - col_off[b]);
+    const int k = std::min(m, n);
+    if (k == 0) continue;
+    SvdBlk B;
+    B.herm = m < n ? 1 : 0;
+    B.mm = B.herm ? n : m;
+    B.nn = B.herm ? m : n;
+    B.N = (B.nn + 1) & ~1;
+    B.extra = extra_host ? (int)extra_host[b] : 0;
+    B.ws_off = ws_tot, B.v_off = v_tot, B.q_off = q_tot, B.sig_off = (int)sig_tot;
+    B.row_off = row_off[b], B.col_off = col_off[b];
+    B.koff = koff;
+    B.null_off = B.herm ? voff : uoff;
+    (B.herm ? voff : uoff) += B.extra;
+    B.tol = 2.220446049250313e-16 * std::sqrt((double)B.mm);
+    ws_tot += (long long)B.mm * B.nn;
+    v_tot += (long long)B.nn * B.nn;
+    q_tot += (long long)B.mm * (B.nn + B.extra);
+    sig_tot += B.nn;
+    koff += k;
+    maxN = std::max(maxN, B.N);
+    maxnn = std::max(maxnn, B.nn);
+    max_elems = std::max(max_elems, (long long)B.mm * (B.nn + B.extra) + (long long)B.nn * B.nn);
+    blks.push_back(B);
+  }
+  const int nblk = (int)blks.size();
+  MPSE_TRY(mpse_memset_zero(ctx, U, size_t(nrow * KU) * es));
+  MPSE_TRY(mpse_memset_zero(ctx, Vt, size_t(KV * ncol) * es));
+  const int64_t nri = row_off[nblocks], nci = col_off[nblocks];
+  TmpBuf IDX(ctx), DB(ctx), WS(ctx), UN(ctx), Q(ctx), VM(ctx), PRM(ctx), SIG(ctx), PERM(ctx), ST(ctx);
+  MPSE_TRY(IDX.alloc(size_t(nri + nci) * 8));
+  MPSE_TRY(DB.alloc(size_t(nblk) * sizeof(SvdBlk)));
+  MPSE_TRY(WS.alloc(size_t(ws_tot) * es));
+  MPSE_TRY(UN.alloc(size_t(ws_tot) * es));
+  MPSE_TRY(Q.alloc(size_t(q_tot) * es));
+  MPSE_TRY(VM.alloc(size_t(v_tot) * es));
+  MPSE_TRY(PRM.alloc(size_t(sig_tot + 1) * sizeof(HhParam)));
+  MPSE_TRY(SIG.alloc(size_t(sig_tot) * 8));
+  MPSE_TRY(PERM.alloc(size_t(sig_tot) * 8));
+  // per block: null2 (double), thresh (double), nrot (int), done (int)
+  const int nblk_pad = (nblk + 1) & ~1;     // `done` is read back as doubles: keep it 8-byte aligned
+  MPSE_TRY(ST.alloc(size_t(nblk_pad) * (8 + 8 + 4 + 4) + 64));
+  double* null2 = ST.as<double>();
+  double* thresh = null2 + nblk_pad;
+  int* nrot = reinterpret_cast<int*>(thresh + nblk_pad);
+  int* done = nrot + nblk_pad;
+  MPSE_TRY(stage_h2d(ctx, IDX.p, row_idx, size_t(nri) * 8));
+  MPSE_TRY(stage_h2d(ctx, IDX.as<char>() + size_t(nri) * 8, col_idx, size_t(nci) * 8));
+  MPSE_TRY(stage_h2d(ctx, DB.p, blks.data(), size_t(nblk) * sizeof(SvdBlk)));
+  const long long* drows = IDX.as<long long>();
+  const long long* dcols = IDX.as<long long>() + nri;
+  const SvdBlk* dblk = DB.as<SvdBlk>();
+  double* ws = WS.as<double>();
+  double* vm = VM.as<double>();
+  double* sigd = SIG.as<double>();
+  int gx = ew_blocks(max_elems);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL((k_gather_blocks<CPLX>), dim3(gx, nblk), dim3(256), 0, ctx->stream, ws, (const double*)coef,
+                     (long long)ncol, drows, dcols, dblk);
+  hipLaunchKernelGGL((k_identity_blocks<CPLX>), dim3(gx, nblk), dim3(256), 0, ctx->stream, vm, dblk);
+  hipLaunchKernelGGL((k_col_norms_b<CPLX>), dim3(maxnn, nblk), dim3(RED_THREADS), 0, ctx->stream, (const double*)ws,
+                     dblk, sigd);
+  hipLaunchKernelGGL(k_null2, dim3(nblk), dim3(64), 0, ctx->stream, dblk, (const double*)sigd, null2, nrot, done);
+  MPSE_HIP(ctx, hipGetLastError());
+  if (maxN > 1) {
+    std::vector<int> hdone(nblk, 0);
+    bool all = false;
+    for (int sweep = 0; sweep < 60 && !all; ++sweep) {
+      for (int step = 0; step < maxN - 1; ++step)
+        hipLaunchKernelGGL((k_jacobi_step_b<CPLX>), dim3(maxN / 2, nblk), dim3(RED_THREADS), 0, ctx->stream, ws, vm,
+                           dblk, step, (const double*)null2, nrot, (const int*)done);
+      hipLaunchKernelGGL(k_sweep_end, dim3((nblk + 255) / 256), dim3(256), 0, ctx->stream, nblk, nrot, done);
+      MPSE_HIP(ctx, hipGetLastError());
+      // one read-back per sweep for all blocks
+      if (nblk <= 2000) {
+        MPSE_TRY(publish_and_wait(ctx, reinterpret_cast<const double*>(done), (nblk + 1) / 2, 8));
+        memcpy(hdone.data(), ctx->pinned + 8, size_t(nblk) * sizeof(int));
+      } else {
+        MPSE_TRY(mpse_memcpy_d2h(ctx, hdone.data(), done, size_t(nblk) * sizeof(int)));
+      }
+      all = true;
+      for (int b = 0; b < nblk; ++b) all = all && hdone[b];
+    }
+    if (!all) return mpse_fail(ctx, MPSE_ERR_NOCONV, "block_svd: Jacobi did not converge within 60 sweeps");
+  }
+  hipLaunchKernelGGL((k_col_norms_b<CPLX>), dim3(maxnn, nblk), dim3(RED_THREADS), 0, ctx->stream, (const double*)ws,
+                     dblk, sigd);
+  std::vector<double> sig((size_t)sig_tot), th((size_t)nblk);
+  MPSE_TRY(mpse_memcpy_d2h(ctx, sig.data(), sigd, size_t(sig_tot) * 8));
+  std::vector<long long> perm((size_t)sig_tot);
+  for (int b = 0; b < nblk; ++b) {
+    const SvdBlk& B = blks[b];
+    long long* p = perm.data() + B.sig_off;
+    const double* sg = sig.data() + B.sig_off;
+    std::iota(p, p + B.nn, 0LL);
+    std::stable_sort(p, p + B.nn, [&](long long x, long long y) { return sg[x] > sg[y]; });
+    for (int j = 0; j < B.nn; ++j) S_host[B.koff + j] = sg[p[j]];
+    th[b] = sg[p[0]] * 2.220446049250313e-16 * (double)B.mm;
+  }
+  MPSE_TRY(stage_h2d(ctx, PERM.p, perm.data(), size_t(sig_tot) * 8));
+  MPSE_TRY(stage_h2d(ctx, thresh, th.data(), size_t(nblk) * 8));
+  double* un = UN.as<double>();
+  hipLaunchKernelGGL((k_normalise_perm_b<CPLX>), dim3(gx, nblk), dim3(256), 0, ctx->stream, un, (const double*)ws, dblk,
+                     (const double*)sigd, PERM.as<const long long>(), (const double*)thresh);
+  MPSE_HIP(ctx, hipGetLastError());
+  // Householder completion of every block's normalised left factor in the same launches
+  std::vector<QrBlk> qb((size_t)nblk);
+  for (int b = 0; b < nblk; ++b) {
+    const SvdBlk& B = blks[b];
+    qb[b] = QrBlk{B.ws_off, B.q_off, B.mm, B.nn, B.nn, B.sig_off, B.nn + B.extra};
+  }
+  MPSE_TRY(hh_qr_batched(ctx, CPLX, un, Q.as<double>(), PRM.as<HhParam>(), qb.data(), nblk, true));
+  hipLaunchKernelGGL((k_scatter_svd_b<CPLX>), dim3(gx, nblk), dim3(256), 0, ctx->stream, (double*)U, (double*)Vt,
+                     (const double*)un, (const double*)Q.as<double>(), (const double*)vm, PERM.as<const long long>(),
+                     (long long)KU, (long long)ncol, drows, dcols, dblk);
+  if (uoff > K || voff > K)
+    hipLaunchKernelGGL((k_scatter_null_b<CPLX>), dim3(gx, nblk), dim3(256), 0, ctx->stream, (double*)U, (double*)Vt,
+                       (const double*)Q.as<double>(), (long long)KU, (long long)ncol, drows, dcols, dblk);
+  MPSE_HIP(ctx, hipGetLastError());
+  (void)E;
   return MPSE_OK;
 }
 

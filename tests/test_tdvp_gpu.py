@@ -271,6 +271,47 @@ def test_headline_size_invariants():
     assert mps.qntot.tolist() == [1] and all(len(q) == d for q, d in zip(mps.qn, mps.bond_dims))
 
 
+def test_config4_full_size_invariants():
+    """BASELINE config 4 at its stated size: FMO, 7 sites x 35 modes, thermofield-doubled at 77 K (497 sites), D = 32,
+    TDVP-PS with dt = 160 a.u., two disorder realisations with their own seeds (what each GPU of the 8-trajectory job
+    runs).  Size-independent properties: norm and exciton number conserved, <H> conserved by the unitary step, the
+    physical (not the tilde) modes pick up energy, bonds and quantum numbers consistent, trajectories distinct; the
+    zero-disorder run is compared with its own T -> 0 limit only through those invariants (the reduced-size runs of
+    test_thermofield_tdvp_matches_reference carry the reference pin)."""
+    import importlib.util
+    from renormalizer_amd.mps.mps import Mps
+    from renormalizer_amd.parallel import trajectory_seed
+    spec = importlib.util.spec_from_file_location("fmo_example", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "examples", "fmo.py"))
+    fmo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fmo)
+    finals = []
+    for unit in (0, 1):
+        rng = np.random.default_rng(trajectory_seed(2024, unit))
+        model = fmo.fmo_model(35, disorder_cm=50.0, rng=rng, temperature_k=77.0)
+        assert len(model.basis) == 7 + 2 * 7 * 35
+        psi = Mpo.onsite(model, r"a^\dagger", dof_set={model.mol_num // 2}).apply(Mps.ground_state(model, False))
+        mpo = Mpo(model, offset=Quantity(psi.expectation(Mpo(model))))
+        assert max(mpo.bond_dims) <= 9                                     # all-to-all excitonic couplings of 7 sites
+        psi.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=32)
+        psi.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+        psi = psi.expand_bond_dimension(mpo).canonicalise()
+        assert max(psi.bond_dims) == 32 and len(psi) == 497
+        e0 = psi.expectation(mpo)
+        occ0 = np.asarray(psi.e_occupations)
+        assert abs(occ0[3] - 1) < 1e-9 and abs(e0) < 1e-9
+        for _ in range(2):
+            psi = psi.evolve(mpo, 160.0)
+        occ = np.asarray(psi.e_occupations)
+        assert abs(psi.mp_norm - 1) < 1e-12
+        assert abs(occ.sum() - 1) < 1e-9 and occ.min() > -1e-12
+        assert abs(psi.expectation(mpo) - e0) < 1e-6
+        assert occ[3] < 0.999 and 1 - occ[3] > 1e-4                         # the exciton started to move
+        assert psi.qntot.tolist() == [1] and all(len(q) == d for q, d in zip(psi.qn, psi.bond_dims))
+        assert psi.evolve_config.stat["nobs"] == 2 * (2 * 497 - 1) and psi.evolve_config.stat["max"] < 40
+        finals.append(occ)
+    assert np.abs(finals[0] - finals[1]).max() > 1e-6                        # different disorder, different dynamics
+
+
 def test_expectations_shared_environments():
     """mps/tests/test_mps.py:30-43: the cached ``expectations`` equals operator-by-operator ``expectation``."""
     from renormalizer_amd.mps.mps import Mps
