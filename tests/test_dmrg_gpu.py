@@ -251,8 +251,10 @@ def test_eigensolver_seams_match_reference(golden_dir):
         cvec = c.to_host()[mask]
         assert np.abs(c.to_host()[~mask]).max() == 0.0
         ref = g("c")
-        # eigenvectors of an iteration stopped at |r| < 1e-6 agree to (|r| / gap)^2 in the overlap
-        assert abs(abs(np.vdot(ref, cvec)) / np.linalg.norm(cvec) - 1.0) < (1e-5 if kind == "it" else 1e-10), (k, kind, two)
+        # eigenvectors of an iteration stopped at |r| < 1e-6 agree to (|r| / gap)^2 in the overlap; the spectrum of
+        # (H - omega)^2 is the square of a narrow window around omega, its gaps are correspondingly small
+        otol = 1e-10 if kind == "di" else (1e-3 if two else 1e-5)
+        assert abs(abs(np.vdot(ref, cvec)) / np.linalg.norm(cvec) - 1.0) < otol, (k, kind, two)
         if kind == "di":
             assert np.abs(cvec - ref).max() < 1e-7                        # same sign convention
     assert {("it", False, 2), ("it", False, 1), ("di", False, 2), ("di", False, 1), ("it", True, 2), ("it", True, 1),
