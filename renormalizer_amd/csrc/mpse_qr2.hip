@@ -16,6 +16,8 @@
 // once per panel instead of once per reflector.  Conventions are LAPACK's (?geqr2 / ?ung2r):
 // H_j = I - tau_j v_j v_j^H, v_j = (0.., 1, scale_j * tail_j), tails stored UNSCALED below the
 // diagonal, R on and above it.
+#include <cstdlib>
+
 #include "mpse_device.h"
 #include "mpse_internal.h"
 
@@ -372,6 +374,221 @@ __global__ __launch_bounds__(256) void k_hh_formq_b(double* q_base, const double
   }
 }
 
+// ---- compact-WY forms: the NB (<= 4) reflectors of a panel act through  Q_p = H_1 .. H_nb = I - V T V^H  with
+// T^{-1} = strict_upper(V^H V) + diag(1 / tau)  (LAPACK ?larft, forward / columnwise).  One reduction round delivers
+// V^H x for the columns a workgroup owns AND the six inner products of V^H V (every workgroup recomputes those - a
+// few multiply-adds per row - instead of waiting for a launch that would produce them once); the triangular solves
+// need no division: z = T^H w is  z_l = conj(tau_l) (w_l - sum_{i<l} conj(G_il) z_i),  z = T w is
+// z_i = tau_i (w_i - sum_{l>i} G_il z_l).  Per panel this is one block-wide round instead of one per reflector.
+template <int NT>
+__device__ __forceinline__ void wy_reduce(double* vals, int nv8, double (*s_part)[32], int tid) {
+  // vals: nv8 groups of eight partial sums per thread -> totals of all 8 nv8 values in every thread
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int g = 0; g < nv8; ++g) {
+    double v8[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v8[t] = vals[g * 8 + t];
+    const double w = wave_sum8(v8, lane);
+    if (lane < 8) s_part[wave][g * 8 + rowsum8_index(lane)] = w;
+  }
+  __syncthreads();
+  for (int t = 0; t < nv8 * 8; ++t) {
+    double a = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) a += s_part[w][t];
+    vals[t] = a;
+  }
+}
+
+// full reflector vectors of a panel for the rows of this thread: u_i[r] = scale_i * tail_i[r] (r > j_i), 1 (r == j_i), 0
+template <bool CPLX, int NT, int RPT>
+__device__ __forceinline__ void wy_load_v(const double* a, const HhParam* prm, int mm, int j0, int nbb, int tid,
+                                          double2 (&u)[4][RPT], double2 (&tau)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool on = i < nbb;
+    const HhParam p = prm[on ? j0 + i : j0];
+    tau[i] = on ? make_double2(p.tau_re, p.tau_im) : make_double2(0.0, 0.0);
+    const double2 sc = make_double2(p.scale_re, p.scale_im);
+    const double* vj = a + (long long)(j0 + (on ? i : 0)) * mm * Cx<CPLX>::E;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + NT * q;
+      double2 t = (on && r > j0 + i && r < mm) ? Cx<CPLX>::ld(vj, r) : make_double2(0.0, 0.0);
+      t = cmul(sc, t);
+      if (on && r == j0 + i) t = make_double2(1.0, 0.0);
+      u[i][q] = t;
+    }
+  }
+}
+
+// vals[0..11]: G_01, G_02, G_03, G_12, G_13, G_23 (re, im) accumulated from this thread's rows
+template <int RPT>
+__device__ __forceinline__ void wy_gram(const double2 (&u)[4][RPT], double* vals) {
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int l = i + 1; l < 4; ++l) {
+        const double2 t = cmulc(u[i][q], u[l][q]);
+        vals[o] += t.x;
+        vals[o + 1] += t.y;
+        o += 2;
+      }
+  }
+}
+__device__ __forceinline__ double2 wy_g(const double* vals, int i, int l) {  // i < l
+  const int o = (i == 0 ? l - 1 : i == 1 ? l + 1 : 5) * 2;
+  return make_double2(vals[o], vals[o + 1]);
+}
+
+// trailing update: columns c0 .. c0+NC-1 receive Q_p^H = I - V T^H V^H
+template <bool CPLX, int NT, int RPT, int NC>
+__global__ __launch_bounds__(NT) void k_hh_apply_wy(double* ws_base, const QrBlk* __restrict__ blks,
+                                                      const HhParam* __restrict__ prm_base, int j0, int nb) {
+  constexpr int E = Cx<CPLX>::E;
+  __shared__ double s_part[NT / 64][32];
+  const QrBlk B = blks[blockIdx.y];
+  if (j0 >= B.k) return;
+  const int nbb = min(nb, B.k - j0);
+  const int c0 = j0 + nbb + blockIdx.x * NC;
+  if (c0 >= B.nn) return;
+  const int mm = B.mm, tid = threadIdx.x;
+  double* a = ws_base + B.ws_off * E;
+  double2 u[4][RPT], tau[4];
+  wy_load_v<CPLX, NT, RPT>(a, prm_base + B.prm_off, mm, j0, nbb, tid, u, tau);
+  double2 x[NC][RPT];
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) {
+    const double* col = a + (long long)(c0 + cc) * mm * E;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + NT * q;
+      x[cc][q] = (c0 + cc < B.nn && r >= j0 && r < mm) ? Cx<CPLX>::ld(col, r) : make_double2(0.0, 0.0);
+    }
+  }
+  // one round: G (12 doubles), then w_i = u_i^H x per column (8 doubles each)
+  constexpr int NV8 = (12 + 8 * NC + 7) / 8;
+  double vals[NV8 * 8];
+#pragma unroll
+  for (int t = 0; t < NV8 * 8; ++t) vals[t] = 0.0;
+  wy_gram<RPT>(u, vals);
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        const double2 t = cmulc(u[i][q], x[cc][q]);
+        vals[12 + 8 * cc + 2 * i] += t.x;
+        vals[12 + 8 * cc + 2 * i + 1] += t.y;
+      }
+  wy_reduce<NT>(vals, NV8, s_part, tid);
+#pragma unroll
+  for (int cc = 0; cc < NC; ++cc) {
+    if (c0 + cc >= B.nn) continue;
+    double2 z[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      double2 w = make_double2(vals[12 + 8 * cc + 2 * l], vals[12 + 8 * cc + 2 * l + 1]);
+#pragma unroll
+      for (int i = 0; i < l; ++i) {
+        const double2 t = cmulc(wy_g(vals, i, l), z[i]);
+        w.x -= t.x;
+        w.y -= t.y;
+      }
+      z[l] = cmulc(tau[l], w);
+    }
+    double* col = a + (long long)(c0 + cc) * mm * E;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + NT * q;
+      double2 y = x[cc][q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double2 t = cmul(u[i][q], z[i]);
+        y.x -= t.x;
+        y.y -= t.y;
+      }
+      if (r >= j0 && r < mm) Cx<CPLX>::st(col, r, y);
+    }
+  }
+}
+
+// column c of Q = Q_0 Q_1 .. e_c, panels applied in reverse, Q_p = I - V T V^H; columns c >= k complete the basis
+template <bool CPLX, int NT, int RPT>
+__global__ __launch_bounds__(NT) void k_hh_formq_wy(double* q_base, const double* __restrict__ ws_base,
+                                                      const QrBlk* __restrict__ blks,
+                                                      const HhParam* __restrict__ prm_base) {
+  constexpr int E = Cx<CPLX>::E;
+  __shared__ double s_part[2][NT / 64][32];
+  const QrBlk B = blks[blockIdx.y];
+  const int c = blockIdx.x;
+  if (c >= (B.nq > B.k ? B.nq : B.k)) return;
+  const int mm = B.mm, tid = threadIdx.x;
+  const double* a = ws_base + B.ws_off * E;
+  double* col = q_base + (B.q_off + (long long)c * mm) * E;
+  double2 x[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) x[q] = make_double2((tid + NT * q) == c ? 1.0 : 0.0, 0.0);
+  const int jtop = c < B.k ? c : B.k - 1;   // reflectors above jtop leave e_c alone
+  int buf = 0;
+  for (int j0 = (jtop / 4) * 4; j0 >= 0; j0 -= 4) {
+    const int nbb = min(4, B.k - j0);
+    double2 u[4][RPT], tau[4];
+    wy_load_v<CPLX, NT, RPT>(a, prm_base + B.prm_off, mm, j0, nbb, tid, u, tau);
+    double vals[24];
+#pragma unroll
+    for (int t = 0; t < 24; ++t) vals[t] = 0.0;
+    wy_gram<RPT>(u, vals);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        const double2 t = cmulc(u[i][q], x[q]);
+        vals[12 + 2 * i] += t.x;
+        vals[12 + 2 * i + 1] += t.y;
+      }
+    wy_reduce<NT>(vals, 3, s_part[buf], tid);   // double buffered: one barrier per panel
+    buf ^= 1;
+    double2 z[4];
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+      double2 w = make_double2(vals[12 + 2 * i], vals[12 + 2 * i + 1]);
+#pragma unroll
+      for (int l = i + 1; l < 4; ++l) {
+        const double2 t = cmul(wy_g(vals, i, l), z[l]);
+        w.x -= t.x;
+        w.y -= t.y;
+      }
+      z[i] = cmul(tau[i], w);
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double2 t = cmul(u[i][q], z[i]);
+        x[q].x -= t.x;
+        x[q].y -= t.y;
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int r = tid + NT * q;
+    if (r < mm) Cx<CPLX>::st(col, r, x[q]);
+  }
+}
+
+inline bool qr_use_wy() {
+  static const bool on = [] {
+    const char* e = getenv("MPSE_QR_WY");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 template <bool CPLX>
 int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk* dblk, int nblk, int max_mm,
                 int max_nn, int max_k, int max_q, bool form_q) {
@@ -393,7 +610,21 @@ int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk*
         hipLaunchKernelGGL((k_hh_panel<CPLX, 512, 8, 4>), dim3(nblk), dim3(512), 0, ctx->stream, ws, dblk, prm, j0);
     }
     const int trailing = max_nn - j0 - 1;  // upper bound on columns to the right of any block's panel
-    if (trailing > 0) {
+    if (trailing > 0 && qr_use_wy()) {
+      // two columns per workgroup share the loads of V where the registers allow (the tallest configuration holds
+      // 4 reflector tails x 8 rows per thread: one column)
+      const dim3 grid2((trailing + 1) / 2, nblk), grid1(trailing, nblk);
+      switch (cfg) {
+        case 0:
+          hipLaunchKernelGGL((k_hh_apply_wy<CPLX, 256, 4, 2>), grid2, dim3(256), 0, ctx->stream, ws, dblk, prm, j0, nb);
+          break;
+        case 1:
+          hipLaunchKernelGGL((k_hh_apply_wy<CPLX, 256, 8, 2>), grid2, dim3(256), 0, ctx->stream, ws, dblk, prm, j0, nb);
+          break;
+        default:
+          hipLaunchKernelGGL((k_hh_apply_wy<CPLX, 512, 8, 1>), grid1, dim3(512), 0, ctx->stream, ws, dblk, prm, j0, nb);
+      }
+    } else if (trailing > 0) {
       dim3 grid(trailing, nblk);
       switch (cfg) {
         case 0:
@@ -407,7 +638,19 @@ int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk*
       }
     }
   }
-  if (form_q && max_q > 0) {
+  if (form_q && max_q > 0 && qr_use_wy()) {
+    dim3 grid(max_q, nblk);
+    switch (cfg) {
+      case 0:
+        hipLaunchKernelGGL((k_hh_formq_wy<CPLX, 256, 4>), grid, dim3(256), 0, ctx->stream, q, ws, dblk, prm);
+        break;
+      case 1:
+        hipLaunchKernelGGL((k_hh_formq_wy<CPLX, 256, 8>), grid, dim3(256), 0, ctx->stream, q, ws, dblk, prm);
+        break;
+      default:
+        hipLaunchKernelGGL((k_hh_formq_wy<CPLX, 512, 8>), grid, dim3(512), 0, ctx->stream, q, ws, dblk, prm);
+    }
+  } else if (form_q && max_q > 0) {
     dim3 grid(max_q, nblk);
     switch (cfg) {
       case 0:
