@@ -18,7 +18,8 @@ __device__ __forceinline__ long long off2(const mpse_index m, long long i) {
 // threads run along j so contiguous columns coalesce
 template <typename T>
 __global__ __launch_bounds__(256) void k_copy_strided(T* dst, const T* src, mpse_index mi, mpse_index ni, mpse_index mo,
-                                                      mpse_index no) {
+                                                      mpse_index no, const int* skip) {
+  if (skip && *skip) return;
   const long long nn = ni.ext;
   const long long total = mi.ext * nn;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -64,10 +65,10 @@ int copy_call(mpse_ctx* ctx, int dtype, const void* src, void* dst, mpse_index m
   if (nb > 65536) nb = 65536;
   if (dtype == MPSE_C128)
     hipLaunchKernelGGL((k_copy_strided<double2>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, (double2*)dst,
-                       (const double2*)src, mi, ni, mo, no);
+                       (const double2*)src, mi, ni, mo, no, ctx->skip_flag);
   else
     hipLaunchKernelGGL((k_copy_strided<double>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, (double*)dst,
-                       (const double*)src, mi, ni, mo, no);
+                       (const double*)src, mi, ni, mo, no, ctx->skip_flag);
   MPSE_HIP(ctx, hipGetLastError());
   return MPSE_OK;
 }

@@ -54,6 +54,7 @@ struct GemmArgs {
   const unsigned long long* bmask;
   int nkw;
   unsigned long long* kt_counter;   // profiling only: every workgroup adds the number of K tiles it multiplied
+  const int* skip;                  // optional device flag: non-zero -> the launch does nothing (mpse_ctx::skip_flag)
 };
 
 __device__ __forceinline__ long long idx_off(const IdxMap& m, int i) {
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
   constexpr int EA = CA ? 2 : 1, EB = CB ? 2 : 1, EC = CC ? 2 : 1;
   // one LDS object: [Are | Aim? | Bre | Bim?], each BK x LD doubles
   __shared__ double smem[(2 + (CA ? 1 : 0) + (CB ? 1 : 0)) * BK * LD];
+  if (g.skip && *g.skip) return;   // workgroup-uniform
   double* sAr = smem;
   double* sAi = sAr + BK * LD;  // only meaningful if CA
   double* sBr = smem + (CA ? 2 : 1) * BK * LD;
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
 template <bool CC>
 __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs g, int batch) {
   constexpr int EC = CC ? 2 : 1;
+  if (g.skip && *g.skip) return;
   const long long mn = (long long)g.M * g.N;
   const int rows = g.M * batch;
   for (int row = blockIdx.y; row < rows; row += gridDim.y) {
@@ -533,7 +536,9 @@ struct OccOperand {
   long long sb;
   unsigned char* flags;   // [batch][tiles][nkw * 8]
 };
-__global__ __launch_bounds__(256) void k_tile_occ(OccOperand oa, OccOperand ob, int K, int nkw, int batch) {
+__global__ __launch_bounds__(256) void k_tile_occ(OccOperand oa, OccOperand ob, int K, int nkw, int batch,
+                                                  const int* skip) {
+  if (skip && *skip) return;
   // one wave per k tile (4 per workgroup); 16 independent loads per lane, lanes along whichever index is contiguous
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int kt = blockIdx.x * 4 + wave, t = blockIdx.y;
@@ -686,6 +691,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.ws = nullptr;
   g.amask = g.bmask = nullptr;
   g.nkw = 0;
+  g.skip = ctx->skip_flag;
   TmpBuf WSB(ctx), MSK(ctx);
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   if (base_blocks < n_cu && nkt_all >= 4) {
@@ -787,7 +793,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
       OccOperand ob{g.B, g.nB, g.kB, g.N, scan_b ? g.tiles_n : 0, cb ? 1 : 0, g.b_kfast, g.sbB, reinterpret_cast<unsigned char*>(bmk)};
       const int tmax = (scan_a ? g.tiles_m : 0) > (scan_b ? g.tiles_n : 0) ? (scan_a ? g.tiles_m : 0) : (scan_b ? g.tiles_n : 0);
       const dim3 og((nkt_all + 3) / 4, tmax, (unsigned)(2 * d->batch));
-      hipLaunchKernelGGL(k_tile_occ, og, dim3(256), 0, ctx->stream, oa, ob, g.K, g.nkw, (int)d->batch);
+      hipLaunchKernelGGL(k_tile_occ, og, dim3(256), 0, ctx->stream, oa, ob, g.K, g.nkw, (int)d->batch, ctx->skip_flag);
     }
     g.amask = sa ? am : nullptr;
     g.bmask = sb_ ? bmk : nullptr;

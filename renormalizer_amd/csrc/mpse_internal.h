@@ -72,6 +72,11 @@ struct mpse_ctx {
     OccKey key;
     void* mask;
   };
+  // Device word that turns every contraction launch into a no-op once it is non-zero: set for the duration of an
+  // asynchronous Lanczos solve, whose iterations are enqueued ahead of the convergence decision (mpse_vec.hip)
+  const int* skip_flag = nullptr;
+  // Krylov dimension of the last solve per problem class (number of sites, vector length): how far to run ahead
+  std::unordered_map<unsigned long long, int> lz_hint;
   bool occ_cache_on = false;
   const char* occ_lo[2] = {nullptr, nullptr};
   const char* occ_hi[2] = {nullptr, nullptr};

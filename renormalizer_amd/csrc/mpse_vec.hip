@@ -5,6 +5,7 @@
 // order, so dot products / norms are bitwise reproducible run to run.
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 
 #include "mpse_device.h"
 #include "mpse_internal.h"
@@ -23,7 +24,9 @@ inline int red_blocks(int64_t n_doubles) {
 // partial[b] = sum over this block's elements of conj(x) * y
 template <bool CPLX>
 __global__ __launch_bounds__(RED_THREADS) void k_dot_partial(const double* __restrict__ x, const double* __restrict__ y,
-                                                             long long n, double* __restrict__ partial) {
+                                                             long long n, double* __restrict__ partial,
+                                                             const int* __restrict__ done) {
+  if (done && *done) return;
   double re = 0, im = 0;
   const long long stride = (long long)gridDim.x * RED_THREADS;
   if (CPLX) {
@@ -64,7 +67,8 @@ __device__ __forceinline__ void sum_partials(const double* __restrict__ partial,
 }
 
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_final(const double* __restrict__ partial, int nb,
-                                                              double* __restrict__ out) {
+                                                              double* __restrict__ out, const int* __restrict__ done) {
+  if (done && *done) return;
   double re = 0, im = 0;
   for (int i = threadIdx.x; i < nb; i += RED_THREADS) {
     re += partial[2 * i];
@@ -131,7 +135,9 @@ template <bool VEC>
 __global__ __launch_bounds__(RED_THREADS) void k_scale_into_dev(double* dst, const double* __restrict__ src,
                                                                 long long n_doubles,
                                                                 const double* __restrict__ partial, int nb,
-                                                                double* __restrict__ b2_out) {
+                                                                double* __restrict__ b2_out,
+                                                                const int* __restrict__ done) {
+  if (done && *done) return;
   double b2, im;
   sum_partials(partial, nb, b2, im);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -166,7 +172,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update(double* __restri
                                                                 const double* __restrict__ a_partial, int a_nb,
                                                                 double* __restrict__ a_out,
                                                                 const double* __restrict__ b2p,
-                                                                double* __restrict__ partial) {
+                                                                double* __restrict__ partial,
+                                                                const int* __restrict__ done) {
+  if (done && *done) return;
   // a = Re <w, v1>: summed here from the partials of the preceding k_dot_partial; block 0 records it
   double a, a_im;
   sum_partials(a_partial, a_nb, a, a_im);
@@ -362,6 +370,156 @@ int read_scalar2(mpse_ctx* ctx, const double* dsrc, double* a, double* b) {
   return MPSE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Asynchronous solve: the host enqueues Lanczos iterations ahead of the convergence decision.  The small-matrix
+// exponential, the closeness test of successive estimates and the decision itself run on the device; once the
+// decision has fallen every later launch of the solve (contractions included, mpse_ctx::skip_flag) returns at once.
+// The host waits once per solve (when its guess of the Krylov dimension, taken from the last solve of the same
+// problem class, was right), instead of twice per convergence check.
+struct LzCtl {
+  int done;       // decision has fallen: later launches do nothing
+  int nvec;       // Krylov dimension of the answer
+  int which;      // 0: answer in `out`, 1: in the spare buffer
+  int bad;        // zero / non-finite start vector
+  int need_host;  // |dt| * spectral bound too large for the on-device exponential: the host takes this check over
+  int forced_m;   // breakdown: the estimate of this check is final, with this many vectors
+  int pad[2];
+};
+constexpr int LZ_MAXM = 64;   // one wavefront holds the Krylov coefficients
+
+// coef = |v| exp(dt T_m) e_1 for the Lanczos tridiagonal T_m (alpha_0.., beta_0..) by a scaled Taylor series, one lane
+// per component (lib/krylov/krylov.py:15-24 computes the same vector through eigh_tridiagonal).  Also applies the
+// reference's breakdown rule retroactively: the first beta_i < tiny (i <= j) ends the space at i + 1 vectors.
+__global__ __launch_bounds__(64) void k_lz_coefs(const double* __restrict__ scal, int j, double dt_re, double dt_im,
+                                                 double tiny, double* __restrict__ coef, LzCtl* ctl) {
+  if (ctl->done) return;
+  const int lane = threadIdx.x;
+  const double n2 = scal[0];
+  if (!(n2 > 0.0) || !(n2 < 1e300)) {
+    if (lane == 0) {
+      ctl->bad = 1;
+      ctl->done = 1;
+    }
+    return;
+  }
+  int m = j + 1;
+  // breakdown scan: beta_i = sqrt(scal[6 + 4 i]), i <= j (beta_j was reduced right before this launch)
+  const double bi2 = lane <= j ? scal[6 + 4 * lane] : 1e300;
+  const unsigned long long low = __ballot(!(sqrt(bi2) >= tiny));
+  if (low) {
+    m = __builtin_ctzll(low) + 1;
+    if (lane == 0) ctl->forced_m = m;
+  }
+  const double a = lane < m ? scal[4 + 4 * lane] : 0.0;
+  const double bup = lane + 1 < m ? sqrt(scal[6 + 4 * lane]) : 0.0;        // beta_lane couples lane and lane + 1
+  double bdn = __shfl_up(bup, 1, 64);
+  if (lane == 0) bdn = 0.0;
+  // spectral bound (Gershgorin) -> scaling so that |dt| * bound / 2^s <= 1
+  double g = lane < m ? fabs(a) + fabs(bup) + fabs(bdn) : 0.0;
+  for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o, 64));
+  const double rho = g * sqrt(dt_re * dt_re + dt_im * dt_im);
+  int sq = 0;
+  while (ldexp(rho, -sq) > 1.0 && sq < 40) ++sq;
+  if (sq > 8) {      // would need more than 256 repetitions: let the host do this one with its eigen-decomposition
+    if (lane == 0) ctl->need_host = 1;
+    return;
+  }
+  const double sr = ldexp(dt_re, -sq), si = ldexp(dt_im, -sq);
+  double yr = lane == 0 ? sqrt(n2) : 0.0, yi = 0.0;
+  const int reps = 1 << sq;
+  for (int rep = 0; rep < reps; ++rep) {
+    double tr = yr, ti = yi;     // current Taylor term
+#pragma unroll 1
+    for (int k = 1; k <= 22; ++k) {
+      // t <- (dt / 2^s) T t / k
+      const double ur = __shfl_up(tr, 1, 64), ui = __shfl_up(ti, 1, 64);
+      const double dr = __shfl_down(tr, 1, 64), di = __shfl_down(ti, 1, 64);
+      const double wr = a * tr + bdn * ur + bup * dr, wi = a * ti + bdn * ui + bup * di;
+      const double ik = 1.0 / (double)k;
+      tr = (sr * wr - si * wi) * ik;
+      ti = (sr * wi + si * wr) * ik;
+      if (lane >= m) tr = ti = 0.0;
+      yr += tr;
+      yi += ti;
+    }
+  }
+  if (lane < LZ_MAXM) {
+    coef[lane] = lane < m ? yr : 0.0;
+    coef[LZ_MAXM + lane] = lane < m ? yi : 0.0;
+  }
+}
+
+// res = sum_{i<m} coef_i V_i with the coefficients in device memory; optional closeness flag as in k_lincomb
+template <bool CPLX>
+__global__ void k_lincomb_dev(double* __restrict__ res, const double* __restrict__ V, long long n, int m,
+                              const double* __restrict__ coef, const double* __restrict__ prev, double rtol, double atol,
+                              unsigned int* __restrict__ flag, unsigned int gen, const LzCtl* __restrict__ ctl) {
+  if (ctl->done || ctl->need_host) return;
+  __shared__ double cr[LZ_MAXM], ci[LZ_MAXM];
+  if (threadIdx.x < LZ_MAXM) {
+    cr[threadIdx.x] = coef[threadIdx.x];
+    ci[threadIdx.x] = coef[LZ_MAXM + threadIdx.x];
+  }
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (CPLX) {
+      double xr = 0, xi = 0;
+      for (int jj = 0; jj < m; ++jj) {
+        const double2 v = reinterpret_cast<const double2*>(V)[(long long)jj * n + i];
+        xr += cr[jj] * v.x - ci[jj] * v.y;
+        xi += cr[jj] * v.y + ci[jj] * v.x;
+      }
+      if (prev) {
+        const double2 p = reinterpret_cast<const double2*>(prev)[i];
+        const double diff = hypot(p.x - xr, p.y - xi);
+        if (!(diff <= atol + rtol * hypot(xr, xi))) bad = true;
+      }
+      reinterpret_cast<double2*>(res)[i] = make_double2(xr, xi);
+    } else {
+      double xr = 0;
+      for (int jj = 0; jj < m; ++jj) xr += cr[jj] * V[(long long)jj * n + i];
+      if (prev) {
+        if (!(fabs(prev[i] - xr) <= atol + rtol * fabs(xr))) bad = true;
+      }
+      res[i] = xr;
+    }
+  }
+  if (prev && bad) atomicMax(flag, gen);
+}
+
+// the decision of the check at iteration j (its estimate went to buffer `which`)
+__global__ void k_lz_decide(LzCtl* ctl, const unsigned int* __restrict__ flag, unsigned int gen, int has_prev, int j,
+                            int which) {
+  if (ctl->done || ctl->need_host) return;
+  if (ctl->forced_m > 0) {
+    ctl->done = 1;
+    ctl->nvec = ctl->forced_m;
+    ctl->which = which;
+  } else if (has_prev && *flag != gen) {
+    ctl->done = 1;
+    ctl->nvec = j + 1;
+    ctl->which = which;
+  }
+}
+
+// answer -> out when it sits in the spare buffer
+__global__ void k_lz_final(double* __restrict__ out, const double* __restrict__ spare, long long n_doubles,
+                           const LzCtl* __restrict__ ctl) {
+  if (!(ctl->done && ctl->which == 1 && !ctl->bad)) return;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_doubles; i += stride) out[i] = spare[i];
+}
+
+inline bool lanczos_async_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("MPSE_LANCZOS_ASYNC");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 }  // namespace
 
 int dotc_sync(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n, double* re, double* im) {
@@ -371,14 +529,189 @@ int dotc_sync(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n,
   double* result = ctx->dscratch + 2 * RED_MAX_BLOCKS;
   if (cplx)
     hipLaunchKernelGGL((k_dot_partial<true>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
-                       (const double*)y, (long long)n, partial);
+                       (const double*)y, (long long)n, partial, (const int*)nullptr);
   else
     hipLaunchKernelGGL((k_dot_partial<false>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
-                       (const double*)y, (long long)n, partial);
-  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, partial, nb, result);
+                       (const double*)y, (long long)n, partial, (const int*)nullptr);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, partial, nb, result, (const int*)nullptr);
   MPSE_HIP(ctx, hipGetLastError());
   return read_scalar2(ctx, result, re, im);
 }
+
+namespace {
+
+// the environments are constant over a solve: their tile-occupancy masks are scanned once (mpse_gemm.hip)
+struct OccScope {
+  mpse_ctx* c;
+  OccScope(mpse_ctx* ctx, const mpse_heff* h) : c(ctx) {
+    const mpse_dims& s = h->dims;
+    const size_t lb = size_t(s.Dl_ket) * s.wl * s.Dl_ket * (h->l_dtype == MPSE_C128 ? 16 : 8);
+    const size_t rb = size_t(s.Dr_ket) * s.wr * s.Dr_ket * (h->r_dtype == MPSE_C128 ? 16 : 8);
+    c->occ_lo[0] = static_cast<const char*>(h->L), c->occ_hi[0] = c->occ_lo[0] + lb;
+    c->occ_lo[1] = static_cast<const char*>(h->R), c->occ_hi[1] = c->occ_lo[1] + rb;
+    c->occ_cache_on = true;
+  }
+  ~OccScope() {
+    c->occ_cache_on = false;
+    for (auto& e : c->occ_cache) mpse_free(c, e.mask);
+    c->occ_cache.clear();
+  }
+};
+
+constexpr int LZ_FALLBACK = -77;   // internal: the asynchronous solve hands the problem to the synchronous one
+
+int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::complex<double> dt, const void* Cin, void* out,
+                       double rtol, double atol, int max_dim, int* nvec, int64_t n) {
+  const bool cplx = dtype == MPSE_C128;
+  const size_t es = dtype_size(dtype);
+  const int64_t nd = n * (cplx ? 2 : 1);
+  const double tiny = 100.0 * double(n) * 2.220446049250313e-16;
+  const int limit = max_dim < LZ_MAXM ? max_dim : LZ_MAXM;
+  const unsigned long long key = ((unsigned long long)h->nsite << 60) ^ ((unsigned long long)n << 1) ^ (cplx ? 1ull : 0ull);
+  int hint = 0;
+  {
+    auto it = ctx->lz_hint.find(key);
+    if (it != ctx->lz_hint.end()) hint = it->second;
+  }
+  // first wait at the check that can confirm the hinted dimension (or at the first check that can decide at all)
+  int wait_from = hint > 0 ? hint - 1 : 6;
+  if (wait_from < 6) wait_from = 6;
+
+  int cap = hint + 4 > 16 ? hint + 4 : 16;
+  if (cap > limit + 1) cap = limit + 1;
+  TmpBuf V(ctx), W(ctx), RES(ctx), SCAL(ctx);
+  MPSE_TRY(V.alloc(size_t(cap) * n * es));
+  MPSE_TRY(W.alloc(size_t(n) * es));
+  MPSE_TRY(RES.alloc(size_t(n) * es));
+  // scalars as in the synchronous solve: [0..1] |v|^2 ; per j: alpha at 4+4j, beta^2 at 6+4j ; then control + coefficients
+  const int SC_CTL = 4 + 4 * 130, SC_COEF = SC_CTL + 8;
+  MPSE_TRY(SCAL.alloc(size_t(SC_COEF + 2 * LZ_MAXM) * sizeof(double)));
+  double* scal = SCAL.as<double>();
+  LzCtl* ctl = reinterpret_cast<LzCtl*>(scal + SC_CTL);
+  double* coef = scal + SC_COEF;
+  MPSE_HIP(ctx, hipMemsetAsync(ctl, 0, sizeof(LzCtl), ctx->stream));
+  const int* done = &ctl->done;
+  const int nb = red_blocks(nd);
+  double* part_a = ctx->dscratch;
+  double* part_b = ctx->dscratch + 4 * RED_MAX_BLOCKS;
+  const bool vec16 = (cplx || n % 2 == 0) && (reinterpret_cast<uintptr_t>(Cin) & 15) == 0;
+  const double vbytes = double(n) * double(es);
+  auto vec = [&](int j) { return V.as<char>() + size_t(j) * n * es; };
+
+  struct SkipScope {
+    mpse_ctx* c;
+    SkipScope(mpse_ctx* ctx, const int* f) : c(ctx) { c->skip_flag = f; }
+    ~SkipScope() { c->skip_flag = nullptr; }
+  } skip_scope(ctx, done);
+  OccScope occ_scope(ctx, h);
+
+  auto bracket = [&](double bytes, auto&& launch) {
+    mpse_ctx::ProfRec rec;
+    const bool pt = prof_begin(ctx, 4, 0.0, bytes, &rec);
+    launch();
+    if (pt) prof_end(ctx, rec);
+  };
+  auto dot_partials = [&](const void* x, const void* y, double* dst) {
+    bracket(2.0 * vbytes, [&] {
+      if (cplx)
+        hipLaunchKernelGGL((k_dot_partial<true>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
+                           (const double*)y, (long long)n, dst, done);
+      else
+        hipLaunchKernelGGL((k_dot_partial<false>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
+                           (const double*)y, (long long)n, dst, done);
+    });
+  };
+  auto scale_into = [&](void* dst, const void* src, double* b2_out) {
+    bracket(2.0 * vbytes, [&] {
+      if (vec16)
+        hipLaunchKernelGGL(k_scale_into_dev<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)dst,
+                           (const double*)src, (long long)nd, (const double*)part_b, nb, b2_out, done);
+      else
+        hipLaunchKernelGGL(k_scale_into_dev<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)dst,
+                           (const double*)src, (long long)nd, (const double*)part_b, nb, b2_out, done);
+    });
+  };
+  // v0 = C / |C|
+  dot_partials(Cin, Cin, part_b);
+  scale_into(vec(0), Cin, scal);
+  MPSE_HIP(ctx, hipGetLastError());
+
+  unsigned int* dflag = reinterpret_cast<unsigned int*>(ctx->dscratch + (size_t(1) << 16) - 8);
+  void* prev = nullptr;
+  bool waited = false;
+  LzCtl hc;
+  memset(&hc, 0, sizeof(hc));
+  for (int j = 0;; ++j) {
+    MPSE_TRY(mpse_heff_apply(ctx, dtype, h, vec(j), W.p));
+    dot_partials(W.p, vec(j), part_a);
+    bracket((j > 0 ? 4.0 : 3.0) * vbytes, [&] {
+      if (vec16)
+        hipLaunchKernelGGL(k_lanczos_update<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
+                           (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
+                           (long long)nd, (const double*)part_a, nb, scal + 4 + 4 * j,
+                           (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b, done);
+      else
+        hipLaunchKernelGGL(k_lanczos_update<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
+                           (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
+                           (long long)nd, (const double*)part_a, nb, scal + 4 + 4 * j,
+                           (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b, done);
+    });
+    const bool check = (j > 3 && j % 2 == 0);          // krylov.py:76-81
+    const bool last = (j + 1 >= limit);
+    if (check) {
+      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, part_b, nb, scal + 6 + 4 * j, done);
+      hipLaunchKernelGGL(k_lz_coefs, dim3(1), dim3(64), 0, ctx->stream, (const double*)scal, j, dt.real(), dt.imag(),
+                         tiny, coef, ctl);
+      void* dst = (prev == out) ? RES.p : out;
+      unsigned int gen = 0;
+      if (prev) {
+        gen = ++ctx->flag_gen;
+        if (gen == 0) {
+          MPSE_HIP(ctx, hipMemsetAsync(dflag, 0, sizeof(unsigned int), ctx->stream));
+          gen = ++ctx->flag_gen;
+        }
+      }
+      if (cplx)
+        hipLaunchKernelGGL((k_lincomb_dev<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst,
+                           V.as<double>(), (long long)n, j + 1, (const double*)coef, (const double*)prev, rtol, atol,
+                           dflag, gen, (const LzCtl*)ctl);
+      else
+        hipLaunchKernelGGL((k_lincomb_dev<false>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst,
+                           V.as<double>(), (long long)n, j + 1, (const double*)coef, (const double*)prev, rtol, atol,
+                           dflag, gen, (const LzCtl*)ctl);
+      hipLaunchKernelGGL(k_lz_decide, dim3(1), dim3(1), 0, ctx->stream, ctl, (const unsigned int*)dflag, gen,
+                         prev ? 1 : 0, j, dst == out ? 0 : 1);
+      prev = dst;
+      MPSE_HIP(ctx, hipGetLastError());
+      if (j >= wait_from || waited || last) {
+        hipLaunchKernelGGL(k_lz_final, dim3(ew_blocks(nd)), dim3(256), 0, ctx->stream, (double*)out,
+                           (const double*)RES.p, (long long)nd, (const LzCtl*)ctl);
+        MPSE_TRY(publish_and_wait(ctx, reinterpret_cast<const double*>(ctl), int(sizeof(LzCtl) / sizeof(double)), 24));
+        if (ctx->prof_pending.size() > 2048) prof_drain(ctx);
+        memcpy(&hc, ctx->pinned + 24, sizeof(LzCtl));
+        waited = true;
+        if (hc.bad) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: zero start vector");
+        if (hc.need_host) return LZ_FALLBACK;
+        if (hc.done) break;
+      }
+    }
+    if (last) return LZ_FALLBACK;     // beyond one wavefront of coefficients (or no convergence): the synchronous solve decides
+    if (j + 2 > cap) {
+      int ncap = cap * 2 < limit + 1 ? cap * 2 : limit + 1;
+      TmpBuf V2(ctx);
+      MPSE_TRY(V2.alloc(size_t(ncap) * n * es));
+      MPSE_TRY(mpse_memcpy_d2d(ctx, V2.p, V.p, size_t(cap) * n * es));
+      std::swap(V.p, V2.p);
+      cap = ncap;
+    }
+    scale_into(vec(j + 1), W.p, scal + 6 + 4 * j);
+  }
+  ctx->lz_hint[key] = hc.nvec;
+  if (nvec) *nvec = hc.nvec;
+  return MPSE_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -503,6 +836,11 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
   if (h->nsite == 2) n *= s.d1 * (s.danc1 > 0 ? s.danc1 : anc);
   if (n <= 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "expm_lanczos: empty centre tensor");
   if (max_dim <= 0 || max_dim > 128) max_dim = 128;
+  if (lanczos_async_enabled() && n > 256) {
+    const int st = expm_lanczos_async(ctx, dtype, h, std::complex<double>(dt_re, dt_im), Cin, out, rtol, atol, max_dim,
+                                      nvec, n);
+    if (st != LZ_FALLBACK) return st;
+  }
   const size_t es = dtype_size(dtype);
   const int64_t nd = n * (cplx ? 2 : 1);  // doubles per vector
   const std::complex<double> dt(dt_re, dt_im);
@@ -535,10 +873,10 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
     } end{ctx, pt ? &rec : nullptr};
     if (cplx)
       hipLaunchKernelGGL((k_dot_partial<true>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
-                         (const double*)y, (long long)n, dst_partial);
+                         (const double*)y, (long long)n, dst_partial, (const int*)nullptr);
     else
       hipLaunchKernelGGL((k_dot_partial<false>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
-                         (const double*)y, (long long)n, dst_partial);
+                         (const double*)y, (long long)n, dst_partial, (const int*)nullptr);
   };
 
   // v0 = C / |C|
@@ -547,10 +885,10 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
   const bool vec16 = (cplx || n % 2 == 0) && (reinterpret_cast<uintptr_t>(Cin) & 15) == 0;
   if (vec16)
     hipLaunchKernelGGL(k_scale_into_dev<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, V.as<double>(),
-                       (const double*)Cin, (long long)nd, (const double*)part_b, nb, scal);
+                       (const double*)Cin, (long long)nd, (const double*)part_b, nb, scal, (const int*)nullptr);
   else
     hipLaunchKernelGGL(k_scale_into_dev<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, V.as<double>(),
-                       (const double*)Cin, (long long)nd, (const double*)part_b, nb, scal);
+                       (const double*)Cin, (long long)nd, (const double*)part_b, nb, scal, (const int*)nullptr);
   MPSE_HIP(ctx, hipGetLastError());
 
   std::vector<double> alpha, beta;
@@ -606,28 +944,13 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
     return -1;
   };
 
-  // the environments are constant over the solve: their tile-occupancy masks are scanned once (mpse_gemm.hip)
-  struct OccScope {
-    mpse_ctx* c;
-    OccScope(mpse_ctx* ctx, const mpse_heff* h) : c(ctx) {
-      const mpse_dims& s = h->dims;
-      const size_t lb = size_t(s.Dl_ket) * s.wl * s.Dl_ket * (h->l_dtype == MPSE_C128 ? 16 : 8);
-      const size_t rb = size_t(s.Dr_ket) * s.wr * s.Dr_ket * (h->r_dtype == MPSE_C128 ? 16 : 8);
-      c->occ_lo[0] = static_cast<const char*>(h->L), c->occ_hi[0] = c->occ_lo[0] + lb;
-      c->occ_lo[1] = static_cast<const char*>(h->R), c->occ_hi[1] = c->occ_lo[1] + rb;
-      c->occ_cache_on = true;
-    }
-    ~OccScope() {
-      c->occ_cache_on = false;
-      for (auto& e : c->occ_cache) mpse_free(c, e.mask);
-      c->occ_cache.clear();
-    }
-  } occ_scope(ctx, h);
+  OccScope occ_scope(ctx, h);
   for (int j = 0;; ++j) {
     MPSE_TRY(mpse_heff_apply(ctx, dtype, h, vec(j), W.p));
     dot_partials(W.p, vec(j), part_a);                             // alpha_j = Re <w, v_j> (partials)
     if (j == n - 1) {                                              // Krylov space == full space (krylov.py:59-61)
-      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, part_a, nb, scal + 4 + 4 * j);
+      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, part_a, nb, scal + 4 + 4 * j,
+                         (const int*)nullptr);
       MPSE_TRY(fetch(j));
       if (!(nrmv > 0)) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: zero start vector");
       int bd = breakdown_at(j - 1);
@@ -642,12 +965,12 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
       hipLaunchKernelGGL(k_lanczos_update<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
                          (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
                          (long long)nd, (const double*)part_a, nb, scal + 4 + 4 * j,
-                         (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b);
+                         (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b, (const int*)nullptr);
     else
       hipLaunchKernelGGL(k_lanczos_update<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
                          (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
                          (long long)nd, (const double*)part_a, nb, scal + 4 + 4 * j,
-                         (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b);
+                         (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b, (const int*)nullptr);
     if (upt) prof_end(ctx, urec);
     // beta_j^2: needed by the host at a check and by the next update; k_scale_into_dev stores it when it runs
     // (every path that continues), the returning paths below read it through k_reduce_final
@@ -660,7 +983,8 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
     const bool defer = check && !have_res && pending_m == 0 && !last;
     const bool sync_now = (check && !defer) || last;
     if (sync_now)
-      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, part_b, nb, scal + 6 + 4 * j);
+      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, part_b, nb, scal + 6 + 4 * j,
+                         (const int*)nullptr);
     MPSE_HIP(ctx, hipGetLastError());
     if (sync_now) {
       MPSE_TRY(fetch(j));
@@ -721,10 +1045,12 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
     const bool spt = prof_begin(ctx, 4, 0.0, 2.0 * vbytes, &srec);
     if (vec16)
       hipLaunchKernelGGL(k_scale_into_dev<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
-                         W.as<const double>(), (long long)nd, (const double*)part_b, nb, scal + 6 + 4 * j);
+                         W.as<const double>(), (long long)nd, (const double*)part_b, nb, scal + 6 + 4 * j,
+                         (const int*)nullptr);
     else
       hipLaunchKernelGGL(k_scale_into_dev<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
-                         W.as<const double>(), (long long)nd, (const double*)part_b, nb, scal + 6 + 4 * j);
+                         W.as<const double>(), (long long)nd, (const double*)part_b, nb, scal + 6 + 4 * j,
+                         (const int*)nullptr);
     if (spt) prof_end(ctx, srec);
   }
 }

@@ -295,3 +295,34 @@ def test_rccl_collective_through_ctypes(tmp_path, monkeypatch):
     assert rows.tolist() == [[0.25, 0.5, 0.125]]
     coll.close()
     assert not os.path.exists(parallel._rendezvous_path())
+
+
+def test_asynchronous_lanczos_guesses_and_fallbacks(eng):
+    """The solve that runs ahead of its convergence decision (vectors longer than 256 elements): Krylov dimension and
+    result equal the oracle's when the run-ahead guess (dimension of the previous solve of the same size) is too
+    short, too long or right; a step whose |dt| * spectral bound exceeds the on-device exponential's range goes
+    through the host's eigen-decomposition; real vectors of odd length use the unvectorised kernels."""
+    rng = np.random.default_rng(21)
+    D, d, w = 9, 5, 3                                     # n = 405
+    l, r = _herm_env(rng, D, w), _herm_env(rng, D, w)
+    wm = rng.standard_normal((w, d, d, w))
+    wm = (wm + wm.transpose(0, 2, 1, 3)) / 2
+    c = rng.standard_normal((D, d, D)) + 1j * rng.standard_normal((D, d, D))
+    hop = hop_expr(eng.asdevice(l), eng.asdevice(r), [eng.asdevice(wm)], c.shape)
+    dims = []
+    for dt in (-0.02j, -1.5j, -0.02j, -0.4j, -0.4j, -60.0j):       # dimensions go up, down, stay; the last is host-side
+        ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(l, r, [wm], y.reshape(c.shape)).ravel(), dt, c.ravel())
+        out, nv = expm_krylov(hop, dt, eng.asdevice(c))
+        assert nv == nref, (dt, nv, nref)
+        assert np.abs(out.to_host().ravel() - ref).max() < 1e-10 * np.abs(ref).max(), dt
+        dims.append(nv)
+    assert len(set(dims)) >= 3
+    lr, rr = l.real + l.real.transpose(2, 1, 0), r.real + r.real.transpose(2, 1, 0)
+    cr = rng.standard_normal((D, d, D))                               # 405 real elements: odd length
+    hop_r = hop_expr(eng.asdevice(lr), eng.asdevice(rr), [eng.asdevice(wm)], cr.shape)
+    for dt in (-0.1, -0.3):
+        ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(lr, rr, [wm], y.reshape(cr.shape)).ravel(), dt, cr.ravel())
+        out, nv = expm_krylov(hop_r, dt, eng.asdevice(cr))
+        assert nv == nref and np.abs(out.to_host().ravel() - ref).max() < 1e-10 * np.abs(ref).max()
+    with pytest.raises(E.EngineError):
+        expm_krylov(hop, -0.1j, eng.asdevice(np.zeros_like(c)))       # zero vector: reported, not a hang
