@@ -221,6 +221,77 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update(double* __restri
   }
 }
 
+// Lanczos step on an UNNORMALISED basis (asynchronous solve): the Krylov vectors are kept as U_j = v_j / s_j with
+// s_0 = 1 / |C|, s_{j+1} = 1 / beta_j, so that no separate normalisation pass over the vector is needed:
+//   y = H U_j (in),  alpha_j = s_j^2 Re <y, U_j>,  w = s_j y - alpha_j s_j U_j - beta_{j-1} s_{j-1} U_{j-1} -> U_{j+1} (out)
+// s_j^2 = 1 / sum(cur_partial) (the |U_j|^2 partials of the previous step; block 0 records the sum at cur_out),
+// s_{j-1}^2 = 1 / *prev2 (recorded one step earlier).  Partials of |w|^2 go to `partial` (a different area than
+// cur_partial: blocks read all of those before any block of the NEXT step overwrites them).
+template <bool VEC>
+__global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __restrict__ u_next,
+                                                                  const double* __restrict__ y,
+                                                                  const double* __restrict__ u1,
+                                                                  const double* __restrict__ u0, long long n_doubles,
+                                                                  const double* __restrict__ a_partial, int a_nb,
+                                                                  double* __restrict__ a_out,
+                                                                  const double* __restrict__ cur_partial,
+                                                                  double* __restrict__ cur_out,
+                                                                  const double* __restrict__ prev2,
+                                                                  double* __restrict__ partial,
+                                                                  const int* __restrict__ done) {
+  if (done && *done) return;
+  double araw, a_im, cur2, z;
+  sum_partials(a_partial, a_nb, araw, a_im);
+  sum_partials(cur_partial, a_nb, cur2, z);
+  const double s1sq = 1.0 / cur2, s1 = sqrt(s1sq);
+  const double a = araw * s1sq;                       // alpha_j
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a_out[0] = a;
+    a_out[1] = a_im * s1sq;
+    cur_out[0] = cur2;                                // |C|^2 (j == 0) or beta_{j-1}^2
+    cur_out[1] = 0.0;
+  }
+  const double c_y = s1, c_1 = a * s1;
+  const double c_0 = u0 ? sqrt(cur2) / sqrt(*prev2) : 0.0;   // beta_{j-1} s_{j-1}
+  double s = 0, zero = 0;
+  const long long stride = (long long)gridDim.x * RED_THREADS;
+  if (VEC) {
+    const long long n2 = n_doubles >> 1;
+    double2* o2 = reinterpret_cast<double2*>(u_next);
+    const double2* py = reinterpret_cast<const double2*>(y);
+    const double2* p1 = reinterpret_cast<const double2*>(u1);
+    const double2* p0 = reinterpret_cast<const double2*>(u0);
+    const double2 zz = make_double2(0.0, 0.0);
+    for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n2; i += 2 * stride) {
+      const long long i1 = i + stride;
+      const bool h1 = i1 < n2;
+      const double2 ya = py[i], va = p1[i], ua = u0 ? p0[i] : zz;
+      const double2 yb = h1 ? py[i1] : zz, vb = h1 ? p1[i1] : zz, ub = (h1 && u0) ? p0[i1] : zz;
+      const double2 xa = make_double2(c_y * ya.x - (c_1 * va.x + c_0 * ua.x), c_y * ya.y - (c_1 * va.y + c_0 * ua.y));
+      const double2 xb = make_double2(c_y * yb.x - (c_1 * vb.x + c_0 * ub.x), c_y * yb.y - (c_1 * vb.y + c_0 * ub.y));
+      o2[i] = xa;
+      s += xa.x * xa.x + xa.y * xa.y;
+      if (h1) {
+        o2[i1] = xb;
+        s += xb.x * xb.x + xb.y * xb.y;
+      }
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n_doubles; i += stride) {
+      double t = c_1 * u1[i];
+      if (u0) t += c_0 * u0[i];
+      const double x = c_y * y[i] - t;
+      u_next[i] = x;
+      s += x * x;
+    }
+  }
+  block_allsum2(s, zero);
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = s;
+    partial[2 * blockIdx.x + 1] = 0.0;
+  }
+}
+
 // x[i] *= m[i]  (real mask / weights on a real or complex vector)
 template <bool CPLX>
 __global__ void k_mul_real(double* x, const double* __restrict__ m, long long n) {
@@ -444,8 +515,11 @@ __global__ __launch_bounds__(64) void k_lz_coefs(const double* __restrict__ scal
     }
   }
   if (lane < LZ_MAXM) {
-    coef[lane] = lane < m ? yr : 0.0;
-    coef[LZ_MAXM + lane] = lane < m ? yi : 0.0;
+    // the stored basis is unnormalised: v_i = s_i U_i, s_0 = 1 / |C|, s_i = 1 / beta_{i-1}
+    double sc = 0.0;
+    if (lane < m) sc = lane == 0 ? 1.0 / sqrt(n2) : 1.0 / sqrt(scal[6 + 4 * (lane - 1)]);
+    coef[lane] = lane < m ? yr * sc : 0.0;
+    coef[LZ_MAXM + lane] = lane < m ? yi * sc : 0.0;
   }
 }
 
@@ -467,6 +541,7 @@ __global__ void k_lincomb_dev(double* __restrict__ res, const double* __restrict
     if (CPLX) {
       double xr = 0, xi = 0;
       for (int jj = 0; jj < m; ++jj) {
+        if (cr[jj] == 0.0 && ci[jj] == 0.0) continue;   // past a breakdown: never touched
         const double2 v = reinterpret_cast<const double2*>(V)[(long long)jj * n + i];
         xr += cr[jj] * v.x - ci[jj] * v.y;
         xi += cr[jj] * v.y + ci[jj] * v.x;
@@ -479,7 +554,10 @@ __global__ void k_lincomb_dev(double* __restrict__ res, const double* __restrict
       reinterpret_cast<double2*>(res)[i] = make_double2(xr, xi);
     } else {
       double xr = 0;
-      for (int jj = 0; jj < m; ++jj) xr += cr[jj] * V[(long long)jj * n + i];
+      for (int jj = 0; jj < m; ++jj) {
+        if (cr[jj] == 0.0) continue;
+        xr += cr[jj] * V[(long long)jj * n + i];
+      }
       if (prev) {
         if (!(fabs(prev[i] - xr) <= atol + rtol * fabs(xr))) bad = true;
       }
@@ -631,9 +709,10 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
                            (const double*)src, (long long)nd, (const double*)part_b, nb, b2_out, done);
     });
   };
-  // v0 = C / |C|
-  dot_partials(Cin, Cin, part_b);
-  scale_into(vec(0), Cin, scal);
+  // U_0 = C itself (the Krylov basis is kept unnormalised, k_lanczos_update_u); |C|^2 partials feed the first step
+  double* part_b2[2] = {ctx->dscratch + 4 * RED_MAX_BLOCKS, ctx->dscratch + 8 * RED_MAX_BLOCKS};
+  MPSE_TRY(mpse_memcpy_d2d(ctx, vec(0), Cin, size_t(n) * es));
+  dot_partials(Cin, Cin, part_b2[0]);
   MPSE_HIP(ctx, hipGetLastError());
 
   unsigned int* dflag = reinterpret_cast<unsigned int*>(ctx->dscratch + (size_t(1) << 16) - 8);
@@ -644,22 +723,37 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
   for (int j = 0;; ++j) {
     MPSE_TRY(mpse_heff_apply(ctx, dtype, h, vec(j), W.p));
     dot_partials(W.p, vec(j), part_a);
+    if (j + 2 > cap) {      // room for U_{j+1}
+      int ncap = cap * 2 < limit + 1 ? cap * 2 : limit + 1;
+      TmpBuf V2(ctx);
+      MPSE_TRY(V2.alloc(size_t(ncap) * n * es));
+      MPSE_TRY(mpse_memcpy_d2d(ctx, V2.p, V.p, size_t(cap) * n * es));
+      std::swap(V.p, V2.p);
+      cap = ncap;
+    }
+    // |U_j|^2 partials came from step j - 1 (or from |C|^2); this step's |w|^2 partials go to the other area
+    double* cur_part = part_b2[j & 1];
+    double* new_part = part_b2[(j + 1) & 1];
+    double* cur_out = j == 0 ? scal : scal + 6 + 4 * (j - 1);
+    const double* prev2 = j == 0 ? scal : (j == 1 ? scal : scal + 6 + 4 * (j - 2));
     bracket((j > 0 ? 4.0 : 3.0) * vbytes, [&] {
       if (vec16)
-        hipLaunchKernelGGL(k_lanczos_update<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
-                           (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
-                           (long long)nd, (const double*)part_a, nb, scal + 4 + 4 * j,
-                           (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b, done);
+        hipLaunchKernelGGL(k_lanczos_update_u<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
+                           W.as<const double>(), (const double*)vec(j),
+                           j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
+                           (const double*)part_a, nb, scal + 4 + 4 * j, (const double*)cur_part, cur_out, prev2, new_part,
+                           done);
       else
-        hipLaunchKernelGGL(k_lanczos_update<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, W.as<double>(),
-                           (const double*)vec(j), j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr,
-                           (long long)nd, (const double*)part_a, nb, scal + 4 + 4 * j,
-                           (const double*)(scal + 6 + 4 * (j > 0 ? j - 1 : 0)), part_b, done);
+        hipLaunchKernelGGL(k_lanczos_update_u<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
+                           W.as<const double>(), (const double*)vec(j),
+                           j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
+                           (const double*)part_a, nb, scal + 4 + 4 * j, (const double*)cur_part, cur_out, prev2, new_part,
+                           done);
     });
     const bool check = (j > 3 && j % 2 == 0);          // krylov.py:76-81
     const bool last = (j + 1 >= limit);
     if (check) {
-      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, part_b, nb, scal + 6 + 4 * j, done);
+      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, new_part, nb, scal + 6 + 4 * j, done);
       hipLaunchKernelGGL(k_lz_coefs, dim3(1), dim3(64), 0, ctx->stream, (const double*)scal, j, dt.real(), dt.imag(),
                          tiny, coef, ctl);
       void* dst = (prev == out) ? RES.p : out;
@@ -696,18 +790,23 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
       }
     }
     if (last) return LZ_FALLBACK;     // beyond one wavefront of coefficients (or no convergence): the synchronous solve decides
-    if (j + 2 > cap) {
-      int ncap = cap * 2 < limit + 1 ? cap * 2 : limit + 1;
-      TmpBuf V2(ctx);
-      MPSE_TRY(V2.alloc(size_t(ncap) * n * es));
-      MPSE_TRY(mpse_memcpy_d2d(ctx, V2.p, V.p, size_t(cap) * n * es));
-      std::swap(V.p, V2.p);
-      cap = ncap;
-    }
-    scale_into(vec(j + 1), W.p, scal + 6 + 4 * j);
   }
   ctx->lz_hint[key] = hc.nvec;
   if (nvec) *nvec = hc.nvec;
+  if (getenv("MPSE_LZ_STATS")) fprintf(stderr, "[lzs] nsite %d n %lld hint %d nvec %d\n", h->nsite, (long long)n, hint, hc.nvec);
+  if (getenv("MPSE_LZ_DEBUG")) {
+    std::vector<double> hs(size_t(SC_COEF + 2 * LZ_MAXM));
+    (void)hipMemcpy(hs.data(), scal, hs.size() * sizeof(double), hipMemcpyDeviceToHost);
+    const int m = hc.nvec;
+    std::vector<double> al, be;
+    for (int i = 0; i < m; ++i) al.push_back(hs[4 + 4 * i]), be.push_back(sqrt(hs[6 + 4 * i]));
+    Coefs c;
+    expm_coefs(m, al, be, sqrt(hs[0]), dt, &c);
+    double err = 0;
+    for (int i = 0; i < m; ++i) err = fmax(err, hypot(c.re[i] - hs[SC_COEF + i], c.im[i] - hs[SC_COEF + LZ_MAXM + i]));
+    fprintf(stderr, "[lz] nvec %d which %d hint %d wait_from %d coef err %.3e (c0 %.6f %.6f dev %.6f %.6f)\n", hc.nvec, hc.which,
+            hint, wait_from, err, c.re[0], c.im[0], hs[SC_COEF], hs[SC_COEF + LZ_MAXM]);
+  }
   return MPSE_OK;
 }
 

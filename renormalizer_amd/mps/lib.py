@@ -5,6 +5,7 @@ Counterpart of renormalizer/mps/lib.py: ``contract_one_site`` (:169-250) is one 
 (:12-118) is a table of HBM-resident handles - the reference's CuPy path copies every
 environment to the host on write and back on read (lib.py:114-118)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -17,9 +18,46 @@ def _as_w(eng, mo):
     return eng.asdevice(np.asarray(mo))
 
 
-def contract_one_site(environ, ms, mo, domain, ms_conj=None):
+_UNIT_PREDICTIONS = {}
+
+
+def predict_unit_channel(mo_host, domain, unit_in):
+    """Unit channel (1-based, 0 = none) of the environment that results from updating an environment whose channel
+    ``unit_in`` is the identity matrix with a site that is an exact isometry in that direction: the outgoing channel g
+    is again the identity when the MPO site passes ``unit_in`` through unchanged and nothing else feeds g.  Pure host
+    logic on the (KB sized) MPO site; the alternative is to measure it on the device (``find_unit_channel``: one small
+    kernel and a read-back per update)."""
+    if unit_in <= 0 or mo_host is None:
+        return 0
+    key = (id(mo_host), domain, int(unit_in))
+    hit = _UNIT_PREDICTIONS.get(key)
+    if hit is not None and hit[0] is mo_host:
+        return hit[1]
+    w = np.asarray(mo_host)
+    u = int(unit_in) - 1
+    eye = np.eye(w.shape[1])
+    out = 0
+    if domain == "L" and u < w.shape[0]:
+        for g in range(w.shape[3]):
+            if np.array_equal(w[u, :, :, g], eye) and not np.any(np.delete(w[:, :, :, g], u, axis=0)):
+                out = g + 1
+                break
+    elif domain == "R" and u < w.shape[3]:
+        for q in range(w.shape[0]):
+            if np.array_equal(w[q, :, :, u], eye) and not np.any(np.delete(w[q], u, axis=2)):
+                out = q + 1
+                break
+    if len(_UNIT_PREDICTIONS) > 4096:
+        _UNIT_PREDICTIONS.clear()
+    _UNIT_PREDICTIONS[key] = (mo_host, out)
+    return out
+
+
+def contract_one_site(environ, ms, mo, domain, ms_conj=None, canonical_mo_host=None):
     """One environment update.  ``ms_conj`` follows the reference convention: it holds the
-    already-conjugated bra tensor; ``None`` means conj(ms) (no copy is made)."""
+    already-conjugated bra tensor; ``None`` means conj(ms) (no copy is made).  ``canonical_mo_host``: the host copy of
+    ``mo`` when the caller guarantees that ``ms`` is an isometry in the direction of the update (it just came out of a
+    QR): the unit channel of the result is then predicted on the host instead of measured on the device."""
     assert domain in ["L", "R"]
     eng = ms.eng
     mo = _as_w(eng, mo)
@@ -47,8 +85,15 @@ def contract_one_site(environ, ms, mo, domain, ms_conj=None):
     eng._check(eng.lib.mpse_env_update(
         eng.ctx, out.code, DOMAIN_L if domain == "L" else DOMAIN_R, C.byref(d), environ.ptr, environ.code,
         ket.ptr, bra.ptr, 1 if ms_conj is None else 0, mo.ptr, mo.code, out.ptr))
-    if ms_conj is None and oshape[0] == oshape[2] and oshape[0] >= UNIT_MIN_BOND:
-        out.unit = find_unit_channel(out)
+    if ms_conj is None and oshape[0] == oshape[2]:
+        if canonical_mo_host is not None and ms.ndim == 3 and environ.unit > 0:
+            # the chain of predictions starts at the sentinel and is carried through small bonds as well
+            out.unit = predict_unit_channel(canonical_mo_host, domain, environ.unit)
+            if os.environ.get("MPSE_VERIFY_UNIT") and oshape[0] >= UNIT_MIN_BOND:
+                measured = find_unit_channel(out)
+                assert measured == out.unit, f"unit channel predicted {out.unit}, measured {measured}"
+        elif oshape[0] >= UNIT_MIN_BOND:
+            out.unit = find_unit_channel(out)
     return out
 
 
@@ -153,7 +198,10 @@ class Environ:
             tensor = self._step(tensor, mps[idx], self._mo(mpo, idx), domain, cj)
             self.write(domain, idx, tensor)
 
-    def GetLR(self, domain, siteidx, mps, mpo, itensor=None, method="Scratch", mps_conj=None):
+    def GetLR(self, domain, siteidx, mps, mpo, itensor=None, method="Scratch", mps_conj=None, canonical=False):
+        """``canonical``: (method "System" only) the site at ``siteidx`` is an exact isometry in the direction of the
+        update - the sweeps pass True right after a QR - so the unit channel of the new environment is predicted from
+        the MPO site instead of being measured."""
         assert domain in ["L", "R"]
         assert method in ["Enviro", "System", "Scratch"]
         if mps_conj is None:
@@ -170,7 +218,11 @@ class Environ:
         else:
             if itensor is None:
                 itensor = self.read(domain, siteidx + (-1 if domain == "L" else 1))
-            itensor = self._step(itensor, mps[siteidx], self._mo(mpo, siteidx), domain, mps_conj[siteidx])
+            mo = self._mo(mpo, siteidx)
+            if canonical and not isinstance(mo, list) and mps_conj[siteidx] is None and hasattr(mpo, "device"):
+                itensor = contract_one_site(itensor, mps[siteidx], mo, domain, canonical_mo_host=mpo[siteidx])
+            else:
+                itensor = self._step(itensor, mps[siteidx], mo, domain, mps_conj[siteidx])
             self.write(domain, siteidx, itensor)
         return itensor
 

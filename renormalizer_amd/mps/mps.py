@@ -1288,45 +1288,61 @@ class Mps:
         environ = Environ(mps, mpo, "R" if mps.to_right else "L")
         local_steps = []
         q = len(mps.qntot)
+
+        def prepare(imps, shape):
+            """Everything the update of site ``imps`` needs that does not depend on the preceding solve: the
+            effective-Hamiltonian descriptor and the quantum-number block plan of its QR.  Called BEFORE the solve whose
+            result the site waits for, so that the host has nothing left to do but enqueue when that solve returns."""
+            hop = hop_expr(environ.read("L", imps - 1), environ.read("R", imps + 1), [mpo.device(imps, eng)], shape)
+            split = (not mps.to_right and imps != 0) or (mps.to_right and imps != n - 1)
+            qnbigl = qnbigr = plan = None
+            if split:
+                qnbigl, qnbigr, _ = mps._get_big_qn([imps], need_mat=False)
+                plan = svd_qn.block_plan(qnbigl, qnbigr, mps.qntot)
+            return hop, split, qnbigl, qnbigr, plan
+
         for _ in range(2):
+            ready = None
             for imps in mps.iter_idx_list(full=True):
                 system = "L" if mps.to_right else "R"
-                l_array = environ.read("L", imps - 1)
-                r_array = environ.read("R", imps + 1)
                 shape = list(mps[imps].shape)
-                w = mpo.device(imps, eng)
-                hop = hop_expr(l_array, r_array, [w], shape)
+                if ready is None:
+                    ready = prepare(imps, shape)
+                hop, split, qnbigl, qnbigr, plan = ready
+                ready = None
+                l_array, r_array = hop.l, hop.r
                 mps_t, j = _local_propagate(cfg, hop, -1j * evolve_dt / 2, mps[imps])
                 local_steps.append(j)
-                qnbigl, qnbigr, _ = mps._get_big_qn([imps], need_mat=False)
-                if (not mps.to_right and imps != 0) or (mps.to_right and imps != n - 1):
-                    u, qnlset, v, qnrset = svd_qn.svd_qn(mps_t, qnbigl, qnbigr, mps.qntot, QR=True, system=system,
-                                                         full_matrices=False)
-                    vt = v.T
-                if not mps.to_right and imps != 0:
+                if not split:
+                    mps[imps] = mps_t.reshape(shape)
+                    continue
+                u, qnlset, v, qnrset = svd_qn.svd_qn(mps_t, qnbigl, qnbigr, mps.qntot, QR=True, system=system,
+                                                     full_matrices=False, plan=plan)
+                vt = v.T
+                if not mps.to_right:
                     mps[imps] = vt.reshape([-1] + shape[1:])
                     mps.qn[imps] = np.array(qnrset, dtype=int).reshape(-1, q)
                     mps.qnidx = imps - 1
-                    r_array = environ.GetLR("R", imps, mps, mpo, itensor=r_array, method="System")
-                    hop_u = hop_expr(l_array, r_array, [], u.shape)
-                    b_t, j = _local_propagate(cfg, hop_u, 1j * evolve_dt / 2, u)
-                    local_steps.append(j)
+                    r_array = environ.GetLR("R", imps, mps, mpo, itensor=r_array, method="System", canonical=True)
+                    hop_b = hop_expr(l_array, r_array, [], u.shape)
                     prv = mps[imps - 1]
+                    ready = prepare(imps - 1, list(prv.shape[:-1]) + [u.shape[1]])
+                    b_t, j = _local_propagate(cfg, hop_b, 1j * evolve_dt / 2, u)
+                    local_steps.append(j)
                     mps[imps - 1] = eng.matmul(prv.reshape(-1, prv.shape[-1]), b_t.reshape(u.shape)) \
                         .reshape(prv.shape[:-1] + (u.shape[1],))
-                elif mps.to_right and imps != n - 1:
+                else:
                     mps[imps] = u.reshape(shape[:-1] + [-1])
                     mps.qn[imps + 1] = np.array(qnlset, dtype=int).reshape(-1, q)
                     mps.qnidx = imps + 1
-                    l_array = environ.GetLR("L", imps, mps, mpo, itensor=l_array, method="System")
-                    hop_svt = hop_expr(l_array, r_array, [], vt.shape)
-                    b_t, j = _local_propagate(cfg, hop_svt, 1j * evolve_dt / 2, vt)
-                    local_steps.append(j)
+                    l_array = environ.GetLR("L", imps, mps, mpo, itensor=l_array, method="System", canonical=True)
+                    hop_b = hop_expr(l_array, r_array, [], vt.shape)
                     nxt = mps[imps + 1]
+                    ready = prepare(imps + 1, [vt.shape[0]] + list(nxt.shape[1:]))
+                    b_t, j = _local_propagate(cfg, hop_b, 1j * evolve_dt / 2, vt)
+                    local_steps.append(j)
                     mps[imps + 1] = eng.matmul(b_t.reshape(vt.shape), nxt.reshape(nxt.shape[0], -1)) \
                         .reshape((vt.shape[0],) + nxt.shape[1:])
-                else:
-                    mps[imps] = mps_t.reshape(shape)
             mps._switch_direction()
         mps.evolve_config.stat = dict(nobs=len(local_steps), min=int(np.min(local_steps)),
                                       max=int(np.max(local_steps)), mean=float(np.mean(local_steps)),

@@ -93,10 +93,12 @@ def _p64(a):
     return a.ctypes.data_as(C.POINTER(C.c_int64))
 
 
-def svd_qn(coef_array, qnbigl, qnbigr, qntot, QR=False, system=None, full_matrices=True, opt_full_matrices=True):
+def svd_qn(coef_array, qnbigl, qnbigr, qntot, QR=False, system=None, full_matrices=True, opt_full_matrices=True,
+           plan=None):
     """Block decomposition of the centre tensor.  Returns ``(u, new_qnl, v, new_qnr)`` for QR and
     ``(u, su, new_qnl, v, sv, new_qnr)`` for SVD with ``coef == u @ diag(s) @ v.T`` (``v.T`` is
-    available as ``v.T``, a device tensor)."""
+    available as ``v.T``, a device tensor).  ``plan``: the result of ``block_plan`` for these quantum numbers when
+    the caller has it already (the sweeps prepare it while the GPU is still busy with the preceding solve)."""
     eng = get_engine()
     coef = eng.asdevice(coef_array)
     qntot = np.asarray(qntot)
@@ -104,7 +106,8 @@ def svd_qn(coef_array, qnbigl, qnbigr, qntot, QR=False, system=None, full_matric
     ncol = int(np.prod(np.asarray(qnbigr).shape[:-1]))
     if coef.size != nrow * ncol:
         raise ValueError(f"coefficient array {coef.shape} does not match quantum numbers ({nrow}x{ncol})")
-    plan = block_plan(qnbigl, qnbigr, qntot)
+    if plan is None:
+        plan = block_plan(qnbigl, qnbigr, qntot)
     blocks, dims, K = plan["blocks"], plan["dims"], plan["K"]
     rows, cols, roff, coff = plan["rows"], plan["cols"], plan["roff"], plan["coff"]
     new_qnl, new_qnr = list(plan["new_qnl"]), list(plan["new_qnr"])
