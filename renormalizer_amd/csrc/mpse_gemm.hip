@@ -20,6 +20,8 @@
 //   * optional structural-zero skipping: a scan kernel flags the 64 x 16 operand tiles that hold data, the K loop
 //     visits only K tiles with data on both sides (block-sparse tensors of the quantum-number-conserving sweeps).
 //   * accumulation order over k is fixed => bitwise reproducible results.
+#include <cstdlib>
+
 #include "mpse_internal.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -55,6 +57,8 @@ struct GemmArgs {
   int nkw;
   unsigned long long* kt_counter;   // profiling only: every workgroup adds the number of K tiles it multiplied
   const int* skip;                  // optional device flag: non-zero -> the launch does nothing (mpse_ctx::skip_flag)
+  unsigned char* cmask;             // optional: flag per output tile (1 = K tiles were multiplied into it); tiles
+                                    // without any are NOT stored - the consumer reads the flags (masked chain)
 };
 
 __device__ __forceinline__ long long idx_off(const IdxMap& m, int i) {
@@ -255,12 +259,23 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
       acc_t2[i][j] = v4d{0, 0, 0, 0};
     }
 
-  // next K tile >= from (and < kt_end) whose A and B tiles both hold non-zeros; kt_end if there is none
+  // next K tile >= from (and < kt_end) whose A and B tiles both hold non-zeros; kt_end if there is none.
+  // The flag words of this workgroup's tile row / column are fetched into LDS once (up to MASKW words each): read
+  // from global memory inside the K loop they put an L2 round trip in front of every tile's loads.
+  constexpr int MASKW = 64;
+  __shared__ unsigned long long s_mask[2][MASKW];
   const unsigned long long* am = nullptr;
   const unsigned long long* bm = nullptr;
   if constexpr (KS) {
     if (g.amask) am = g.amask + ((long long)b * g.tiles_m + tm) * g.nkw;
     if (g.bmask) bm = g.bmask + ((long long)b * g.tiles_n + tn) * g.nkw;
+    if ((am || bm) && g.nkw <= MASKW) {
+      if (tid < g.nkw) s_mask[0][tid] = am ? am[tid] : 0x0101010101010101ull;
+      if (tid >= 64 && tid < 64 + g.nkw) s_mask[1][tid - 64] = bm ? bm[tid - 64] : 0x0101010101010101ull;
+      __syncthreads();
+      am = s_mask[0];
+      bm = s_mask[1];
+    }
   }
   auto next_kt = [&](int from) -> int {
     if (!am && !bm) return from;
@@ -391,6 +406,10 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
   }
 
   if (g.kt_counter && tid == 0 && kt_done) atomicAdd(g.kt_counter, (unsigned long long)kt_done);
+  if (g.cmask) {   // workgroup-uniform
+    if (tid == 0) g.cmask[((long long)b * g.tiles_m + tm) * g.tiles_n + tn] = kt_done > 0 ? 1 : 0;
+    if (kt_done == 0) return;
+  }
   if constexpr (M3) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -646,7 +665,8 @@ __global__ __launch_bounds__(256) void k_transpose_inner(double* out, const doub
 
 }  // namespace
 
-static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C, int skip_zero) {
+static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C, int skip_zero,
+                     const void* amask_ext = nullptr, void* cmask_out = nullptr) {
   if (!ctx || !d) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
   if ((d->dtype_a != MPSE_F64 && d->dtype_a != MPSE_C128) || (d->dtype_b != MPSE_F64 && d->dtype_b != MPSE_C128))
@@ -692,12 +712,19 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.amask = g.bmask = nullptr;
   g.nkw = 0;
   g.skip = ctx->skip_flag;
+  g.cmask = nullptr;
   TmpBuf WSB(ctx), MSK(ctx);
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-  if (base_blocks < n_cu && nkt_all >= 4) {
+  // tuning knobs of the split-K policy (environment, read once): output tiles below which K is sliced, and how many
+  // workgroups the slicing aims at
+  static const int sk_tiles = [] { const char* e = getenv("MPSE_SPLITK_TILES"); return e ? atoi(e) : 0; }();
+  static const int sk_target = [] { const char* e = getenv("MPSE_SPLITK_TARGET"); return e ? atoi(e) : 0; }();
+  const int tiles_limit = sk_tiles > 0 ? sk_tiles : n_cu;
+  const long long wg_target = sk_target > 0 ? sk_target : 2LL * n_cu;
+  if (base_blocks < tiles_limit && nkt_all >= 4) {
     // fewer output tiles than CUs: slice K until ~2 workgroups per CU exist.  (One tile per CU runs as fast
     // unsplit as split in two + reduction pass since the K loop prefetches fragments: measured, 4096x256 C-step.)
-    int want = (int)((2LL * n_cu + base_blocks - 1) / base_blocks);
+    int want = (int)((wg_target + base_blocks - 1) / base_blocks);
     int maxs = nkt_all / 2;                                           // at least two k-tiles per slice
     int S = want < maxs ? want : maxs;
     if (S > 1) {
@@ -710,6 +737,11 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   }
   long long nblk = base_blocks * g.ksplit;
   if (nblk > 0x7fffffffLL) return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpse_gemm: grid too large");
+  if (cmask_out) {
+    if (g.ksplit != 1 || g.use_beta)
+      return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_gemm: output tile flags need an unsplit, non-accumulating product");
+    g.cmask = static_cast<unsigned char*>(cmask_out);
+  }
 
   dim3 grid((unsigned)nblk), block(256);
   mpse_ctx::ProfRec rec;
@@ -722,12 +754,14 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
                           double(g.M) * g.N * ((ca || cb) ? 16 : 8) * (g.use_beta ? 2 : 1)),
       &rec);
   g.kt_counter = prof_this && ctx->prof_ktiles ? ctx->prof_ktiles + variant : nullptr;
-  if (skip_zero && is_single(g.kA) && is_single(g.kB) && nkt_all >= 2 && d->batch <= 16384) {
+  if (amask_ext && !(is_single(g.kA) && is_single(g.kB)))
+    return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_gemm: a producer's operand mask needs single-level K indices");
+  if ((skip_zero || amask_ext) && is_single(g.kA) && is_single(g.kB) && (nkt_all >= 2 || amask_ext) && d->batch <= 16384) {
     // tile occupancy of both operands (one small scan launch), then only K tiles with data on both sides are visited
     g.nkw = (nkt_all + 7) / 8;
     const size_t wa = size_t(d->batch) * g.tiles_m * g.nkw, wb = size_t(d->batch) * g.tiles_n * g.nkw;
     // skip_zero bit 0: scan A, bit 1: scan B (an operand that is as large as the product itself is not worth a pass)
-    const bool sa = skip_zero & 1, sb_ = skip_zero & 2;
+    const bool sa = (skip_zero & 1) && !amask_ext, sb_ = skip_zero & 2;
     // Inside a Krylov solve the environments do not change: their masks are computed once and kept (mpse_internal.h)
     auto cacheable = [&](const void* p) {
       if (!ctx->occ_cache_on) return false;
@@ -795,7 +829,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
       const dim3 og((nkt_all + 3) / 4, tmax, (unsigned)(2 * d->batch));
       hipLaunchKernelGGL(k_tile_occ, og, dim3(256), 0, ctx->stream, oa, ob, g.K, g.nkw, (int)d->batch, ctx->skip_flag);
     }
-    g.amask = sa ? am : nullptr;
+    g.amask = sa ? am : static_cast<const unsigned long long*>(amask_ext);
     g.bmask = sb_ ? bmk : nullptr;
   }
   const bool ks = is_single(g.kA) && is_single(g.kB);
@@ -834,7 +868,8 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
 
 int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index ma, mpse_index ka, mpse_index kb,
               mpse_index nb, mpse_index mc, mpse_index nc, int64_t batch, int64_t sba, int64_t sbb, int64_t sbc,
-              const void* A, const void* B, void* C, double alpha, double beta, int skip_zero) {
+              const void* A, const void* B, void* C, double alpha, double beta, int skip_zero, const void* amask_ext,
+              void* cmask_out) {
   mpse_gemm_desc d;
   d.dtype_a = dta;
   d.dtype_b = dtb;
@@ -855,7 +890,7 @@ int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index 
   d.beta_re = beta;
   d.beta_im = 0.0;
   d.skip_zero_tiles = skip_zero;
-  return gemm_impl(ctx, &d, A, B, C, skip_zero);
+  return gemm_impl(ctx, &d, A, B, C, skip_zero, amask_ext, cmask_out);
 }
 
 extern "C" int mpse_transpose_inner(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t d0, int64_t d1,

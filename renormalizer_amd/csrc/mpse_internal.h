@@ -77,6 +77,15 @@ struct mpse_ctx {
   const int* skip_flag = nullptr;
   // Krylov dimension of the last solve per problem class (number of sites, vector length): how far to run ahead
   std::unordered_map<unsigned long long, int> lz_hint;
+  // sparse forms of MPO sites built for the masked one-site chain (mpse_contract.hip), kept like the occupancy
+  // masks for the duration of a Krylov solve
+  struct WCsr {
+    const void* w;
+    long long wl, d, wr;
+    void* cnt;
+    void* ent;
+  };
+  std::vector<WCsr> wcsr_cache;
   bool occ_cache_on = false;
   const char* occ_lo[2] = {nullptr, nullptr};
   const char* occ_hi[2] = {nullptr, nullptr};
@@ -140,7 +149,7 @@ static inline mpse_index idx2(int64_t hi_ext, int64_t lo_ext, int64_t s_hi, int6
 int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index ma, mpse_index ka,
               mpse_index kb, mpse_index nb, mpse_index mc, mpse_index nc, int64_t batch, int64_t sba,
               int64_t sbb, int64_t sbc, const void* A, const void* B, void* C, double alpha = 1.0,
-              double beta = 0.0, int skip_zero = 0);
+              double beta = 0.0, int skip_zero = 0, const void* amask_ext = nullptr, void* cmask_out = nullptr);
 
 // Low-latency read-back of a few device doubles: a one-wave kernel copies them into the mapped pinned buffer
 // and then publishes a sequence number; the host spins on that number instead of going through a copy-engine

@@ -10,6 +10,7 @@
 // All index permutations are absorbed in operand strides; nothing is transposed in memory.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -23,7 +24,20 @@ namespace mpse_plan {
 enum Buf { B_L = 0, B_R, B_W0, B_W1, B_C, B_BRA, B_OUT, B_T1, B_T2, B_T3, B_W2, B_W3, B_COUNT };
 inline int w_buf(int layer) { return layer == 0 ? B_W0 : layer == 1 ? B_W1 : layer == 2 ? B_W2 : B_W3; }
 
-enum Kind { K_GEMM = 0, K_COPY = 1 };
+enum Kind { K_GEMM = 0, K_COPY = 1, K_WSTEP = 2 };
+enum Mask { M_T1_LO = 0, M_T1_HI, M_T2_LO, M_T2_HI, M_COUNT };
+
+// MPO step of the masked one-site chain (K_WSTEP): T2[a,d,f,k] = sum_{b,e} W[b,d,e,f] X[b][a,e,k] with X[b] = T1[b]
+// (channel-outer intermediate of the first GEMMs) or, for the unit channel of the left environment, the centre tensor
+// itself.  Tiles of T1 into which nothing was multiplied were never stored: they are recognised by the producers'
+// tile flags and never read; tiles of T2 that stay empty are not stored either and flagged for the consumer GEMMs.
+struct WStepDesc {
+  int64_t Da = 0, d = 0, wl = 0, wr = 0, Dk = 0;
+  int64_t l_unit = -1;        // 0-based channel of X that is the centre tensor (buffer a), -1: none
+  int64_t r_unit = -1;        // 0-based channel f that is always stored (the consumer copies it), -1: none
+  int64_t t1_tiles_n = 0;     // tile columns of the producers' flag arrays (ceil(d Dk / 64))
+  int64_t nkw_lo = 0, nkw_hi = 0;   // 64-bit words per tile row of the consumers' masks (f < r_unit / f > r_unit)
+};
 
 struct Step {
   int a, b, c;                 // buffer ids
@@ -35,11 +49,16 @@ struct Step {
   int kind = K_GEMM;           // K_COPY: C(i,j) = A(i,j) with A indexed by (ma, ka), C by (mc, nc); b unused
   double beta = 0.0;           // K_GEMM: C = A.B + beta C
   int skip_zero = 0;           // K_GEMM: scan both operands for all-zero tiles and skip them (block-sparse sweeps)
+  int cmask_slot = -1;         // K_GEMM: byte flag per 64 x 64 output tile into this mask buffer (1 = something was
+                               // multiplied into it); tiles with nothing are NOT stored (consumer: K_WSTEP)
+  int amask_slot = -1;         // K_GEMM: tile-occupancy mask of operand A written by a K_WSTEP producer (no scan)
+  WStepDesc ws;                // K_WSTEP (a = centre tensor, b = W site, c = T2; T1 is B_T1)
 };
 
 struct Plan {
   std::vector<Step> steps;
   int64_t tmp_elems[3] = {0, 0, 0};  // T1, T2, T3 sizes (elements of the working dtype)
+  int64_t mask_bytes[M_COUNT] = {0, 0, 0, 0};   // tile-flag buffers of the masked chain
   const char* error = nullptr;
 };
 
@@ -139,6 +158,86 @@ inline void push_w(Plan& p, int wbuf, int w_dtype, int tin, int tout, int t_dtyp
        /*C=T_out[a]: (d,f), n*/ i1(d * wr, N), i1(N, 1), na, 0, d * N, d * wr * N);
 }
 
+// One-site matvec whose intermediates never carry their structural zeros through HBM (large centres only):
+//   A: T1[b] = L[:, b, :] C for the channels that are not the left unit channel; output tiles into which no K tile
+//      was multiplied are flagged and not stored;
+//   W: custom MPO step (K_WSTEP) reading the flagged tiles of T1 and the centre itself for the unit channel, writing
+//      the non-empty parts of T2 and their tile mask;
+//   C: out = T2 . R with the mask of T2 (from W) and the scanned mask of R.
+inline int64_t& masked_chain_min() {   // smallest M1 * N (elements of T1 per channel) that takes this path
+  static int64_t v = [] {                // off unless MPSE_MASKED_CHAIN=1: measured slower than the dense chain, DESIGN.md
+    const char* e = getenv("MPSE_MASKED_CHAIN");
+    return (e && e[0] == '1') ? (int64_t(1) << 20) : (int64_t(1) << 62);
+  }();
+  return v;
+}
+inline bool masked_chain_ok(int dtype, const mpse_heff& h) {
+  const mpse_dims& s = h.dims;
+  const int64_t Dl = s.Dl_ket, Dr = s.Dr_ket, d = s.d0;
+  const int64_t Dlb = s.Dl_bra > 0 ? s.Dl_bra : Dl, Drb = s.Dr_bra > 0 ? s.Dr_bra : Dr;
+  if (h.nsite != 1 || (s.danc > 1) || h.w_dtype != MPSE_F64) return false;
+  if (Dr % 64 != 0 || (Dlb * d) % 64 != 0 || Dlb % 64 != 0) return false;
+  if (64 % d != 0 || s.wl * d > 96 || s.wr > 32) return false;     // limits of the MPO-step kernel (LDS staging)
+  if (Dlb * d * Dr < masked_chain_min()) return false;
+  (void)dtype;
+  (void)Drb;
+  return true;
+}
+
+inline Plan plan_heff1_masked(int dtype, const mpse_heff& h) {
+  Plan p;
+  const mpse_dims& s = h.dims;
+  const int64_t Dl = s.Dl_ket, Dr = s.Dr_ket, wl = s.wl, wr = s.wr, d = s.d0;
+  const int64_t Dlb = s.Dl_bra > 0 ? s.Dl_bra : Dl, Drb = s.Dr_bra > 0 ? s.Dr_bra : Dr;
+  const int64_t N = d * Dr;
+  p.tmp_elems[0] = Dlb * wl * N;
+  p.tmp_elems[1] = Dlb * d * wr * Dr;
+  const int64_t lu = (h.l_unit >= 1 && h.l_unit <= wl && Dlb == Dl) ? h.l_unit - 1 : -1;
+  const int64_t ru = (h.r_unit >= 1 && h.r_unit <= wr && Drb == Dr) ? h.r_unit - 1 : -1;
+  const int64_t tiles_n1 = (N + 63) / 64;
+  // A: channels below / above the unit channel (all of them when there is none)
+  const int64_t lo[2] = {0, lu + 1}, hi[2] = {lu >= 0 ? lu : wl, lu >= 0 ? wl : 0};
+  for (int r = 0; r < 2; ++r) {
+    const int64_t b0 = lo[r], nb = hi[r] - lo[r];
+    if (nb <= 0) continue;
+    push(p, B_L, b0 * Dl, h.l_dtype, 0, B_C, 0, dtype, 0, B_T1, b0 * Dlb * N, i2(nb, Dlb, Dl, wl * Dl), i1(Dl, 1),
+         i1(Dl, N), i1(N, 1), i1(nb * Dlb, N), i1(N, 1));
+    p.steps.back().skip_zero = 3;
+    p.steps.back().cmask_slot = r == 0 ? M_T1_LO : M_T1_HI;
+    p.mask_bytes[r == 0 ? M_T1_LO : M_T1_HI] = ((nb * Dlb + 63) / 64) * tiles_n1;
+  }
+  // W
+  Step w{B_C, B_W0, B_T2, 0, 0, 0, dtype, h.w_dtype, 0, 0, {}, {}, {}, {}, {}, {}, 1, 0, 0, 0};
+  w.kind = K_WSTEP;
+  w.ws.Da = Dlb, w.ws.d = d, w.ws.wl = wl, w.ws.wr = wr, w.ws.Dk = Dr;
+  w.ws.l_unit = lu, w.ws.r_unit = ru, w.ws.t1_tiles_n = tiles_n1;
+  const int64_t nf_lo = ru >= 0 ? ru : wr, nf_hi = ru >= 0 ? wr - ru - 1 : 0;
+  w.ws.nkw_lo = ((nf_lo * Dr + 15) / 16 + 7) / 8;
+  w.ws.nkw_hi = ((nf_hi * Dr + 15) / 16 + 7) / 8;
+  const int64_t tiles_m2 = (Dlb * d + 63) / 64;
+  p.mask_bytes[M_T2_LO] = tiles_m2 * w.ws.nkw_lo * 8;
+  p.mask_bytes[M_T2_HI] = tiles_m2 * w.ws.nkw_hi * 8;
+  p.steps.push_back(w);
+  // C
+  double beta = 0.0;
+  if (ru >= 0) {
+    push_copy(p, B_T2, ru * Dr, B_OUT, 0, dtype, i2(Dlb * d, 1, wr * Dr, Dr), i1(Dr, 1), i1(Dlb * d, Drb), i1(Drb, 1));
+    beta = 1.0;
+  }
+  const int64_t flo[2] = {0, ru + 1}, fhi[2] = {ru >= 0 ? ru : wr, ru >= 0 ? wr : 0};
+  for (int r = 0; r < 2; ++r) {
+    const int64_t f0 = flo[r], nf = fhi[r] - flo[r];
+    if (nf <= 0) continue;
+    push(p, B_T2, f0 * Dr, dtype, 0, B_R, f0 * Dr, h.r_dtype, 0, B_OUT, 0, i1(Dlb * d, wr * Dr), i1(nf * Dr, 1),
+         i1(nf * Dr, 1), i1(Drb, wr * Dr), i1(Dlb * d, Drb), i1(Drb, 1));
+    p.steps.back().beta = beta;
+    p.steps.back().skip_zero = 2;
+    p.steps.back().amask_slot = r == 0 ? M_T2_LO : M_T2_HI;
+    beta = 1.0;
+  }
+  return p;
+}
+
 // Effective Hamiltonian matvec, mps/hop_expr.py:57-115.  The bra-side bonds (rows of L / R, bonds of `out`) may
 // differ from the ket-side bonds (columns of L / R, bonds of C): that is the projection of H C onto another
 // state's bond spaces used by the variational compression (mps/mp.py:513-650); the Krylov / Davidson drivers
@@ -161,6 +260,7 @@ inline Plan plan_heff(int dtype, const mpse_heff& h) {
     return p;
   }
   if (h.nsite == 1) {
+    if (masked_chain_ok(dtype, h)) return plan_heff1_masked(dtype, h);
     // abc,bdef,lfk,cek->adl (hop_expr.py:75-79); ancilla cegk->adgl (87-91)
     const int64_t d = s.d0, N = d * anc * Dr, Nb = anc * Dr;
     p.tmp_elems[0] = Dlb * wl * N;

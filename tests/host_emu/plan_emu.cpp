@@ -67,6 +67,40 @@ static int run(int dtype, const Plan& p, const void* bufs_in[B_COUNT]) {
     const size_t ea = s.dta == MPSE_C128 ? 16 : 8, eb = s.dtb == MPSE_C128 ? 16 : 8;
     const int dtc = (s.dta == MPSE_C128 || s.dtb == MPSE_C128) ? MPSE_C128 : MPSE_F64;
     if (dtc != dtype) return MPSE_ERR_ARG;
+    if (s.kind == K_WSTEP) {   // dense restatement of the masked MPO step (tile flags play no role on the host)
+      const WStepDesc& w = s.ws;
+      const cd* X0c = (const cd*)bufs[s.a];
+      const double* X0r = (const double*)bufs[s.a];
+      const double* W = (const double*)bufs[s.b];
+      const void* T1 = bufs[B_T1];
+      void* T2 = const_cast<void*>(bufs[s.c]);
+      for (int64_t a = 0; a < w.Da; ++a)
+        for (int64_t dd = 0; dd < w.d; ++dd)
+          for (int64_t f = 0; f < w.wr; ++f)
+            for (int64_t k = 0; k < w.Dk; ++k) {
+              cd acc = 0;
+              for (int64_t b = 0; b < w.wl; ++b)
+                for (int64_t e = 0; e < w.d; ++e) {
+                  const double v = W[((b * w.d + dd) * w.d + e) * w.wr + f];
+                  if (v == 0.0) continue;
+                  cd x;
+                  if (b == w.l_unit) {
+                    const int64_t o = (a * w.d + e) * w.Dk + k;
+                    x = dtype == MPSE_C128 ? X0c[o] : cd(X0r[o], 0.0);
+                  } else {
+                    const int64_t o = ((b * w.Da + a) * w.d + e) * w.Dk + k;
+                    x = dtype == MPSE_C128 ? ((const cd*)T1)[o] : cd(((const double*)T1)[o], 0.0);
+                  }
+                  acc += v * x;
+                }
+              const int64_t o = ((a * w.d + dd) * w.wr + f) * w.Dk + k;
+              if (dtype == MPSE_C128)
+                ((cd*)T2)[o] = acc;
+              else
+                ((double*)T2)[o] = acc.real();
+            }
+      continue;
+    }
     if (s.kind == K_COPY) {
       naive_copy(s, dtc, (const char*)bufs[s.a] + s.a_off * ea, (char*)const_cast<void*>(bufs[s.c]) + s.c_off * es);
       continue;
@@ -129,3 +163,4 @@ extern "C" int emu_heff_apply2(int dtype, const mpse_heff* h, const void* C, voi
 }
 
 extern "C" void emu_set_unit_threshold(long long macs) { unit_threshold() = macs; }
+extern "C" void emu_set_masked_chain_min(long long elems) { masked_chain_min() = elems; }

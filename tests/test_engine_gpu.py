@@ -8,6 +8,7 @@ import pytest
 
 from oracle import mps_oracle as orc
 from renormalizer_amd import engine as E
+from renormalizer_amd.mps.hop_expr import hop_expr
 
 pytestmark = pytest.mark.gpu
 
@@ -506,3 +507,34 @@ def test_device_copies_all_alignments(eng):
             dst = eng.empty((n - 1,), np.float64)
             eng._check(eng.lib.mpse_memcpy_d2d(eng.ctx, dst.ptr, shifted.ptr, (n - 1) * 8))
             assert np.array_equal(dst.to_host(), a[1:])
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_masked_one_site_chain_block_sparse_vs_oracle(eng, cplx):
+    """The one-site matvec whose intermediates skip their structural zeros (tile-flagged T1 / T2, custom MPO step,
+    mpse_plans.h plan_heff1_masked) at a size that takes that path (D = 256, d = 16): block-sparse operands with two
+    bond sectors that do not align with the 64-wide tiles, with and without unit channels, against the oracle."""
+    rng = np.random.default_rng(31)
+    D, d, wl, wr = 256, 16, 5, 4
+    sec = np.array([0] * 100 + [1] * 156)
+    dl = np.array([0, 0, 1, -1, 0])                       # charge carried by the channels of L
+    dr = np.array([0, 1, -1, 0])
+    l = _rand(rng, (D, wl, D), cplx) * (sec[:, None, None] - sec[None, None, :] == dl[None, :, None])
+    r = _rand(rng, (D, wr, D), cplx) * (sec[:, None, None] - sec[None, None, :] == dr[None, :, None])
+    w = rng.standard_normal((wl, d, d, wr)) * (rng.random((wl, d, d, wr)) < 0.05)
+    c = _rand(rng, (D, d, D), cplx) * (sec[:, None, None] == sec[None, None, :])
+    for lu, ru in ((0, 0), (1, wr)):
+        l2, r2 = l.copy(), r.copy()
+        if lu:
+            l2[:, lu - 1, :] = np.eye(D)
+        if ru:
+            r2[:, ru - 1, :] = np.eye(D)
+        ld, rd = eng.asdevice(l2), eng.asdevice(r2)
+        ld.unit, rd.unit = lu, ru
+        hop = hop_expr(ld, rd, [eng.asdevice(w)], c.shape)
+        out = hop(eng.asdevice(c)).to_host()
+        ref = orc.hop_apply(l2, r2, [w], c)
+        assert _relerr(out.ravel(), ref.ravel()) < 1e-12, (lu, ru)
+        # an all-zero centre passes through the flags untouched
+        z = hop(eng.zeros(c.shape, c.dtype)).to_host()
+        assert np.abs(z).max() == 0.0

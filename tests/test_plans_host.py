@@ -364,3 +364,33 @@ def test_stacked_mpo_plans_vs_golden(emu, golden_dir):
         assert emu.emu_heff_apply2(E.dtype_code(c.dtype), C.byref(h), cz.ctypes.data, outz.ctypes.data) == 0
         assert np.abs(outz[..., 0, :] - g("out")).max() < 1e-11 * max(1, np.abs(g("out")).max())
         assert np.abs(outz[..., 1, :] - 2 * g("out")).max() < 1e-10 * max(1, np.abs(g("out")).max())
+
+
+def test_masked_one_site_chain_plan(emu):
+    """plan_heff1_masked (tile-flagged intermediates, custom MPO step): the same numbers as the oracle, with and
+    without unit channels on either side, square and projected (bra bonds != ket bonds)."""
+    emu.emu_set_masked_chain_min.argtypes = [C.c_longlong]
+    emu.emu_set_masked_chain_min(1)
+    try:
+        rng = np.random.default_rng(17)
+        for cplx in (False, True):
+            for (Dl, Dr, d, wl, wr, Dlb, Drb) in ((64, 64, 2, 3, 4, 64, 64), (64, 64, 1, 2, 3, 128, 64)):
+                l = _rand(rng, (Dlb, wl, Dl), cplx)
+                r = _rand(rng, (Drb, wr, Dr), cplx)
+                w0 = _rand(rng, (wl, d, d, wr), False) * (rng.random((wl, d, d, wr)) < 0.4)
+                c = _rand(rng, (Dl, d, Dr), cplx)
+                ref = np.einsum("abc,bdef,lfk,cek->adl", l, w0, r, c)
+                out = emu_heff(emu, l, r, [w0], c)
+                assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max()
+                if Dl == Dlb and Dr == Drb:
+                    for lu, ru in ((1, 0), (0, wr), (2, 1)):
+                        l2, r2 = l.copy(), r.copy()
+                        if lu:
+                            l2[:, lu - 1, :] = np.eye(Dl)
+                        if ru:
+                            r2[:, ru - 1, :] = np.eye(Dr)
+                        ref = np.einsum("abc,bdef,lfk,cek->adl", l2, w0, r2, c)
+                        out = emu_heff(emu, l2, r2, [w0], c, l_unit=lu, r_unit=ru)
+                        assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max(), (lu, ru)
+    finally:
+        emu.emu_set_masked_chain_min(1 << 20)
