@@ -40,7 +40,8 @@ struct GemmArgs {
   IdxMap mA, kA, kB, nB, mC, nC;
   long long sbA, sbB, sbC;  // batch strides in elements
   int M, N, K;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n;     // workgroup tiles
+  int mtiles_m, mtiles_n;   // 64 x 64 tiles (granularity of the occupancy masks)
   int a_kfast, b_kfast;
   int conjA, conjB;
   int use_beta;
@@ -72,12 +73,17 @@ __device__ __forceinline__ long long idx_off(const IdxMap& m, int i) {
 #ifndef MPSE_GEMM_3M
 #define MPSE_GEMM_3M 1
 #endif
-constexpr int BM = 64, BN = 64, BK = 16, LD = 80, LDK = BK + 1;  // panel = BK*LD >= BM*LDK doubles
-constexpr int NLD = BM * BK / 256;                             // staged elements per thread and operand
+constexpr int BM = 64, BN = 64, BK = 16, LDK = BK + 1;   // BM x BN: granularity of the tile-occupancy masks
 
 // KS: both K maps are single level -> no integer division in the K loop
-template <bool CA, bool CB, bool KS>
-__global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(const GemmArgs g) {
+// WS: waves per side of the workgroup tile.  WS = 2: 256 threads own 64 x 64 (the workhorse); WS = 1: ONE wave owns
+// 32 x 32 - for products whose 64 x 64 tiles cannot fill the chip, four times as many workgroups instead of slicing K
+// into partial sums that a second kernel has to add up.
+template <bool CA, bool CB, bool KS, int WS>
+__global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_3M ? 2 : 3)) void k_gemm(const GemmArgs g) {
+  constexpr int TBM = 32 * WS, TBN = 32 * WS, NT = 64 * WS * WS;
+  constexpr int LD = WS == 2 ? 80 : 48;          // [k][i] panel rows; LD mod 32 == 16 keeps the fragment reads conflict free
+  constexpr int NLD = TBM * BK / NT;             // staged elements per thread and operand (panel = BK*LD >= TBM*LDK doubles)
   constexpr bool CC = CA || CB;
   constexpr int EA = CA ? 2 : 1, EB = CB ? 2 : 1, EC = CC ? 2 : 1;
   // one LDS object: [Are | Aim? | Bre | Bim?], each BK x LD doubles
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WS == 2 ? wave >> 1 : 0, wn = WS == 2 ? wave & 1 : 0;
 
   const int ntile = g.tiles_m * g.tiles_n;
   const int bid = blockIdx.x;
@@ -113,22 +119,22 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
   for (int r = 0; r < NLD; ++r) {
     if (g.a_kfast) {
       ak[r] = tid % BK;
-      ai[r] = tid / BK + (256 / BK) * r;
+      ai[r] = tid / BK + (NT / BK) * r;
     } else {
-      ai[r] = tid & 63;
-      ak[r] = (tid >> 6) + 4 * r;
+      ai[r] = tid % TBM;
+      ak[r] = tid / TBM + (NT / TBM) * r;
     }
     if (g.b_kfast) {
       bk[r] = tid % BK;
-      bj[r] = tid / BK + (256 / BK) * r;
+      bj[r] = tid / BK + (NT / BK) * r;
     } else {
-      bj[r] = tid & 63;
-      bk[r] = (tid >> 6) + 4 * r;
+      bj[r] = tid % TBN;
+      bk[r] = tid / TBN + (NT / TBN) * r;
     }
     // rows / columns past the edge read a clamped (valid) address: they only feed outputs that
     // are never stored, so no predication is needed and every load below is unconditional
-    int gi = min(tm * BM + ai[r], g.M - 1);
-    int gj = min(tn * BN + bj[r], g.N - 1);
+    int gi = min(tm * TBM + ai[r], g.M - 1);
+    int gj = min(tn * TBN + bj[r], g.N - 1);
     aoff[r] = idx_off(g.mA, gi);
     boff[r] = idx_off(g.nB, gj);
   }
@@ -267,11 +273,14 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
   const unsigned long long* am = nullptr;
   const unsigned long long* bm = nullptr;
   if constexpr (KS) {
-    if (g.amask) am = g.amask + ((long long)b * g.tiles_m + tm) * g.nkw;
-    if (g.bmask) bm = g.bmask + ((long long)b * g.tiles_n + tn) * g.nkw;
+    // masks are kept per 64 rows / columns whatever the workgroup tile
+    if (g.amask) am = g.amask + ((long long)b * g.mtiles_m + (tm * TBM) / BM) * g.nkw;
+    if (g.bmask) bm = g.bmask + ((long long)b * g.mtiles_n + (tn * TBN) / BN) * g.nkw;
     if ((am || bm) && g.nkw <= MASKW) {
-      if (tid < g.nkw) s_mask[0][tid] = am ? am[tid] : 0x0101010101010101ull;
-      if (tid >= 64 && tid < 64 + g.nkw) s_mask[1][tid - 64] = bm ? bm[tid - 64] : 0x0101010101010101ull;
+      if (tid < g.nkw) {
+        s_mask[0][tid] = am ? am[tid] : 0x0101010101010101ull;
+        s_mask[1][tid] = bm ? bm[tid] : 0x0101010101010101ull;
+      }
       __syncthreads();
       am = s_mask[0];
       bm = s_mask[1];
@@ -425,13 +434,13 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
     double* wsb = g.ws + (long long)bs * g.M * g.N * EC;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int gj = tn * BN + wn * 32 + j * 16 + (lane & 15);
+      const int gj = tn * TBN + wn * 32 + j * 16 + (lane & 15);
       if (gj >= g.N) continue;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int gi = tm * BM + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+          const int gi = tm * TBM + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
           if (gi >= g.M) continue;
           double* p = wsb + ((long long)gi * g.N + gj) * EC;
           if constexpr (CC)
@@ -444,14 +453,14 @@ __global__ __launch_bounds__(256, CA && CB && MPSE_GEMM_3M ? 2 : 3) void k_gemm(
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int gj = tn * BN + wn * 32 + j * 16 + (lane & 15);
+    const int gj = tn * TBN + wn * 32 + j * 16 + (lane & 15);
     if (gj >= g.N) continue;
     const long long coffn = idx_off(g.nC, gj);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gi = tm * BM + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        const int gi = tm * TBM + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
         if (gi >= g.M) continue;
         double* p = C + (idx_off(g.mC, gi) + coffn) * EC;
         const double xr = acc_re[i][j][r];
@@ -690,8 +699,18 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.M = g.mA.ext;
   g.N = g.nB.ext;
   g.K = g.kA.ext;
-  g.tiles_m = (g.M + BM - 1) / BM;
-  g.tiles_n = (g.N + BN - 1) / BN;
+  g.mtiles_m = (g.M + BM - 1) / BM;
+  g.mtiles_n = (g.N + BN - 1) / BN;
+  // workgroup tile: 64 x 64 (four waves).  A 32 x 32 one-wave tile for products whose 64 x 64 tiles cannot fill the
+  // chip (four times the workgroups before K has to be sliced) exists behind MPSE_SMALL_TILES=1; measured on the
+  // headline run it loses to split-K by 17 % (one wave walking the whole K is a longer latency chain than many
+  // workgroups walking two K tiles each plus a reduction pass), so it is off.
+  static const bool small_ok = [] { const char* e = getenv("MPSE_SMALL_TILES"); return e && e[0] == '1'; }();
+  const int n_cu0 = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  const bool small = small_ok && !cmask_out && (long long)g.mtiles_m * g.mtiles_n * d->batch < n_cu0;
+  const int TB = small ? 32 : 64;
+  g.tiles_m = (g.M + TB - 1) / TB;
+  g.tiles_n = (g.N + TB - 1) / TB;
   auto fast = [](const IdxMap& m) { return m.ext <= 1 ? (long long)1 << 60 : (m.s_lo < 0 ? -m.s_lo : m.s_lo); };
   g.a_kfast = fast(g.kA) <= fast(g.mA);
   g.b_kfast = fast(g.kB) <= fast(g.nB);
@@ -743,7 +762,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     g.cmask = static_cast<unsigned char*>(cmask_out);
   }
 
-  dim3 grid((unsigned)nblk), block(256);
+  dim3 grid((unsigned)nblk), block(small ? 64 : 256);
   mpse_ctx::ProfRec rec;
   const int variant = (ca ? 1 : 0) + (cb ? 2 : 0);
   const double mnk = double(g.M) * double(g.N) * double(g.K) * double(d->batch);
@@ -759,7 +778,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   if ((skip_zero || amask_ext) && is_single(g.kA) && is_single(g.kB) && (nkt_all >= 2 || amask_ext) && d->batch <= 16384) {
     // tile occupancy of both operands (one small scan launch), then only K tiles with data on both sides are visited
     g.nkw = (nkt_all + 7) / 8;
-    const size_t wa = size_t(d->batch) * g.tiles_m * g.nkw, wb = size_t(d->batch) * g.tiles_n * g.nkw;
+    const size_t wa = size_t(d->batch) * g.mtiles_m * g.nkw, wb = size_t(d->batch) * g.mtiles_n * g.nkw;
     // skip_zero bit 0: scan A, bit 1: scan B (an operand that is as large as the product itself is not worth a pass)
     const bool sa = (skip_zero & 1) && !amask_ext, sb_ = skip_zero & 2;
     // Inside a Krylov solve the environments do not change: their masks are computed once and kept (mpse_internal.h)
@@ -787,11 +806,11 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     mpse_ctx::OccKey ka, kb;
     const bool ca_ok = sa && cacheable(g.A), cb_ok = sb_ && cacheable(g.B);
     if (ca_ok) {
-      ka = make_key(g.A, g.mA, g.kA, g.sbA, g.M, g.tiles_m, ca ? 1 : 0);
+      ka = make_key(g.A, g.mA, g.kA, g.sbA, g.M, g.mtiles_m, ca ? 1 : 0);
       if (void* hit = find(ka)) am = static_cast<unsigned long long*>(hit), scan_a = false;
     }
     if (cb_ok) {
-      kb = make_key(g.B, g.nB, g.kB, g.sbB, g.N, g.tiles_n, cb ? 1 : 0);
+      kb = make_key(g.B, g.nB, g.kB, g.sbB, g.N, g.mtiles_n, cb ? 1 : 0);
       if (void* hit = find(kb)) bmk = static_cast<unsigned long long*>(hit), scan_b = false;
     }
     // storage: cached masks live until the solve ends, the others in a temporary of this call
@@ -823,9 +842,9 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     }
     // (flag bytes past the last k tile stay unwritten: next_kt never looks beyond kt_end)
     if (scan_a || scan_b) {
-      OccOperand oa{g.A, g.mA, g.kA, g.M, scan_a ? g.tiles_m : 0, ca ? 1 : 0, g.a_kfast, g.sbA, reinterpret_cast<unsigned char*>(am)};
-      OccOperand ob{g.B, g.nB, g.kB, g.N, scan_b ? g.tiles_n : 0, cb ? 1 : 0, g.b_kfast, g.sbB, reinterpret_cast<unsigned char*>(bmk)};
-      const int tmax = (scan_a ? g.tiles_m : 0) > (scan_b ? g.tiles_n : 0) ? (scan_a ? g.tiles_m : 0) : (scan_b ? g.tiles_n : 0);
+      OccOperand oa{g.A, g.mA, g.kA, g.M, scan_a ? g.mtiles_m : 0, ca ? 1 : 0, g.a_kfast, g.sbA, reinterpret_cast<unsigned char*>(am)};
+      OccOperand ob{g.B, g.nB, g.kB, g.N, scan_b ? g.mtiles_n : 0, cb ? 1 : 0, g.b_kfast, g.sbB, reinterpret_cast<unsigned char*>(bmk)};
+      const int tmax = (scan_a ? g.mtiles_m : 0) > (scan_b ? g.mtiles_n : 0) ? (scan_a ? g.mtiles_m : 0) : (scan_b ? g.mtiles_n : 0);
       const dim3 og((nkt_all + 3) / 4, tmax, (unsigned)(2 * d->batch));
       hipLaunchKernelGGL(k_tile_occ, og, dim3(256), 0, ctx->stream, oa, ob, g.K, g.nkw, (int)d->batch, ctx->skip_flag);
     }
@@ -835,10 +854,14 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   const bool ks = is_single(g.kA) && is_single(g.kB);
 #define MPSE_LAUNCH(CA_, CB_)                                                                         \
   do {                                                                                                \
-    if (ks)                                                                                           \
-      hipLaunchKernelGGL((k_gemm<CA_, CB_, true>), grid, block, 0, ctx->stream, g);                   \
+    if (ks && small)                                                                                  \
+      hipLaunchKernelGGL((k_gemm<CA_, CB_, true, 1>), grid, block, 0, ctx->stream, g);                \
+    else if (ks)                                                                                      \
+      hipLaunchKernelGGL((k_gemm<CA_, CB_, true, 2>), grid, block, 0, ctx->stream, g);                \
+    else if (small)                                                                                   \
+      hipLaunchKernelGGL((k_gemm<CA_, CB_, false, 1>), grid, block, 0, ctx->stream, g);               \
     else                                                                                              \
-      hipLaunchKernelGGL((k_gemm<CA_, CB_, false>), grid, block, 0, ctx->stream, g);                  \
+      hipLaunchKernelGGL((k_gemm<CA_, CB_, false, 2>), grid, block, 0, ctx->stream, g);               \
   } while (0)
   if (ca && cb)
     MPSE_LAUNCH(true, true);
