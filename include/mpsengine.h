@@ -112,6 +112,12 @@ int mpse_dotc(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n,
 /* out_host[0] = ||x||_2 (xp.linalg.norm); synchronous */
 int mpse_nrm2(mpse_ctx* ctx, int dtype, const void* x, int64_t n, double* out_host);
 
+/* out_host[0] = sqrt(mean_i |x_i|^2 / (atol + rtol max(|y1_i|, |y2_i|))^2): the error norm and the initial-step
+ * norms of the embedded Runge-Kutta pairs that propagate single sites (ivp_solver = "RK45", mps/mps.py:1299-1315, and
+ * the per-site integrations of TDVP-CMF, :1096-1265, where the reference calls scipy.integrate.solve_ivp).  Synchronous. */
+int mpse_scaled_rms(mpse_ctx* ctx, int dtype, const void* x, const void* y1, const void* y2, int64_t n, double rtol,
+                    double atol, double* out_host);
+
 /* ------------------------------------------- general tensor contraction */
 
 /* A logical matrix index that addresses memory through up to two levels:

@@ -292,6 +292,34 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
   }
 }
 
+// partial sums of |x_i|^2 / (atol + rtol max(|y1_i|, |y2_i|))^2  (error norm of an embedded Runge-Kutta pair)
+template <bool CPLX>
+__global__ __launch_bounds__(RED_THREADS) void k_scaled_sq(const double* __restrict__ x, const double* __restrict__ y1,
+                                                           const double* __restrict__ y2, long long n, double rtol,
+                                                           double atol, double* __restrict__ partial) {
+  double s = 0, zero = 0;
+  const long long stride = (long long)gridDim.x * RED_THREADS;
+  for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += stride) {
+    double ax, a1, a2;
+    if (CPLX) {
+      ax = hypot(x[2 * i], x[2 * i + 1]);
+      a1 = hypot(y1[2 * i], y1[2 * i + 1]);
+      a2 = hypot(y2[2 * i], y2[2 * i + 1]);
+    } else {
+      ax = fabs(x[i]);
+      a1 = fabs(y1[i]);
+      a2 = fabs(y2[i]);
+    }
+    const double q = ax / (atol + rtol * fmax(a1, a2));
+    s += q * q;
+  }
+  block_allsum2(s, zero);
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = s;
+    partial[2 * blockIdx.x + 1] = 0.0;
+  }
+}
+
 // x[i] *= m[i]  (real mask / weights on a real or complex vector)
 template <bool CPLX>
 __global__ void k_mul_real(double* x, const double* __restrict__ m, long long n) {
@@ -911,6 +939,29 @@ int mpse_dotc(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n,
   out_host[0] = out_host[1] = 0.0;
   if (n <= 0) return MPSE_OK;
   return dotc_sync(ctx, dtype, x, y, n, &out_host[0], &out_host[1]);
+}
+
+int mpse_scaled_rms(mpse_ctx* ctx, int dtype, const void* x, const void* y1, const void* y2, int64_t n, double rtol,
+                    double atol, double* out_host) {
+  if (!ctx || !out_host || (n && (!x || !y1 || !y2))) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
+  out_host[0] = 0.0;
+  if (n <= 0) return MPSE_OK;
+  const int nb = red_blocks(n);
+  double* partial = ctx->dscratch;
+  double* result = ctx->dscratch + 2 * RED_MAX_BLOCKS;
+  if (dtype == MPSE_C128)
+    hipLaunchKernelGGL((k_scaled_sq<true>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
+                       (const double*)y1, (const double*)y2, (long long)n, rtol, atol, partial);
+  else
+    hipLaunchKernelGGL((k_scaled_sq<false>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (const double*)x,
+                       (const double*)y1, (const double*)y2, (long long)n, rtol, atol, partial);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, partial, nb, result, (const int*)nullptr);
+  MPSE_HIP(ctx, hipGetLastError());
+  double re = 0, im = 0;
+  MPSE_TRY(read_scalar2(ctx, result, &re, &im));
+  out_host[0] = sqrt(re / double(n));
+  return MPSE_OK;
 }
 
 int mpse_nrm2(mpse_ctx* ctx, int dtype, const void* x, int64_t n, double* out_host) {

@@ -107,6 +107,7 @@ _SIGNATURES = {
     "mpse_real_part": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64],
     "mpse_dotc": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, _dblp],
     "mpse_nrm2": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, _dblp],
+    "mpse_scaled_rms": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, _dblp],
     "mpse_gemm": [C.c_void_p, C.POINTER(mpse_gemm_desc), C.c_void_p, C.c_void_p, C.c_void_p],
     "mpse_transpose_inner": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int],
     "mpse_env_update": [C.c_void_p, C.c_int, C.c_int, C.POINTER(mpse_dims), C.c_void_p, C.c_int, C.c_void_p,

@@ -1352,19 +1352,33 @@ class Mps:
 
 def _local_propagate(config, hop, factor, y):
     """exp(factor * H_eff) y for one centre tensor: the engine's Lanczos exponential (``ivp_solver="krylov"``, the
-    default), or any explicit scheme of ``scipy.integrate.solve_ivp`` named by ``ivp_solver`` ("RK45", "RK23",
-    "DOP853") with ``ivp_rtol / ivp_atol`` as in mps/mps.py:1299-1315: dy/dt = (factor / |factor|) H y over
-    (0, |factor|); the step control runs on the host, every H y on the device.  Returns (tensor, number of H y)."""
+    default), or an explicit scheme named by ``ivp_solver`` with ``ivp_rtol / ivp_atol`` as in mps/mps.py:1299-1315:
+    dy/dt = (factor / |factor|) H y over (0, |factor|).  "RK45" runs on device-resident vectors (lib/rk45.py, scipy's
+    step-size rules on the host); "RK23" / "DOP853" go through ``scipy.integrate.solve_ivp`` with every H y on the
+    device.  Returns (tensor, number of H y)."""
     if config.ivp_solver == "krylov":
         return expm_krylov(hop, factor, y)
-    from scipy.integrate import solve_ivp
     eng = get_engine()
     span = abs(factor)
     phase = complex(factor) / span
     phase = phase.real if phase.imag == 0 else phase
+    cplx = np.iscomplexobj(phase) or hop.operator_is_complex
+    if config.ivp_solver == "RK45":
+        # Dormand-Prince on the device (lib/rk45.py): state, stages and error estimate stay in HBM, the step control
+        # follows scipy's rules
+        from ..lib.rk45 import solve_rk45
+        y0 = y.to_complex() if cplx else y
+
+        def rhs_dev(t, v):
+            out = hop(v)
+            return out.scale_(phase) if phase != 1.0 else out
+
+        res, nfev, _ = solve_rk45(rhs_dev, span, y0, rtol=config.ivp_rtol, atol=config.ivp_atol)
+        return res, nfev
+    from scipy.integrate import solve_ivp
     y0 = y.to_host()
     shape = y0.shape
-    if np.iscomplexobj(phase) or hop.operator_is_complex:
+    if cplx:
         y0 = y0.astype(complex)
 
     def rhs(t, v):

@@ -164,3 +164,43 @@ def svd_qn(coef_array, qnbigl, qnbigr, qntot, QR=False, system=None, full_matric
         new_qnl = np.array(new_qnl)[order].tolist()
         new_qnr = np.array(new_qnr)[order].tolist()
     return u, s, new_qnl, TransposedView(vt), s, new_qnr
+
+
+def eigh_qn(dm, qnbigl, qnbigr, qntot, system):
+    """Diagonalisation of a reduced density matrix by quantum-number block (mps/svd_qn.py:243-302, used by the
+    multi-state update mps/mp.py:800): returns ``(u, s, new_qn)`` with s = sqrt(eigenvalue) and the eigenvectors as the
+    columns of ``u``, blocks in lexicographic order of their quantum number.  A density matrix is Hermitian positive
+    semi-definite, so its eigen-decomposition is its singular value decomposition: the blocks go through the engine's
+    batched one-sided Jacobi SVD (``mpse_block_svd``; eigenvalues come out descending inside a block where LAPACK's
+    eigh returns them ascending - an ordering the callers do not rely on, they select by ``s``)."""
+    assert system in ["L", "R"]
+    eng = get_engine()
+    qnbig, comp = (qnbigl, qnbigr) if system == "L" else (qnbigr, qnbigl)
+    qntot = np.asarray(qntot)
+    q = len(qntot)
+    local = np.ascontiguousarray(np.asarray(qnbig).reshape(-1, q))
+    comp = np.asarray(comp).reshape(-1, q)
+    n = len(local)
+    d = eng.asdevice(dm)
+    if d.size != n * n:
+        raise ValueError(f"density matrix {d.shape} does not match the quantum numbers ({n} states)")
+    uniq, inv = np.unique(local, axis=0, return_inverse=True)
+    inv = np.asarray(inv).reshape(-1)
+    sets, new_qn = [], []
+    for k, nl in enumerate(uniq):
+        if not np.any(np.all(comp == qntot - nl, axis=1)):
+            continue
+        lset = np.nonzero(inv == k)[0].astype(np.int64)
+        sets.append(lset)
+        new_qn += [nl.astype(int).tolist()] * len(lset)
+    if not sets:
+        raise ValueError("Invalid quantum number")
+    idx = np.ascontiguousarray(np.concatenate(sets))
+    off = np.cumsum([0] + [len(x) for x in sets]).astype(np.int64)
+    K = int(off[-1])
+    u = eng.empty((n, K), d.dtype)
+    vt = eng.empty((K, n), d.dtype)
+    s2 = np.zeros(K)
+    eng._check(eng.lib.mpse_block_svd(eng.ctx, d.code, d.ptr, n, n, len(sets), _p64(idx), _p64(off), _p64(idx), _p64(off),
+                                      u.ptr, vt.ptr, s2.ctypes.data_as(C.POINTER(C.c_double)), K))
+    return u, np.sqrt(np.maximum(s2, 0.0)), new_qn

@@ -6,14 +6,17 @@ State: left-canonical sites L L ... L C.  For every site  i dA_i/dt = S_L,i^-1 (
 the projector P_i = S_L,i A_i S_L,i+1^-1 A_i^+ (plain A A^+ when ``force_ovlp`` is off), the left overlaps S_L, and
 the inverse of the right density matrix S_R: eigenvalues regularised as w + eps exp(-w / eps) (``tdvp_vmf``) or,
 matrix unfolding, the singular values of the right block as s + sqrt(eps) exp(-s / sqrt(eps)) (``tdvp_mu_vmf``).
-The time stepping is SciPy's adaptive RK45 over the concatenated symmetry-allowed entries of all sites, exactly as
-in the reference (step control on the host); every derivative evaluation - environments, effective-Hamiltonian
-products, projector and overlap products, the block SVDs of the MU scheme - runs on the device."""
+The time stepping of VMF is SciPy's adaptive RK45 over the concatenated symmetry-allowed entries of all sites, exactly
+as in the reference (step control on the host); every derivative evaluation - environments, effective-Hamiltonian
+products, projector and overlap products, the block SVDs of the MU scheme - runs on the device.  The per-site
+integrations of CMF run Dormand-Prince on device-resident vectors (lib/rk45.py, scipy's step-size rules)."""
 import logging
 
 import numpy as np
 import scipy.linalg
 from scipy.integrate import solve_ivp
+
+from ..lib.rk45 import solve_rk45
 
 from ..engine import get_engine
 from ..utils import EvolveMethod
@@ -274,6 +277,10 @@ def evolve_tdvp_mu_cmf(self, mpo, evolve_dt):
                     if config.ivp_solver == "krylov":
                         ms, nvec = expm_krylov(lambda v: f.device(v.reshape(shape)), evolve_dt / coef, mps[i])
                         mps[i] = ms.reshape(shape)
+                    elif config.ivp_solver == "RK45":
+                        y0 = mps[i].to_complex() if dtype == np.complex128 else mps[i]
+                        mps[i], _, _ = solve_rk45(lambda t, y, f=f: f.device(y).scale_(1.0 / coef), evolve_dt, y0,
+                                                  rtol=config.ivp_rtol, atol=config.ivp_atol)
                     else:
                         y0 = mps[i].to_host().astype(dtype)
                         sol = solve_ivp(lambda t, y: f(eng.asdevice(y.reshape(shape))).ravel(), (0, evolve_dt), y0.ravel(),
@@ -297,10 +304,11 @@ def evolve_tdvp_mu_cmf(self, mpo, evolve_dt):
             s_inv = (u.to_host().conj() / regular_s).T
             hop = hop_expr(ltensor, rtensor, [mpo.device(i, eng)], shape[:-1] + [len(s)])
             f = SiteDerivative(eng, shape, hop, False, s_inv, coef, s_l_inv[i + 1], s_l_inv[i], s_l[i], pre=us)
-            y0 = mps[i].to_host().astype(dtype)
-            sol = solve_ivp(lambda t, y: f(eng.asdevice(y.reshape(shape))).ravel(), (0, evolve_dt), y0.ravel(), method="RK45")
-            rk_steps.append(len(sol.t))
-            mps[i] = sol.y[:, -1].reshape(shape)
+            # per-site Dormand-Prince on the device at scipy's default tolerances (the reference calls solve_ivp
+            # without rtol / atol here, mps.py:1241-1247); rk_steps counts the time points like len(sol.t)
+            y0 = mps[i].to_complex() if dtype == np.complex128 else mps[i]
+            mps[i], _, nst = solve_rk45(lambda t, y, f=f: f.device(y).scale_(1.0 / coef), evolve_dt, y0)
+            rk_steps.append(nst + 1)
         if loop == 2:
             environ_mps = mps
             evolve_dt /= 2.0

@@ -538,3 +538,25 @@ def test_masked_one_site_chain_block_sparse_vs_oracle(eng, cplx):
         # an all-zero centre passes through the flags untouched
         z = hop(eng.zeros(c.shape, c.dtype)).to_host()
         assert np.abs(z).max() == 0.0
+
+
+def test_eigh_qn_density_matrix_blocks(eng):
+    """svd_qn.eigh_qn (mps/svd_qn.py:243-302): block eigen-decomposition of a reduced density matrix against LAPACK."""
+    from renormalizer_amd.mps import svd_qn
+    rng = np.random.default_rng(12)
+    qn = rng.integers(0, 3, size=(40, 1))
+    comp = np.array([[2], [1], [0], [0]])                     # every sector has a partner for qntot = 2
+    a = _rand(rng, (40, 25), True) * 1.0
+    same = (qn == qn.T)
+    dm = (a @ a.conj().T) * same                              # Hermitian, positive semi-definite, block structured
+    u, s, new_qn = svd_qn.eigh_qn(dm, qn, comp, np.array([2]), "L")
+    uh = u.to_host()
+    assert uh.shape == (40, 40) and len(new_qn) == 40
+    assert np.abs(uh.conj().T @ uh - np.eye(40)).max() < 1e-12
+    assert np.abs(uh.conj().T @ dm @ uh - np.diag(s ** 2)).max() < 1e-11 * np.abs(dm).max()
+    for sector in (0, 1, 2):
+        rows = np.nonzero(qn[:, 0] == sector)[0]
+        w = np.linalg.eigvalsh(dm[np.ix_(rows, rows)])
+        mine = np.sort(np.array([x for x, qq in zip(s, new_qn) if qq == [sector]]) ** 2)
+        assert np.abs(mine - np.clip(w, 0, None)).max() < 1e-11 * np.abs(dm).max()
+        assert not np.any(np.abs(uh[np.ix_(np.nonzero(qn[:, 0] != sector)[0], [i for i, qq in enumerate(new_qn) if qq == [sector]])]))
