@@ -6,6 +6,7 @@ deliberately no CPU fallback (the NumPy restatement lives in ``oracle/`` and is
 test infrastructure only).
 """
 import ctypes as C
+import math
 import os
 import threading
 
@@ -203,7 +204,7 @@ class DeviceTensor:
 
     @property
     def size(self):
-        return int(np.prod(self.shape, dtype=np.int64))
+        return math.prod(self.shape)
 
     @property
     def nbytes(self):
@@ -222,14 +223,15 @@ class DeviceTensor:
 
     # -- views / copies
     def reshape(self, *shape):
-        if len(shape) == 1 and not np.isscalar(shape[0]):
+        if len(shape) == 1 and not isinstance(shape[0], (int, np.integer)):
             shape = tuple(shape[0])
-        shape = list(int(s) for s in shape)
+        shape = [int(s) for s in shape]
+        size = math.prod(self.shape)
         if -1 in shape:
             i = shape.index(-1)
-            rest = int(np.prod([s for s in shape if s != -1], dtype=np.int64))
-            shape[i] = self.size // rest if rest else 0
-        if int(np.prod(shape, dtype=np.int64)) != self.size:
+            rest = math.prod(s for s in shape if s != -1)
+            shape[i] = size // rest if rest else 0
+        if math.prod(shape) != size:
             raise ValueError(f"cannot reshape {self.shape} into {tuple(shape)}")
         return DeviceTensor(self.eng, self.buf, self.offset, shape, self.dtype)
 
@@ -238,7 +240,7 @@ class DeviceTensor:
 
     def row_block(self, start, stop):
         """View of rows [start, stop) along the first axis (contiguous)."""
-        inner = int(np.prod(self.shape[1:], dtype=np.int64)) * self.dtype.itemsize
+        inner = math.prod(self.shape[1:]) * self.dtype.itemsize
         return DeviceTensor(self.eng, self.buf, self.offset + start * inner, (stop - start,) + self.shape[1:], self.dtype)
 
     def shifted(self, nelem):
@@ -372,11 +374,11 @@ class Engine:
 
     # -- tensor factories
     def empty(self, shape, dtype=np.float64):
-        if np.isscalar(shape):
+        if isinstance(shape, (int, np.integer)):
             shape = (shape,)
         dtype = np.dtype(dtype)
         dtype_code(dtype)
-        n = int(np.prod(shape, dtype=np.int64))
+        n = math.prod(int(x) for x in shape)
         buf = _Buffer(self, n * dtype.itemsize)
         return DeviceTensor(self, buf, 0, shape, dtype)
 

@@ -229,5 +229,10 @@ class Environ:
     def write(self, domain, siteidx, tensor):
         self._virtual_disk[(domain, siteidx)] = tensor
 
+    def drop(self, domain):
+        """forget the environments of one direction (the sentinels stay)"""
+        for key in [k for k, v in self._virtual_disk.items() if k[0] == domain and v is not self.sentinel]:
+            del self._virtual_disk[key]
+
     def read(self, domain, siteidx):
         return self._virtual_disk[(domain, siteidx)]

@@ -7,6 +7,8 @@ reference drivers, cited per method); every tensor is a ``DeviceTensor`` and eve
 libmpsengine.so.  Integer quantum-number bookkeeping stays on the host in NumPy int arrays."""
 import ctypes
 import logging
+import os
+import threading
 from typing import Dict, List
 
 import numpy as np
@@ -1284,8 +1286,13 @@ class Mps:
         evolve_dt = complex(evolve_dt)
         n = len(mps)
         # Only the environments ahead of the sweep are needed: the reference builds both
-        # directions and discards half (mps.py:1281-1283).
-        environ = Environ(mps, mpo, "R" if mps.to_right else "L")
+        # directions and discards half (mps.py:1281-1283).  The second half sweep of the previous step left exactly
+        # those environments behind, computed from the very site tensors this step starts with: they are taken over
+        # when every tensor they depend on is still the same object (site buffers are immutable by convention).
+        ahead = "R" if mps.to_right else "L"
+        environ = _carried_environ(mps, mpo, ahead)
+        if environ is None:
+            environ = Environ(mps, mpo, ahead)
         local_steps = []
         q = len(mps.qntot)
 
@@ -1347,7 +1354,38 @@ class Mps:
         mps.evolve_config.stat = dict(nobs=len(local_steps), min=int(np.min(local_steps)),
                                       max=int(np.max(local_steps)), mean=float(np.mean(local_steps)),
                                       steps=list(local_steps))
+        _carry_environ(mps, mpo, environ)
         return mps
+
+
+# One slot per host thread (= per trajectory): the environments ahead of the next half sweep, as the last TDVP-PS step
+# left them, with the objects they were computed from.  Bounded: a new step replaces the slot.
+_CARRY = threading.local()
+
+
+def _carry_environ(mps, mpo, environ):
+    ahead = "R" if mps.to_right else "L"
+    environ.drop("L" if ahead == "R" else "R")
+    _CARRY.slot = (mpo, list(mpo._mp) if hasattr(mpo, "_mp") else None, ahead, environ, list(mps._mp))
+
+
+def _carried_environ(mps, mpo, ahead):
+    slot = getattr(_CARRY, "slot", None)
+    _CARRY.slot = None
+    if slot is None or os.environ.get("MPSE_ENV_CARRY", "1") == "0":
+        return None
+    cmpo, cmpo_sites, cahead, environ, csites = slot
+    n = len(mps)
+    if cmpo is not mpo or cmpo_sites is None or cahead != ahead or len(csites) != n or len(cmpo_sites) != n:
+        return None
+    if any(a is not b for a, b in zip(mpo._mp, cmpo_sites)):
+        return None
+    # R(i) depends on the sites i .. n-1 (needed for i >= 1), L(i) on 0 .. i (needed for i <= n-2); the centre site
+    # (rescaled by normalize) is in neither
+    sites = range(1, n) if ahead == "R" else range(0, n - 1)
+    if any(mps._mp[i] is not csites[i] for i in sites):
+        return None
+    return environ
 
 
 def _local_propagate(config, hop, factor, y):

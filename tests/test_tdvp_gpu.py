@@ -734,3 +734,44 @@ def test_on_the_fly_swapping_tdvp_ps2_matches_reference(golden_dir, tag):
             bad.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps2)
             bad.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=5, ofs=OFS.ofs_s)
             bad.evolve(Mpo(hol), 1.0)
+
+
+def test_environments_carried_between_tdvp_ps_steps(golden_dir, monkeypatch):
+    """The environments ahead of the first half sweep are taken over from the previous step instead of being rebuilt
+    (the reference rebuilds both directions every step, mps/mps.py:1281-1283): same tensors to the last bit, and the
+    slot is not used when a site tensor or the MPO is a different object."""
+    import renormalizer_amd.mps.mps as M
+    from renormalizer_amd.mps.lib import Environ
+    mps0, mpo, obs = _small_expanded_state(golden_dir)
+    mps0.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    built = []
+    real_construct = Environ._construct
+
+    def counting(self, *a, **k):
+        built.append(1)
+        return real_construct(self, *a, **k)
+
+    monkeypatch.setattr(Environ, "_construct", counting)
+    runs = []
+    for carry in ("1", "0"):
+        monkeypatch.setenv("MPSE_ENV_CARRY", carry)
+        M._CARRY.slot = None
+        built.clear()
+        mps = mps0.copy()
+        for _ in range(3):
+            mps = mps.evolve(mpo, 10.0)
+            mps.e_occupations          # observables in between do not invalidate the slot
+        runs.append([t.to_host() for t in mps])
+        assert len(built) >= (1 if carry == "1" else 3)
+        if carry == "1":
+            # 1 construction for the first step (+ those of the observables, which build their own environments)
+            n_first = len(built)
+            mps2 = mps.evolve(mpo, 10.0)
+            assert len(built) == n_first          # taken over
+            other = mps2.copy()
+            other[2] = other[2].copy()            # same values, different object: must rebuild
+            nb = len(built)
+            other.evolve(mpo, 10.0)
+            assert len(built) == nb + 1
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
