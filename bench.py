@@ -59,7 +59,7 @@ def _roctx():
 DISORDER_AU = 50.0 * 4.556335e-6   # static diagonal disorder of the trajectories beyond the first: sigma = 50 cm^-1
 
 
-def build_workload(nmol, pdim, bond_dim, seed, init, unit=0):
+def build_workload(nmol, pdim, bond_dim, seed, init, unit=0, state_file=None):
     from renormalizer_amd import (HolsteinModel, Phonon, Mol, Quantity, Mpo, CompressConfig, CompressCriteria,
                                   EvolveConfig, EvolveMethod)
     from renormalizer_amd.mps.mps import Mps
@@ -75,7 +75,9 @@ def build_workload(nmol, pdim, bond_dim, seed, init, unit=0):
     fc = Mps.hartree_product_state(model, {nmol // 2: 1})          # electron created on the centre molecule
     e0 = fc.expectation(Mpo(model))
     mpo = Mpo(model, offset=Quantity(e0))
-    if init == "random":
+    if state_file and os.path.exists(state_file):
+        mps = Mps.load(model, state_file)
+    elif init == "random":
         mps = Mps.random(model, 1, bond_dim, percent=1.0, rng=np.random.default_rng(seed))
     elif init == "physical":
         # transport/dynamics.py:173-199: vacuum, electron created on the centre molecule, bonds expanded
@@ -86,6 +88,8 @@ def build_workload(nmol, pdim, bond_dim, seed, init, unit=0):
         mps.canonicalise()
     else:
         raise SystemExit(f"unknown --init {init}")
+    if state_file and not os.path.exists(state_file):
+        mps.dump(state_file)
     mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=bond_dim)
     mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
     return model, mpo, mps
@@ -141,6 +145,9 @@ def main():
     ap.add_argument("--traj-per-gpu", type=int, default=1,
                     help="independent trajectories sharing each GPU (threads with their own stream); 1 = headline")
     ap.add_argument("--cpu-updates", type=int, default=9, help="site updates in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--state-file", default=None,
+                    help="single trajectory only: load the prepared start state from this npz if it exists, else build "
+                         "it and write it there (lets a profiler pass skip the preparation sweeps)")
     ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "gloo"],
                     help="gloo + --share-gpu exercises the multi-rank flow on a single GPU (testing only)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use GPU 0 (testing only)")
@@ -182,7 +189,8 @@ def main():
         try:
             use_engine(engines[t])
             model, mpo, mps = build_workload(args.nmol, args.pdim, args.bond_dim, seed=1234 + rank * T + t,
-                                             init=args.init, unit=rank * T + t)
+                                             init=args.init, unit=rank * T + t,
+                                             state_file=args.state_file if (T == 1 and world == 1) else None)
             for _ in range(args.warmup):
                 mps = mps.evolve(mpo, args.dt)
             engines[t].prof_reset()

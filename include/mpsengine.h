@@ -118,6 +118,24 @@ int mpse_nrm2(mpse_ctx* ctx, int dtype, const void* x, int64_t n, double* out_ho
 int mpse_scaled_rms(mpse_ctx* ctx, int dtype, const void* x, const void* y1, const void* y2, int64_t n, double rtol,
                     double atol, double* out_host);
 
+/* ------------------------------------------- deferred calls
+ * A sweep knows what follows a local solve before the solve has converged: the QR of the new centre and the
+ * environment update after a site step (mps/mps.py:1316-1378), the absorption of the bond factor into the next site
+ * after a bond step (:1379-1395).  The host can only issue them once the solve has returned - and while the host
+ * language gets there the GPU idles.  Between mpse_defer_begin and mpse_defer_end the calls mpse_gemm, mpse_block_qr
+ * and mpse_env_update on this context are stored (scalar arguments and host index arrays copied, device pointers as
+ * given - the buffers must exist) instead of executed; mpse_defer_arm(list) makes the next mpse_expm_lanczos run the
+ * stored calls of that list, in order, right after it has enqueued the end of the solve, before it returns.  Two
+ * lists (0, 1) so that the calls following the next-but-one solve can be recorded while one list waits.  Device blocks
+ * freed while a list is open or waiting are released only after it has run.  Any other entry point called while a
+ * list is being recorded executes at once, as usual (it must not depend on results of stored calls).
+ * mpse_defer_run executes a list immediately; mpse_defer_discard drops everything (error paths). */
+int mpse_defer_begin(mpse_ctx* ctx, int list);
+int mpse_defer_end(mpse_ctx* ctx);
+int mpse_defer_arm(mpse_ctx* ctx, int list);
+int mpse_defer_run(mpse_ctx* ctx, int list);
+int mpse_defer_discard(mpse_ctx* ctx);
+
 /* ------------------------------------------- general tensor contraction */
 
 /* A logical matrix index that addresses memory through up to two levels:

@@ -414,6 +414,13 @@ extern "C" int mpse_env_update(mpse_ctx* ctx, int dtype, int domain, const mpse_
                                int env_dtype, const void* ket, const void* bra, int bra_conj, const void* W,
                                int w_dtype, void* out) {
   if (!ctx || !dims || !env || !ket || !W || !out) return MPSE_ERR_ARG;
+  if (MPSE_RECORDING(ctx)) {
+    const mpse_dims dc = *dims;
+    ctx->defer_ops[ctx->defer_recording].push_back([=] {
+      return mpse_env_update(ctx, dtype, domain, &dc, env, env_dtype, ket, bra, bra_conj, W, w_dtype, out);
+    });
+    return MPSE_OK;
+  }
   MPSE_BIND(ctx);
   if (dtype != MPSE_C128 && (env_dtype == MPSE_C128 || w_dtype == MPSE_C128))
     return mpse_fail(ctx, MPSE_ERR_ARG, "env_update: real sites with complex env/mpo");

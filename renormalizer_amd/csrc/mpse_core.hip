@@ -80,6 +80,37 @@ __global__ void k_copy16(double2* __restrict__ dst, const double2* __restrict__ 
 }
 }  // namespace
 
+static void defer_update_hold(mpse_ctx* ctx) {
+  const bool hold = ctx->defer_recording >= 0 || !ctx->defer_ops[0].empty() || !ctx->defer_ops[1].empty();
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
+  ctx->defer_hold = hold;
+  if (hold) return;
+  for (void* p : ctx->defer_frees) {
+    auto it = ctx->live.find(p);
+    if (it == ctx->live.end()) continue;
+    ctx->free_blocks.emplace(it->second, p);
+    ctx->in_use_bytes -= it->second;
+    ctx->live.erase(it);
+  }
+  ctx->defer_frees.clear();
+}
+
+int defer_replay(mpse_ctx* ctx, int status) {
+  const int list = ctx->defer_armed;
+  if (list < 0) return status;
+  ctx->defer_armed = -1;
+  std::vector<std::function<int()>> ops;
+  ops.swap(ctx->defer_ops[list]);
+  if (status == MPSE_OK)
+    for (auto& f : ops) {
+      status = f();
+      if (status != MPSE_OK) break;
+    }
+  ops.clear();
+  defer_update_hold(ctx);
+  return status;
+}
+
 extern "C" {
 
 int mpse_prof_enable(mpse_ctx* ctx, int on) {
@@ -244,6 +275,7 @@ int mpse_malloc(mpse_ctx* ctx, size_t bytes, void** dptr) {
     ctx->free_blocks.erase(it);
   } else {
     hipError_t e = hipMalloc(&p, b);
+    ++ctx->n_device_allocs;
     if (e != hipSuccess) {
       // give cached blocks back to the driver and retry once
       (void)hipGetLastError();  // the failed call leaves a sticky error that later hipGetLastError() checks would see
@@ -270,16 +302,68 @@ int mpse_free(mpse_ctx* ctx, void* dptr) {
   std::lock_guard<std::mutex> lock(ctx->pool_mu);
   auto it = ctx->live.find(dptr);
   if (it == ctx->live.end()) return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_free: unknown pointer %p", dptr);
+  if (ctx->defer_hold) {   // a recorded call may still read this block: released after the replay
+    ctx->defer_frees.push_back(dptr);
+    return MPSE_OK;
+  }
   ctx->free_blocks.emplace(it->second, dptr);
   ctx->in_use_bytes -= it->second;
   ctx->live.erase(it);
   return MPSE_OK;
 }
 
+// ---- deferred calls ---------------------------------------------------------------------------------------------
+
+int mpse_defer_begin(mpse_ctx* ctx, int list) {
+  if (!ctx || list < 0 || list > 1) return MPSE_ERR_ARG;
+  if (ctx->defer_recording >= 0) return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_defer_begin: already recording");
+  if (ctx->defer_armed == list) return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_defer_begin: list %d is armed", list);
+  ctx->defer_ops[list].clear();
+  ctx->defer_recording = list;
+  defer_update_hold(ctx);
+  return MPSE_OK;
+}
+
+int mpse_defer_end(mpse_ctx* ctx) {
+  if (!ctx) return MPSE_ERR_ARG;
+  if (ctx->defer_recording < 0) return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_defer_end: not recording");
+  ctx->defer_recording = -1;
+  defer_update_hold(ctx);
+  return MPSE_OK;
+}
+
+int mpse_defer_arm(mpse_ctx* ctx, int list) {
+  if (!ctx || list < 0 || list > 1) return MPSE_ERR_ARG;
+  if (ctx->defer_recording >= 0) return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_defer_arm: still recording");
+  ctx->defer_armed = list;
+  return MPSE_OK;
+}
+
+int mpse_defer_discard(mpse_ctx* ctx) {
+  if (!ctx) return MPSE_ERR_ARG;
+  ctx->defer_ops[0].clear();
+  ctx->defer_ops[1].clear();
+  ctx->defer_recording = ctx->defer_armed = -1;
+  defer_update_hold(ctx);
+  return MPSE_OK;
+}
+
+int mpse_defer_run(mpse_ctx* ctx, int list) {
+  if (!ctx || list < 0 || list > 1) return MPSE_ERR_ARG;
+  if (ctx->defer_recording >= 0) return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_defer_run: still recording");
+  MPSE_BIND(ctx);
+  ctx->defer_armed = list;
+  return defer_replay(ctx, MPSE_OK);
+}
+
+
 int mpse_mem_info(mpse_ctx* ctx, size_t* pool_bytes, size_t* in_use_bytes, size_t* device_free,
                   size_t* device_total) {
   if (!ctx) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
+  if (getenv("MPSE_POOL_STATS"))
+    fprintf(stderr, "[mpsengine] pool %zu B, in use %zu B, hipMalloc calls %llu, held frees %zu\n", ctx->pool_bytes,
+            ctx->in_use_bytes, ctx->n_device_allocs, ctx->defer_frees.size());
   if (pool_bytes) *pool_bytes = ctx->pool_bytes;
   if (in_use_bytes) *in_use_bytes = ctx->in_use_bytes;
   size_t f = 0, t = 0;

@@ -886,6 +886,11 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
 }
 
 extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C) {
+  if (ctx && d && MPSE_RECORDING(ctx)) {
+    const mpse_gemm_desc dc = *d;
+    ctx->defer_ops[ctx->defer_recording].push_back([ctx, dc, A, B, C] { return mpse_gemm(ctx, &dc, A, B, C); });
+    return MPSE_OK;
+  }
   return gemm_impl(ctx, d, A, B, C, d ? (d->skip_zero_tiles & 3) : 0);
 }
 

@@ -3,9 +3,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -29,6 +31,7 @@ struct mpse_ctx {
   std::unordered_map<void*, size_t> live;   // ptr -> bucket size
   size_t pool_bytes = 0;
   size_t in_use_bytes = 0;
+  unsigned long long n_device_allocs = 0;   // hipMalloc calls (pool misses)
 
   // optional HIP-event profiling of the contraction kernel (mpse_prof_*)
   struct ProfRec {
@@ -86,6 +89,15 @@ struct mpse_ctx {
     void* ent;
   };
   std::vector<WCsr> wcsr_cache;
+  // Deferred calls (mpse_defer_*): mpse_gemm / mpse_block_qr / mpse_env_update issued while a list is being recorded
+  // are stored with copies of their arguments; an armed list runs at the end of the next mpse_expm_lanczos, right
+  // after the solve has been enqueued to its end.  While a list is recorded or waiting, freed device blocks are held
+  // back (a recorded call may still read them).
+  std::vector<std::function<int()>> defer_ops[2];
+  int defer_recording = -1;
+  int defer_armed = -1;
+  bool defer_hold = false;                  // guarded by pool_mu
+  std::vector<void*> defer_frees;           // guarded by pool_mu
   bool occ_cache_on = false;
   const char* occ_lo[2] = {nullptr, nullptr};
   const char* occ_hi[2] = {nullptr, nullptr};
@@ -125,6 +137,12 @@ void prof_end(mpse_ctx* ctx, const mpse_ctx::ProfRec& rec);
   } while (0)
 
 #define MPSE_BIND(ctx) MPSE_TRY(mpse_bind(ctx))
+
+// Entry points that may be recorded start with this: true -> the call was stored, return MPSE_OK.
+#define MPSE_RECORDING(ctx) ((ctx)->defer_recording >= 0)
+// runs and empties the armed list (no-op when none is armed); `status` of the solve it follows: a failed solve
+// drops the list
+int defer_replay(mpse_ctx* ctx, int status);
 
 // RAII temporary from the pool
 struct TmpBuf {

@@ -390,6 +390,17 @@ int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int6
                   const int64_t* col_off_host, int system_is_R, void* U, void* Vt, int64_t K) {
   if (!ctx || !coef || !U || !Vt || !row_idx_host || !row_off_host || !col_idx_host || !col_off_host)
     return MPSE_ERR_ARG;
+  if (MPSE_RECORDING(ctx) && nblocks > 0) {
+    std::vector<int64_t> roff(row_off_host, row_off_host + nblocks + 1), coff(col_off_host, col_off_host + nblocks + 1);
+    std::vector<int64_t> ridx(row_idx_host, row_idx_host + roff[nblocks]), cidx(col_idx_host, col_idx_host + coff[nblocks]);
+    ctx->defer_ops[ctx->defer_recording].push_back(
+        [ctx, dtype, coef, nrow, ncol, nblocks, ridx = std::move(ridx), roff = std::move(roff), cidx = std::move(cidx),
+         coff = std::move(coff), system_is_R, U, Vt, K] {
+          return mpse_block_qr(ctx, dtype, coef, nrow, ncol, nblocks, ridx.data(), roff.data(), cidx.data(), coff.data(),
+                               system_is_R, U, Vt, K);
+        });
+    return MPSE_OK;
+  }
   MPSE_BIND(ctx);
   if (nblocks <= 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
   if (dtype == MPSE_C128)

@@ -975,10 +975,21 @@ int mpse_nrm2(mpse_ctx* ctx, int dtype, const void* x, int64_t n, double* out_ho
   return MPSE_OK;
 }
 
+static int expm_lanczos_solve(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re, double dt_im, const void* Cin,
+                              void* out, double rtol, double atol, int max_dim, int* nvec);
+
 int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re, double dt_im, const void* Cin,
                       void* out, double rtol, double atol, int max_dim, int* nvec) {
   if (!ctx || !h || !Cin || !out) return MPSE_ERR_ARG;
+  if (MPSE_RECORDING(ctx)) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: cannot be recorded (mpse_defer_begin is open)");
   MPSE_BIND(ctx);
+  // calls recorded by the caller for the time the result exists (QR of the new centre, environment update, absorption
+  // of a bond factor) are issued here, before control goes back to the host language
+  return defer_replay(ctx, expm_lanczos_solve(ctx, dtype, h, dt_re, dt_im, Cin, out, rtol, atol, max_dim, nvec));
+}
+
+static int expm_lanczos_solve(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re, double dt_im, const void* Cin,
+                              void* out, double rtol, double atol, int max_dim, int* nvec) {
   const bool cplx = dtype == MPSE_C128;
   if (!cplx && dt_im != 0.0)
     return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: complex time step needs a complex128 centre tensor");

@@ -109,6 +109,11 @@ _SIGNATURES = {
     "mpse_dotc": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, _dblp],
     "mpse_nrm2": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, _dblp],
     "mpse_scaled_rms": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, _dblp],
+    "mpse_defer_begin": [C.c_void_p, C.c_int],
+    "mpse_defer_end": [C.c_void_p],
+    "mpse_defer_arm": [C.c_void_p, C.c_int],
+    "mpse_defer_run": [C.c_void_p, C.c_int],
+    "mpse_defer_discard": [C.c_void_p],
     "mpse_gemm": [C.c_void_p, C.POINTER(mpse_gemm_desc), C.c_void_p, C.c_void_p, C.c_void_p],
     "mpse_transpose_inner": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int],
     "mpse_env_update": [C.c_void_p, C.c_int, C.c_int, C.POINTER(mpse_dims), C.c_void_p, C.c_int, C.c_void_p,
@@ -152,6 +157,24 @@ def load_library(path=LIB_PATH):
     lib.mpse_version.argtypes = []
     lib.mpse_version.restype = C.c_char_p
     return lib
+
+
+class _Recording:
+    def __init__(self, eng, which):
+        self.eng, self.which = eng, which
+
+    def __enter__(self):
+        self.eng._check(self.eng.lib.mpse_defer_begin(self.eng.ctx, self.which))
+        self.eng.recording_list = self.which
+        return self
+
+    def __exit__(self, et, ev, tb):
+        self.eng.recording_list = -1
+        if et is None:
+            self.eng._check(self.eng.lib.mpse_defer_end(self.eng.ctx))
+        else:
+            self.eng.lib.mpse_defer_discard(self.eng.ctx)
+        return False
 
 
 class _Buffer:
@@ -319,6 +342,7 @@ class Engine:
         self.n_cu = ncu.value
         self.stream = stream.value
         self._ones = {}
+        self.recording_list = -1            # list being recorded (mpse_defer_begin), -1 = none
 
     def close(self):
         if self.ctx is not None:
@@ -339,6 +363,18 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.mpse_sync(self.ctx))
+
+    # -- deferred calls (mpse_defer_*): gemm / block QR / environment updates issued inside ``recording(list)`` are
+    # stored and run at the end of the Lanczos solve that follows ``arm(list)``
+    def recording(self, which):
+        return _Recording(self, which)
+
+    def arm(self, which):
+        self._check(self.lib.mpse_defer_arm(self.ctx, which))
+
+    def defer_discard(self):
+        self.recording_list = -1
+        self.lib.mpse_defer_discard(self.ctx)
 
     def mem_info(self):
         v = [C.c_size_t() for _ in range(4)]

@@ -13,14 +13,19 @@ from ..engine import get_engine
 from ..mps.hop_expr import Hop
 
 
-def expm_krylov(Afunc, dt, vstart, block_size=50, rtol=1e-5, atol=1e-8):
+def expm_krylov(Afunc, dt, vstart, block_size=50, rtol=1e-5, atol=1e-8, out=None):
+    """``out``: (engine Hop only) an existing device tensor of the result's shape and dtype to receive it - calls
+    recorded with ``Engine.recording`` refer to it before the solve has run."""
     eng = get_engine()
     dt = complex(dt)
     v = eng.asdevice(vstart)
     if isinstance(Afunc, Hop):
         if (dt.imag != 0 or Afunc.operator_is_complex) and not v.is_complex:
             v = v.to_complex()
-        out = eng.empty(v.shape, v.dtype)
+        if out is None:
+            out = eng.empty(v.shape, v.dtype)
+        elif out.size != v.size or out.dtype != v.dtype:
+            raise ValueError("expm_krylov: out does not match the start vector")
         nv = C.c_int()
         eng._check(eng.lib.mpse_expm_lanczos(eng.ctx, v.code, C.byref(Afunc.heff), dt.real, dt.imag, v.ptr, out.ptr,
                                              rtol, atol, 0, C.byref(nv)))

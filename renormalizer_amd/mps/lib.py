@@ -86,13 +86,16 @@ def contract_one_site(environ, ms, mo, domain, ms_conj=None, canonical_mo_host=N
         eng.ctx, out.code, DOMAIN_L if domain == "L" else DOMAIN_R, C.byref(d), environ.ptr, environ.code,
         ket.ptr, bra.ptr, 1 if ms_conj is None else 0, mo.ptr, mo.code, out.ptr))
     if ms_conj is None and oshape[0] == oshape[2]:
+        deferred = eng.recording_list >= 0      # the update has only been recorded: nothing to measure yet
         if canonical_mo_host is not None and ms.ndim == 3 and environ.unit > 0:
             # the chain of predictions starts at the sentinel and is carried through small bonds as well
             out.unit = predict_unit_channel(canonical_mo_host, domain, environ.unit)
-            if os.environ.get("MPSE_VERIFY_UNIT") and oshape[0] >= UNIT_MIN_BOND:
+            if os.environ.get("MPSE_VERIFY_UNIT") and oshape[0] >= UNIT_MIN_BOND and not deferred:
                 measured = find_unit_channel(out)
                 assert measured == out.unit, f"unit channel predicted {out.unit}, measured {measured}"
-        elif oshape[0] >= UNIT_MIN_BOND:
+        elif oshape[0] >= UNIT_MIN_BOND and not deferred:
+            # (a recorded update behind an environment without unit channel keeps unit = 0: an isometric site cannot
+            # create one, and a missed unit channel costs a GEMM, never correctness)
             out.unit = find_unit_channel(out)
     return out
 

@@ -1308,49 +1308,92 @@ class Mps:
                 plan = svd_qn.block_plan(qnbigl, qnbigr, mps.qntot)
             return hop, split, qnbigl, qnbigr, plan
 
-        for _ in range(2):
-            ready = None
-            for imps in mps.iter_idx_list(full=True):
-                system = "L" if mps.to_right else "R"
-                shape = list(mps[imps].shape)
-                if ready is None:
-                    ready = prepare(imps, shape)
-                hop, split, qnbigl, qnbigr, plan = ready
-                ready = None
-                l_array, r_array = hop.l, hop.r
-                mps_t, j = _local_propagate(cfg, hop, -1j * evolve_dt / 2, mps[imps])
-                local_steps.append(j)
-                if not split:
-                    mps[imps] = mps_t.reshape(shape)
-                    continue
-                u, qnlset, v, qnrset = svd_qn.svd_qn(mps_t, qnbigl, qnbigr, mps.qntot, QR=True, system=system,
-                                                     full_matrices=False, plan=plan)
-                vt = v.T
-                if not mps.to_right:
-                    mps[imps] = vt.reshape([-1] + shape[1:])
-                    mps.qn[imps] = np.array(qnrset, dtype=int).reshape(-1, q)
-                    mps.qnidx = imps - 1
-                    r_array = environ.GetLR("R", imps, mps, mpo, itensor=r_array, method="System", canonical=True)
-                    hop_b = hop_expr(l_array, r_array, [], u.shape)
-                    prv = mps[imps - 1]
-                    ready = prepare(imps - 1, list(prv.shape[:-1]) + [u.shape[1]])
-                    b_t, j = _local_propagate(cfg, hop_b, 1j * evolve_dt / 2, u)
+        def split_site(imps, centre, ready, shape):
+            """What follows the forward step of a split site, on ``centre`` (the result of that step, or the buffer
+            that will receive it): QR / RQ by quantum-number block, installation of the isometry, one environment
+            update.  Returns the effective Hamiltonian of the bond factor, the bond factor and the site it goes to."""
+            hop, _, qnbigl, qnbigr, plan = ready
+            l_array, r_array = hop.l, hop.r
+            u, qnlset, v, qnrset = svd_qn.svd_qn(centre, qnbigl, qnbigr, mps.qntot, QR=True,
+                                                 system="L" if mps.to_right else "R", full_matrices=False, plan=plan)
+            vt = v.T
+            if not mps.to_right:
+                mps[imps] = vt.reshape([-1] + shape[1:])
+                mps.qn[imps] = np.array(qnrset, dtype=int).reshape(-1, q)
+                mps.qnidx = imps - 1
+                r_array = environ.GetLR("R", imps, mps, mpo, itensor=r_array, method="System", canonical=True)
+                return hop_expr(l_array, r_array, [], u.shape), u, imps - 1
+            mps[imps] = u.reshape(shape[:-1] + [-1])
+            mps.qn[imps + 1] = np.array(qnlset, dtype=int).reshape(-1, q)
+            mps.qnidx = imps + 1
+            l_array = environ.GetLR("L", imps, mps, mpo, itensor=l_array, method="System", canonical=True)
+            return hop_expr(l_array, r_array, [], vt.shape), vt, imps + 1
+
+        def absorb(bond, nbr):
+            """the evolved bond factor times the neighbouring site: the next centre"""
+            t = mps[nbr]
+            if mps.to_right:
+                return eng.matmul(bond, t.reshape(t.shape[0], -1)).reshape((bond.shape[0],) + t.shape[1:])
+            return eng.matmul(t.reshape(-1, t.shape[-1]), bond).reshape(t.shape[:-1] + (bond.shape[1],))
+
+        # The calls that follow a local solve do not depend on WHEN it converges, only on the buffer its result lands
+        # in: with MPSE_DEFER=1 they are recorded ahead (Engine.recording) and issued by the engine the moment the
+        # solve has been enqueued to its end, so the GPU does not wait for the host language between a solve and its
+        # QR / absorption.  Off by default: on the headline run the idle time after a solve halves (41 -> 22 us) but
+        # the step time does not change within the noise (DESIGN.md section 5).
+        same_dtype = mps.is_complex or (evolve_dt.real == 0 and not mpo.is_complex)
+        pipelined = (cfg.ivp_solver == "krylov" and same_dtype and os.environ.get("MPSE_DEFER", "0") == "1"
+                     and not os.environ.get("MPSE_VERIFY_UNIT"))
+        try:
+            for _ in range(2):
+                order = list(mps.iter_idx_list(full=True))
+                centre = mps[order[0]]
+                ready = prepare(order[0], list(centre.shape))
+                after_site = None
+                if pipelined and ready[1]:
+                    out = eng.empty(centre.shape, centre.dtype)
+                    with eng.recording(0):
+                        after_site = (out,) + split_site(order[0], out, ready, list(centre.shape))
+                for imps in order:
+                    shape = list(centre.shape)
+                    hop, split = ready[0], ready[1]
+                    if not split:
+                        mps_t, j = _local_propagate(cfg, hop, -1j * evolve_dt / 2, centre)
+                        local_steps.append(j)
+                        mps[imps] = mps_t.reshape(shape)
+                        continue
+                    if not pipelined:
+                        mps_t, j = _local_propagate(cfg, hop, -1j * evolve_dt / 2, centre)
+                        local_steps.append(j)
+                        hop_b, bond, nbr = split_site(imps, mps_t, ready, shape)
+                        ready = prepare(nbr, list(mps[nbr].shape[:-1]) + [bond.shape[1]] if not mps.to_right
+                                        else [bond.shape[0]] + list(mps[nbr].shape[1:]))
+                        b_t, j = _local_propagate(cfg, hop_b, 1j * evolve_dt / 2, bond)
+                        local_steps.append(j)
+                        centre = mps[nbr] = absorb(b_t.reshape(bond.shape), nbr)
+                        continue
+                    out, hop_b, bond, nbr = after_site
+                    eng.arm(0)
+                    _, j = expm_krylov(hop, -1j * evolve_dt / 2, centre, out=out)       # + QR, environment update
                     local_steps.append(j)
-                    mps[imps - 1] = eng.matmul(prv.reshape(-1, prv.shape[-1]), b_t.reshape(u.shape)) \
-                        .reshape(prv.shape[:-1] + (u.shape[1],))
-                else:
-                    mps[imps] = u.reshape(shape[:-1] + [-1])
-                    mps.qn[imps + 1] = np.array(qnlset, dtype=int).reshape(-1, q)
-                    mps.qnidx = imps + 1
-                    l_array = environ.GetLR("L", imps, mps, mpo, itensor=l_array, method="System", canonical=True)
-                    hop_b = hop_expr(l_array, r_array, [], vt.shape)
-                    nxt = mps[imps + 1]
-                    ready = prepare(imps + 1, [vt.shape[0]] + list(nxt.shape[1:]))
-                    b_t, j = _local_propagate(cfg, hop_b, 1j * evolve_dt / 2, vt)
+                    b_out = eng.empty(bond.shape, bond.dtype)
+                    with eng.recording(1):
+                        new_centre = absorb(b_out, nbr)
+                    mps[nbr] = new_centre
+                    ready = prepare(nbr, list(new_centre.shape))
+                    after_site = None
+                    if ready[1]:
+                        out = eng.empty(new_centre.shape, new_centre.dtype)
+                        with eng.recording(0):
+                            after_site = (out,) + split_site(nbr, out, ready, list(new_centre.shape))
+                    eng.arm(1)
+                    _, j = expm_krylov(hop_b, 1j * evolve_dt / 2, bond, out=b_out)        # + absorption
                     local_steps.append(j)
-                    mps[imps + 1] = eng.matmul(b_t.reshape(vt.shape), nxt.reshape(nxt.shape[0], -1)) \
-                        .reshape((vt.shape[0],) + nxt.shape[1:])
-            mps._switch_direction()
+                    centre = new_centre
+                mps._switch_direction()
+        except BaseException:
+            eng.defer_discard()
+            raise
         mps.evolve_config.stat = dict(nobs=len(local_steps), min=int(np.min(local_steps)),
                                       max=int(np.max(local_steps)), mean=float(np.mean(local_steps)),
                                       steps=list(local_steps))

@@ -338,3 +338,59 @@ def test_asynchronous_lanczos_guesses_and_fallbacks(eng):
         assert nv == nref and np.abs(out.to_host().ravel() - ref).max() < 1e-10 * np.abs(ref).max()
     with pytest.raises(E.EngineError):
         expm_krylov(hop, -0.1j, eng.asdevice(np.zeros_like(c)))       # zero vector: reported, not a hang
+
+
+def test_deferred_calls_run_after_the_armed_solve():
+    """mpse_defer_*: a recorded GEMM reads the buffer the next Lanczos solve writes; blocks freed while the list waits are
+    not handed out again before it has run; discard drops everything."""
+    import ctypes as C
+    from renormalizer_amd.engine import get_engine
+    from renormalizer_amd.lib.krylov import expm_krylov
+    from renormalizer_amd.mps.hop_expr import hop_expr
+    eng = get_engine()
+    rng = np.random.default_rng(3)
+    D, w = 24, 3
+    l = rng.normal(size=(D, w, D))
+    l = l + l.transpose(2, 1, 0)
+    r = rng.normal(size=(D, w, D))
+    r = r + r.transpose(2, 1, 0)
+    hop = hop_expr(eng.asdevice(l), eng.asdevice(r), [], (D, D))
+    c = rng.normal(size=(D, D)) + 1j * rng.normal(size=(D, D))
+    c /= np.linalg.norm(c)
+    m = rng.normal(size=(D, 7)) + 0j
+    cd, md = eng.asdevice(c), eng.asdevice(m)
+    ref, nref = expm_krylov(hop, -0.3j, cd)
+    expect = ref.to_host() @ m
+    out = eng.empty((D, D), np.complex128)
+    scratch = eng.asdevice(np.full((D, 7), 7.0 + 0j))
+    with eng.recording(1):
+        prod = eng.matmul(out, md)
+        ptr = scratch.ptr
+        del scratch                       # freed while the list is open: must stay out of the pool
+        other = eng.empty((D, 7), np.complex128)
+        assert other.ptr != ptr
+    assert eng.recording_list == -1
+    eng.arm(1)
+    res, n = expm_krylov(hop, -0.3j, cd, out=out)
+    assert n == nref and res is out
+    assert np.abs(prod.to_host() - expect).max() < 1e-13
+    again = eng.empty((D, 7), np.complex128)      # the held block is back in the pool now
+    del again
+    # an unarmed list does not run; discard empties it
+    with eng.recording(0):
+        prod2 = eng.matmul(out, md)
+    eng._check(eng.lib.mpse_memset_zero(eng.ctx, prod2.ptr, prod2.nbytes))
+    expm_krylov(hop, -0.3j, cd)
+    assert np.all(prod2.to_host() == 0)
+    eng._check(eng.lib.mpse_defer_run(eng.ctx, 0))
+    assert np.abs(prod2.to_host() - expect).max() < 1e-13
+    with eng.recording(0):
+        eng.matmul(out, md)
+    eng.defer_discard()
+    assert eng.lib.mpse_defer_run(eng.ctx, 0) == 0
+    # nesting and solving while recording are refused
+    with eng.recording(0):
+        assert eng.lib.mpse_defer_begin(eng.ctx, 1) != 0
+        with pytest.raises(Exception):
+            expm_krylov(hop, -0.3j, cd)
+    eng.defer_discard()

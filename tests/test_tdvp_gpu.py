@@ -775,3 +775,28 @@ def test_environments_carried_between_tdvp_ps_steps(golden_dir, monkeypatch):
             assert len(built) == nb + 1
     for a, b in zip(*runs):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("imag", [False, True])
+def test_recorded_post_solve_calls_do_not_change_tdvp_ps(golden_dir, monkeypatch, imag):
+    """The QR / environment update / absorption that follow a local solve are recorded ahead and issued by the engine
+    at the end of the solve (mpse_defer_*): the same kernels on the same data in the same order as the plain loop -
+    identical tensors, real time (complex tensors) and imaginary time (real tensors)."""
+    import renormalizer_amd.mps.mps as M
+    mps0, mpo, obs = _small_expanded_state(golden_dir)
+    mps0.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    dt = -2.0j if imag else 10.0
+    runs = []
+    for defer in ("1", "0"):
+        monkeypatch.setenv("MPSE_DEFER", defer)
+        M._CARRY.slot = None
+        mps = mps0.copy()
+        for _ in range(3):
+            mps = mps.evolve(mpo, dt)
+        assert mps.is_complex != imag
+        runs.append(([t.to_host() for t in mps], [np.array(x) for x in mps.qn], list(mps.evolve_config.stat["steps"])))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.array_equal(a, b)
+    assert runs[0][2] == runs[1][2]
