@@ -257,10 +257,12 @@ def main():
         traffic, traffic_src = None, None
         try:
             with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as fh:
-                traffic = json.load(fh)["kernels"]["void k_gemm<true, true, true>"]["hbm_bytes_per_launch"]
+                kern = json.load(fh)["kernels"]
+            key = next(k for k in kern if k.startswith("void k_gemm<true, true, true"))   # (+ the tile-shape argument)
+            traffic = kern[key]["hbm_bytes_per_launch"]
             traffic_src = ("profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                            "command, bench.py --init physical; counters cannot be read from inside the process)")
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         zz = prof["c128xc128"]
         sec = zz["ms"] * 1e-3

@@ -386,6 +386,10 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
       MPSE_TRY(copy_call(ctx, dtc, a, c, s.ma, s.ka, s.mc, s.nc));
       continue;
     }
+    // the last step completes the result: it takes the caller's dot request along when it is a plain product into
+    // the whole of `out`
+    if (ctx->dot_req.y && &s == &p.steps.back() && s.c == B_OUT && s.c_off == 0 && s.batch == 1 && s.cmask_slot < 0)
+      ctx->dot_now = true;
     MPSE_TRY(gemm_call(ctx, s.dta, s.dtb, s.conja, s.conjb, s.ma, s.ka, s.kb, s.nb, s.mc, s.nc, s.batch, s.sba,
                        s.sbb, s.sbc, a, b, c, 1.0, s.beta, s.skip_zero,
                        s.amask_slot >= 0 ? msk[s.amask_slot].p : nullptr,

@@ -22,6 +22,7 @@
 //   * accumulation order over k is fixed => bitwise reproducible results.
 #include <cstdlib>
 
+#include "mpse_device.h"
 #include "mpse_internal.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -60,7 +61,18 @@ struct GemmArgs {
   const int* skip;                  // optional device flag: non-zero -> the launch does nothing (mpse_ctx::skip_flag)
   unsigned char* cmask;             // optional: flag per output tile (1 = K tiles were multiplied into it); tiles
                                     // without any are NOT stored - the consumer reads the flags (masked chain)
+  // optional (batch == 1): the kernel that stores the final values of C also accumulates sum conj(C) . y over its
+  // share of C (y laid out like C) and stores one (re, im) partial per workgroup at dot_part - the Lanczos
+  // coefficient alpha_j = <H v_j, v_j> without a pass of its own over the two vectors
+  const double* dot_y;
+  double* dot_part;
 };
+
+// (re, im) += conj(c) * y
+__device__ __forceinline__ void dot_acc(double& re, double& im, double2 c, double2 y) {
+  re += c.x * y.x + c.y * y.y;
+  im += c.x * y.y - c.y * y.x;
+}
 
 __device__ __forceinline__ long long idx_off(const IdxMap& m, int i) {
   // single-level maps are canonicalised on the host to lo == INT_MAX: skip the integer division (uniform branch)
@@ -451,6 +463,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
     }
     return;
   }
+  double dre = 0.0, dim = 0.0;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int gj = tn * TBN + wn * 32 + j * 16 + (lane & 15);
@@ -462,7 +475,8 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
       for (int r = 0; r < 4; ++r) {
         const int gi = tm * TBM + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
         if (gi >= g.M) continue;
-        double* p = C + (idx_off(g.mC, gi) + coffn) * EC;
+        const long long co = idx_off(g.mC, gi) + coffn;
+        double* p = C + co * EC;
         const double xr = acc_re[i][j][r];
         if constexpr (CC) {
           const double xi = acc_im[i][j][r];
@@ -475,11 +489,22 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
             o.y += g.beta_re * c0.y + g.beta_im * c0.x;
           }
           *reinterpret_cast<double2*>(p) = o;
+          if (g.dot_y) dot_acc(dre, dim, o, reinterpret_cast<const double2*>(g.dot_y)[co]);
         } else {
           double o = g.alpha_re * xr;
           if (g.use_beta) o += g.beta_re * (*p);
           *p = o;
+          if (g.dot_y) dre += o * g.dot_y[co];
         }
+      }
+    }
+  }
+  if constexpr (WS == 2) {
+    if (g.dot_y) {   // workgroup-uniform
+      block_allsum2(dre, dim);
+      if (tid == 0) {
+        g.dot_part[2 * bid] = dre;
+        g.dot_part[2 * bid + 1] = dim;
       }
     }
   }
@@ -493,6 +518,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs g, int bat
   if (g.skip && *g.skip) return;
   const long long mn = (long long)g.M * g.N;
   const int rows = g.M * batch;
+  double dre = 0.0, dim = 0.0;
   for (int row = blockIdx.y; row < rows; row += gridDim.y) {
     const int b = row / g.M;
     const int i = row - b * g.M;
@@ -535,7 +561,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs g, int bat
           xr += w[(long long)s * mn];
         }
       }
-      double* p = crow + idx_off(g.nC, j) * EC;
+      const long long co = idx_off(g.nC, j);
+      double* p = crow + co * EC;
       if constexpr (CC) {
         double2 o = make_double2(g.alpha_re * xr - g.alpha_im * xi, g.alpha_re * xi + g.alpha_im * xr);
         if (g.use_beta) {
@@ -544,11 +571,21 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs g, int bat
           o.y += g.beta_re * c0.y + g.beta_im * c0.x;
         }
         *reinterpret_cast<double2*>(p) = o;
+        if (g.dot_y) dot_acc(dre, dim, o, reinterpret_cast<const double2*>(g.dot_y)[idx_off(g.mC, i) + co]);
       } else {
         double o = g.alpha_re * xr;
         if (g.use_beta) o += g.beta_re * (*p);
         *p = o;
+        if (g.dot_y) dre += o * g.dot_y[idx_off(g.mC, i) + co];
       }
+    }
+  }
+  if (g.dot_y) {   // grid-uniform; batch == 1
+    block_allsum2(dre, dim);
+    if (threadIdx.x == 0) {
+      const long long bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+      g.dot_part[2 * bid] = dre;
+      g.dot_part[2 * bid + 1] = dim;
     }
   }
 }
@@ -732,6 +769,8 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.nkw = 0;
   g.skip = ctx->skip_flag;
   g.cmask = nullptr;
+  g.dot_y = nullptr;
+  g.dot_part = nullptr;
   TmpBuf WSB(ctx), MSK(ctx);
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   // tuning knobs of the split-K policy (environment, read once): output tiles below which K is sliced, and how many
@@ -760,6 +799,25 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     if (g.ksplit != 1 || g.use_beta)
       return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_gemm: output tile flags need an unsplit, non-accumulating product");
     g.cmask = static_cast<unsigned char*>(cmask_out);
+  }
+
+  // dot request of the caller (mpse_ctx::dot_req, armed by run_plan for the step that completes the result)
+  const bool want_dot = ctx->dot_now;
+  ctx->dot_now = false;
+  long long rgx = (g.N + 255) / 256 > 64 ? 64 : (g.N + 255) / 256;
+  long long rgy = (long long)g.M * d->batch > 32768 ? 32768 : (long long)g.M * d->batch;
+  if (want_dot && !small && d->batch == 1 && !cmask_out) {
+    long long producers = base_blocks;
+    if (g.ksplit > 1) {
+      const long long cap_y = ctx->dot_req.cap / rgx;
+      if (cap_y >= 1 && rgy > cap_y) rgy = cap_y;
+      producers = rgx * rgy;
+    }
+    if (producers >= 1 && producers <= ctx->dot_req.cap) {
+      g.dot_y = static_cast<const double*>(ctx->dot_req.y);
+      g.dot_part = ctx->dot_req.part;
+      ctx->dot_req.nb_out = (int)producers;
+    }
   }
 
   dim3 grid((unsigned)nblk), block(small ? 64 : 256);
@@ -873,8 +931,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     MPSE_LAUNCH(false, false);
 #undef MPSE_LAUNCH
   if (g.ksplit > 1) {
-    const long long rows = (long long)g.M * d->batch;
-    const dim3 rgrid((unsigned)((g.N + 255) / 256 > 64 ? 64 : (g.N + 255) / 256), (unsigned)(rows > 32768 ? 32768 : rows));
+    const dim3 rgrid((unsigned)rgx, (unsigned)rgy);
     if (ca || cb)
       hipLaunchKernelGGL((k_splitk_reduce<true>), rgrid, dim3(256), 0, ctx->stream, g, (int)d->batch);
     else

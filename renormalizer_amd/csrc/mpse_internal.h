@@ -98,6 +98,16 @@ struct mpse_ctx {
   int defer_armed = -1;
   bool defer_hold = false;                  // guarded by pool_mu
   std::vector<void*> defer_frees;           // guarded by pool_mu
+  // Request to the contraction plan that produces a matvec result (mpse_heff_apply): also accumulate
+  // sum conj(result) . y, as per-workgroup partials at `part` (room for `cap` of them); nb_out = number written
+  // (0: the plan could not take it, the caller runs its own reduction)
+  struct DotReq {
+    const void* y = nullptr;
+    double* part = nullptr;
+    int cap = 0;
+    int nb_out = 0;
+  } dot_req;
+  bool dot_now = false;   // set by run_plan for the one GEMM launch that completes the result
   bool occ_cache_on = false;
   const char* occ_lo[2] = {nullptr, nullptr};
   const char* occ_hi[2] = {nullptr, nullptr};

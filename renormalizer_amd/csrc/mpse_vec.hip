@@ -234,7 +234,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
                                                                   const double* __restrict__ u0, long long n_doubles,
                                                                   const double* __restrict__ a_partial, int a_nb,
                                                                   double* __restrict__ a_out,
-                                                                  const double* __restrict__ cur_partial,
+                                                                  const double* __restrict__ cur_partial, int cur_nb,
                                                                   double* __restrict__ cur_out,
                                                                   const double* __restrict__ prev2,
                                                                   double* __restrict__ partial,
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
   if (done && *done) return;
   double araw, a_im, cur2, z;
   sum_partials(a_partial, a_nb, araw, a_im);
-  sum_partials(cur_partial, a_nb, cur2, z);
+  sum_partials(cur_partial, cur_nb, cur2, z);
   const double s1sq = 1.0 / cur2, s1 = sqrt(s1sq);
   const double a = araw * s1sq;                       // alpha_j
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -489,10 +489,24 @@ constexpr int LZ_MAXM = 64;   // one wavefront holds the Krylov coefficients
 // coef = |v| exp(dt T_m) e_1 for the Lanczos tridiagonal T_m (alpha_0.., beta_0..) by a scaled Taylor series, one lane
 // per component (lib/krylov/krylov.py:15-24 computes the same vector through eigh_tridiagonal).  Also applies the
 // reference's breakdown rule retroactively: the first beta_i < tiny (i <= j) ends the space at i + 1 vectors.
-__global__ __launch_bounds__(64) void k_lz_coefs(const double* __restrict__ scal, int j, double dt_re, double dt_im,
-                                                 double tiny, double* __restrict__ coef, LzCtl* ctl) {
+// ``part`` / ``nb``: the |w|^2 partials of the update kernel launched just before; their sum beta_j^2 is formed
+// here (in the order of k_reduce_final) and recorded at scal[6 + 4 j] - one launch less per convergence check.
+__global__ __launch_bounds__(64) void k_lz_coefs(double* __restrict__ scal, int j, double dt_re, double dt_im,
+                                                 double tiny, double* __restrict__ coef, LzCtl* ctl,
+                                                 const double* __restrict__ part, int nb) {
   if (ctl->done) return;
   const int lane = threadIdx.x;
+  if (part) {
+    double re = 0.0;
+    for (int i = lane; i < nb; i += 64) re += part[2 * i];
+    re = wave_sum(re);
+    if (lane == 0) {
+      scal[6 + 4 * j] = re;
+      scal[6 + 4 * j + 1] = 0.0;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
   const double n2 = scal[0];
   if (!(n2 > 0.0) || !(n2 < 1e300)) {
     if (lane == 0) {
@@ -754,8 +768,25 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
   LzCtl hc;
   memset(&hc, 0, sizeof(hc));
   for (int j = 0;; ++j) {
-    MPSE_TRY(mpse_heff_apply(ctx, dtype, h, vec(j), W.p));
-    dot_partials(W.p, vec(j), part_a);
+    // <H U_j, U_j> rides on the launch that completes H U_j (mpse_ctx::dot_req); plans that cannot take it leave
+    // nb_out = 0 and the reduction runs as a pass of its own
+    static const bool dot_fused = [] {
+      const char* e = getenv("MPSE_DOT_FUSED");
+      return !(e && e[0] == '0');
+    }();
+    if (dot_fused) {
+      ctx->dot_req.y = vec(j);
+      ctx->dot_req.part = part_a;
+      ctx->dot_req.cap = 2 * RED_MAX_BLOCKS;
+      ctx->dot_req.nb_out = 0;
+    }
+    const int st_mv = mpse_heff_apply(ctx, dtype, h, vec(j), W.p);
+    const bool dot_done = ctx->dot_req.nb_out > 0;
+    const int a_nb = dot_done ? ctx->dot_req.nb_out : nb;
+    ctx->dot_req = mpse_ctx::DotReq();
+    ctx->dot_now = false;
+    MPSE_TRY(st_mv);
+    if (!dot_done) dot_partials(W.p, vec(j), part_a);
     if (j + 2 > cap) {      // room for U_{j+1}
       int ncap = cap * 2 < limit + 1 ? cap * 2 : limit + 1;
       TmpBuf V2(ctx);
@@ -774,21 +805,20 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
         hipLaunchKernelGGL(k_lanczos_update_u<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
                            W.as<const double>(), (const double*)vec(j),
                            j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
-                           (const double*)part_a, nb, scal + 4 + 4 * j, (const double*)cur_part, cur_out, prev2, new_part,
-                           done);
+                           (const double*)part_a, a_nb, scal + 4 + 4 * j, (const double*)cur_part, nb, cur_out, prev2,
+                           new_part, done);
       else
         hipLaunchKernelGGL(k_lanczos_update_u<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
                            W.as<const double>(), (const double*)vec(j),
                            j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
-                           (const double*)part_a, nb, scal + 4 + 4 * j, (const double*)cur_part, cur_out, prev2, new_part,
-                           done);
+                           (const double*)part_a, a_nb, scal + 4 + 4 * j, (const double*)cur_part, nb, cur_out, prev2,
+                           new_part, done);
     });
     const bool check = (j > 3 && j % 2 == 0);          // krylov.py:76-81
     const bool last = (j + 1 >= limit);
     if (check) {
-      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(RED_THREADS), 0, ctx->stream, new_part, nb, scal + 6 + 4 * j, done);
-      hipLaunchKernelGGL(k_lz_coefs, dim3(1), dim3(64), 0, ctx->stream, (const double*)scal, j, dt.real(), dt.imag(),
-                         tiny, coef, ctl);
+      hipLaunchKernelGGL(k_lz_coefs, dim3(1), dim3(64), 0, ctx->stream, scal, j, dt.real(), dt.imag(), tiny, coef, ctl,
+                         (const double*)new_part, nb);
       void* dst = (prev == out) ? RES.p : out;
       unsigned int gen = 0;
       if (prev) {

@@ -1,0 +1,4 @@
+mkdir -p gpurun_out/r3e; cd $GRAFT_REPO_ROOT; O=gpurun_out/r3e
+python -m pytest tests/test_engine_gpu.py tests/test_tdvp_gpu.py tests/test_edge_cases_gpu.py -m gpu -q -x 2>&1 | tail -3
+P='import json,sys; d=json.loads(sys.stdin.read()); print(round(d["value"],1), round(d["ms_per_step"],1), round(d["config"]["mean_krylov_dim"],3))'
+for f in 1 0 1 0 1 0; do echo "dot_fused=$f"; MPSE_DOT_FUSED=$f python bench.py --steps 5 --warmup 2 --cpu-updates 0 --state-file /tmp/state.npz 2>/dev/null | python -c "$P"; done
