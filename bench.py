@@ -311,7 +311,10 @@ def main():
                                    % (nsite, T, "y" if T == 1 else "ies"),
                        "nsite": nsite, "bond_dim": args.bond_dim, "dphys": [2, args.pdim], "mpo_bond": max(mpo.bond_dims),
                        "dt": args.dt, "init": args.init, "mean_krylov_dim": float(np.mean(kry)),
-                       "device": eng.device_name, "collective": coll.kind},
+                       "device": eng.device_name, "collective": coll.kind,
+                       "environments": ("rebuilt at every step (MPSE_ENV_CARRY=0)" if os.environ.get("MPSE_ENV_CARRY") == "0"
+                                        else "those ahead of the first half sweep are taken over from the previous step "
+                                             "(identical tensors; every step performs all 2 N site updates)")},
             "roofline": {"bound": "mfma", "kernel": "k_gemm<c128,c128> (FP64 MFMA strided contraction, 3M complex products)",
                          "achieved": issued, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": issued / FP64_MFMA_PEAK_TFLOPS,
