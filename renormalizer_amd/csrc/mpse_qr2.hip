@@ -596,34 +596,56 @@ int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk*
   // each).  Per column the kernel pays one reduction round (eight values through the halving butterfly), the
   // scalar reflector set-up in wave 0 and the branch-free update; the waves of one SIMD serialise on the VALU, so
   // tall blocks prefer more rows per thread over more waves (cycle breakdown by s_memtime).
+  // Rows per thread follow the tallest block (256 x 1..4 up to 1024 rows, 512 x 5..8 above 2048): the panel is bound
+  // by the FP64 vector work of its CU, and row slots that do not exist still cost their share of it (headline: 400
+  // rows -> 256 x 2 instead of 256 x 4: -16 % per d = 2 QR; 3200 rows -> 512 x 7).  MPSE_QR_FIT=0: the three
+  // coarse configurations only.
+  static const bool fit = [] {
+    const char* e = getenv("MPSE_QR_FIT");
+    return !(e && e[0] == '0');
+  }();
   const int cfg = max_mm <= 1024 ? 0 : max_mm <= 2048 ? 1 : 2;
+  const int rpt = !fit ? (cfg == 2 ? 8 : 4) : cfg == 0 ? (max_mm + 255) / 256 : cfg == 2 ? (max_mm + 511) / 512 : 4;
   const int nb = 4;
+  const bool wy = qr_use_wy();
+#define MPSE_QR_CASES_256(KERNEL, GRID, ...)                                                                        \
+  switch (rpt) {                                                                                                    \
+    case 1: hipLaunchKernelGGL((KERNEL<CPLX, 256, 1 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(256), 0, ctx->stream, ARGS); break; \
+    case 2: hipLaunchKernelGGL((KERNEL<CPLX, 256, 2 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(256), 0, ctx->stream, ARGS); break; \
+    case 3: hipLaunchKernelGGL((KERNEL<CPLX, 256, 3 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(256), 0, ctx->stream, ARGS); break; \
+    default: hipLaunchKernelGGL((KERNEL<CPLX, 256, 4 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(256), 0, ctx->stream, ARGS);       \
+  }
+#define MPSE_QR_CASES_512(KERNEL, GRID, ...)                                                                        \
+  switch (rpt) {                                                                                                    \
+    case 5: hipLaunchKernelGGL((KERNEL<CPLX, 512, 5 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(512), 0, ctx->stream, ARGS); break; \
+    case 6: hipLaunchKernelGGL((KERNEL<CPLX, 512, 6 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(512), 0, ctx->stream, ARGS); break; \
+    case 7: hipLaunchKernelGGL((KERNEL<CPLX, 512, 7 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(512), 0, ctx->stream, ARGS); break; \
+    default: hipLaunchKernelGGL((KERNEL<CPLX, 512, 8 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(512), 0, ctx->stream, ARGS);       \
+  }
   for (int j0 = 0; j0 < max_k; j0 += nb) {
-    switch (cfg) {
-      case 0:
-        hipLaunchKernelGGL((k_hh_panel<CPLX, 256, 4, 4>), dim3(nblk), dim3(256), 0, ctx->stream, ws, dblk, prm, j0);
-        break;
-      case 1:
-        hipLaunchKernelGGL((k_hh_panel<CPLX, 512, 4, 4>), dim3(nblk), dim3(512), 0, ctx->stream, ws, dblk, prm, j0);
-        break;
-      default:
-        hipLaunchKernelGGL((k_hh_panel<CPLX, 512, 8, 4>), dim3(nblk), dim3(512), 0, ctx->stream, ws, dblk, prm, j0);
+#define ARGS ws, dblk, prm, j0
+    if (cfg == 0) {
+      MPSE_QR_CASES_256(k_hh_panel, dim3(nblk), 4)
+    } else if (cfg == 1) {
+      hipLaunchKernelGGL((k_hh_panel<CPLX, 512, 4, 4>), dim3(nblk), dim3(512), 0, ctx->stream, ws, dblk, prm, j0);
+    } else {
+      MPSE_QR_CASES_512(k_hh_panel, dim3(nblk), 4)
     }
+#undef ARGS
     const int trailing = max_nn - j0 - 1;  // upper bound on columns to the right of any block's panel
-    if (trailing > 0 && qr_use_wy()) {
+    if (trailing > 0 && wy) {
       // two columns per workgroup share the loads of V where the registers allow (the tallest configuration holds
       // 4 reflector tails x 8 rows per thread: one column)
       const dim3 grid2((trailing + 1) / 2, nblk), grid1(trailing, nblk);
-      switch (cfg) {
-        case 0:
-          hipLaunchKernelGGL((k_hh_apply_wy<CPLX, 256, 4, 2>), grid2, dim3(256), 0, ctx->stream, ws, dblk, prm, j0, nb);
-          break;
-        case 1:
-          hipLaunchKernelGGL((k_hh_apply_wy<CPLX, 256, 8, 2>), grid2, dim3(256), 0, ctx->stream, ws, dblk, prm, j0, nb);
-          break;
-        default:
-          hipLaunchKernelGGL((k_hh_apply_wy<CPLX, 512, 8, 1>), grid1, dim3(512), 0, ctx->stream, ws, dblk, prm, j0, nb);
+#define ARGS ws, dblk, prm, j0, nb
+      if (cfg == 0) {
+        MPSE_QR_CASES_256(k_hh_apply_wy, grid2, 2)
+      } else if (cfg == 1) {
+        hipLaunchKernelGGL((k_hh_apply_wy<CPLX, 256, 8, 2>), grid2, dim3(256), 0, ctx->stream, ws, dblk, prm, j0, nb);
+      } else {
+        MPSE_QR_CASES_512(k_hh_apply_wy, grid1, 1)
       }
+#undef ARGS
     } else if (trailing > 0) {
       dim3 grid(trailing, nblk);
       switch (cfg) {
@@ -638,18 +660,17 @@ int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk*
       }
     }
   }
-  if (form_q && max_q > 0 && qr_use_wy()) {
+  if (form_q && max_q > 0 && wy) {
     dim3 grid(max_q, nblk);
-    switch (cfg) {
-      case 0:
-        hipLaunchKernelGGL((k_hh_formq_wy<CPLX, 256, 4>), grid, dim3(256), 0, ctx->stream, q, ws, dblk, prm);
-        break;
-      case 1:
-        hipLaunchKernelGGL((k_hh_formq_wy<CPLX, 256, 8>), grid, dim3(256), 0, ctx->stream, q, ws, dblk, prm);
-        break;
-      default:
-        hipLaunchKernelGGL((k_hh_formq_wy<CPLX, 512, 8>), grid, dim3(512), 0, ctx->stream, q, ws, dblk, prm);
+#define ARGS q, ws, dblk, prm
+    if (cfg == 0) {
+      MPSE_QR_CASES_256(k_hh_formq_wy, grid)
+    } else if (cfg == 1) {
+      hipLaunchKernelGGL((k_hh_formq_wy<CPLX, 256, 8>), grid, dim3(256), 0, ctx->stream, q, ws, dblk, prm);
+    } else {
+      MPSE_QR_CASES_512(k_hh_formq_wy, grid)
     }
+#undef ARGS
   } else if (form_q && max_q > 0) {
     dim3 grid(max_q, nblk);
     switch (cfg) {
@@ -663,6 +684,8 @@ int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk*
         hipLaunchKernelGGL((k_hh_formq_b<CPLX, 16>), grid, dim3(256), 0, ctx->stream, q, ws, dblk, prm);
     }
   }
+#undef MPSE_QR_CASES_256
+#undef MPSE_QR_CASES_512
   MPSE_HIP(ctx, hipGetLastError());
   return MPSE_OK;
 }

@@ -355,7 +355,8 @@ def test_block_qr_golden_inputs(eng, golden_dir):
 def test_block_qr_rank_deficient_and_shapes(eng, cplx):
     rng = np.random.default_rng(9)
     # single block (no symmetry), tall / wide / square, with exactly dependent and zero columns
-    for (m, n) in [(300, 40), (40, 300), (64, 64), (1, 7), (7, 1), (513, 130), (1500, 66), (2600, 37), (37, 2600), (6, 1100), (1030, 5)]:
+    for (m, n) in [(300, 40), (40, 300), (64, 64), (1, 7), (7, 1), (513, 130), (1500, 66), (2600, 37), (37, 2600), (6, 1100), (1030, 5),
+                   (700, 33), (2100, 20), (3300, 30), (4000, 12)]:   # every rows-per-thread configuration of the panels
         a = _rand(rng, (m, n), cplx)
         if n > 3:
             a[:, 2] = a[:, 0] * (2.0 - 0.5j if cplx else 2.0)   # dependent column
