@@ -390,6 +390,12 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
     // the whole of `out`
     if (ctx->dot_req.y && &s == &p.steps.back() && s.c == B_OUT && s.c_off == 0 && s.batch == 1 && s.cmask_slot < 0)
       ctx->dot_now = true;
+    if (s.cin >= 0) {
+      if (!bufs[s.cin]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing beta source");
+      ctx->cin_req.ptr = (const char*)bufs[s.cin] + size_t(s.cin_off) * dtype_size(dtc);
+      ctx->cin_req.m = s.mcin;
+      ctx->cin_req.n = s.ncin;
+    }
     MPSE_TRY(gemm_call(ctx, s.dta, s.dtb, s.conja, s.conjb, s.ma, s.ka, s.kb, s.nb, s.mc, s.nc, s.batch, s.sba,
                        s.sbb, s.sbc, a, b, c, 1.0, s.beta, s.skip_zero,
                        s.amask_slot >= 0 ? msk[s.amask_slot].p : nullptr,

@@ -66,6 +66,10 @@ struct GemmArgs {
   // coefficient alpha_j = <H v_j, v_j> without a pass of its own over the two vectors
   const double* dot_y;
   double* dot_part;
+  // optional (batch == 1): the beta term is read from here (own index maps) instead of from C - a product that
+  // accumulates onto a slice of another tensor needs no copy of that slice into C first
+  const double* Cin;
+  IdxMap mCin, nCin;
 };
 
 // (re, im) += conj(c) * y
@@ -477,6 +481,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
         if (gi >= g.M) continue;
         const long long co = idx_off(g.mC, gi) + coffn;
         double* p = C + co * EC;
+        const double* pin = g.Cin ? g.Cin + (idx_off(g.mCin, gi) + idx_off(g.nCin, gj)) * EC : p;
         const double xr = acc_re[i][j][r];
         if constexpr (CC) {
           const double xi = acc_im[i][j][r];
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
           o.x = g.alpha_re * xr - g.alpha_im * xi;
           o.y = g.alpha_re * xi + g.alpha_im * xr;
           if (g.use_beta) {
-            const double2 c0 = *reinterpret_cast<const double2*>(p);
+            const double2 c0 = *reinterpret_cast<const double2*>(pin);
             o.x += g.beta_re * c0.x - g.beta_im * c0.y;
             o.y += g.beta_re * c0.y + g.beta_im * c0.x;
           }
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
           if (g.dot_y) dot_acc(dre, dim, o, reinterpret_cast<const double2*>(g.dot_y)[co]);
         } else {
           double o = g.alpha_re * xr;
-          if (g.use_beta) o += g.beta_re * (*p);
+          if (g.use_beta) o += g.beta_re * (*pin);
           *p = o;
           if (g.dot_y) dre += o * g.dot_y[co];
         }
@@ -563,10 +568,11 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs g, int bat
       }
       const long long co = idx_off(g.nC, j);
       double* p = crow + co * EC;
+      const double* pin = g.Cin ? g.Cin + (idx_off(g.mCin, i) + idx_off(g.nCin, j)) * EC : p;
       if constexpr (CC) {
         double2 o = make_double2(g.alpha_re * xr - g.alpha_im * xi, g.alpha_re * xi + g.alpha_im * xr);
         if (g.use_beta) {
-          const double2 c0 = *reinterpret_cast<const double2*>(p);
+          const double2 c0 = *reinterpret_cast<const double2*>(pin);
           o.x += g.beta_re * c0.x - g.beta_im * c0.y;
           o.y += g.beta_re * c0.y + g.beta_im * c0.x;
         }
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs g, int bat
         if (g.dot_y) dot_acc(dre, dim, o, reinterpret_cast<const double2*>(g.dot_y)[idx_off(g.mC, i) + co]);
       } else {
         double o = g.alpha_re * xr;
-        if (g.use_beta) o += g.beta_re * (*p);
+        if (g.use_beta) o += g.beta_re * (*pin);
         *p = o;
         if (g.dot_y) dre += o * g.dot_y[idx_off(g.mC, i) + co];
       }
@@ -758,6 +764,16 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.beta_re = d->beta_re;
   g.beta_im = d->beta_im;
   g.use_beta = (d->beta_re != 0.0 || d->beta_im != 0.0);
+  // beta source of the caller (mpse_ctx::cin_req, set by run_plan for this one call)
+  g.Cin = nullptr;
+  if (ctx->cin_req.ptr) {
+    const mpse_ctx::CinReq rq = ctx->cin_req;
+    ctx->cin_req = mpse_ctx::CinReq();
+    if (d->batch != 1 || !g.use_beta || !to_map(rq.m, &g.mCin) || !to_map(rq.n, &g.nCin) || g.mCin.ext != g.mC.ext ||
+        g.nCin.ext != g.nC.ext)
+      return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_gemm: beta source needs batch == 1, beta != 0 and the extents of C");
+    g.Cin = static_cast<const double*>(rq.ptr);
+  }
   const bool ca = d->dtype_a == MPSE_C128, cb = d->dtype_b == MPSE_C128;
   // split-K when the output tiles alone cannot fill the 256 CUs (skinny results with long K)
   const long long base_blocks = (long long)g.tiles_m * g.tiles_n * d->batch;

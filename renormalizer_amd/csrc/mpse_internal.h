@@ -108,6 +108,11 @@ struct mpse_ctx {
     int nb_out = 0;
   } dot_req;
   bool dot_now = false;   // set by run_plan for the one GEMM launch that completes the result
+  // beta source for the next GEMM call (consumed by it): C = A.B + beta * Cin(i, j) with Cin's own index maps
+  struct CinReq {
+    const void* ptr = nullptr;
+    mpse_index m{}, n{};
+  } cin_req;
   bool occ_cache_on = false;
   const char* occ_lo[2] = {nullptr, nullptr};
   const char* occ_hi[2] = {nullptr, nullptr};

@@ -53,6 +53,9 @@ struct Step {
                                // multiplied into it); tiles with nothing are NOT stored (consumer: K_WSTEP)
   int amask_slot = -1;         // K_GEMM: tile-occupancy mask of operand A written by a K_WSTEP producer (no scan)
   WStepDesc ws;                // K_WSTEP (a = centre tensor, b = W site, c = T2; T1 is B_T1)
+  int cin = -1;                // K_GEMM with beta != 0: buffer the beta term is read from (-1: C itself) ...
+  int64_t cin_off = 0;         // ... at this element offset, through these index maps
+  mpse_index mcin{}, ncin{};
 };
 
 struct Plan {
@@ -80,6 +83,14 @@ inline int64_t& unit_threshold() {   // multiply-adds; a test hook lowers it so 
   return v;
 }
 inline bool unit_pays(int64_t m, int64_t k, int64_t n) { return m * k * n >= unit_threshold(); }
+inline bool& beta_source_flag() {
+  static bool v = [] {
+    const char* e = getenv("MPSE_BETA_SOURCE");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+inline bool beta_source_on() { return beta_source_flag(); }
 // Scanning the operands of a GEMM for structurally zero tiles costs two small launches and one pass over the
 // operands; worth it from ~3e7 multiply-adds on.
 // The result says which operands to scan: bit 0 = A, bit 1 = B.
@@ -130,11 +141,15 @@ inline void push_times_env(Plan& p, int tbuf, int t_dtype, int ebuf, int e_dtype
                            int64_t w, int64_t Dk, int64_t Dout, int64_t unit) {
   const int64_t u = (unit >= 1 && unit <= w && Dout == Dk && unit_pays(M1 * anc, Dk, Dout)) ? unit - 1 : -1;
   double beta = 0.0;
-  if (u >= 0) {
+  // The unit channel contributes T[m, u, g, l] itself: the first product reads it as its beta term straight from T
+  // (no copy into `out` first), unless there is no product at all (w == 1) or MPSE_BETA_SOURCE=0.
+  const bool direct = u >= 0 && w > 1 && beta_source_on();
+  if (u >= 0 && !direct) {
     push_copy(p, tbuf, u * anc * Dk, obuf, 0, t_dtype, i2(M1, anc, w * anc * Dk, Dk), i1(Dk, 1), i1(M1 * anc, Dout),
               i1(Dout, 1));
     beta = 1.0;
   }
+  bool first = true;
   const int64_t lo[2] = {0, u + 1}, hi[2] = {u >= 0 ? u : w, u >= 0 ? w : 0};
   for (int r = 0; r < 2; ++r) {
     const int64_t f0 = lo[r], nf = hi[r] - lo[r];
@@ -142,6 +157,15 @@ inline void push_times_env(Plan& p, int tbuf, int t_dtype, int ebuf, int e_dtype
     push(p, tbuf, f0 * anc * Dk, t_dtype, 0, ebuf, f0 * Dk, e_dtype, 0, obuf, 0,
          /*A: m=(m1 | g)*/ i2(M1, anc, w * anc * Dk, Dk), /*k=(f | k)*/ i2(nf, Dk, anc * Dk, 1),
          /*B=E: k=(f,k), n=l*/ i1(nf * Dk, 1), i1(Dout, w * Dk), i1(M1 * anc, Dout), i1(Dout, 1));
+    if (direct && first) {
+      Step& s = p.steps.back();
+      s.cin = tbuf;
+      s.cin_off = u * anc * Dk;
+      s.mcin = i2(M1, anc, w * anc * Dk, Dk);
+      s.ncin = i1(Dk, 1);
+      beta = 1.0;
+    }
+    first = false;
     p.steps.back().beta = beta;
     p.steps.back().skip_zero = skip_pays(M1 * anc, nf * Dk, Dout, 2);   // A = the big intermediate: environment side only
     beta = 1.0;

@@ -25,7 +25,7 @@ static inline cd ld(const void* p, int dt, int64_t o, int conj) {
   return cd(((const double*)p)[o], 0.0);
 }
 
-static void naive_gemm(const Step& s, const void* A, const void* B, void* C) {
+static void naive_gemm(const Step& s, const void* A, const void* B, void* C, const void* Cin) {
   const int dtc = (s.dta == MPSE_C128 || s.dtb == MPSE_C128) ? MPSE_C128 : MPSE_F64;
   for (int64_t b = 0; b < s.batch; ++b)
     for (int64_t i = 0; i < s.ma.ext; ++i)
@@ -35,10 +35,13 @@ static void naive_gemm(const Step& s, const void* A, const void* B, void* C) {
           acc += ld(A, s.dta, b * s.sba + off(s.ma, i) + off(s.ka, k), s.conja) *
                  ld(B, s.dtb, b * s.sbb + off(s.kb, k) + off(s.nb, j), s.conjb);
         int64_t o = b * s.sbc + off(s.mc, i) + off(s.nc, j);
+        // the beta term comes from C itself or, for steps with a beta source, from that tensor through its own maps
+        const void* src = Cin ? Cin : C;
+        const int64_t oi = Cin ? off(s.mcin, i) + off(s.ncin, j) : o;
         if (dtc == MPSE_C128)
-          ((cd*)C)[o] = acc + (s.beta != 0.0 ? s.beta * ((cd*)C)[o] : cd(0));
+          ((cd*)C)[o] = acc + (s.beta != 0.0 ? s.beta * ((const cd*)src)[oi] : cd(0));
         else
-          ((double*)C)[o] = acc.real() + (s.beta != 0.0 ? s.beta * ((double*)C)[o] : 0.0);
+          ((double*)C)[o] = acc.real() + (s.beta != 0.0 ? s.beta * ((const double*)src)[oi] : 0.0);
       }
 }
 
@@ -106,7 +109,8 @@ static int run(int dtype, const Plan& p, const void* bufs_in[B_COUNT]) {
       continue;
     }
     naive_gemm(s, (const char*)bufs[s.a] + s.a_off * ea, (const char*)bufs[s.b] + s.b_off * eb,
-               (char*)const_cast<void*>(bufs[s.c]) + s.c_off * es);
+               (char*)const_cast<void*>(bufs[s.c]) + s.c_off * es,
+               s.cin >= 0 ? (const char*)bufs[s.cin] + s.cin_off * es : nullptr);
   }
   return MPSE_OK;
 }
@@ -164,3 +168,4 @@ extern "C" int emu_heff_apply2(int dtype, const mpse_heff* h, const void* C, voi
 
 extern "C" void emu_set_unit_threshold(long long macs) { unit_threshold() = macs; }
 extern "C" void emu_set_masked_chain_min(long long elems) { masked_chain_min() = elems; }
+extern "C" void emu_set_beta_source(int on) { beta_source_flag() = on != 0; }

@@ -195,10 +195,14 @@ def test_heff_plans_rectangular(emu, cplx):
         assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-11 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("beta_source", [1, 0])
 @pytest.mark.parametrize("cplx", [False, True])
-def test_plans_unit_channels(emu, cplx):
+def test_plans_unit_channels(emu, cplx, beta_source):
     """Environments whose channel u is the identity matrix (canonical MPS, no operator applied yet): with
-    l_unit / r_unit / env_unit set the plans copy that slice instead of multiplying by it; same result."""
+    l_unit / r_unit / env_unit set the plans copy that slice instead of multiplying by it; same result.  On the
+    right-hand side the slice is either copied into the result first or read by the first product as its beta term
+    straight from the intermediate (``beta_source``); includes w = 1, where no product follows."""
+    emu.emu_set_beta_source(beta_source)
     rng = np.random.default_rng(23)
 
     def with_unit(D, w, u):
@@ -241,6 +245,7 @@ def test_plans_unit_channels(emu, cplx):
     env = _rand(rng, (3, 2, 4), cplx)
     ref = orc.contract_one_site(env, ket, mo, "L", ms_conj=bra.conj())
     assert np.abs(emu_env(emu, env, ket, mo, "L", bra=bra, env_unit=1) - ref).max() < 1e-11 * np.abs(ref).max()
+    emu.emu_set_beta_source(1)
 
 
 def test_plans_random_shapes_property(emu):
