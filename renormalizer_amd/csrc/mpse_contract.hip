@@ -396,10 +396,14 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
       ctx->cin_req.m = s.mcin;
       ctx->cin_req.n = s.ncin;
     }
-    MPSE_TRY(gemm_call(ctx, s.dta, s.dtb, s.conja, s.conjb, s.ma, s.ka, s.kb, s.nb, s.mc, s.nc, s.batch, s.sba,
-                       s.sbb, s.sbc, a, b, c, 1.0, s.beta, s.skip_zero,
-                       s.amask_slot >= 0 ? msk[s.amask_slot].p : nullptr,
-                       s.cmask_slot >= 0 ? msk[s.cmask_slot].p : nullptr));
+    const int st = gemm_call(ctx, s.dta, s.dtb, s.conja, s.conjb, s.ma, s.ka, s.kb, s.nb, s.mc, s.nc, s.batch, s.sba,
+                             s.sbb, s.sbc, a, b, c, 1.0, s.beta, s.skip_zero,
+                             s.amask_slot >= 0 ? msk[s.amask_slot].p : nullptr,
+                             s.cmask_slot >= 0 ? msk[s.cmask_slot].p : nullptr);
+    // requests the call did not take (degenerate product, error) must not reach a later one
+    ctx->cin_req = mpse_ctx::CinReq();
+    ctx->dot_now = false;
+    MPSE_TRY(st);
   }
   return MPSE_OK;
 }
