@@ -55,6 +55,7 @@ struct mpse_ctx {
 
   // pinned ring for small host->device uploads that must not stall the stream (index lists, descriptors)
   char* stage = nullptr;
+  char* stage_dev = nullptr;   // the ring as the device sees it (mapped), null: copies go through the runtime
   size_t stage_size = 0, stage_pos = 0;
 
   // small pinned staging buffer for scalar read-backs
@@ -130,6 +131,8 @@ inline int mpse_bind(mpse_ctx* ctx) {
 }
 // asynchronous upload of a small host array through the pinned ring (the host buffer may be reused at once)
 int stage_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes);
+// zero fill as a plain kernel on the context stream (8-byte aligned ranges; others go through hipMemsetAsync)
+int device_zero(mpse_ctx* ctx, void* dst, size_t bytes);
 // fold finished profiling records into the totals; call only when the stream is idle
 void prof_drain(mpse_ctx* ctx);
 // HIP-event bracket around a group of launches on the context stream; begin returns false when this call is not

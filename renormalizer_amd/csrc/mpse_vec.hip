@@ -714,7 +714,7 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
   double* scal = SCAL.as<double>();
   LzCtl* ctl = reinterpret_cast<LzCtl*>(scal + SC_CTL);
   double* coef = scal + SC_COEF;
-  MPSE_HIP(ctx, hipMemsetAsync(ctl, 0, sizeof(LzCtl), ctx->stream));
+  MPSE_TRY(device_zero(ctx, ctl, sizeof(LzCtl)));
   const int* done = &ctl->done;
   const int nb = red_blocks(nd);
   double* part_a = ctx->dscratch;
