@@ -22,6 +22,29 @@ __global__ __launch_bounds__(256) void k_copy8(unsigned long long* dst, const un
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = src[i];
 }
 
+__global__ __launch_bounds__(256) void k_zero8x2(unsigned long long* a, long long na, unsigned long long* b, long long nb) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += (long long)gridDim.x * 256) {
+    if (i < na)
+      a[i] = 0ull;
+    else
+      b[i - na] = 0ull;
+  }
+}
+
+int device_zero2(mpse_ctx* ctx, void* a, size_t abytes, void* b, size_t bbytes) {
+  if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | abytes | bbytes) & 7) != 0 || !abytes || !bbytes) {
+    MPSE_TRY(device_zero(ctx, a, abytes));
+    return device_zero(ctx, b, bbytes);
+  }
+  const long long na = (long long)(abytes / 8), nb = (long long)(bbytes / 8);
+  long long blocks = (na + nb + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_zero8x2, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, static_cast<unsigned long long*>(a), na,
+                     static_cast<unsigned long long*>(b), nb);
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
 int device_zero(mpse_ctx* ctx, void* dst, size_t bytes) {
   if (!bytes) return MPSE_OK;
   if ((reinterpret_cast<uintptr_t>(dst) & 7) == 0 && (bytes & 7) == 0) {

@@ -213,7 +213,11 @@ struct QrBlk {
   int mm, nn, k;
   int prm_off;       // offset of its reflector parameters
   int nq = 0;        // columns of Q to form (0 -> k); columns beyond k complete the basis (full_matrices SVD)
+  long long row_off = 0, col_off = 0;   // block_qr: where the block's row / column index lists start (device lists)
 };
 constexpr int HH_BATCH_MAX_ROWS = 4096;
+// ``blks_dev``: the same descriptors already on the device (else they are uploaded here)
 int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm, const QrBlk* blks_host, int nblk,
-                  bool form_q);
+                  bool form_q, const QrBlk* blks_dev = nullptr);
+// zero fill of two ranges in one launch (8-byte aligned)
+int device_zero2(mpse_ctx* ctx, void* a, size_t abytes, void* b, size_t bbytes);

@@ -38,33 +38,6 @@ __device__ __forceinline__ double2 cmulc(double2 a, double2 b) {  // conj(a) * b
   return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
 }
 
-// gather a block into the column-major workspace: ws[r + c*mm]
-//   !herm: ws[r,c] = coef[rows[r], cols[c]]          (mm = #rows)
-//    herm: ws[r,c] = conj(coef[rows[c], cols[r]])    (mm = #cols)  -> QR of the adjoint gives RQ
-template <bool CPLX>
-__global__ void k_gather_block(double* ws, const double* __restrict__ coef, long long ncol,
-                               const long long* __restrict__ rows, const long long* __restrict__ cols, int mm, int nn,
-                               int herm) {
-  const long long total = (long long)mm * nn;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    // make the SOURCE access coalesced: consecutive threads walk along a coef row
-    int r, c;
-    if (!herm) {
-      c = (int)(t % nn);
-      r = (int)(t / nn);
-      double2 v = Cx<CPLX>::ld(coef, rows[r] * ncol + cols[c]);
-      Cx<CPLX>::st(ws, r + (long long)c * mm, v);
-    } else {
-      r = (int)(t % mm);
-      c = (int)(t / mm);
-      double2 v = Cx<CPLX>::ld(coef, rows[c] * ncol + cols[r]);
-      v.y = -v.y;
-      Cx<CPLX>::st(ws, r + (long long)c * mm, v);
-    }
-  }
-}
-
 // reflector parameters for column j from its current content (rows >= j); one workgroup.
 template <bool CPLX>
 __device__ void hh_make_params(double* a, int mm, int j, HhParam* prm) {
@@ -179,42 +152,76 @@ __global__ __launch_bounds__(RED_THREADS) void k_hh_formq(double* q, const doubl
   }
 }
 
-// scatter Q (mm x k col-major) and R (upper triangle of a, k x nn) to U (nrow x K) / Vt (K x ncol)
-//   !herm: U[rows[r], koff+c] = Q[r,c] ; Vt[koff+i, cols[c]] = R[i,c]
-//    herm: Vt[koff+c, cols[r]] = conj(Q[r,c]) ; U[rows[c], koff+i] = conj(R[i,c])
+// gather the blocks into their column-major workspaces, ws[r + c*mm] - all blocks of a decomposition in one launch
+// (blockIdx.y = block, descriptors and index lists on the device):
+//   !herm: ws[r,c] = coef[rows[r], cols[c]]          (mm = #rows)
+//    herm: ws[r,c] = conj(coef[rows[c], cols[r]])    (mm = #cols)  -> QR of the adjoint gives RQ
 template <bool CPLX>
-__global__ void k_scatter_q(double* U, double* Vt, const double* __restrict__ q, long long K, long long ncol,
-                            const long long* __restrict__ rows, const long long* __restrict__ cols, int mm, int k,
-                            long long koff, int herm) {
-  const long long total = (long long)mm * k;
+__global__ void k_gather_blocks(double* ws_base, const double* __restrict__ coef, long long ncol,
+                                const long long* __restrict__ drows, const long long* __restrict__ dcols,
+                                const QrBlk* __restrict__ blks, int herm) {
+  const QrBlk B = blks[blockIdx.y];
+  double* ws = ws_base + B.ws_off * Cx<CPLX>::E;
+  const long long* rows = drows + B.row_off;
+  const long long* cols = dcols + B.col_off;
+  const int mm = B.mm, nn = B.nn;
+  const long long total = (long long)mm * nn;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    int r, c;
     if (!herm) {
-      const int c = (int)(t % k), r = (int)(t / k);  // consecutive threads along a U row
-      Cx<CPLX>::st(U, rows[r] * K + koff + c, Cx<CPLX>::ld(q, r + (long long)c * mm));
+      c = (int)(t % nn);
+      r = (int)(t / nn);
+      Cx<CPLX>::st(ws, r + (long long)c * mm, Cx<CPLX>::ld(coef, rows[r] * ncol + cols[c]));
     } else {
-      const int r = (int)(t % mm), c = (int)(t / mm);
-      double2 v = Cx<CPLX>::ld(q, r + (long long)c * mm);
+      r = (int)(t % mm);
+      c = (int)(t / mm);
+      double2 v = Cx<CPLX>::ld(coef, rows[c] * ncol + cols[r]);
       v.y = -v.y;
-      Cx<CPLX>::st(Vt, (koff + c) * ncol + cols[r], v);
+      Cx<CPLX>::st(ws, r + (long long)c * mm, v);
     }
   }
 }
 
+// scatter Q (mm x k col-major) and R (upper triangle of the workspace, k x nn) of every block to U (nrow x K) /
+// Vt (K x ncol), one launch:
+//   !herm: U[rows[r], koff+c] = Q[r,c] ; Vt[koff+i, cols[c]] = R[i,c]
+//    herm: Vt[koff+c, cols[r]] = conj(Q[r,c]) ; U[rows[c], koff+i] = conj(R[i,c])
 template <bool CPLX>
-__global__ void k_scatter_r(double* U, double* Vt, const double* __restrict__ a, long long K, long long ncol,
-                            const long long* __restrict__ rows, const long long* __restrict__ cols, int mm, int nn,
-                            int k, long long koff, int herm) {
-  const long long total = (long long)k * nn;
+__global__ void k_scatter_blocks(double* U, double* Vt, const double* __restrict__ q_base,
+                                 const double* __restrict__ ws_base, long long K, long long ncol,
+                                 const long long* __restrict__ drows, const long long* __restrict__ dcols,
+                                 const QrBlk* __restrict__ blks, int herm) {
+  const QrBlk B = blks[blockIdx.y];
+  const double* q = q_base + B.q_off * Cx<CPLX>::E;
+  const double* a = ws_base + B.ws_off * Cx<CPLX>::E;
+  const long long* rows = drows + B.row_off;
+  const long long* cols = dcols + B.col_off;
+  const int mm = B.mm, nn = B.nn, k = B.k;
+  const long long koff = B.prm_off;
+  const long long tq = (long long)mm * k, total = tq + (long long)k * nn;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int c = (int)(t % nn), i = (int)(t / nn);
-    double2 v = (i <= c) ? Cx<CPLX>::ld(a, i + (long long)c * mm) : make_double2(0.0, 0.0);
-    if (!herm) {
-      Cx<CPLX>::st(Vt, (koff + i) * ncol + cols[c], v);
+    if (t < tq) {
+      if (!herm) {
+        const int c = (int)(t % k), r = (int)(t / k);
+        Cx<CPLX>::st(U, rows[r] * K + koff + c, Cx<CPLX>::ld(q, r + (long long)c * mm));
+      } else {
+        const int r = (int)(t % mm), c = (int)(t / mm);
+        double2 v = Cx<CPLX>::ld(q, r + (long long)c * mm);
+        v.y = -v.y;
+        Cx<CPLX>::st(Vt, (koff + c) * ncol + cols[r], v);
+      }
     } else {
-      v.y = -v.y;
-      Cx<CPLX>::st(U, rows[c] * K + koff + i, v);
+      const long long u = t - tq;
+      const int c = (int)(u % nn), i = (int)(u / nn);
+      double2 v = (i <= c) ? Cx<CPLX>::ld(a, i + (long long)c * mm) : make_double2(0.0, 0.0);
+      if (!herm) {
+        Cx<CPLX>::st(Vt, (koff + i) * ncol + cols[c], v);
+      } else {
+        v.y = -v.y;
+        Cx<CPLX>::st(U, rows[c] * K + koff + i, v);
+      }
     }
   }
 }
@@ -291,9 +298,15 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   }
   if (ktot != K) return mpse_fail(ctx, MPSE_ERR_SHAPE, "block_qr: K=%lld but blocks give %lld", (long long)K, (long long)ktot);
   if (ktot == 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
-  MPSE_TRY(mpse_memset_zero(ctx, U, size_t(nrow * K) * es));
-  MPSE_TRY(mpse_memset_zero(ctx, Vt, size_t(K * ncol) * es));
+  MPSE_TRY(device_zero2(ctx, U, size_t(nrow * K) * es, Vt, size_t(K * ncol) * es));
   const int64_t nri = row_off[nblocks], nci = col_off[nblocks];
+  int64_t max_el = 0, max_sc = 0;
+  for (size_t i = 0; i < blks.size(); ++i) {
+    blks[i].row_off = row_off[which[i]];
+    blks[i].col_off = col_off[which[i]];
+    max_el = std::max<int64_t>(max_el, (int64_t)blks[i].mm * blks[i].nn);
+    max_sc = std::max<int64_t>(max_sc, (int64_t)blks[i].mm * blks[i].k + (int64_t)blks[i].k * blks[i].nn);
+  }
   TmpBuf IDX(ctx), WS(ctx), Q(ctx), PRM(ctx);
   // optional HIP-event sampling of the whole decomposition (mpse_prof_*, variant 5): Householder factorisation +
   // explicit economic Q, F = (c/2) (4 m n^2 - 4 n^3 / 3) per block with c = 8 complex / 2 real
@@ -305,45 +318,38 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   }
   mpse_ctx::ProfRec qrec;
   const bool qpt = prof_begin(ctx, 5, qr_flops, qr_bytes, &qrec);
-  MPSE_TRY(IDX.alloc(size_t(nri + nci) * sizeof(int64_t)));
+  // one upload: row index lists | column index lists | block descriptors
+  const size_t ib = size_t(nri + nci) * sizeof(int64_t), db = blks.size() * sizeof(QrBlk);
+  static_assert(sizeof(QrBlk) % 8 == 0, "descriptors follow the 8-byte index lists");
+  std::vector<char> host(ib + db);
+  memcpy(host.data(), row_idx, size_t(nri) * sizeof(int64_t));
+  memcpy(host.data() + size_t(nri) * sizeof(int64_t), col_idx, size_t(nci) * sizeof(int64_t));
+  memcpy(host.data() + ib, blks.data(), db);
+  MPSE_TRY(IDX.alloc(ib + db));
   MPSE_TRY(WS.alloc(size_t(ws_tot) * es));
   MPSE_TRY(Q.alloc(size_t(q_tot) * es));
   MPSE_TRY(PRM.alloc(size_t(ktot + 1) * sizeof(HhParam)));
-  MPSE_TRY(stage_h2d(ctx, IDX.p, row_idx, size_t(nri) * sizeof(int64_t)));
-  MPSE_TRY(stage_h2d(ctx, IDX.as<char>() + size_t(nri) * sizeof(int64_t), col_idx, size_t(nci) * sizeof(int64_t)));
+  MPSE_TRY(stage_h2d(ctx, IDX.p, host.data(), ib + db));
   const long long* drows = IDX.as<long long>();
   const long long* dcols = IDX.as<long long>() + nri;
+  const QrBlk* dblk = reinterpret_cast<const QrBlk*>(IDX.as<char>() + ib);
   double* ws = WS.as<double>();
   double* q = Q.as<double>();
   HhParam* prm = PRM.as<HhParam>();
   constexpr int E = CPLX ? 2 : 1;
-  for (size_t i = 0; i < blks.size(); ++i) {
-    const QrBlk& B = blks[i];
-    const int b = which[i];
-    hipLaunchKernelGGL((k_gather_block<CPLX>), dim3(ew_blocks((int64_t)B.mm * B.nn)), dim3(256), 0, ctx->stream,
-                       ws + B.ws_off * E, (const double*)coef, (long long)ncol, drows + row_off[b], dcols + col_off[b],
-                       B.mm, B.nn, herm);
-  }
+  hipLaunchKernelGGL((k_gather_blocks<CPLX>), dim3(ew_blocks(max_el), (unsigned)blks.size()), dim3(256), 0, ctx->stream, ws,
+                     (const double*)coef, (long long)ncol, drows, dcols, dblk, herm);
   if (max_mm <= HH_BATCH_MAX_ROWS) {
-    MPSE_TRY(hh_qr_batched(ctx, CPLX, ws, q, prm, blks.data(), (int)blks.size(), true));
+    MPSE_TRY(hh_qr_batched(ctx, CPLX, ws, q, prm, blks.data(), (int)blks.size(), true, dblk));
   } else {
     for (const QrBlk& B : blks) {
       MPSE_TRY(hh_factor_colmajor(ctx, CPLX, ws + B.ws_off * E, B.mm, B.nn, B.k, prm + B.prm_off));
       MPSE_TRY(hh_formq_colmajor(ctx, CPLX, q + B.q_off * E, ws + B.ws_off * E, B.mm, B.k, prm + B.prm_off, B.k));
     }
   }
-  for (size_t i = 0; i < blks.size(); ++i) {
-    const QrBlk& B = blks[i];
-    const int b = which[i];
-    const long long* rows = drows + row_off[b];
-    const long long* cols = dcols + col_off[b];
-    hipLaunchKernelGGL((k_scatter_q<CPLX>), dim3(ew_blocks((int64_t)B.mm * B.k)), dim3(256), 0, ctx->stream,
-                       (double*)U, (double*)Vt, (const double*)(q + B.q_off * E), (long long)K, (long long)ncol, rows,
-                       cols, B.mm, B.k, (long long)B.prm_off, herm);
-    hipLaunchKernelGGL((k_scatter_r<CPLX>), dim3(ew_blocks((int64_t)B.k * B.nn)), dim3(256), 0, ctx->stream,
-                       (double*)U, (double*)Vt, (const double*)(ws + B.ws_off * E), (long long)K, (long long)ncol, rows,
-                       cols, B.mm, B.nn, B.k, (long long)B.prm_off, herm);
-  }
+  hipLaunchKernelGGL((k_scatter_blocks<CPLX>), dim3(ew_blocks(max_sc), (unsigned)blks.size()), dim3(256), 0, ctx->stream,
+                     (double*)U, (double*)Vt, (const double*)q, (const double*)ws, (long long)K, (long long)ncol, drows, dcols,
+                     dblk, herm);
   if (qpt) prof_end(ctx, qrec);
   MPSE_HIP(ctx, hipGetLastError());
   return MPSE_OK;

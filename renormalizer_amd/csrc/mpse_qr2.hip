@@ -695,7 +695,7 @@ int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk*
 // Factorise (and optionally form Q for) nblk column-major blocks living in one workspace.
 // Requires max mm <= HH_BATCH_MAX_ROWS; callers fall back to the unblocked kernels otherwise.
 int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm, const QrBlk* blks_host, int nblk,
-                  bool form_q) {
+                  bool form_q, const QrBlk* blks_dev) {
   if (nblk <= 0) return MPSE_OK;
   int max_mm = 0, max_nn = 0, max_k = 0, max_q = 0;
   for (int b = 0; b < nblk; ++b) {
@@ -707,8 +707,11 @@ int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm,
   }
   if (max_mm > HH_BATCH_MAX_ROWS) return mpse_fail(ctx, MPSE_ERR_SHAPE, "hh_qr_batched: block too tall");
   TmpBuf DB(ctx);
-  MPSE_TRY(DB.alloc(size_t(nblk) * sizeof(QrBlk)));
-  MPSE_TRY(stage_h2d(ctx, DB.p, blks_host, size_t(nblk) * sizeof(QrBlk)));
-  if (cplx) return run_batched<true>(ctx, ws, q, prm, DB.as<QrBlk>(), nblk, max_mm, max_nn, max_k, max_q, form_q);
-  return run_batched<false>(ctx, ws, q, prm, DB.as<QrBlk>(), nblk, max_mm, max_nn, max_k, max_q, form_q);
+  if (!blks_dev) {
+    MPSE_TRY(DB.alloc(size_t(nblk) * sizeof(QrBlk)));
+    MPSE_TRY(stage_h2d(ctx, DB.p, blks_host, size_t(nblk) * sizeof(QrBlk)));
+    blks_dev = DB.as<QrBlk>();
+  }
+  if (cplx) return run_batched<true>(ctx, ws, q, prm, blks_dev, nblk, max_mm, max_nn, max_k, max_q, form_q);
+  return run_batched<false>(ctx, ws, q, prm, blks_dev, nblk, max_mm, max_nn, max_k, max_q, form_q);
 }
