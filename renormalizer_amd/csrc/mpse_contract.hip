@@ -104,6 +104,65 @@ __global__ __launch_bounds__(256) void k_w_csr(const double* __restrict__ W, int
   if (threadIdx.x == 0) cnt[no] = s_ptr[no];
 }
 
+// ---- MPO step of a small site (wl d <= 16 inputs, d wr <= 16 outputs per bond state and trailing index: the d = 2
+// sites of a Holstein chain):  T2[a, dd, f, n] = sum_{b,e} W[b, dd, e, f] T1[b, a, e, n].  As a batched MFMA product
+// this is 8 x 8 x 256 per bond state padded to 64 x 64 tiles (14 us); here one thread owns one (a, n), reads its
+// inputs (coalesced along n), multiplies by W out of LDS and stores its outputs: two passes over 18 MB.
+struct WsmArgs {
+  const double* T1;
+  double* T2;
+  const double* W;
+  int Da, d, wl, wr, N;
+  const int* skip;
+};
+
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_wsmall(const WsmArgs g) {
+  if (g.skip && *g.skip) return;
+  constexpr int E = CPLX ? 2 : 1;
+  __shared__ double s_w[16][16];   // [o = dd * wr + f][be = b * d + e]
+  const int nrow = g.wl * g.d, no = g.d * g.wr;
+  {
+    const int o = threadIdx.x >> 4, be = threadIdx.x & 15;
+    double v = 0.0;
+    if (o < no && be < nrow) {
+      const int dd = o / g.wr, f = o - dd * g.wr, b = be / g.d, e = be - b * g.d;
+      v = g.W[(((long long)b * g.d + dd) * g.d + e) * g.wr + f];
+    }
+    s_w[o][be] = v;
+  }
+  __syncthreads();
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)g.Da * g.N) return;
+  const int a = (int)(idx / g.N), n = (int)(idx - (long long)a * g.N);
+  double xr[16], xi[16];
+#pragma unroll
+  for (int be = 0; be < 16; ++be) {
+    xr[be] = 0.0;
+    xi[be] = 0.0;
+    if (be < nrow) {
+      const int b = be / g.d, e = be - b * g.d;
+      const double* src = g.T1 + ((((long long)b * g.Da + a) * g.d + e) * g.N + n) * E;
+      xr[be] = src[0];
+      if constexpr (CPLX) xi[be] = src[1];
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    if (o >= no) break;
+    double ar = 0.0, ai = 0.0;
+#pragma unroll
+    for (int be = 0; be < 16; ++be) {
+      const double w = s_w[o][be];   // zero beyond nrow
+      ar += w * xr[be];
+      if constexpr (CPLX) ai += w * xi[be];
+    }
+    double* dst = g.T2 + (((long long)a * no + o) * g.N + n) * E;
+    dst[0] = ar;
+    if constexpr (CPLX) dst[1] = ai;
+  }
+}
+
 struct WsArgs {
   const double* T1;
   const double* X0;       // centre tensor (unit channel of the left environment), or null
@@ -311,7 +370,30 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
   TmpBuf msk[M_COUNT] = {TmpBuf(ctx), TmpBuf(ctx), TmpBuf(ctx), TmpBuf(ctx)};
   for (int i = 0; i < M_COUNT; ++i)
     if (p.mask_bytes[i] > 0) MPSE_TRY(msk[i].alloc(size_t(p.mask_bytes[i]) + 64));
+  // MPSE_WSMALL=0: the MPO step of small sites as a batched MFMA product like the large ones
+  static const bool wsmall_on = [] {
+    const char* e = getenv("MPSE_WSMALL");
+    return !(e && e[0] == '0');
+  }();
   for (const Step& s : p.steps) {
+    if (s.kind == K_GEMM && s.is_wstep && wsmall_on && s.dta == MPSE_F64 && s.a_off == 0 && s.b_off == 0 &&
+        s.c_off == 0 && s.beta == 0.0 && s.w_wl * s.w_d <= 16 && s.w_d * s.w_wr <= 16) {
+      if (!bufs[s.a] || !bufs[s.b] || !bufs[s.c]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing buffer");
+      WsmArgs g;
+      g.T1 = (const double*)bufs[s.b];
+      g.T2 = (double*)const_cast<void*>(bufs[s.c]);
+      g.W = (const double*)bufs[s.a];
+      g.Da = (int)s.w_Da, g.d = (int)s.w_d, g.wl = (int)s.w_wl, g.wr = (int)s.w_wr, g.N = (int)s.w_N;
+      g.skip = ctx->skip_flag;
+      const long long total = s.w_Da * s.w_N;
+      const dim3 grid((unsigned)((total + 255) / 256));
+      if (s.dtb == MPSE_C128)
+        hipLaunchKernelGGL((k_wsmall<true>), grid, dim3(256), 0, ctx->stream, g);
+      else
+        hipLaunchKernelGGL((k_wsmall<false>), grid, dim3(256), 0, ctx->stream, g);
+      MPSE_HIP(ctx, hipGetLastError());
+      continue;
+    }
     if (s.kind == K_WSTEP) {
       const WStepDesc& w = s.ws;
       if (w.wl * w.d > WS_MAXROWS || w.wr > 32 || 64 % w.d != 0 || w.d * w.wr > 1024)

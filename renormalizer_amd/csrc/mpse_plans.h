@@ -53,6 +53,10 @@ struct Step {
                                // multiplied into it); tiles with nothing are NOT stored (consumer: K_WSTEP)
   int amask_slot = -1;         // K_GEMM: tile-occupancy mask of operand A written by a K_WSTEP producer (no scan)
   WStepDesc ws;                // K_WSTEP (a = centre tensor, b = W site, c = T2; T1 is B_T1)
+  // K_GEMM steps written by push_w also carry the sizes of the MPO step they are (Da = batch of bond states, N =
+  // trailing block): the executor runs small ones (d = 2 sites) through an elementwise kernel instead of MFMA tiles
+  bool is_wstep = false;
+  int64_t w_Da = 0, w_wl = 0, w_d = 0, w_wr = 0, w_N = 0;
   int cin = -1;                // K_GEMM with beta != 0: buffer the beta term is read from (-1: C itself) ...
   int64_t cin_off = 0;         // ... at this element offset, through these index maps
   mpse_index mcin{}, ncin{};
@@ -180,6 +184,9 @@ inline void push_w(Plan& p, int wbuf, int w_dtype, int tin, int tout, int t_dtyp
        /*A=W: i=(d | f), k=(b | e)*/ i2(d, wr, d * wr, 1), i2(wl, d, d * d * wr, wr),
        /*B=T_in[:, a]: k=(b | e), n*/ i2(wl, d, na * d * N, N), i1(N, 1),
        /*C=T_out[a]: (d,f), n*/ i1(d * wr, N), i1(N, 1), na, 0, d * N, d * wr * N);
+  Step& s = p.steps.back();
+  s.is_wstep = true;
+  s.w_Da = na, s.w_wl = wl, s.w_d = d, s.w_wr = wr, s.w_N = N;
 }
 
 // One-site matvec whose intermediates never carry their structural zeros through HBM (large centres only):
