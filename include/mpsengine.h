@@ -245,6 +245,16 @@ int mpse_heff_apply2(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C
  * recurrence without re-orthogonalisation, same stopping rule: successive
  * approximations allclose(rtol,atol) on even j > 3, breakdown at beta < 100 n eps).
  * Synchronous; *nvec receives the Krylov dimension. */
+/* Optional, for the NEXT mpse_expm_lanczos on this context only: the tile-occupancy pattern of the centre tensor as
+ * the sweep knows it from the quantum numbers (mps/mp.py:308-352: entry (a, sigma, b) can be non-zero only where the
+ * bond and physical quantum numbers add up to the total) - the same for every Krylov vector of the solve, so the
+ * engine need not scan each vector for empty tiles before multiplying it by the left environment.  Layout: for the
+ * centre tensor viewed as the matrix C[a, (sigma.., b)] (Dl rows, N columns): byte [tn * nkw * 8 + kt] is 1 if any
+ * entry with a in [16 kt, 16 kt + 16) and column in [64 tn, 64 tn + 64) may be non-zero, nkw = ceil(ceil(Dl / 16) / 8),
+ * tn < ceil(N / 64); nbytes = ceil(N / 64) * nkw * 8.  A mask of another size is ignored.  The mask must mark every
+ * tile that holds a non-zero (a superset is fine, a missing tile drops its contribution). */
+int mpse_expm_centre_mask(mpse_ctx* ctx, const void* mask_dev, int64_t nbytes);
+
 int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re, double dt_im,
                       const void* C, void* out, double rtol, double atol, int max_dim, int* nvec);
 

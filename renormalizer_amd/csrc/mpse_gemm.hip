@@ -887,6 +887,14 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
       kb = make_key(g.B, g.nB, g.kB, g.sbB, g.N, g.mtiles_n, cb ? 1 : 0);
       if (void* hit = find(kb)) bmk = static_cast<unsigned long long*>(hit), scan_b = false;
     }
+    // B is a Krylov vector of a solve whose caller supplied the structural mask of the centre tensor: no scan
+    if (scan_b && ctx->cmask.ptr && d->batch == 1 && (long long)(wb * sizeof(unsigned long long)) == ctx->cmask.bytes) {
+      const char* pb_ = reinterpret_cast<const char*>(g.B);
+      if (pb_ >= ctx->cmask.lo && pb_ < ctx->cmask.hi) {
+        bmk = static_cast<unsigned long long*>(const_cast<void*>(ctx->cmask.ptr));
+        scan_b = false;
+      }
+    }
     // storage: cached masks live until the solve ends, the others in a temporary of this call
     size_t tmp_words = 0;
     if (scan_a && !ca_ok) tmp_words += wa;

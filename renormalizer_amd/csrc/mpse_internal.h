@@ -109,6 +109,15 @@ struct mpse_ctx {
     int nb_out = 0;
   } dot_req;
   bool dot_now = false;   // set by run_plan for the one GEMM launch that completes the result
+  // Tile-occupancy mask of the centre tensor as operand B of the first products of a matvec, supplied by the caller
+  // (mpse_expm_centre_mask: the structural pattern of the quantum numbers, the same for every Krylov vector).
+  // `pending` holds what the caller set for the next solve; during that solve lo / hi delimit the Krylov vectors.
+  struct CMask {
+    const void* ptr = nullptr;
+    long long bytes = 0;
+    const char* lo = nullptr;
+    const char* hi = nullptr;
+  } cmask_pending, cmask;
   // beta source for the next GEMM call (consumed by it): C = A.B + beta * Cin(i, j) with Cin's own index maps
   struct CinReq {
     const void* ptr = nullptr;

@@ -729,6 +729,14 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
     ~SkipScope() { c->skip_flag = nullptr; }
   } skip_scope(ctx, done);
   OccScope occ_scope(ctx, h);
+  struct CMaskScope {   // the caller's structural mask applies to the Krylov vectors of THIS solve only
+    mpse_ctx* c;
+    CMaskScope(mpse_ctx* ctx) : c(ctx) {
+      c->cmask = c->cmask_pending;
+      c->cmask_pending = mpse_ctx::CMask();
+    }
+    ~CMaskScope() { c->cmask = mpse_ctx::CMask(); }
+  } cmask_scope(ctx);
 
   auto bracket = [&](double bytes, auto&& launch) {
     mpse_ctx::ProfRec rec;
@@ -780,6 +788,8 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
       ctx->dot_req.cap = 2 * RED_MAX_BLOCKS;
       ctx->dot_req.nb_out = 0;
     }
+    ctx->cmask.lo = V.as<char>();
+    ctx->cmask.hi = V.as<char>() + size_t(cap) * n * es;
     const int st_mv = mpse_heff_apply(ctx, dtype, h, vec(j), W.p);
     const bool dot_done = ctx->dot_req.nb_out > 0;
     const int a_nb = dot_done ? ctx->dot_req.nb_out : nb;
@@ -1008,6 +1018,16 @@ int mpse_nrm2(mpse_ctx* ctx, int dtype, const void* x, int64_t n, double* out_ho
 static int expm_lanczos_solve(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re, double dt_im, const void* Cin,
                               void* out, double rtol, double atol, int max_dim, int* nvec);
 
+int mpse_expm_centre_mask(mpse_ctx* ctx, const void* mask_dev, int64_t nbytes) {
+  if (!ctx || (nbytes > 0 && !mask_dev) || nbytes < 0) return MPSE_ERR_ARG;
+  ctx->cmask_pending = mpse_ctx::CMask();
+  if (nbytes > 0) {
+    ctx->cmask_pending.ptr = mask_dev;
+    ctx->cmask_pending.bytes = nbytes;
+  }
+  return MPSE_OK;
+}
+
 int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re, double dt_im, const void* Cin,
                       void* out, double rtol, double atol, int max_dim, int* nvec) {
   if (!ctx || !h || !Cin || !out) return MPSE_ERR_ARG;
@@ -1015,7 +1035,10 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
   MPSE_BIND(ctx);
   // calls recorded by the caller for the time the result exists (QR of the new centre, environment update, absorption
   // of a bond factor) are issued here, before control goes back to the host language
-  return defer_replay(ctx, expm_lanczos_solve(ctx, dtype, h, dt_re, dt_im, Cin, out, rtol, atol, max_dim, nvec));
+  const int st = expm_lanczos_solve(ctx, dtype, h, dt_re, dt_im, Cin, out, rtol, atol, max_dim, nvec);
+  ctx->cmask_pending = mpse_ctx::CMask();   // a mask is good for the solve it was set for, whatever path that took
+  ctx->cmask = mpse_ctx::CMask();
+  return defer_replay(ctx, st);
 }
 
 static int expm_lanczos_solve(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re, double dt_im, const void* Cin,

@@ -109,6 +109,7 @@ _SIGNATURES = {
     "mpse_dotc": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, _dblp],
     "mpse_nrm2": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, _dblp],
     "mpse_scaled_rms": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, _dblp],
+    "mpse_expm_centre_mask": [C.c_void_p, C.c_void_p, C.c_int64],
     "mpse_defer_begin": [C.c_void_p, C.c_int],
     "mpse_defer_end": [C.c_void_p],
     "mpse_defer_arm": [C.c_void_p, C.c_int],

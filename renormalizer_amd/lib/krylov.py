@@ -27,6 +27,8 @@ def expm_krylov(Afunc, dt, vstart, block_size=50, rtol=1e-5, atol=1e-8, out=None
         elif out.size != v.size or out.dtype != v.dtype:
             raise ValueError("expm_krylov: out does not match the start vector")
         nv = C.c_int()
+        if Afunc.cmask is not None:
+            eng._check(eng.lib.mpse_expm_centre_mask(eng.ctx, Afunc.cmask.ptr, Afunc.cmask.nbytes))
         eng._check(eng.lib.mpse_expm_lanczos(eng.ctx, v.code, C.byref(Afunc.heff), dt.real, dt.imag, v.ptr, out.ptr,
                                              rtol, atol, 0, C.byref(nv)))
         return out, nv.value

@@ -22,6 +22,7 @@ class Hop:
             assert nsite + 2 == len(cshape)
         self.nsite = nsite
         self.cshape = cshape
+        self.cmask = None          # optional structural tile mask of the centre (centre_tile_mask), used by expm_krylov
         self.l = eng.asdevice(ltensor)
         self.r = eng.asdevice(rtensor)
         if self.twolayer:
@@ -96,3 +97,45 @@ class Hop:
 
 def hop_expr(ltensor, rtensor, cmo, cshape, twolayer: bool = False):
     return Hop(ltensor, rtensor, list(cmo), cshape, twolayer)
+
+
+_CMASK_CACHE = {}
+
+
+def centre_tile_mask(eng, qnbigl, qnbigr, qntot, cshape):
+    """Tile-occupancy pattern of a one-site centre tensor from its quantum numbers, for ``mpse_expm_centre_mask``:
+    entry (a, sigma, b) can be non-zero only where ``qnbigl[a, sigma] + qnbigr[b] == qntot`` (the rule the block
+    decompositions use, mps/mp.py:308-352).  Returns a device byte array in the layout of include/mpsengine.h - flag
+    [tn][kt] for rows a in [16 kt, 16 kt + 16) and columns (sigma, b) in [64 tn, 64 tn + 64) - or None when the
+    quantum numbers do not describe this shape.  Cached per quantum-number pattern (sites keep theirs from step to
+    step)."""
+    Dl, Dr = int(cshape[0]), int(cshape[-1])
+    inner = int(np.prod(cshape[1:-1]))
+    ql = np.ascontiguousarray(np.asarray(qnbigl).reshape(-1, np.asarray(qnbigl).shape[-1]))
+    qr = np.ascontiguousarray(np.asarray(qnbigr).reshape(-1, np.asarray(qnbigr).shape[-1]))
+    qt = np.asarray(qntot).reshape(-1)
+    if ql.shape[0] != Dl * inner or qr.shape[0] != Dr:
+        return None
+    key = (id(eng), Dl, inner, Dr, ql.tobytes(), qr.tobytes(), qt.tobytes())
+    hit = _CMASK_CACHE.get(key)
+    if hit is not None:
+        return hit
+    # allowed[(a, sigma), b]: compare through the distinct quantum numbers (a handful) instead of row by row
+    ul, il = np.unique(ql, axis=0, return_inverse=True)
+    ur, ir = np.unique(qr, axis=0, return_inverse=True)
+    ok = (ul[:, None, :] + ur[None, :, :] == qt).all(-1)                    # (distinct left, distinct right)
+    allowed = ok[np.asarray(il).reshape(-1)][:, np.asarray(ir).reshape(-1)]  # (Dl * inner, Dr)
+    n = inner * Dr
+    view = allowed.reshape(Dl, n)
+    nkt, ntn = (Dl + 15) // 16, (n + 63) // 64
+    pad = np.zeros((nkt * 16, ntn * 64), dtype=bool)
+    pad[:Dl, :n] = view
+    flags = pad.reshape(nkt, 16, ntn, 64).any(axis=(1, 3))                  # (kt, tn)
+    nkw = (nkt + 7) // 8
+    out = np.zeros((ntn, nkw * 8), dtype=np.uint8)
+    out[:, :nkt] = flags.T
+    dev = eng.asdevice(out.view(np.float64).reshape(-1))
+    if len(_CMASK_CACHE) > 4096:
+        _CMASK_CACHE.clear()
+    _CMASK_CACHE[key] = dev
+    return dev

@@ -18,7 +18,7 @@ from ..lib.krylov import expm_krylov
 from ..model import Model, Op, OpSum
 from ..utils import CompressConfig, CompressCriteria, EvolveConfig, EvolveMethod, OptimizeConfig
 from . import svd_qn
-from .hop_expr import hop_expr
+from .hop_expr import centre_tile_mask, hop_expr
 from .lib import Environ, contract_one_site
 from .mpo import Mpo
 from .svd_qn import add_outer, get_qn_mask
@@ -1296,6 +1296,8 @@ class Mps:
         local_steps = []
         q = len(mps.qntot)
 
+        use_cmask = os.environ.get("MPSE_CENTRE_MASK", "1") != "0"
+
         def prepare(imps, shape):
             """Everything the update of site ``imps`` needs that does not depend on the preceding solve: the
             effective-Hamiltonian descriptor and the quantum-number block plan of its QR.  Called BEFORE the solve whose
@@ -1306,6 +1308,15 @@ class Mps:
             if split:
                 qnbigl, qnbigr, _ = mps._get_big_qn([imps], need_mat=False)
                 plan = svd_qn.block_plan(qnbigl, qnbigr, mps.qntot)
+                # large centres: the engine skips the empty tiles of the Krylov vectors by the pattern of their
+                # quantum numbers instead of scanning every vector (row / column grouping as the QR sees the site)
+                if use_cmask and len(shape) == 3 and shape[0] * shape[0] * shape[1] * shape[2] >= (1 << 26):
+                    if mps.to_right:
+                        ql, qr = qnbigl, qnbigr
+                    else:               # sweeping left the QR groups the site as (a | sigma, b): regroup (a, sigma | b)
+                        ql = add_outer(np.array(mps.qn[imps]), mps._get_sigmaqn(imps))
+                        qr = np.array(mps.qn[imps + 1])
+                    hop.cmask = centre_tile_mask(eng, ql, qr, mps.qntot, shape)
             return hop, split, qnbigl, qnbigr, plan
 
         def split_site(imps, centre, ready, shape):

@@ -50,3 +50,33 @@ def test_environments_are_taken_over_only_from_identical_objects(monkeypatch):
     M._carry_environ(_Mps(sites, True), mpo, env)
     monkeypatch.setenv("MPSE_ENV_CARRY", "0")
     assert M._carried_environ(_Mps(sites, True), mpo, "R") is None
+
+
+def test_centre_tile_mask_matches_the_allowed_pattern():
+    """hop_expr.centre_tile_mask: byte [tn][kt] marks the 16 x 64 tiles of C[a, (sigma, b)] that hold an entry allowed by
+    the quantum numbers (include/mpsengine.h, mpse_expm_centre_mask)."""
+    import numpy as np
+    import renormalizer_amd.mps.hop_expr as H
+
+    class _Eng:
+        def asdevice(self, a):
+            return np.array(a)
+
+    rng = np.random.default_rng(0)
+    eng = _Eng()
+    for (Dl, d, Dr, nq) in ((40, 3, 70, 1), (16, 16, 64, 2), (5, 2, 3, 1)):
+        qnl, sig, qnr = (rng.integers(0, 2, size=(n, nq)) for n in (Dl, d, Dr))
+        qt = np.ones(nq, dtype=int)
+        ql = qnl[:, None, :] + sig[None, :, :]
+        H._CMASK_CACHE.clear()
+        m = H.centre_tile_mask(eng, ql, qnr, qt, (Dl, d, Dr))
+        allowed = ((qnl[:, None, None, :] + sig[None, :, None, :] + qnr[None, None, :, :]) == qt).all(-1).reshape(Dl, d * Dr)
+        nkt, ntn = (Dl + 15) // 16, (d * Dr + 63) // 64
+        nkw = (nkt + 7) // 8
+        ref = np.zeros((ntn, nkw * 8), np.uint8)
+        for kt in range(nkt):
+            for tn in range(ntn):
+                ref[tn, kt] = allowed[kt * 16:(kt + 1) * 16, tn * 64:(tn + 1) * 64].any()
+        assert np.array_equal(m.view(np.uint8).reshape(ntn, nkw * 8), ref)
+        assert H.centre_tile_mask(eng, ql, qnr, qt, (Dl, d, Dr)) is m        # cached
+    assert H.centre_tile_mask(eng, ql, qnr, qt, (Dl + 1, d, Dr)) is None      # quantum numbers of another shape
