@@ -794,9 +794,10 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   static const int sk_tiles = [] { const char* e = getenv("MPSE_SPLITK_TILES"); return e ? atoi(e) : 0; }();
   static const int sk_target = [] { const char* e = getenv("MPSE_SPLITK_TARGET"); return e ? atoi(e) : 0; }();
   const int tiles_limit = sk_tiles > 0 ? sk_tiles : n_cu;
-  const long long wg_target = sk_target > 0 ? sk_target : 2LL * n_cu;
+  const long long wg_target = sk_target > 0 ? sk_target : n_cu;   // one workgroup per CU (sweep of the headline run)
   if (base_blocks < tiles_limit && nkt_all >= 4) {
-    // fewer output tiles than CUs: slice K until ~2 workgroups per CU exist.  (One tile per CU runs as fast
+    // fewer output tiles than CUs: slice K until ~1 workgroup per CU exists (2 per CU: equal to 1.7 % slower on the
+    // headline run depending on the box - the reduction pass reads twice the slices; 3 per CU: -3 %; 0.5 per CU: -7 %).  (One tile per CU runs as fast
     // unsplit as split in two + reduction pass since the K loop prefetches fragments: measured, 4096x256 C-step.)
     int want = (int)((wg_target + base_blocks - 1) / base_blocks);
     int maxs = nkt_all / 2;                                           // at least two k-tiles per slice
