@@ -37,7 +37,7 @@ import numpy as np  # noqa: E402
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PROF_STRIDE = 7                   # HIP-event timing of every 7th contraction launch inside the timed region
+PROF_STRIDE = int(os.environ.get("MPSE_BENCH_PROF_STRIDE", "23"))   # HIP-event timing of every 23rd launch of each class inside the timed region (every 7th costs 1.7 % of the step)
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (AMD datasheet)
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (MI355X_MICROARCH.md)
 
