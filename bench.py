@@ -168,7 +168,12 @@ def main():
     eng = engines[0]
     nsite = 2 * args.nmol
     # one communicator per process (ctypes RCCL on the engine's device and stream); serial for a single process
-    coll = make_collective(eng, backend="gloo" if (world > 1 and args.dist_backend == "gloo") else None)
+    if world > 1 and args.dist_backend == "gloo":      # testing only: the CPU stand-in lives with the tests
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from gloo_collective import GlooCollective
+        coll = GlooCollective()
+    else:
+        coll = make_collective(eng)
     if world > 1:
         print(f"[rank {rank}] device {local_rank}: {eng.device_name}; {coll.kind} communicator of {coll.world} ranks",
               file=sys.stderr, flush=True)
@@ -244,10 +249,13 @@ def main():
 
     elapsed = max_over_ranks(coll, elapsed)
     # the only collective of the whole job besides the barriers: all-gather of the per-trajectory observables (KBs)
-    occ_table = gather_observables(coll, np.asarray(mps.e_occupations)[None, :], [rank], world)
-    assert occ_table.shape[0] == world
+    # (each row: the electronic populations of the rank's trajectory, then the device ordinal the rank ran on)
+    row = np.concatenate([np.asarray(mps.e_occupations, dtype=np.float64), [float(local_rank)]])
+    table = gather_observables(coll, row[None, :], [rank], world)
+    assert table.shape[0] == world
+    occ_table, rank_devices = table[:, :-1], [int(x) for x in table[:, -1]]
+    distinct = len({tuple(np.round(r, 10)) for r in occ_table})
     if world > 1 and rank == 0:
-        distinct = len({tuple(np.round(r, 10)) for r in occ_table})
         print(f"[rank 0] gathered populations of {world} trajectories, {distinct} distinct", file=sys.stderr, flush=True)
 
     if rank == 0:
@@ -311,7 +319,9 @@ def main():
                                    % (nsite, T, "y" if T == 1 else "ies"),
                        "nsite": nsite, "bond_dim": args.bond_dim, "dphys": [2, args.pdim], "mpo_bond": max(mpo.bond_dims),
                        "dt": args.dt, "init": args.init, "mean_krylov_dim": float(np.mean(kry)),
-                       "device": eng.device_name, "collective": coll.kind,
+                       "device": eng.device_name, "collective": coll.kind, "ranks": coll.world,
+                       "rank_devices": rank_devices, "distinct_trajectories": distinct,
+                       "bond_dims": [int(d) for d in mps.bond_dims],
                        "environments": ("rebuilt at every step (MPSE_ENV_CARRY=0)" if os.environ.get("MPSE_ENV_CARRY") == "0"
                                         else "those ahead of the first half sweep are taken over from the previous step "
                                              "(identical tensors; every step performs all 2 N site updates)")},

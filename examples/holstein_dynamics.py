@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Charge transport in a Holstein chain (the headline workload at a size of your choice):
-electron created on the centre molecule of the phonon vacuum, bonds expanded, TDVP-PS.
+"""Charge transport in a Holstein chain (the headline workload at a size of your choice) as a ``TdMpsJob``:
+electron created on the centre molecule of the phonon vacuum, bonds expanded, TDVP-PS; after every step the
+accumulated observables go to ``<dump_dir>/<job_name>.npz`` under the keys the reference's
+``ChargeDiffusionDynamics.get_dump_dict`` writes (transport/dynamics.py:250-267), so its analysis scripts read them.
 
-    python examples/holstein_dynamics.py [nmol=9] [pdim=8] [D=32] [nsteps=10]"""
+    python examples/holstein_dynamics.py [nmol=9] [pdim=8] [D=32] [nsteps=10] [dump_dir]"""
 import os
 import sys
 
@@ -12,19 +14,56 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from renormalizer_amd import (CompressConfig, CompressCriteria, EvolveConfig, EvolveMethod, HolsteinModel, Mol, Mpo,  # noqa: E402
                               Mps, Phonon, Quantity)
+from renormalizer_amd.utils.tdmps import TdMpsJob  # noqa: E402
 
-nmol, pdim, D, nsteps = [int(a) for a in sys.argv[1:5]] + [9, 8, 32, 10][len(sys.argv[1:5]):]
-ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), pdim)      # example/std.yaml
-model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
-psi = Mpo.onsite(model, r"a^\dagger", dof_set={nmol // 2}).apply(Mps.ground_state(model, False))
-mpo = Mpo(model, offset=Quantity(psi.expectation(Mpo(model))))
-psi.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=D)
-psi.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
-psi = psi.expand_bond_dimension(mpo).canonicalise()
-sites = np.arange(nmol) - nmol // 2
-for step in range(nsteps + 1):
-    occ = np.asarray(psi.e_occupations)
-    print(f"t = {10.0 * step:6.1f} a.u.  <r^2> = {float(np.sum(occ * sites ** 2)):9.5f}  norm = {psi.mp_norm:.12f}  "
-          f"E = {psi.expectation(mpo):+.3e}")
-    if step < nsteps:
-        psi = psi.evolve(mpo, 10.0)
+
+class ChargeDiffusion(TdMpsJob):
+    """T = 0 pure-state variant of transport/dynamics.py::ChargeDiffusionDynamics (InitElectron.fc)."""
+
+    def __init__(self, nmol, pdim, bond_dim, **kwargs):
+        ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), pdim)      # example/std.yaml
+        self.model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
+        self.bond_dim = bond_dim
+        self.r_square_array, self.e_occupations_array, self.ph_occupations_array = [], [], []
+        self.energies, self.bond_vn_entropy_array = [], []
+        super().__init__(EvolveConfig(EvolveMethod.tdvp_ps), **kwargs)
+
+    def init_mps(self):
+        nmol = self.model.mol_num
+        psi = Mpo.onsite(self.model, r"a^\dagger", dof_set={nmol // 2}).apply(Mps.ground_state(self.model, False))
+        self.mpo = Mpo(self.model, offset=Quantity(psi.expectation(Mpo(self.model))))
+        psi.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=self.bond_dim)
+        psi.evolve_config = self.evolve_config
+        return psi.expand_bond_dimension(self.mpo).canonicalise()
+
+    def process_mps(self, mps):
+        occ = np.asarray(mps.e_occupations)
+        sites = np.arange(len(occ)) - len(occ) // 2
+        self.e_occupations_array.append(occ)
+        self.ph_occupations_array.append(np.asarray(mps.ph_occupations))
+        self.r_square_array.append(float(np.sum(occ * sites ** 2)))
+        self.energies.append(float(np.real(mps.expectation(self.mpo))))
+        self.bond_vn_entropy_array.append(np.asarray(mps.calc_bond_entropy()))
+        print(f"t = {self.latest_evolve_time:6.1f} a.u.  <r^2> = {self.r_square_array[-1]:9.5f}  "
+              f"norm = {mps.mp_norm:.12f}  E = {self.energies[-1]:+.3e}")
+
+    def evolve_single_step(self, evolve_dt):
+        return self.latest_mps.evolve(self.mpo, evolve_dt)
+
+    def get_dump_dict(self):
+        return {"tempearture": 0.0,                                # (sic: the reference's key)
+                "total time": self.evolve_times[-1],
+                "r square array": np.array(self.r_square_array),
+                "electron occupations array": np.array(self.e_occupations_array),
+                "phonon occupations array": np.array(self.ph_occupations_array),
+                "bond entropy": np.array(self.bond_vn_entropy_array),
+                "energies": np.array(self.energies),
+                "time series": list(self.evolve_times)}
+
+
+if __name__ == "__main__":
+    nmol, pdim, D, nsteps = [int(a) for a in sys.argv[1:5]] + [9, 8, 32, 10][len(sys.argv[1:5]):]
+    dump_dir = sys.argv[5] if len(sys.argv) > 5 else None
+    job = ChargeDiffusion(nmol, pdim, D, dump_dir=dump_dir, job_name="holstein_dynamics" if dump_dir else None,
+                          dump_mps="one" if dump_dir else None)
+    job.evolve(evolve_dt=10.0, nsteps=nsteps)

@@ -43,34 +43,40 @@ def _rms(eng, x, y1, y2, rtol, atol):
 
 
 def solve_rk45(fun, t_bound, y0, rtol=1e-3, atol=1e-6):
-    """Integrate dy/dt = fun(t, y) from 0 to ``t_bound`` > 0.  ``fun`` maps a device tensor to a device tensor of the
-    same shape and dtype.  Returns (y(t_bound), number of evaluations of fun, number of accepted steps)."""
+    """Integrate dy/dt = fun(t, y) from 0 to ``t_bound`` (either sign: a negative bound integrates backwards, as
+    ``solve_ivp((0, t_bound))`` does).  ``fun`` maps a device tensor to a device tensor of the same shape and dtype.
+    Returns (y(t_bound), number of evaluations of fun, number of accepted steps)."""
     eng = get_engine()
+    t_bound = float(t_bound)
     t, y = 0.0, y0
     if y.size == 0 or t_bound == 0:
         return y, 0, 0
+    direction = 1.0 if t_bound > 0 else -1.0
+    span = abs(t_bound)
     f = fun(t, y)
     nfev = 1
     # scipy/integrate/_ivp/common.py select_initial_step (order of the error estimator: 4)
     d0, d1 = _rms(eng, y, y, y, rtol, atol), _rms(eng, f, y, y, rtol, atol)
     h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
-    h0 = min(h0, t_bound)
-    f1 = fun(t + h0, _combine(eng, y, [f], [1.0], h0))
+    h0 = min(h0, span)
+    f1 = fun(t + h0 * direction, _combine(eng, y, [f], [1.0], h0 * direction))
     nfev += 1
     diff = f1.copy()
     _axpy(eng, diff, f, -1.0)
     d2 = _rms(eng, diff, y, y, rtol, atol) / h0
     h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** 0.2
-    h_abs = min(100 * h0, h1, t_bound)
+    h_abs = min(100 * h0, h1, span)
     nsteps = 0
-    while t < t_bound:
-        min_step = 10 * abs(np.nextafter(t, np.inf) - t)
+    while direction * (t - t_bound) < 0:
+        min_step = 10 * abs(np.nextafter(t, direction * np.inf) - t)
         h_abs = max(h_abs, min_step)
         rejected = False
         while True:
             if h_abs < min_step:
                 raise RuntimeError("solve_rk45: required step size is less than spacing between numbers")
-            t_new = min(t + h_abs, t_bound)
+            t_new = t + h_abs * direction
+            if direction * (t_new - t_bound) > 0:
+                t_new = t_bound
             h = t_new - t
             h_abs = abs(h)
             ks = [f]

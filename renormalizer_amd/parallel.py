@@ -7,8 +7,8 @@ xGMI.
 
 The product path binds ``librccl.so`` directly through ctypes (``RcclCollective``: ncclGetUniqueId / ncclCommInitRank /
 ncclAllGather / ncclAllReduce on the engine's HIP stream, buffers from the engine's allocator; the 128-byte unique id
-travels through a file named after the launcher's process id).  No PyTorch.  ``GlooCollective`` is the CPU stand-in of
-the same three operations for the world_size-2 tests (torch.distributed's gloo backend, imported only there)."""
+travels through a private file keyed by the launcher's process instance, single node only).  No PyTorch: the CPU
+stand-in of the same three operations that the world_size-2 tests use lives in ``tests/gloo_collective.py``."""
 import ctypes as C
 import os
 import time
@@ -49,12 +49,90 @@ class _ncclUniqueId(C.Structure):
 _NCCL_FLOAT64, _NCCL_SUM, _NCCL_MAX = 8, 0, 2
 
 
+def _parent_instance():
+    """pid and start time (clock ticks since boot, /proc/<pid>/stat field 22) of the parent: all local ranks of one
+    launch share their parent (the torch.distributed.run agent or the shell that started them), and the start time
+    tells a re-used pid from the same process."""
+    ppid = os.getppid()
+    try:
+        with open(f"/proc/{ppid}/stat", "rb") as fh:
+            start = fh.read().rsplit(b")", 1)[1].split()[19].decode()
+    except (OSError, IndexError):
+        start = "0"
+    return ppid, start
+
+
+def _rendezvous_dir():
+    """Private directory (mode 0700, owned by this user) for the id files: nobody else can plant or link one."""
+    d = os.environ.get("MPSE_RENDEZVOUS_DIR") or os.path.join(
+        os.environ.get("XDG_RUNTIME_DIR") or "/tmp", f"mpse_rccl_{os.getuid()}")
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.lstat(d)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid():
+        raise RuntimeError(f"rendezvous directory {d} is not a directory owned by this user")
+    return d
+
+
 def _rendezvous_path():
-    """All local ranks of one launch share their parent (the torch.distributed.run / torchrun agent or the shell that
-    started them): its pid plus the advertised port name the id file."""
-    tag = os.environ.get("MPSE_RENDEZVOUS_TAG") or f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
-    d = os.environ.get("MPSE_RENDEZVOUS_DIR", "/tmp")
-    return os.path.join(d, f"mpse_rccl_{tag}.id")
+    """One file per launch: MPSE_RENDEZVOUS_TAG / TORCHELASTIC_RUN_ID when the launcher gives a real one, else the
+    parent's pid and start time, plus the advertised port.  Single node only (shared file system path)."""
+    tag = os.environ.get("MPSE_RENDEZVOUS_TAG")
+    if not tag:
+        run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
+        ppid, start = _parent_instance()
+        tag = f"{run_id if run_id not in ('', 'none') else 'p'}_{ppid}_{start}_{os.environ.get('MASTER_PORT', '0')}"
+    return os.path.join(_rendezvous_dir(), f"mpse_rccl_{tag}.id")
+
+
+def _process_start_time():
+    """Wall-clock start of this process (seconds since the epoch)."""
+    try:
+        with open("/proc/self/stat", "rb") as fh:
+            ticks = float(fh.read().rsplit(b")", 1)[1].split()[19])
+        with open("/proc/uptime") as fh:
+            up = float(fh.read().split()[0])
+        return time.time() - up + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, IndexError, ValueError):
+        return time.time()
+
+
+_STALE_SLACK_S = 120.0     # an id file older than this before the reader started belongs to an earlier launch
+
+
+def publish_id(path: str, raw: bytes):
+    """Rank 0: replace whatever an earlier launch with the same tag left behind by this launch's id (created
+    exclusively with mode 0600, moved into place atomically: readers never see a partial id)."""
+    try:
+        os.unlink(path)
+    except FileNotFoundError:
+        pass
+    tmp = f"{path}.{os.getpid()}.tmp"
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    with os.fdopen(fd, "wb") as fh:
+        fh.write(raw)
+    os.replace(tmp, path)
+
+
+def await_id(path: str, timeout_s: float, rank: int = -1) -> bytes:
+    """Ranks > 0: wait for a FRESH id file of this user.  A file written long before this process existed is a
+    crashed launch's (rank 0 of this launch replaces it): it is ignored, never trusted."""
+    t0 = time.time()
+    born = _process_start_time()
+    while True:
+        try:
+            st = os.stat(path)
+            if st.st_uid == os.getuid() and st.st_mtime >= born - _STALE_SLACK_S:
+                with open(path, "rb") as fh:
+                    raw = fh.read()
+                if len(raw) == 128:
+                    return raw
+        except OSError:
+            pass
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError(f"rank {rank}: no fresh RCCL unique id at {path} after {timeout_s} s "
+                               f"(is rank 0 of this launch running on this node?)")
+        time.sleep(0.01)
 
 
 class RcclCollective:
@@ -76,27 +154,30 @@ class RcclCollective:
         self._path = path if self.rank == 0 else None
         if self.rank == 0:
             self._ok(L.ncclGetUniqueId(C.byref(uid)))
-            tmp = f"{path}.{os.getpid()}.tmp"
-            with open(tmp, "wb") as fh:
-                fh.write(bytes(uid.internal))
-            os.replace(tmp, path)                      # atomic: readers never see a partial id
+            publish_id(path, bytes(uid.internal))
         else:
-            t0 = time.time()
-            while True:
-                try:
-                    with open(path, "rb") as fh:
-                        raw = fh.read()
-                    if len(raw) == 128:
-                        break
-                except OSError:
-                    pass
-                if time.time() - t0 > timeout_s:
-                    raise TimeoutError(f"rank {self.rank}: no RCCL unique id at {path} after {timeout_s} s")
-                time.sleep(0.01)
-            C.memmove(C.byref(uid), raw, 128)
+            C.memmove(C.byref(uid), await_id(path, timeout_s, self.rank), 128)
         eng.sync()                                     # binds this thread to the engine's device (the comm's device)
         self.comm = C.c_void_p()
-        self._ok(L.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank))
+        # ncclCommInitRank blocks until every rank has called it with the same id: a mismatched id (or a rank that
+        # died) must end in an error, not in a hang
+        import threading
+        res = {}
+
+        def init():
+            eng.sync()                                 # the HIP device is per thread: bind this one as well
+            res["st"] = L.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
+
+        if self.world > 1:
+            th = threading.Thread(target=init, daemon=True)
+            th.start()
+            th.join(timeout_s)
+            if th.is_alive():
+                raise TimeoutError(f"rank {self.rank}: ncclCommInitRank did not return within {timeout_s} s "
+                                   f"({self.world} ranks expected; id file {path})")
+        else:
+            init()
+        self._ok(res["st"])
 
     def _ok(self, st):
         if st != 0:
@@ -131,45 +212,11 @@ class RcclCollective:
                     pass
 
 
-class GlooCollective:
-    """CPU stand-in (tests): the same three operations on torch.distributed's gloo backend."""
-    kind = "gloo"
-
-    def __init__(self):
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            dist.init_process_group(backend="gloo")
-        self.dist = dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-
-    def barrier(self):
-        self.dist.barrier()
-
-    def allreduce_max(self, value: float) -> float:
-        import torch
-        t = torch.tensor([value], dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def allgather(self, row: np.ndarray) -> np.ndarray:
-        import torch
-        t = torch.as_tensor(np.ascontiguousarray(row, dtype=np.float64).ravel())
-        parts = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(parts, t)
-        return np.stack([p.numpy() for p in parts])
-
-    def close(self):
-        self.dist.destroy_process_group()
-
-
 def make_collective(eng=None, backend=None):
     """Collective of this process from the launcher's environment (RANK / WORLD_SIZE as set by
-    torch.distributed.run): serial for one process, RCCL (ctypes) otherwise; ``backend="gloo"`` selects the CPU
-    stand-in."""
+    torch.distributed.run): serial for one process, RCCL (ctypes) otherwise."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if backend == "gloo":
-        return GlooCollective()
     if world == 1 and backend != "rccl":
         return SerialCollective()
     if eng is None:

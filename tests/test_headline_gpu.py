@@ -1,0 +1,147 @@
+"""BASELINE headline size (50 sites, dphys 2/16, Dbond 256, complex128) pinned to the oracle, where every
+performance path of the engine is engaged: quantum-number centre masks (only at (256, 16, 256)), carried
+environments, host-predicted unit channels, beta-source C-step, asynchronous Lanczos, the blocked QR at 4096 rows.
+
+  * one full ``Mps.evolve`` on the device against ``oracle.tdvp_ps_step`` from the same ``to_arrays()`` state
+    (reference order of operations: mps/mps.py:1267-1404);
+  * A/B of every engine switch that selects an alternative implementation (separate processes: the library reads its
+    switches once), bitwise where the design claims bit-identity, <= 1e-10 on observables otherwise;
+  * the actual bond dimensions of the benchmark state.
+pytest -m gpu; the oracle leg needs about a minute of host time."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import mps_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _sorted_rows(a):
+    a = np.asarray(a).reshape(len(a), -1)
+    return a[np.lexsort(a.T[::-1])]
+
+
+@pytest.fixture(scope="module")
+def headline(tmp_path_factory):
+    """The benchmark's start state (device-side preparation, ~6 s), evolved once so that it is a generic complex
+    state with filled bonds, written to a checkpoint the A/B processes start from."""
+    import bench
+    path = str(tmp_path_factory.mktemp("headline") / "state.npz")
+    model, mpo, mps = bench.build_workload(25, 16, 256, 0, "physical")
+    mps = mps.evolve(mpo, 10.0)
+    mps.dump(path)
+    return model, mpo, mps, path
+
+
+def test_headline_bond_dims(headline):
+    """Dbond = 256 is reached on every interior bond of the benchmark state (the edges are capped by the product of
+    the physical dimensions and the 1-exciton sector)."""
+    _, _, mps, _ = headline
+    dims = list(mps.bond_dims)
+    assert len(dims) == 51 and dims[0] == dims[-1] == 1
+    assert all(d == 256 for d in dims[4:-4]), dims
+    assert all(len(q) == d for q, d in zip(mps.qn, dims))
+
+
+def test_headline_one_evolve_vs_oracle(headline):
+    """One evolve at the headline size on the device and in the oracle from the same tensors: electronic
+    occupations and <H> within 1e-8 (north_star: 1e-6 relative), integer bookkeeping exact, same number of Krylov
+    solves, |<psi_oracle|psi_device>| = 1."""
+    model, mpo, mps, _ = headline
+    sites = mps.to_arrays()
+    ost = orc.MpsState(sites, [q.copy() for q in mps.qn], mps.qnidx, mps.qntot.copy(), mps.to_right,
+                       [np.array(b.sigmaqn) for b in model.basis], complex(mps.coeff))
+    w_host = [mpo[i] for i in range(len(mpo))]
+    e0 = mps.expectation(mpo)
+    dev = mps.evolve(mpo, 10.0)
+    ost = orc.tdvp_ps_step(ost, w_host, 10.0)
+    occ_dev = np.asarray(dev.e_occupations)
+    occ_orc = np.array([orc.expectation(ost.sites, [m[i] for i in range(len(m))]).real
+                        for m in model.mpos["e_occupations"]])
+    assert np.abs(occ_dev - occ_orc).max() < 1e-8, np.abs(occ_dev - occ_orc).max()
+    e_dev, e_orc = dev.expectation(mpo), orc.expectation(ost.sites, w_host)
+    assert abs(e_dev - e_orc) < 1e-8 and abs(e_dev - e0) < 1e-6
+    assert abs(dev.mp_norm - 1.0) < 1e-12
+    # integer bookkeeping: bit exact
+    assert list(dev.bond_dims) == list(ost.bond_dims)
+    assert dev.qnidx == ost.qnidx and dev.to_right == ost.to_right
+    for a, b in zip(dev.qn, ost.qn):
+        assert np.array_equal(_sorted_rows(a), _sorted_rows(b))
+    st = dev.evolve_config.stat
+    assert st["nobs"] == len(ost.krylov_dims) == 2 * (2 * len(mps) - 1)
+    # the Krylov dimension of a solve depends on the gauge of the local tensor where a stopping test is marginal:
+    # the counts agree, the dimensions agree on average
+    assert abs(st["mean"] - float(np.mean(ost.krylov_dims))) < 0.5
+    ov = orc.mps_dot([s.conj() for s in ost.sites], dev.to_arrays())
+    assert abs(abs(ov) - 1.0) < 1e-9, abs(ov)
+
+
+_VARIANT = r"""
+import sys, numpy as np
+sys.path.insert(0, {repo!r})
+import bench
+from renormalizer_amd import Mpo
+model, mpo, mps = bench.build_workload(25, 16, 256, 0, "physical", state_file={state!r})
+for _ in range(2):                       # the second evolve starts from carried environments
+    mps = mps.evolve(mpo, 10.0)
+arrs = mps.to_arrays()
+np.savez({out!r}, occ=np.asarray(mps.e_occupations), energy=mps.expectation(mpo), norm=mps.mp_norm,
+         bond_dims=np.array(mps.bond_dims), steps=np.array(mps.evolve_config.stat["steps"]),
+         **{{f"s{{i}}": a for i, a in enumerate(arrs)}})
+"""
+
+
+def _run_variant(state, out, env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    env["PYTHONPATH"] = REPO + os.pathsep + env.get("PYTHONPATH", "")
+    code = _VARIANT.format(repo=REPO, state=state, out=out)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
+
+
+# switch -> True: the alternative path is designed to give the same bits; False: same state to rounding
+_SWITCHES = {
+    "MPSE_CENTRE_MASK=0": True,       # scan every Krylov vector instead of the quantum-number tile mask
+    "MPSE_ENV_CARRY=0": True,         # rebuild the environments at every step
+    "MPSE_BETA_SOURCE=0": True,       # copy the unit-channel slice, then accumulate onto it
+    "MPSE_DOT_FUSED=0": False,        # Lanczos coefficient by its own reduction kernel (other summation order)
+    "MPSE_WSMALL=0": False,           # MPO step of the d = 2 sites as an MFMA product
+    "MPSE_LANCZOS_ASYNC=0": False,    # host-side eigen-decomposition of the tridiagonal matrix
+    "MPSE_QR_CAQR=0": False,          # panel-blocked Householder QR instead of the communication-avoiding tree
+    "MPSE_HEFF_FUSED=0": False,       # unfused one-site matvec chain
+}
+
+
+@pytest.fixture(scope="module")
+def baseline_variant(headline, tmp_path_factory):
+    _, _, _, state = headline
+    return _run_variant(state, str(tmp_path_factory.mktemp("ab") / "base.npz"), {})
+
+
+@pytest.mark.parametrize("switch", sorted(_SWITCHES))
+def test_headline_switch_ab(headline, baseline_variant, tmp_path, switch):
+    """Two evolves at the headline size with one engine switch flipped, against the default path."""
+    _, _, _, state = headline
+    k, v = switch.split("=")
+    got = _run_variant(state, str(tmp_path / "v.npz"), {k: v})
+    base = baseline_variant
+    assert np.array_equal(got["bond_dims"], base["bond_dims"])
+    if _SWITCHES[switch]:
+        assert np.array_equal(got["steps"], base["steps"])
+        for i in range(len(base["bond_dims"]) - 1):
+            assert np.array_equal(got[f"s{i}"], base[f"s{i}"]), (switch, i)
+        return
+    assert len(got["steps"]) == len(base["steps"])
+    assert np.abs(got["occ"] - base["occ"]).max() < 1e-10
+    assert abs(got["energy"] - base["energy"]) < 1e-10
+    assert abs(got["norm"] - base["norm"]) < 1e-12
+    ov = orc.mps_dot([got[f"s{i}"].conj() for i in range(50)], [base[f"s{i}"] for i in range(50)])
+    assert abs(abs(ov) - 1.0) < 1e-10, abs(ov)

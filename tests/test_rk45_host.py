@@ -74,3 +74,15 @@ def test_rk45_controller_follows_scipy(monkeypatch):
     _run(monkeypatch, lambda t, v: lam * v, 1.0, np.ones(16), rtol=1e-6, atol=1e-9)          # rejections
     _run(monkeypatch, lambda t, v: 0 * v, 1.0, np.arange(1.0, 5.0))                          # zero derivative
     _run(monkeypatch, lambda t, v: np.cos(t) * v, 1e-7, np.ones(3))                          # span below the first step
+
+
+def test_rk45_backward_integration(monkeypatch):
+    """A negative bound integrates backwards like solve_ivp((0, t_bound)) - TDVP-CMF with a negative real evolve_dt
+    (the reference supports it through scipy; a forward-only loop returned y0 unchanged)."""
+    rng = np.random.default_rng(1)
+    a = rng.normal(size=(10, 10))
+    h = (a + a.T) / 4
+    y0 = rng.normal(size=10) + 1j * rng.normal(size=10)
+    _run(monkeypatch, lambda t, v: -1j * (h @ v), -3.0, y0)
+    _run(monkeypatch, lambda t, v: -1j * (h @ v) * (1 + 0.1 * t), -12.0, y0, rtol=1e-8, atol=1e-11)
+    _run(monkeypatch, lambda t, v: np.cos(t) * v, -1e-7, np.ones(3))

@@ -1,7 +1,7 @@
 """Trajectory sharding across ranks: one independent trajectory per rank, no data-path
 collective, one all_gather of the observables at the end.  Exercised here with world_size 2 on the gloo
-backend (CPU): ``GlooCollective`` is the stand-in of the ctypes ``RcclCollective`` that bench.py and
-examples/fmo.py use on the GPUs (same three operations: barrier, max, all-gather)."""
+backend (CPU): ``tests/gloo_collective.py::GlooCollective`` is the stand-in of the ctypes ``RcclCollective`` that
+bench.py and examples/fmo.py use on the GPUs (same three operations: barrier, max, all-gather)."""
 import os
 import socket
 import subprocess
@@ -24,10 +24,11 @@ def test_two_rank_gather(tmp_path):
     script.write_text(textwrap.dedent(f"""
         import os, sys
         sys.path.insert(0, {REPO!r})
+        sys.path.insert(0, os.path.join({REPO!r}, "tests"))
         import numpy as np
-        from renormalizer_amd.parallel import (trajectory_seed, gather_observables, max_over_ranks, make_collective,
-                                               units_of_rank)
-        coll = make_collective(backend="gloo")          # CPU stand-in of the RCCL collective (same interface)
+        from renormalizer_amd.parallel import trajectory_seed, gather_observables, max_over_ranks, units_of_rank
+        from gloo_collective import GlooCollective
+        coll = GlooCollective()                          # CPU stand-in of the RCCL collective (same interface)
         rank, world = coll.rank, coll.world
         # unit u -> rank u mod world; every rank works on its own trajectories only
         units = units_of_rank(5, rank, world)
@@ -52,15 +53,47 @@ def test_two_rank_gather(tmp_path):
 
 
 def test_rendezvous_file_and_serial_collective(tmp_path, monkeypatch):
-    """The unique-id rendezvous is keyed by the launcher's pid and port; one process needs no communicator."""
+    """The unique-id rendezvous is keyed by the launcher's process instance (pid + start time) and port, in a
+    private directory; one process needs no communicator."""
     import numpy as np
     from renormalizer_amd import parallel
     monkeypatch.setenv("MPSE_RENDEZVOUS_DIR", str(tmp_path))
     monkeypatch.setenv("MASTER_PORT", "29517")
+    monkeypatch.delenv("MPSE_RENDEZVOUS_TAG", raising=False)
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
     p = parallel._rendezvous_path()
-    assert p.startswith(str(tmp_path)) and str(os.getppid()) in p and p.endswith("_29517.id")
+    ppid, start = parallel._parent_instance()
+    assert p.startswith(str(tmp_path)) and f"_{ppid}_{start}_29517.id" in p and int(start) > 0
+    monkeypatch.setenv("MPSE_RENDEZVOUS_TAG", "job42")
+    assert parallel._rendezvous_path().endswith("mpse_rccl_job42.id")
+    assert abs(parallel._process_start_time() - __import__("time").time()) < 3600
     monkeypatch.setenv("WORLD_SIZE", "1")
     coll = parallel.make_collective()
     assert coll.kind == "serial" and coll.allreduce_max(3.5) == 3.5
     tab = parallel.gather_observables(coll, np.array([[1.0, 2.0], [3.0, 4.0]]), [0, 1], 2)
     assert tab.tolist() == [[1.0, 2.0], [3.0, 4.0]]
+
+
+def test_stale_rendezvous_file_is_ignored(tmp_path):
+    """An id file left by a crashed launch with the same tag (older than this process by more than the slack) is
+    never handed to a reader; the id that rank 0 publishes afterwards is."""
+    import threading
+    import time
+    import pytest
+    from renormalizer_amd import parallel
+    path = str(tmp_path / "mpse_rccl_x.id")
+    with open(path, "wb") as fh:
+        fh.write(b"\x01" * 128)
+    old = time.time() - 3600
+    os.utime(path, (old, old))
+    with pytest.raises(TimeoutError):
+        parallel.await_id(path, 0.3, rank=1)
+    fresh = bytes(range(128))
+    threading.Timer(0.2, parallel.publish_id, args=(path, fresh)).start()
+    assert parallel.await_id(path, 10.0, rank=1) == fresh
+    assert (os.stat(path).st_mode & 0o777) == 0o600
+    # a truncated file is not an id
+    with open(path, "wb") as fh:
+        fh.write(b"\x02" * 64)
+    with pytest.raises(TimeoutError):
+        parallel.await_id(path, 0.2, rank=1)
