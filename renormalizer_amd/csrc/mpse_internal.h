@@ -228,5 +228,11 @@ constexpr int HH_BATCH_MAX_ROWS = 4096;
 // ``blks_dev``: the same descriptors already on the device (else they are uploaded here)
 int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm, const QrBlk* blks_host, int nblk,
                   bool form_q, const QrBlk* blks_dev = nullptr);
+// Communication-avoiding QR of the same blocks (mpse_caqr.hip): TSQR panels of 16 columns over chunks of 256 rows.
+// No per-reflector parameters; R in the upper triangle of the workspaces, the leading max(nq, k) columns of Q in q.
+constexpr int CAQR_MAX_ROWS = 4096;
+bool caqr_enabled();   // MPSE_QR_CAQR=0 selects the panel-blocked kernels of mpse_qr2.hip
+int caqr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, const QrBlk* blks_host, int nblk, bool form_q,
+                 const QrBlk* blks_dev = nullptr);
 // zero fill of two ranges in one launch (8-byte aligned)
 int device_zero2(mpse_ctx* ctx, void* a, size_t abytes, void* b, size_t bbytes);

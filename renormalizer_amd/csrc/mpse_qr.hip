@@ -339,7 +339,9 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   constexpr int E = CPLX ? 2 : 1;
   hipLaunchKernelGGL((k_gather_blocks<CPLX>), dim3(ew_blocks(max_el), (unsigned)blks.size()), dim3(256), 0, ctx->stream, ws,
                      (const double*)coef, (long long)ncol, drows, dcols, dblk, herm);
-  if (max_mm <= HH_BATCH_MAX_ROWS) {
+  if (max_mm <= CAQR_MAX_ROWS && caqr_enabled()) {
+    MPSE_TRY(caqr_batched(ctx, CPLX, ws, q, blks.data(), (int)blks.size(), true, dblk));
+  } else if (max_mm <= HH_BATCH_MAX_ROWS) {
     MPSE_TRY(hh_qr_batched(ctx, CPLX, ws, q, prm, blks.data(), (int)blks.size(), true, dblk));
   } else {
     for (const QrBlk& B : blks) {

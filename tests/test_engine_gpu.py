@@ -372,6 +372,41 @@ def test_block_qr_rank_deficient_and_shapes(eng, cplx):
             assert np.abs(iso.conj().T @ iso - np.eye(iso.shape[1])).max() < 1e-13
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_block_qr_many_ragged_blocks_tree_shapes(eng, cplx):
+    """Several quantum-number blocks of different heights in ONE decomposition, chosen around the chunk (256 rows) and
+    panel (16 columns) boundaries of the communication-avoiding QR: single chunk, chunk + a few rows, many chunks,
+    the full 4096-row tree, blocks with fewer rows than columns, one-row and one-column blocks; interleaved row /
+    column order.  Reconstruction, isometry, and the triangular shape of every block's R."""
+    rng = np.random.default_rng(21)
+    heights = [255, 256, 257, 511, 17, 1, 4096, 1300, 16, 15, 33]
+    widths = [40, 16, 130, 17, 33, 5, 256, 48, 16, 31, 1]
+    qnl = np.concatenate([np.full(h, b) for b, h in enumerate(heights)])
+    qnr = np.concatenate([np.full(w, b) for b, w in enumerate(widths)])
+    pl, pr = rng.permutation(len(qnl)), rng.permutation(len(qnr))
+    qnl, qnr = qnl[pl], qnr[pr]
+    mask = (qnl[:, None] - qnr[None, :]) == 0
+    a = _rand(rng, (len(qnl), len(qnr)), cplx) * mask
+    a[:, np.where(qnr == 6)[0][3]] = 0                                   # a zero column inside the big block
+    a[:, np.where(qnr == 6)[0][7]] = a[:, np.where(qnr == 6)[0][5]]     # an exactly dependent one
+    for system in ("L", "R"):
+        # blocks: qnl - qnr = 0  <=>  add_outer(qnl, -qnr) == 0
+        u, vt, blocks = dev_block_qr(eng, a, qnl[:, None], -qnr[:, None], np.array([0]), system)
+        assert _relerr(u @ vt, a) < 1e-13
+        iso = u if system == "L" else vt.conj().T
+        assert np.abs(iso.conj().T @ iso - np.eye(iso.shape[1])).max() < 1e-13
+        k0 = 0
+        for _, _, rows, cols in blocks:
+            k = min(len(rows), len(cols))
+            if system == "L":
+                r = vt[k0:k0 + k][:, cols]                                # k x n, upper triangular
+                assert np.abs(np.tril(r, -1)).max() == 0
+            else:
+                l = u[rows][:, k0:k0 + k]                                 # m x k factor of A = L Q: lower triangular
+                assert np.abs(np.triu(l, 1)).max() == 0
+            k0 += k
+
+
 # -------------------------------------------------------------- block SVD
 
 def dev_block_svd(eng, c, qnbigl, qnbigr, qntot):
