@@ -48,6 +48,26 @@ __device__ __forceinline__ double2 cmulc(double2 a, double2 b) {  // conj(a) * b
   return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
 }
 __device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+// fused accumulations: four dependent-pair FMAs per complex multiply-add (a product followed by an add costs six
+// FP64 issue slots and a longer dependency chain)
+__device__ __forceinline__ void cmac(double2& acc, double2 a, double2 b) {     // acc += a * b
+  acc.x = fma(a.x, b.x, acc.x);
+  acc.y = fma(a.x, b.y, acc.y);
+  acc.x = fma(-a.y, b.y, acc.x);
+  acc.y = fma(a.y, b.x, acc.y);
+}
+__device__ __forceinline__ void cmacc(double2& acc, double2 a, double2 b) {    // acc += conj(a) * b
+  acc.x = fma(a.x, b.x, acc.x);
+  acc.y = fma(a.x, b.y, acc.y);
+  acc.x = fma(a.y, b.y, acc.x);
+  acc.y = fma(-a.y, b.x, acc.y);
+}
+__device__ __forceinline__ void cnmac(double2& acc, double2 a, double2 b) {    // acc -= a * b
+  acc.x = fma(-a.x, b.x, acc.x);
+  acc.y = fma(-a.x, b.y, acc.y);
+  acc.x = fma(a.y, b.y, acc.x);
+  acc.y = fma(-a.y, b.x, acc.y);
+}
 
 template <bool CPLX>
 __device__ __forceinline__ double2 ld_el(const double* p, long long i) {
@@ -203,17 +223,17 @@ __global__ __launch_bounds__(CH) void k_caqr_factor(const CaqrArgs a, int p, int
     make_reflector(alpha, ssq, &tau, &scale, &beta);
     if (lane >= 1 && lane < NB) {
       const double2 head = s_head[pb][lane];
-      double2 fs = make_double2(0.0, 0.0);
+      double2 fs = make_double2(0.0, 0.0), fc = make_double2(0.0, 0.0);
       if (lane <= NB - 1 - j) {          // a remaining column: coefficients of its update by H_j^H
         const double2 sc = cmulc(scale, d);
-        const double2 fc = cmulc(tau, make_double2(head.x + sc.x, head.y + sc.y));
+        fc = cmulc(tau, make_double2(head.x + sc.x, head.y + sc.y));
         fs = cmul(fc, scale);
-        s_fc[wave][lane] = fc;           // (only the diagonal row reads it)
       } else if (wave == 0) {            // a finished reflector v_l: g = v_l^H v_j = conj(head) + scale * conj(d)
         const double2 sd = cmul(scale, cconj(d));
         s_G[lane - (NB - j)][j] = make_double2(head.x + sd.x, sd.y - head.y);
       }
       s_coef[wave][lane] = fs;
+      s_fc[wave][lane] = fc;             // (only the diagonal row reads it)
     }
     if (wave == 0 && lane == 0) s_tau[j] = tau;
     wave_lds_sync();
@@ -221,20 +241,15 @@ __global__ __launch_bounds__(CH) void k_caqr_factor(const CaqrArgs a, int p, int
     const bool diag = tid == j;
     const double2 sv = cmul(scale, pv);                                  // v_j below the diagonal
 #pragma unroll
-    for (int t = 1; t < NB; ++t) {
-      const double2 fs = s_coef[wave][t];
-      const double2 u = cmul(fs, pv);
-      ring[t].x -= u.x;
-      ring[t].y -= u.y;
-    }
-    if (diag) {
+    for (int t = 1; t < NB; ++t) cnmac(ring[t], s_coef[wave][t], pv);
+    if (diag) {     // one branch, the 15 loads in flight together (slots of finished reflectors hold a zero fc)
+      double2 fcv[NB];
+#pragma unroll
+      for (int t = 1; t < NB; ++t) fcv[t] = s_fc[wave][t];
 #pragma unroll
       for (int t = 1; t < NB; ++t) {
-        if (t <= NB - 1 - j) {
-          const double2 fc = s_fc[wave][t];
-          ring[t].x -= fc.x;
-          ring[t].y -= fc.y;
-        }
+        ring[t].x -= fcv[t].x;
+        ring[t].y -= fcv[t].y;
       }
     }
     // --- the pivot column is final: R above / on the diagonal, v_j below
@@ -352,18 +367,20 @@ __global__ __launch_bounds__(CH) void k_caqr_apply(const CaqrArgs a, int p, int 
   const int lane = tid & 63;
 #pragma unroll 1
   for (int g = 0; g < 4; ++g) {
+    double2 acc[4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) acc[ii] = make_double2(0.0, 0.0);
+    const double2* vcol = sV + g * 4 * CH + seg;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {          // four independent accumulation chains, four LDS loads per row slot
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) cmacc(acc[ii], vcol[ii * CH + 16 * q], x[q]);
+    }
     double v8[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) v8[t] = 0.0;
-#pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
-      const double2* vcol = sV + (g * 4 + ii) * CH + seg;
-#pragma unroll
-      for (int q = 0; q < NB; ++q) {
-        const double2 u = cmulc(vcol[16 * q], x[q]);
-        v8[2 * ii] += u.x;
-        v8[2 * ii + 1] += u.y;
-      }
+      v8[2 * ii] = acc[ii].x;
+      v8[2 * ii + 1] = acc[ii].y;
     }
     const double s = wave_rowsum8(v8, lane);
     if ((lane & 8) == 0) reinterpret_cast<double*>(sW + cl * NB)[g * 8 + rowsum8_index(lane & 15)] = s;
@@ -375,9 +392,10 @@ __global__ __launch_bounds__(CH) void k_caqr_apply(const CaqrArgs a, int p, int 
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const double2 wi = sW[cl * NB + i];
-      const double2 u = adjoint ? cmulc(sT[i * NB + seg], wi) : cmul(sT[seg * NB + i], wi);
-      z.x += u.x;
-      z.y += u.y;
+      if (adjoint)
+        cmacc(z, sT[i * NB + seg], wi);
+      else
+        cmac(z, sT[seg * NB + i], wi);
     }
     sZ[cl * NB + seg] = z;
   }
@@ -388,11 +406,7 @@ __global__ __launch_bounds__(CH) void k_caqr_apply(const CaqrArgs a, int p, int 
     const double2 zi = sZ[cl * NB + i];
     const double2* vcol = sV + i * CH + seg;
 #pragma unroll
-    for (int q = 0; q < NB; ++q) {
-      const double2 u = cmul(vcol[16 * q], zi);
-      x[q].x -= u.x;
-      x[q].y -= u.y;
-    }
+    for (int q = 0; q < NB; ++q) cnmac(x[q], vcol[16 * q], zi);
   }
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
@@ -482,12 +496,9 @@ int run_caqr(mpse_ctx* ctx, double* ws, double* q, const QrBlk* blks_host, const
 
 }  // namespace
 
-bool caqr_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("MPSE_QR_CAQR");
-    return !(e && e[0] == '0');
-  }();
-  return on;
+bool caqr_enabled() {   // read at every call: tests flip it inside one process
+  const char* e = getenv("MPSE_QR_CAQR");
+  return e && e[0] == '1';
 }
 
 // Same contract as hh_qr_batched (mpse_qr2.hip) without the per-reflector parameters: on return the upper triangle of

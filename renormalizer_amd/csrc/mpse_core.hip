@@ -297,6 +297,9 @@ int mpse_ctx_destroy(mpse_ctx* ctx) {
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->stage) (void)hipHostFree(ctx->stage);
+  for (auto& kv : ctx->qr_graphs) (void)hipGraphExecDestroy(kv.second);
+  for (void* b : ctx->qr_buf)
+    if (b) (void)hipFree(b);
   if (ctx->dscratch) (void)hipFree(ctx->dscratch);
   if (ctx->prof_ktiles) (void)hipFree(ctx->prof_ktiles);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -123,6 +123,12 @@ struct mpse_ctx {
     const void* ptr = nullptr;
     mpse_index m{}, n{};
   } cin_req;
+  // Block QR as HIP graphs (mpse_qr.hip): the panel / update / Q-formation launches of a decomposition are captured
+  // once per launch signature and replayed - the d = 2 sites' kernels take 4-5 us, less than the host needs to enqueue
+  // one.  The kernels' operands live in persistent buffers (a graph bakes the pointers in); growing one drops the graphs.
+  void* qr_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // index lists + descriptors | workspaces | Q | reflector parameters
+  size_t qr_cap[4] = {0, 0, 0, 0};
+  std::map<std::vector<long long>, hipGraphExec_t> qr_graphs;
   bool occ_cache_on = false;
   const char* occ_lo[2] = {nullptr, nullptr};
   const char* occ_hi[2] = {nullptr, nullptr};
@@ -231,7 +237,7 @@ int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm,
 // Communication-avoiding QR of the same blocks (mpse_caqr.hip): TSQR panels of 16 columns over chunks of 256 rows.
 // No per-reflector parameters; R in the upper triangle of the workspaces, the leading max(nq, k) columns of Q in q.
 constexpr int CAQR_MAX_ROWS = 4096;
-bool caqr_enabled();   // MPSE_QR_CAQR=0 selects the panel-blocked kernels of mpse_qr2.hip
+bool caqr_enabled();   // MPSE_QR_CAQR=1 (measured slower than the panel-blocked kernels of mpse_qr2.hip: off by default)
 int caqr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, const QrBlk* blks_host, int nblk, bool form_q,
                  const QrBlk* blks_dev = nullptr);
 // zero fill of two ranges in one launch (8-byte aligned)

@@ -372,12 +372,16 @@ def test_block_qr_rank_deficient_and_shapes(eng, cplx):
             assert np.abs(iso.conj().T @ iso - np.eye(iso.shape[1])).max() < 1e-13
 
 
+@pytest.mark.parametrize("caqr", ["0", "1"])
 @pytest.mark.parametrize("cplx", [False, True])
-def test_block_qr_many_ragged_blocks_tree_shapes(eng, cplx):
+def test_block_qr_many_ragged_blocks_tree_shapes(eng, cplx, caqr, monkeypatch):
     """Several quantum-number blocks of different heights in ONE decomposition, chosen around the chunk (256 rows) and
     panel (16 columns) boundaries of the communication-avoiding QR: single chunk, chunk + a few rows, many chunks,
     the full 4096-row tree, blocks with fewer rows than columns, one-row and one-column blocks; interleaved row /
-    column order.  Reconstruction, isometry, and the triangular shape of every block's R."""
+    column order.  Reconstruction, isometry, and the triangular shape of every block's R.  Both implementations:
+    the panel-blocked kernels (default, replayed from a HIP graph - run twice so that the replay is exercised) and
+    the communication-avoiding tree (MPSE_QR_CAQR=1)."""
+    monkeypatch.setenv("MPSE_QR_CAQR", caqr)
     rng = np.random.default_rng(21)
     heights = [255, 256, 257, 511, 17, 1, 4096, 1300, 16, 15, 33]
     widths = [40, 16, 130, 17, 33, 5, 256, 48, 16, 31, 1]
@@ -389,7 +393,7 @@ def test_block_qr_many_ragged_blocks_tree_shapes(eng, cplx):
     a = _rand(rng, (len(qnl), len(qnr)), cplx) * mask
     a[:, np.where(qnr == 6)[0][3]] = 0                                   # a zero column inside the big block
     a[:, np.where(qnr == 6)[0][7]] = a[:, np.where(qnr == 6)[0][5]]     # an exactly dependent one
-    for system in ("L", "R"):
+    for system in ("L", "R", "L", "R"):
         # blocks: qnl - qnr = 0  <=>  add_outer(qnl, -qnr) == 0
         u, vt, blocks = dev_block_qr(eng, a, qnl[:, None], -qnr[:, None], np.array([0]), system)
         assert _relerr(u @ vt, a) < 1e-13

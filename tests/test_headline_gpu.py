@@ -115,8 +115,8 @@ _SWITCHES = {
     "MPSE_DOT_FUSED=0": False,        # Lanczos coefficient by its own reduction kernel (other summation order)
     "MPSE_WSMALL=0": False,           # MPO step of the d = 2 sites as an MFMA product
     "MPSE_LANCZOS_ASYNC=0": False,    # host-side eigen-decomposition of the tridiagonal matrix
-    "MPSE_QR_CAQR=0": False,          # panel-blocked Householder QR instead of the communication-avoiding tree
-    "MPSE_HEFF_FUSED=0": False,       # unfused one-site matvec chain
+    "MPSE_QR_CAQR=1": False,          # communication-avoiding tree QR instead of the panel-blocked kernels
+    "MPSE_QR_GRAPH=0": True,          # the QR's launches enqueued one by one instead of replayed from a HIP graph
 }
 
 
