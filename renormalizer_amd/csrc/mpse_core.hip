@@ -216,6 +216,20 @@ int mpse_prof_get(mpse_ctx* ctx, int variant, double* total_ms, double* total_fl
   if (!ctx || variant < 0 || variant >= mpse_ctx::PROF_NVAR) return MPSE_ERR_ARG;
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   prof_drain(ctx);
+  if (variant == 0 && ctx->gemm_trace) {     // debug timeline of the contraction kernel (MPSE_GEMM_TRACE=<file>)
+    const char* path = getenv("MPSE_GEMM_TRACE");
+    unsigned long long n = 0;
+    if (path && hipMemcpy(&n, ctx->gemm_trace, sizeof(n), hipMemcpyDeviceToHost) == hipSuccess) {
+      if (n > GEMM_TRACE_CAP) n = GEMM_TRACE_CAP;
+      std::vector<unsigned long long> rec(size_t(n) * 8);
+      if (n && hipMemcpy(rec.data(), ctx->gemm_trace + 1, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+        if (FILE* fh = fopen(path, "wb")) {
+          fwrite(rec.data(), sizeof(unsigned long long), rec.size(), fh);
+          fclose(fh);
+        }
+      }
+    }
+  }
   if (total_ms) *total_ms = ctx->prof_ms[variant];
   if (total_flops) *total_flops = ctx->prof_flops[variant];
   if (total_bytes) *total_bytes = ctx->prof_bytes[variant];

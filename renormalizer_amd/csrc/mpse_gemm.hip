@@ -70,6 +70,7 @@ struct GemmArgs {
   // accumulates onto a slice of another tensor needs no copy of that slice into C first
   const double* Cin;
   IdxMap mCin, nCin;
+  unsigned long long* trace;        // debug timeline (mpse_ctx::gemm_trace), null normally
 };
 
 // (re, im) += conj(c) * y
@@ -105,6 +106,8 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
   // one LDS object: [Are | Aim? | Bre | Bim?], each BK x LD doubles
   __shared__ double smem[(2 + (CA ? 1 : 0) + (CB ? 1 : 0)) * BK * LD];
   if (g.skip && *g.skip) return;   // workgroup-uniform
+  const unsigned long long tr0 = g.trace ? __builtin_readcyclecounter() : 0ull;
+  unsigned long long tr1 = 0, tr2 = 0, tr3 = 0;
   double* sAr = smem;
   double* sAi = sAr + BK * LD;  // only meaningful if CA
   double* sBr = smem + (CA ? 2 : 1) * BK * LD;
@@ -331,6 +334,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
     }
   };
   int kt = next_kt(kt_begin);
+  if (g.trace) tr1 = __builtin_readcyclecounter();
   if (kt < kt_end) {
     skip_to(kt_begin, kt);
     load_tile(kt);
@@ -368,6 +372,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
   while (kt < kt_end) {
     ++kt_done;
     __syncthreads();
+    if (g.trace && kt_done == 1) tr2 = __builtin_readcyclecounter();
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
       if constexpr (KS) {  // out-of-range k were staged as zeros by load_ks
@@ -430,6 +435,31 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
     }
   }
 
+  if (g.trace) tr3 = __builtin_readcyclecounter();
+  struct TraceEnd {     // the record is written when the workgroup leaves the kernel, whichever way
+    const GemmArgs& g;
+    unsigned long long t0, &t1, &t2, &t3;
+    int tid;
+    int& ktd;
+    __device__ ~TraceEnd() {
+      if (g.trace && tid == 0) {
+        const unsigned long long slot = atomicAdd(g.trace, 1ull);
+        if (slot < GEMM_TRACE_CAP) {
+          unsigned long long* r = g.trace + 1 + slot * 8;
+          unsigned xcc = 0;
+          r[0] = ((unsigned long long)gridDim.x << 32) | (unsigned long long)blockIdx.x;
+          r[1] = ((unsigned long long)(CA ? 1 : 0) << 62) | ((unsigned long long)(CB ? 1 : 0) << 61) |
+                 ((unsigned long long)g.ksplit << 40) | ((unsigned long long)(unsigned)g.K << 8) | xcc;
+          r[2] = (unsigned long long)ktd;
+          r[3] = t0;
+          r[4] = t1;
+          r[5] = t2;
+          r[6] = t3;
+          r[7] = __builtin_readcyclecounter();
+        }
+      }
+    }
+  } trace_end{g, tr0, tr1, tr2, tr3, tid, kt_done};
   if (g.kt_counter && tid == 0 && kt_done) atomicAdd(g.kt_counter, (unsigned long long)kt_done);
   if (g.cmask) {   // workgroup-uniform
     if (tid == 0) g.cmask[((long long)b * g.tiles_m + tm) * g.tiles_n + tn] = kt_done > 0 ? 1 : 0;
@@ -787,6 +817,17 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.cmask = nullptr;
   g.dot_y = nullptr;
   g.dot_part = nullptr;
+  if (!ctx->gemm_trace_checked) {
+    ctx->gemm_trace_checked = true;
+    if (getenv("MPSE_GEMM_TRACE")) {
+      void* pt = nullptr;
+      if (hipMalloc(&pt, (1 + GEMM_TRACE_CAP * 8) * sizeof(unsigned long long)) == hipSuccess) {
+        (void)hipMemsetAsync(pt, 0, sizeof(unsigned long long), ctx->stream);
+        ctx->gemm_trace = static_cast<unsigned long long*>(pt);
+      }
+    }
+  }
+  g.trace = ctx->prof_on ? ctx->gemm_trace : nullptr;    // only inside the profiled (timed) region
   TmpBuf WSB(ctx), MSK(ctx);
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   // tuning knobs of the split-K policy (environment, read once): output tiles below which K is sliced, and how many
