@@ -73,6 +73,10 @@ struct GemmArgs {
   unsigned long long* trace;        // debug timeline (mpse_ctx::gemm_trace), null normally
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load in flight
+// (s_waitcnt vmcnt(0)): operand tiles prefetched across the barrier would be drained at each one.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // (re, im) += conj(c) * y
 __device__ __forceinline__ void dot_acc(double& re, double& im, double2 c, double2 y) {
   re += c.x * y.x + c.y * y.y;
@@ -97,7 +101,7 @@ constexpr int BM = 64, BN = 64, BK = 16, LDK = BK + 1;   // BM x BN: granularity
 // 32 x 32 - for products whose 64 x 64 tiles cannot fill the chip, four times as many workgroups instead of slicing K
 // into partial sums that a second kernel has to add up.
 template <bool CA, bool CB, bool KS, int WS>
-__global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_3M ? 2 : 3)) void k_gemm(const GemmArgs g) {
+__global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA || CB) ? 2 : 3)) void k_gemm(const GemmArgs g) {
   constexpr int TBM = 32 * WS, TBN = 32 * WS, NT = 64 * WS * WS;
   constexpr int LD = WS == 2 ? 80 : 48;          // [k][i] panel rows; LD mod 32 == 16 keeps the fragment reads conflict free
   constexpr int NLD = TBM * BK / NT;             // staged elements per thread and operand (panel = BK*LD >= TBM*LDK doubles)
@@ -201,22 +205,41 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
   const int nkt_all = (g.K + BK - 1) / BK;
   const int kt_begin = ks_id * g.kt_per_split;
   const int kt_end = min(nkt_all, kt_begin + g.kt_per_split);
-  // fast path (single-level K maps, full K tile): running pointers, no clamps, no index arithmetic in the loop
-  const double* pa[NLD];
-  const double* pb[NLD];
+  // fast path (single-level K maps; the launcher guarantees non-negative strides and operand spans below 4 GB):
+  // a uniform tile base (scalar registers, recomputed from the tile number) plus one 32-bit byte offset per lane and
+  // staged element - the global_load saddr + voffset form: no per-lane 64-bit pointers to keep and to advance
+  unsigned int loa[NLD], lob[NLD];
+  const char* a_row0 = nullptr;
+  const char* b_col0 = nullptr;
   long long step_a = 0, step_b = 0;
   if constexpr (KS) {
+    // tile bases = the smallest row / column offset of the tile.  Inside one group of a two-level map the offset
+    // grows with the index (strides >= 0), so the minimum sits at the first row or at the first row of a later group:
+    // a short uniform loop over the group starts inside the tile (scalar code, no LDS, no barrier)
+    auto tile_min = [&](const IdxMap& m, int first, int count, int ext) -> long long {
+      const int last = min(first + count, ext);          // exclusive
+      long long best = idx_off(m, min(first, ext - 1));
+      if (m.lo != 0x7fffffff) {
+        for (int r = (first / m.lo + 1) * m.lo; r < last; r += m.lo) best = min(best, idx_off(m, r));
+      }
+      return best;
+    };
+    const long long a0 = tile_min(g.mA, tm * TBM, TBM, g.M), b0 = tile_min(g.nB, tn * TBN, TBN, g.N);
+    a_row0 = reinterpret_cast<const char*>(A + a0 * EA);
+    b_col0 = reinterpret_cast<const char*>(B + b0 * EB);
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
-      pa[r] = A + (aoff[r] + (long long)(kt_begin * BK + ak[r]) * g.kA.s_lo) * EA;
-      pb[r] = B + (boff[r] + (long long)(kt_begin * BK + bk[r]) * g.kB.s_lo) * EB;
+      loa[r] = (unsigned int)((aoff[r] - a0 + (long long)ak[r] * g.kA.s_lo) * EA * 8);
+      lob[r] = (unsigned int)((boff[r] - b0 + (long long)bk[r] * g.kB.s_lo) * EB * 8);
     }
-    step_a = (long long)BK * g.kA.s_lo * EA;
-    step_b = (long long)BK * g.kB.s_lo * EB;
+    step_a = (long long)BK * g.kA.s_lo * EA * 8;   // bytes per K tile
+    step_b = (long long)BK * g.kB.s_lo * EB * 8;
   }
   // FULL: every k of the tile is < K.  Otherwise (at most the last K tile of a GEMM) lanes past K skip the
   // load and stage zeros.
   auto load_ks = [&](int kt, bool full) {
+    const char* at = a_row0 + (long long)kt * step_a;
+    const char* bt = b_col0 + (long long)kt * step_b;
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
       const bool ina = full || kt * BK + ak[r] < g.K;
@@ -225,43 +248,41 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
       rb[r] = make_double2(0.0, 0.0);
       if (ina) {
         if constexpr (CA)
-          ra[r] = *reinterpret_cast<const double2*>(pa[r]);
+          ra[r] = *reinterpret_cast<const double2*>(at + loa[r]);
         else
-          ra[r].x = *pa[r];
+          ra[r].x = *reinterpret_cast<const double*>(at + loa[r]);
       }
       if (inb) {
         if constexpr (CB)
-          rb[r] = *reinterpret_cast<const double2*>(pb[r]);
+          rb[r] = *reinterpret_cast<const double2*>(bt + lob[r]);
         else
-          rb[r].x = *pb[r];
+          rb[r].x = *reinterpret_cast<const double*>(bt + lob[r]);
       }
-      pa[r] += step_a;
-      pb[r] += step_b;
     }
   };
-  auto load_full = [&]() {
+  auto load_full = [&](int kt) {
+    const char* at = a_row0 + (long long)kt * step_a;
+    const char* bt = b_col0 + (long long)kt * step_b;
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
       if constexpr (CA) {
-        ra[r] = *reinterpret_cast<const double2*>(pa[r]);
+        ra[r] = *reinterpret_cast<const double2*>(at + loa[r]);
       } else {
-        ra[r].x = *pa[r];
+        ra[r].x = *reinterpret_cast<const double*>(at + loa[r]);
         ra[r].y = 0.0;
       }
-      pa[r] += step_a;
       if constexpr (CB) {
-        rb[r] = *reinterpret_cast<const double2*>(pb[r]);
+        rb[r] = *reinterpret_cast<const double2*>(bt + lob[r]);
       } else {
-        rb[r].x = *pb[r];
+        rb[r].x = *reinterpret_cast<const double*>(bt + lob[r]);
         rb[r].y = 0.0;
       }
-      pb[r] += step_b;
     }
   };
   auto load_tile = [&](int kt) {
     if constexpr (KS) {
       if ((kt + 1) * BK <= g.K)
-        load_full();
+        load_full(kt);
       else
         load_ks(kt, false);
     } else {
@@ -291,6 +312,8 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
   __shared__ unsigned long long s_mask[2][MASKW];
   const unsigned long long* am = nullptr;
   const unsigned long long* bm = nullptr;
+  bool mlds = false;   // the flag words are in LDS (read with ds_read: a generic pointer would make every look-up a
+                       // flat load, whose wait drains the operand loads in flight as well)
   if constexpr (KS) {
     // masks are kept per 64 rows / columns whatever the workgroup tile
     if (g.amask) am = g.amask + ((long long)b * g.mtiles_m + (tm * TBM) / BM) * g.nkw;
@@ -301,8 +324,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
         s_mask[1][tid] = bm ? bm[tid] : 0x0101010101010101ull;
       }
       __syncthreads();
-      am = s_mask[0];
-      bm = s_mask[1];
+      mlds = true;
     }
   }
   auto next_kt = [&](int from) -> int {
@@ -310,8 +332,12 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
     while (from < kt_end) {
       const int w = from >> 3;                      // 8 byte flags per word
       unsigned long long word = 0x0101010101010101ull;
-      if (am) word &= am[w];
-      if (bm) word &= bm[w];
+      if (mlds) {
+        word &= s_mask[0][w] & s_mask[1][w];
+      } else {
+        if (am) word &= am[w];
+        if (bm) word &= bm[w];
+      }
       word &= ~0ull << ((from & 7) * 8);
       if (word) {
         const int kt = (w << 3) + (__builtin_ctzll(word) >> 3);
@@ -321,22 +347,9 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
     }
     return kt_end;
   };
-  auto skip_to = [&](int cur_next, int target) {  // running pointers stand at tile cur_next; move them to target
-    if constexpr (KS) {
-      if (target != cur_next) {
-        const long long da = (long long)(target - cur_next) * step_a, db = (long long)(target - cur_next) * step_b;
-#pragma unroll
-        for (int r = 0; r < NLD; ++r) {
-          pa[r] += da;
-          pb[r] += db;
-        }
-      }
-    }
-  };
   int kt = next_kt(kt_begin);
   if (g.trace) tr1 = __builtin_readcyclecounter();
   if (kt < kt_end) {
-    skip_to(kt_begin, kt);
     load_tile(kt);
   }
   const int frow = lane & 15, fk = lane >> 4;
@@ -358,65 +371,51 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
   // operand fragments of one k-group (4 of K): double buffered so that the ds_reads of group kk+1 are in
   // flight under the 16 MFMAs of group kk
   double f_ar[2][2], f_ai[2][2], f_br[2][2], f_bi[2][2];
+  constexpr int lds_set = 0;
   auto read_frag = [&](int buf, int kk) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      f_ar[buf][i] = sAr[rofa[i] + kk * 4 * sak];
-      if constexpr (CA) f_ai[buf][i] = sAi[rofa[i] + kk * 4 * sak];
-      f_br[buf][i] = sBr[rofb[i] + kk * 4 * sbk];
-      if constexpr (CB) f_bi[buf][i] = sBi[rofb[i] + kk * 4 * sbk];
+      f_ar[buf][i] = sAr[lds_set + rofa[i] + kk * 4 * sak];
+      if constexpr (CA) f_ai[buf][i] = sAi[lds_set + rofa[i] + kk * 4 * sak];
+      f_br[buf][i] = sBr[lds_set + rofb[i] + kk * 4 * sbk];
+      if constexpr (CB) f_bi[buf][i] = sBi[lds_set + rofb[i] + kk * 4 * sbk];
     }
   };
-
-  int kt_done = 0;
-  while (kt < kt_end) {
-    ++kt_done;
-    __syncthreads();
-    if (g.trace && kt_done == 1) tr2 = __builtin_readcyclecounter();
+  // staged registers -> LDS panels of set `off`
+  auto stage_to_lds = [&](int off) {
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
       if constexpr (KS) {  // out-of-range k were staged as zeros by load_ks
-        sAr[wofa[r]] = ra[r].x;
-        if constexpr (CA) sAi[wofa[r]] = sgn_a * ra[r].y;
-        sBr[wofb[r]] = rb[r].x;
-        if constexpr (CB) sBi[wofb[r]] = sgn_b * rb[r].y;
+        sAr[off + wofa[r]] = ra[r].x;
+        if constexpr (CA) sAi[off + wofa[r]] = sgn_a * ra[r].y;
+        sBr[off + wofb[r]] = rb[r].x;
+        if constexpr (CB) sBi[off + wofb[r]] = sgn_b * rb[r].y;
       } else {
-        sAr[wofa[r]] = ka_in[r] ? ra[r].x : 0.0;
-        if constexpr (CA) sAi[wofa[r]] = ka_in[r] ? sgn_a * ra[r].y : 0.0;
-        sBr[wofb[r]] = kb_in[r] ? rb[r].x : 0.0;
-        if constexpr (CB) sBi[wofb[r]] = kb_in[r] ? sgn_b * rb[r].y : 0.0;
+        sAr[off + wofa[r]] = ka_in[r] ? ra[r].x : 0.0;
+        if constexpr (CA) sAi[off + wofa[r]] = ka_in[r] ? sgn_a * ra[r].y : 0.0;
+        sBr[off + wofb[r]] = kb_in[r] ? rb[r].x : 0.0;
+        if constexpr (CB) sBi[off + wofb[r]] = kb_in[r] ? sgn_b * rb[r].y : 0.0;
       }
     }
-    __syncthreads();
-    const int nk = next_kt(kt + 1);
-    if (nk < kt_end) {
-      skip_to(kt + 1, nk);
-      load_tile(nk);
-    }
-    kt = nk;
-
-    read_frag(0, 0);
+  };
+  // the 16 (x3 / x4 / x2 / x1) MFMAs of k-group kk on fragment buffer cb
+  auto mfma_group = [&](int cb) {
+    if constexpr (M3) {
+      double as[2], bs[2];
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      const int cb = kk & 1;
-      if (kk + 1 < BK / 4) read_frag(cb ^ 1, kk + 1);
-      if constexpr (M3) {
-        double as[2], bs[2];
+      for (int i = 0; i < 2; ++i) {
+        as[i] = f_ar[cb][i] + f_ai[cb][i];
+        bs[i] = f_br[cb][i] + f_bi[cb][i];
+      }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          as[i] = f_ar[cb][i] + f_ai[cb][i];
-          bs[i] = f_br[cb][i] + f_bi[cb][i];
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_br[cb][j], acc_re[i][j], 0, 0, 0);
+          acc_t2[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ai[cb][i], f_bi[cb][j], acc_t2[i][j], 0, 0, 0);
+          acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[i], bs[j], acc_im[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_br[cb][j], acc_re[i][j], 0, 0, 0);
-            acc_t2[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ai[cb][i], f_bi[cb][j], acc_t2[i][j], 0, 0, 0);
-            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[i], bs[j], acc_im[i][j], 0, 0, 0);
-          }
-        continue;
-      }
+    } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -433,6 +432,131 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
           }
         }
     }
+  };
+
+  // the last k-group of a tile with the staging stores of the next tile between its MFMAs (one register of each
+  // operand per output sub-tile; KS variants)
+  auto mfma_group_staging = [&](int cb) {
+    double as[2], bs[2];
+    if constexpr (M3) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        as[i] = f_ar[cb][i] + f_ai[cb][i];
+        bs[i] = f_br[cb][i] + f_bi[cb][i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (M3) {
+          acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_br[cb][j], acc_re[i][j], 0, 0, 0);
+          acc_t2[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ai[cb][i], f_bi[cb][j], acc_t2[i][j], 0, 0, 0);
+          acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[i], bs[j], acc_im[i][j], 0, 0, 0);
+        } else {
+          acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_br[cb][j], acc_re[i][j], 0, 0, 0);
+          if constexpr (CA && CB) {
+            acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-f_ai[cb][i], f_bi[cb][j], acc_re[i][j], 0, 0, 0);
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_bi[cb][j], acc_im[i][j], 0, 0, 0);
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ai[cb][i], f_br[cb][j], acc_im[i][j], 0, 0, 0);
+          } else if constexpr (CA) {
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ai[cb][i], f_br[cb][j], acc_im[i][j], 0, 0, 0);
+          } else if constexpr (CB) {
+            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_bi[cb][j], acc_im[i][j], 0, 0, 0);
+          }
+        }
+        constexpr int PER = NLD / 4 > 0 ? NLD / 4 : 1;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          const int r = (2 * i + j) * PER + q;
+          if (r < NLD) {
+            sAr[wofa[r]] = ra[r].x;
+            if constexpr (CA) sAi[wofa[r]] = sgn_a * ra[r].y;
+            sBr[wofb[r]] = rb[r].x;
+            if constexpr (CB) sBi[wofb[r]] = sgn_b * rb[r].y;
+          }
+        }
+        // pin the interleave: the MFMAs of this sub-tile, then its staging stores (left alone the scheduler issues
+        // the MFMAs first and the stores in a block behind them)
+        constexpr int NM = M3 ? 3 : (CA && CB) ? 4 : (CA || CB) ? 2 : 1;
+        __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, (2 + (CA ? 1 : 0) + (CB ? 1 : 0)) * PER, 0);
+      }
+  };
+
+#ifndef MPSE_GEMM_PIPE
+#define MPSE_GEMM_PIPE 1
+#endif
+  int kt_done = 0;
+  if constexpr (KS && MPSE_GEMM_PIPE) {
+    // Software-pipelined K loop.  A wave issues in order: every instruction that is not an MFMA and sits between the
+    // last MFMA of one K tile and the first of the next (barrier, staging stores, barrier, mask look-up, pointer
+    // updates, loads, first fragment reads) is time the matrix pipe idles unless a second workgroup on the CU fills it
+    // - 1460 of 4530 cycles per tile for a workgroup alone on its CU (tools/gemm_trace.py).  So the last k-group of a
+    // tile is multiplied AFTER the barrier that frees the panels, interleaved with the staging stores of the next
+    // tile; the loads of the tile after that are issued under the first k-group of the next iteration.
+    int nk = kt_end;
+    if (kt < kt_end) {
+      stage_to_lds(0);
+      nk = next_kt(kt + 1);
+      if (nk < kt_end) {
+        load_tile(nk);
+      }
+      lds_barrier();
+      if (g.trace) tr2 = __builtin_readcyclecounter();
+      read_frag(0, 0);
+    }
+    const bool any = kt < kt_end;
+    while (nk < kt_end) {          // tile kt has a successor (single-exit loop: an exit in the middle made the
+      ++kt_done;                   // compiler keep two copies of the accumulators and spill)
+      read_frag(1, 1);
+      mfma_group(0);
+      read_frag(0, 2);
+      mfma_group(1);
+      read_frag(1, 3);
+      mfma_group(0);
+      lds_barrier();               // every wave holds its last fragments: the panels may be overwritten
+      mfma_group_staging(1);       // the MFMAs of the last k-group, the staging stores of tile nk between them
+      // the tile after nk (mask words in LDS: no global load is waited for); its loads stay in flight across the
+      // barrier (lds_barrier does not wait for them) and across the next iteration's MFMAs
+      const int after = next_kt(nk + 1);
+      if (after < kt_end) load_tile(after);
+      kt = nk;
+      nk = after;
+      lds_barrier();               // panels of the next tile complete
+      read_frag(0, 0);
+    }
+    if (any) {                     // last tile: nothing left to stage
+      ++kt_done;
+      read_frag(1, 1);
+      mfma_group(0);
+      read_frag(0, 2);
+      mfma_group(1);
+      read_frag(1, 3);
+      mfma_group(0);
+      mfma_group(1);
+    }
+  } else {
+  while (kt < kt_end) {
+    ++kt_done;
+    __syncthreads();
+    if (g.trace && kt_done == 1) tr2 = __builtin_readcyclecounter();
+    stage_to_lds(0);
+    __syncthreads();
+    const int nk = next_kt(kt + 1);
+    if (nk < kt_end) {
+      load_tile(nk);
+    }
+    kt = nk;
+
+    read_frag(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int cb = kk & 1;
+      if (kk + 1 < BK / 4) read_frag(cb ^ 1, kk + 1);
+      mfma_group(cb);
+    }
+  }
   }
 
   if (g.trace) tr3 = __builtin_readcyclecounter();
@@ -498,6 +622,40 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
     return;
   }
   double dre = 0.0, dim = 0.0;
+  // Two passes: first every load of the beta term and of the dot partner is issued (16 elements per lane, nothing
+  // stored yet, so the loads are in flight together), then the results are formed and stored.  Interleaved with the
+  // stores, the loads went out one by one (they may alias C for all the compiler knows): 30 000 cycles of epilogue
+  // on the C-step of the one-site matvec, a quarter of that workgroup's life (tools/gemm_trace.py).
+  double2 pre_c[2][2][4], pre_y[2][2][4];
+  const bool need_c = g.use_beta, need_y = g.dot_y != nullptr;
+  if (need_c || need_y) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gj = min(tn * TBN + wn * 32 + j * 16 + (lane & 15), g.N - 1);     // clamped: never stored past the edge
+      const long long coffn = idx_off(g.nC, gj);
+      const long long cinn = g.Cin ? idx_off(g.nCin, gj) : 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = min(tm * TBM + wm * 32 + i * 16 + (lane >> 4) + 4 * r, g.M - 1);
+          const long long co = idx_off(g.mC, gi) + coffn;
+          if (need_c) {
+            const double* pin = g.Cin ? g.Cin + (idx_off(g.mCin, gi) + cinn) * EC : C + co * EC;
+            if constexpr (CC)
+              pre_c[i][j][r] = *reinterpret_cast<const double2*>(pin);
+            else
+              pre_c[i][j][r] = make_double2(*pin, 0.0);
+          }
+          if (need_y) {
+            if constexpr (CC)
+              pre_y[i][j][r] = reinterpret_cast<const double2*>(g.dot_y)[co];
+            else
+              pre_y[i][j][r] = make_double2(g.dot_y[co], 0.0);
+          }
+        }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int gj = tn * TBN + wn * 32 + j * 16 + (lane & 15);
@@ -511,25 +669,24 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : (CA && CB && MPSE_GEMM_
         if (gi >= g.M) continue;
         const long long co = idx_off(g.mC, gi) + coffn;
         double* p = C + co * EC;
-        const double* pin = g.Cin ? g.Cin + (idx_off(g.mCin, gi) + idx_off(g.nCin, gj)) * EC : p;
         const double xr = acc_re[i][j][r];
         if constexpr (CC) {
           const double xi = acc_im[i][j][r];
           double2 o;
           o.x = g.alpha_re * xr - g.alpha_im * xi;
           o.y = g.alpha_re * xi + g.alpha_im * xr;
-          if (g.use_beta) {
-            const double2 c0 = *reinterpret_cast<const double2*>(pin);
+          if (need_c) {
+            const double2 c0 = pre_c[i][j][r];
             o.x += g.beta_re * c0.x - g.beta_im * c0.y;
             o.y += g.beta_re * c0.y + g.beta_im * c0.x;
           }
           *reinterpret_cast<double2*>(p) = o;
-          if (g.dot_y) dot_acc(dre, dim, o, reinterpret_cast<const double2*>(g.dot_y)[co]);
+          if (need_y) dot_acc(dre, dim, o, pre_y[i][j][r]);
         } else {
           double o = g.alpha_re * xr;
-          if (g.use_beta) o += g.beta_re * (*pin);
+          if (need_c) o += g.beta_re * pre_c[i][j][r].x;
           *p = o;
-          if (g.dot_y) dre += o * g.dot_y[co];
+          if (need_y) dre += o * pre_y[i][j][r].x;
         }
       }
     }
@@ -975,7 +1132,17 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     g.amask = sa ? am : static_cast<const unsigned long long*>(amask_ext);
     g.bmask = sb_ ? bmk : nullptr;
   }
-  const bool ks = is_single(g.kA) && is_single(g.kB);
+  // the fast kernel addresses its operands as uniform base + 32-bit lane offset: non-negative strides, spans < 4 GB
+  auto span_ok = [](const IdxMap& m, const IdxMap& k, bool cplx) {
+    if (m.s_hi < 0 || m.s_lo < 0 || k.s_hi < 0 || k.s_lo < 0) return false;
+    auto span = [](const IdxMap& x) {
+      if (x.ext <= 1) return 0.0;
+      if (x.lo == 0x7fffffff) return double(x.ext - 1) * double(x.s_lo);
+      return double((x.ext - 1) / x.lo) * double(x.s_hi) + double(x.lo - 1) * double(x.s_lo);
+    };
+    return (span(m) + span(k) + 1.0) * (cplx ? 16.0 : 8.0) < 4.0e9;
+  };
+  const bool ks = is_single(g.kA) && is_single(g.kB) && span_ok(g.mA, g.kA, ca) && span_ok(g.nB, g.kB, cb);
 #define MPSE_LAUNCH(CA_, CB_)                                                                         \
   do {                                                                                                \
     if (ks && small)                                                                                  \
