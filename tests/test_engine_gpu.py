@@ -375,12 +375,13 @@ def test_block_qr_rank_deficient_and_shapes(eng, cplx):
 @pytest.mark.parametrize("caqr", ["0", "1"])
 @pytest.mark.parametrize("cplx", [False, True])
 def test_block_qr_many_ragged_blocks_tree_shapes(eng, cplx, caqr, monkeypatch):
+    # (MPSE_QR_GRAPH is read once per process: the graph replay of the default kernels is exercised by
+    # test_headline_switch_ab[MPSE_QR_GRAPH=1] in its own process)
     """Several quantum-number blocks of different heights in ONE decomposition, chosen around the chunk (256 rows) and
     panel (16 columns) boundaries of the communication-avoiding QR: single chunk, chunk + a few rows, many chunks,
     the full 4096-row tree, blocks with fewer rows than columns, one-row and one-column blocks; interleaved row /
     column order.  Reconstruction, isometry, and the triangular shape of every block's R.  Both implementations:
-    the panel-blocked kernels (default, replayed from a HIP graph - run twice so that the replay is exercised) and
-    the communication-avoiding tree (MPSE_QR_CAQR=1)."""
+    the panel-blocked kernels (default) and the communication-avoiding tree (MPSE_QR_CAQR=1)."""
     monkeypatch.setenv("MPSE_QR_CAQR", caqr)
     rng = np.random.default_rng(21)
     heights = [255, 256, 257, 511, 17, 1, 4096, 1300, 16, 15, 33]

@@ -116,7 +116,7 @@ _SWITCHES = {
     "MPSE_WSMALL=0": False,           # MPO step of the d = 2 sites as an MFMA product
     "MPSE_LANCZOS_ASYNC=0": False,    # host-side eigen-decomposition of the tridiagonal matrix
     "MPSE_QR_CAQR=1": False,          # communication-avoiding tree QR instead of the panel-blocked kernels
-    "MPSE_QR_GRAPH=0": True,          # the QR's launches enqueued one by one instead of replayed from a HIP graph
+    "MPSE_QR_GRAPH=1": True,          # the QR's launches replayed from a HIP graph instead of enqueued one by one
 }
 
 
