@@ -261,7 +261,8 @@ int mpse_expm_lanczos(mpse_ctx* ctx, int dtype, const mpse_heff* h, double dt_re
 /* Davidson eigensolver for the lowest nroots eigenpairs of the effective Hamiltonian, replaces
  * lib/davidson/davidson.py:154-441 as called at mps/gs.py:533-538 (diagonal preconditioner r / (hdiag - e + shift),
  * Gram-Schmidt twice, restart from the Ritz vectors when max_space vectors are held, convergence of a root when
- * |de| < tol and |r| < sqrt(tol), new directions dropped when their squared norm falls under lindep).
+ * |de| < tol and |r| < sqrt(tol), new directions dropped when their squared norm falls under lindep; tol < 0: the
+ * residual alone decides, |r| < -tol - the convergence test of the reference's algo = "primme", gs.py:552-569).
  *   h         : the projected operator (mpse_heff_apply; twolayer != 0: mpse_heff_apply2, the (H - omega)^2 form)
  *   hdiag_f64 : its diagonal (n doubles, device);  mask_f64: 0/1 weights of the symmetry-allowed entries or NULL
  *               (the reference compresses vectors to those entries on the host, mps/gs.py:260, 520-523)

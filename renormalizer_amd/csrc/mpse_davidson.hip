@@ -361,7 +361,10 @@ extern "C" int mpse_davidson(mpse_ctx* ctx, int dtype, const mpse_heff* h, int t
   if (max_cycle <= 0) max_cycle = 100;
   const bool cplx = dtype == MPSE_C128;
   const size_t es = dtype_size(dtype);
-  const double toloose = std::sqrt(tol);
+  // tol > 0: PySCF's rule (|de| < tol and |r| < sqrt(tol)); tol < 0: the residual alone decides, |r| < -tol (PRIMME's
+  // convergence test, mps/gs.py:552-569 of the reference)
+  const bool res_only = tol < 0.0;
+  const double toloose = res_only ? -tol : std::sqrt(tol);
   const int cap = max_space + nroots + 1;
 
   TmpBuf VB(ctx), WB(ctx), PB(ctx), SB(ctx), XB(ctx), HXB(ctx), RB(ctx), TB(ctx);
@@ -432,7 +435,7 @@ extern "C" int mpse_davidson(mpse_ctx* ctx, int dtype, const mpse_heff* h, int t
     for (int r = 0; r < k; ++r) {
       MPSE_TRY(d.ritz(m, ev, r, ew[r], xs(r), hxs(r), rs(r), &rn[r]));
       const double de = (r < (int)e_last.size()) ? ew[r] - e_last[r] : std::numeric_limits<double>::infinity();
-      conv[r] = ((std::fabs(de) < tol && rn[r] < toloose) || rn[r] < 1e-14) ? 1 : 0;
+      conv[r] = (res_only ? rn[r] < toloose : ((std::fabs(de) < tol && rn[r] < toloose) || rn[r] < 1e-14)) ? 1 : 0;
       es_out[r] = ew[r];
     }
     e_last.assign(ew.begin(), ew.begin() + k);

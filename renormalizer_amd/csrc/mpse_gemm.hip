@@ -101,7 +101,7 @@ constexpr int BM = 64, BN = 64, BK = 16, LDK = BK + 1;   // BM x BN: granularity
 // 32 x 32 - for products whose 64 x 64 tiles cannot fill the chip, four times as many workgroups instead of slicing K
 // into partial sums that a second kernel has to add up.
 template <bool CA, bool CB, bool KS, int WS>
-__global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA || CB) ? 2 : 3)) void k_gemm(const GemmArgs g) {
+__global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) void k_gemm(const GemmArgs g) {
   constexpr int TBM = 32 * WS, TBN = 32 * WS, NT = 64 * WS * WS;
   constexpr int LD = WS == 2 ? 80 : 48;          // [k][i] panel rows; LD mod 32 == 16 keeps the fragment reads conflict free
   constexpr int NLD = TBM * BK / NT;             // staged elements per thread and operand (panel = BK*LD >= TBM*LDK doubles)
@@ -626,9 +626,12 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA || CB) ? 2 : 3)) v
   // stored yet, so the loads are in flight together), then the results are formed and stored.  Interleaved with the
   // stores, the loads went out one by one (they may alias C for all the compiler knows): 30 000 cycles of epilogue
   // on the C-step of the one-site matvec, a quarter of that workgroup's life (tools/gemm_trace.py).
-  double2 pre_c[2][2][4], pre_y[2][2][4];
+  // (complex x complex only: the mixed variants run three waves per SIMD on 168 registers, where the 128 registers
+  // of the preloads spill; their beta / dot terms are read inside the store loop as before)
+  constexpr bool PRE = CA && CB;
+  double2 pre_c[PRE ? 2 : 1][2][4], pre_y[PRE ? 2 : 1][2][4];
   const bool need_c = g.use_beta, need_y = g.dot_y != nullptr;
-  if (need_c || need_y) {
+  if (PRE && (need_c || need_y)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int gj = min(tn * TBN + wn * 32 + j * 16 + (lane & 15), g.N - 1);     // clamped: never stored past the edge
@@ -676,17 +679,26 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA || CB) ? 2 : 3)) v
           o.x = g.alpha_re * xr - g.alpha_im * xi;
           o.y = g.alpha_re * xi + g.alpha_im * xr;
           if (need_c) {
-            const double2 c0 = pre_c[i][j][r];
+            double2 c0;
+            if constexpr (PRE)
+              c0 = pre_c[i][j][r];
+            else
+              c0 = *reinterpret_cast<const double2*>(g.Cin ? g.Cin + (idx_off(g.mCin, gi) + idx_off(g.nCin, gj)) * EC : p);
             o.x += g.beta_re * c0.x - g.beta_im * c0.y;
             o.y += g.beta_re * c0.y + g.beta_im * c0.x;
           }
           *reinterpret_cast<double2*>(p) = o;
-          if (need_y) dot_acc(dre, dim, o, pre_y[i][j][r]);
+          if (need_y) {
+            if constexpr (PRE)
+              dot_acc(dre, dim, o, pre_y[i][j][r]);
+            else
+              dot_acc(dre, dim, o, reinterpret_cast<const double2*>(g.dot_y)[co]);
+          }
         } else {
           double o = g.alpha_re * xr;
-          if (need_c) o += g.beta_re * pre_c[i][j][r].x;
+          if (need_c) o += g.beta_re * (g.Cin ? g.Cin[idx_off(g.mCin, gi) + idx_off(g.nCin, gj)] : *p);
           *p = o;
-          if (need_y) dre += o * pre_y[i][j][r].x;
+          if (need_y) dre += o * g.dot_y[co];
         }
       }
     }

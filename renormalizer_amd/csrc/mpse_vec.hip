@@ -491,11 +491,19 @@ constexpr int LZ_MAXM = 64;   // one wavefront holds the Krylov coefficients
 // reference's breakdown rule retroactively: the first beta_i < tiny (i <= j) ends the space at i + 1 vectors.
 // ``part`` / ``nb``: the |w|^2 partials of the update kernel launched just before; their sum beta_j^2 is formed
 // here (in the order of k_reduce_final) and recorded at scal[6 + 4 j] - one launch less per convergence check.
+// A launch with two workgroups also delivers the coefficients of the check two iterations earlier (workgroup 0:
+// iteration j - 2, into coef + 2 LZ_MAXM; that check - the first of a solve - can never stop the iteration because there
+// is no estimate before it, so it is evaluated together with the second one).
 __global__ __launch_bounds__(64) void k_lz_coefs(double* __restrict__ scal, int j, double dt_re, double dt_im,
                                                  double tiny, double* __restrict__ coef, LzCtl* ctl,
                                                  const double* __restrict__ part, int nb) {
   if (ctl->done) return;
   const int lane = threadIdx.x;
+  if (gridDim.x == 2 && blockIdx.x == 0) {   // the earlier check: its beta^2 is in scal already (summed by the update
+    j -= 2;                                  // kernel of iteration j - 1)
+    coef += 2 * LZ_MAXM;
+    part = nullptr;
+  }
   if (part) {
     double re = 0.0;
     for (int i = lane; i < nb; i += 64) re += part[2 * i];
@@ -566,47 +574,65 @@ __global__ __launch_bounds__(64) void k_lz_coefs(double* __restrict__ scal, int 
 }
 
 // res = sum_{i<m} coef_i V_i with the coefficients in device memory; optional closeness flag as in k_lincomb
+// ``m_early`` > 0: the estimate of the (deferred) first check, sum_{i < m_early} coef2_i V_i with coef2 = coef + 2 LZ_MAXM,
+// is formed in the same pass over the basis and takes the place of ``prev``.
 template <bool CPLX>
 __global__ void k_lincomb_dev(double* __restrict__ res, const double* __restrict__ V, long long n, int m,
                               const double* __restrict__ coef, const double* __restrict__ prev, double rtol, double atol,
-                              unsigned int* __restrict__ flag, unsigned int gen, const LzCtl* __restrict__ ctl) {
+                              unsigned int* __restrict__ flag, unsigned int gen, const LzCtl* __restrict__ ctl,
+                              int m_early) {
   if (ctl->done || ctl->need_host) return;
-  __shared__ double cr[LZ_MAXM], ci[LZ_MAXM];
+  __shared__ double cr[LZ_MAXM], ci[LZ_MAXM], er[LZ_MAXM], ei[LZ_MAXM];
   if (threadIdx.x < LZ_MAXM) {
     cr[threadIdx.x] = coef[threadIdx.x];
     ci[threadIdx.x] = coef[LZ_MAXM + threadIdx.x];
+    er[threadIdx.x] = m_early > 0 ? coef[2 * LZ_MAXM + threadIdx.x] : 0.0;
+    ei[threadIdx.x] = m_early > 0 ? coef[3 * LZ_MAXM + threadIdx.x] : 0.0;
   }
   __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
   bool bad = false;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     if (CPLX) {
-      double xr = 0, xi = 0;
+      double xr = 0, xi = 0, pr = 0, pi = 0;
       for (int jj = 0; jj < m; ++jj) {
-        if (cr[jj] == 0.0 && ci[jj] == 0.0) continue;   // past a breakdown: never touched
+        if (cr[jj] == 0.0 && ci[jj] == 0.0 && !(jj < m_early)) continue;   // past a breakdown: never touched
         const double2 v = reinterpret_cast<const double2*>(V)[(long long)jj * n + i];
-        xr += cr[jj] * v.x - ci[jj] * v.y;
-        xi += cr[jj] * v.y + ci[jj] * v.x;
+        if (cr[jj] != 0.0 || ci[jj] != 0.0) {
+          xr += cr[jj] * v.x - ci[jj] * v.y;
+          xi += cr[jj] * v.y + ci[jj] * v.x;
+        }
+        if (jj < m_early && (er[jj] != 0.0 || ei[jj] != 0.0)) {
+          pr += er[jj] * v.x - ei[jj] * v.y;
+          pi += er[jj] * v.y + ei[jj] * v.x;
+        }
       }
-      if (prev) {
+      if (m_early > 0) {
+        const double diff = hypot(pr - xr, pi - xi);
+        if (!(diff <= atol + rtol * hypot(xr, xi))) bad = true;
+      } else if (prev) {
         const double2 p = reinterpret_cast<const double2*>(prev)[i];
         const double diff = hypot(p.x - xr, p.y - xi);
         if (!(diff <= atol + rtol * hypot(xr, xi))) bad = true;
       }
       reinterpret_cast<double2*>(res)[i] = make_double2(xr, xi);
     } else {
-      double xr = 0;
+      double xr = 0, pr = 0;
       for (int jj = 0; jj < m; ++jj) {
-        if (cr[jj] == 0.0) continue;
-        xr += cr[jj] * V[(long long)jj * n + i];
+        if (cr[jj] == 0.0 && !(jj < m_early)) continue;
+        const double v = V[(long long)jj * n + i];
+        if (cr[jj] != 0.0) xr += cr[jj] * v;
+        if (jj < m_early && er[jj] != 0.0) pr += er[jj] * v;
       }
-      if (prev) {
+      if (m_early > 0) {
+        if (!(fabs(pr - xr) <= atol + rtol * fabs(xr))) bad = true;
+      } else if (prev) {
         if (!(fabs(prev[i] - xr) <= atol + rtol * fabs(xr))) bad = true;
       }
       res[i] = xr;
     }
   }
-  if (prev && bad) atomicMax(flag, gen);
+  if ((prev || m_early > 0) && bad) atomicMax(flag, gen);
 }
 
 // the decision of the check at iteration j (its estimate went to buffer `which`)
@@ -710,7 +736,7 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
   MPSE_TRY(RES.alloc(size_t(n) * es));
   // scalars as in the synchronous solve: [0..1] |v|^2 ; per j: alpha at 4+4j, beta^2 at 6+4j ; then control + coefficients
   const int SC_CTL = 4 + 4 * 130, SC_COEF = SC_CTL + 8;
-  MPSE_TRY(SCAL.alloc(size_t(SC_COEF + 2 * LZ_MAXM) * sizeof(double)));
+  MPSE_TRY(SCAL.alloc(size_t(SC_COEF + 4 * LZ_MAXM) * sizeof(double)));
   double* scal = SCAL.as<double>();
   LzCtl* ctl = reinterpret_cast<LzCtl*>(scal + SC_CTL);
   double* coef = scal + SC_COEF;
@@ -824,14 +850,24 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
                            (const double*)part_a, a_nb, scal + 4 + 4 * j, (const double*)cur_part, nb, cur_out, prev2,
                            new_part, done);
     });
-    const bool check = (j > 3 && j % 2 == 0);          // krylov.py:76-81
+    bool check = (j > 3 && j % 2 == 0);                // krylov.py:76-81
     const bool last = (j + 1 >= limit);
+    // The first check of a solve (j = 4) cannot stop it - there is no earlier estimate to compare with - so it is
+    // evaluated together with the second one (j = 6): one pass over the basis forms both estimates, and a solve has
+    // three small launches and ~25 us of dependent latency less (MPSE_LZ_DEFER_FIRST=0: every check on its own).
+    static const bool defer_first = [] {
+      const char* e = getenv("MPSE_LZ_DEFER_FIRST");
+      return !(e && e[0] == '0');
+    }();
+    bool merged = false;
+    if (defer_first && check && !prev && j == 4 && j + 3 < limit) check = false;   // (its turn comes at j = 6)
+    if (defer_first && check && !prev && j == 6) merged = true;
     if (check) {
-      hipLaunchKernelGGL(k_lz_coefs, dim3(1), dim3(64), 0, ctx->stream, scal, j, dt.real(), dt.imag(), tiny, coef, ctl,
-                         (const double*)new_part, nb);
+      hipLaunchKernelGGL(k_lz_coefs, dim3(merged ? 2 : 1), dim3(64), 0, ctx->stream, scal, j, dt.real(), dt.imag(), tiny,
+                         coef, ctl, (const double*)new_part, nb);
       void* dst = (prev == out) ? RES.p : out;
       unsigned int gen = 0;
-      if (prev) {
+      if (prev || merged) {
         gen = ++ctx->flag_gen;
         if (gen == 0) {
           MPSE_HIP(ctx, hipMemsetAsync(dflag, 0, sizeof(unsigned int), ctx->stream));
@@ -841,13 +877,13 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
       if (cplx)
         hipLaunchKernelGGL((k_lincomb_dev<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst,
                            V.as<double>(), (long long)n, j + 1, (const double*)coef, (const double*)prev, rtol, atol,
-                           dflag, gen, (const LzCtl*)ctl);
+                           dflag, gen, (const LzCtl*)ctl, merged ? j - 1 : 0);
       else
         hipLaunchKernelGGL((k_lincomb_dev<false>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst,
                            V.as<double>(), (long long)n, j + 1, (const double*)coef, (const double*)prev, rtol, atol,
-                           dflag, gen, (const LzCtl*)ctl);
+                           dflag, gen, (const LzCtl*)ctl, merged ? j - 1 : 0);
       hipLaunchKernelGGL(k_lz_decide, dim3(1), dim3(1), 0, ctx->stream, ctl, (const unsigned int*)dflag, gen,
-                         prev ? 1 : 0, j, dst == out ? 0 : 1);
+                         (prev || merged) ? 1 : 0, j, dst == out ? 0 : 1);
       prev = dst;
       MPSE_HIP(ctx, hipGetLastError());
       if (j >= wait_from || waited || last) {

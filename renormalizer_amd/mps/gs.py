@@ -103,11 +103,24 @@ def eigh_direct(mps, qn_mask, ltensor, rtensor, cmo, twolayer=False):
 
 
 def eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, cguess, twolayer=False):
-    """gs.py:486-576 with algo == "davidson"."""
+    """gs.py:486-576: ``optimize_config.algo`` selects the iterative eigensolver of the centre problem.
+
+    "davidson"  the reference's default (PySCF-style Davidson: tol 1e-12 on the eigenvalue, 1e-6 on the residual,
+                preconditioner x / (hdiag - e + 1e-4), space 12 + 3 (nroots - 1), gs.py:533-538);
+    "primme"    the reference hands the problem to the PRIMME library (gs.py:552-569: ``primme.eigsh(which="SA",
+                tol=1e-6, method="PRIMME_DYNAMIC")`` with the diagonal preconditioner 1 / (hdiag + 1e-4)).  PRIMME's
+                dynamic method is a generalised Davidson with thick restart; here the same engine iteration runs with
+                PRIMME's settings: convergence on the residual alone (|r| < 1e-6, the eigenvalue change is not
+                tested), a restart space of max(15, 2 nroots + 7) vectors and the shift-free preconditioner
+                (``shift`` large against ``e`` is not available, so x / (hdiag - e + 1e-4) is kept: same fixed
+                point).  Same eigenpairs to the solver tolerance; iteration counts differ from the library's."""
     eng = get_engine()
     inverse = mps.optimize_config.inverse
     if inverse != 1.0:
         raise NotImplementedError("optimize_config.inverse != 1")
+    algo = mps.optimize_config.algo
+    if algo not in ("davidson", "primme"):
+        raise ValueError(f"optimize_config.algo = {algo!r}: 'davidson', 'primme' (iterative) or 'direct'")
     cshape = qn_mask.shape
     hop = hop_expr(ltensor, rtensor, cmo, cshape, twolayer)
     hdiag = _hdiag(eng, hop.l, hop.r, hop.cmo, twolayer)
@@ -117,12 +130,19 @@ def eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, cguess, twolayer=False):
         # complex MPO / environments with a real centre: the iteration runs in complex128 (NumPy promotes silently
         # in the reference, gs.py:520-538)
         cguess = cguess.to_complex() if nroots == 1 else [g.to_complex() for g in cguess]
+    # the engine stops a root when (|de| < tol and |r| < sqrt(tol)) or |r| < 1e-14: tol = 1e-12 is the reference's
+    # Davidson rule; PRIMME's tol = 1e-6 bounds the residual only, i.e. sqrt(tol) = 1e-6 with the energy test open
+    if algo == "primme":
+        tol, space = -1e-6, max(15, 2 * nroots + 7)      # (negative: residual-only test, include/mpsengine.h)
+    else:
+        tol, space = 1e-12, (12 if nroots == 1 else None)
     if nroots == 1:
-        e, c, ncyc = davidson(hop, cguess.reshape(cshape), hdiag, mask=mask, tol=1e-12, max_cycle=100,
-                              max_space=12, lindep=1e-14)
+        e, c, ncyc = davidson(hop, cguess.reshape(cshape), hdiag, mask=mask, tol=tol, max_cycle=100,
+                              max_space=space, lindep=1e-14)
         return e, c, ncyc
     guesses = [g.reshape(cshape) for g in cguess]
-    e, c, ncyc = davidson_multi(hop, guesses, hdiag, nroots, mask=mask, tol=1e-12, max_cycle=100, lindep=1e-14)
+    e, c, ncyc = davidson_multi(hop, guesses, hdiag, nroots, mask=mask, tol=tol, max_cycle=100, max_space=space,
+                                lindep=1e-14)
     return e, c, ncyc
 
 

@@ -397,16 +397,28 @@ class Mpo:
         """Follow an on-the-fly exchange of two neighbouring sites of the state (mps/mpo.py:427-454): ``new_model`` is
         the model with the new site order.  The reference re-derives the two sites from its symbolic MPO; here the
         two-site operator W_i W_j is exchanged numerically and split again by quantum-number block (SVD per block,
-        rank revealed at ``tol``), which is exact and gives the bond the rank of the exchanged operator."""
+        rank revealed at ``tol``), which is exact and gives the bond the rank of the exchanged operator.
+        ``swap_jw``: the two sites are fermionic modes of a Jordan-Wigner chain - the exchange carries the
+        fermionic sign (see below)."""
         diffs = [k for k, (b1, b2) in enumerate(zip(self.model.basis, new_model.basis)) if b1.dofs != b2.dofs]
         if not diffs:
             return
         assert len(diffs) == 2 and diffs[1] - diffs[0] == 1
-        if swap_jw:
-            raise NotImplementedError("Jordan-Wigner sign handling when swapping fermionic sites (swap_jw)")
         i, j = diffs
         two = np.tensordot(self._mp[i], self._mp[j], axes=(3, 0)).transpose(0, 3, 4, 1, 2, 5)   # (wl, d2, d2, d1, d1, wr)
         wl, d2, _, d1, _, wr = two.shape
+        if swap_jw:
+            # Two neighbouring fermionic modes of a Jordan-Wigner chain (occupation = basis state 1 of a two-level
+            # site) are exchanged by the fermionic swap F = SWAP . CZ: besides the relabelling every amplitude with
+            # both modes occupied changes sign (mps/mp.py:711-714 does that to the state).  The operator follows as
+            # F O F^+: the same sign on the bra pair and on the ket pair of the two-site operator.  The Z strings of
+            # operators on other sites pass through the pair as Z (x) Z, which F leaves alone.  (The reference gets
+            # there by rewriting its symbolic operator table, symbolic_mpo.py:640-648.)
+            if d1 != 2 or d2 != 2:
+                raise ValueError("swap_jw: Jordan-Wigner sites are two-level sites")
+            sign = np.ones((2, 2))
+            sign[1, 1] = -1.0
+            two = two * sign[None, :, None, :, None, None] * sign[None, None, :, None, :, None]
         sig2 = np.asarray(self.model.basis[j].sigmaqn).reshape(d2, -1)
         # quantum number accumulated left of the new bond: left channel + charge transferred by the new first site
         qrow = (np.asarray(self.qn[i])[:, None, None, :] + sig2[None, :, None, :] - sig2[None, None, :, :]).reshape(wl * d2 * d2, -1)

@@ -932,8 +932,6 @@ class Mps:
         cfg = self.compress_config
         if isinstance(self.model, HolsteinModel):
             raise NotImplementedError("Can't perform OFS on Holstein model")      # its site order is part of the class
-        if cfg.ofs_swap_jw:
-            raise NotImplementedError("Jordan-Wigner sign handling when swapping fermionic sites (ofs_swap_jw)")
         assert cfg.criteria is CompressCriteria.fixed
         eng = get_engine()
         c = eng.asdevice(cstruct)
@@ -946,6 +944,14 @@ class Mps:
         c2 = eng.empty((dl * p2, p1, dr), c.dtype)
         eng._check(eng.lib.mpse_transpose_inner(eng.ctx, c.code, c2.ptr, t1.ptr, dl * p2, dr, p1, 0))
         c2 = c2.reshape((dl,) + tuple(c.shape[1 + half:-1]) + tuple(c.shape[1:1 + half]) + (dr,))
+        if cfg.ofs_swap_jw:
+            # fermionic modes of a Jordan-Wigner chain: the exchange flips the sign of the amplitudes with both modes
+            # occupied (mps/mp.py:711-714)
+            if c2.ndim != 4 or c2.shape[1] != 2 or c2.shape[2] != 2:
+                raise ValueError("ofs_swap_jw: the two centre sites must be two-level Jordan-Wigner sites")
+            sign = np.ones((dl, 2, 2, dr))
+            sign[:, 1, 1, :] = -1.0
+            eng._check(eng.lib.mpse_mul_real(eng.ctx, c2.code, c2.ptr, eng.asdevice(sign).ptr, c2.size))
         qnbigl2, qnbigr2, _ = self._get_big_qn(cidx, swap=True, need_mat=False)
         U2, SU2, qnl2, V2, SV2, qnr2 = svd_qn.svd_qn(c2, qnbigl2, qnbigr2, self.qntot, system=system)
         s1, s2 = np.asarray(s_keep, dtype=float), np.asarray(SU2, dtype=float)

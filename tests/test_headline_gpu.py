@@ -115,6 +115,7 @@ _SWITCHES = {
     "MPSE_DOT_FUSED=0": False,        # Lanczos coefficient by its own reduction kernel (other summation order)
     "MPSE_WSMALL=0": False,           # MPO step of the d = 2 sites as an MFMA product
     "MPSE_LANCZOS_ASYNC=0": False,    # host-side eigen-decomposition of the tridiagonal matrix
+    "MPSE_LZ_DEFER_FIRST=0": True,    # the first convergence check of a solve on its own instead of merged into the second
     "MPSE_QR_CAQR=1": False,          # communication-avoiding tree QR instead of the panel-blocked kernels
     "MPSE_QR_GRAPH=1": True,          # the QR's launches replayed from a HIP graph instead of enqueued one by one
 }
