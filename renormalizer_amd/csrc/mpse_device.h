@@ -4,6 +4,11 @@
 
 constexpr int RED_THREADS = 256;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)): prefetches would be drained and the write latency of results that only
+// later kernels read would sit on the critical path of a loop.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // One DPP move of a 64-bit value (two 32-bit v_mov_dpp); lanes without a source receive 0.
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {

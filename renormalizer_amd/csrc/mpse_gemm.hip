@@ -75,7 +75,6 @@ struct GemmArgs {
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load in flight
 // (s_waitcnt vmcnt(0)): operand tiles prefetched across the barrier would be drained at each one.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // (re, im) += conj(c) * y
 __device__ __forceinline__ void dot_acc(double& re, double& im, double2 c, double2 y) {

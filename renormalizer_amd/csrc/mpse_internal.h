@@ -219,6 +219,10 @@ int dotc_sync(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n,
 struct HhParam {  // per reflector: H = I - tau v v^H, v = (1, scale * tail)
   double tau_re, tau_im;
   double scale_re, scale_im;
+  // panel-blocked kernels (mpse_qr2.hip): inner products u_i^H u_l with the earlier reflectors i of the same
+  // four-column panel (re, im; i = 0 .. l-1), by-products of the panel factorisation that the compact-WY
+  // applications need for T
+  double g[6];
 };
 int hh_factor_colmajor(mpse_ctx* ctx, bool cplx, double* ws, int mm, int nn, int k, HhParam* prm);
 // nq >= k columns of Q are formed (columns beyond k span the orthogonal complement)

@@ -118,6 +118,7 @@ _SWITCHES = {
     "MPSE_LZ_DEFER_FIRST=0": True,    # the first convergence check of a solve on its own instead of merged into the second
     "MPSE_QR_CAQR=1": False,          # communication-avoiding tree QR instead of the panel-blocked kernels
     "MPSE_QR_GRAPH=1": True,          # the QR's launches replayed from a HIP graph instead of enqueued one by one
+    "MPSE_QR_LOOKAHEAD=0": False,     # panel and trailing update of the short blocks as two launches instead of one
 }
 
 
