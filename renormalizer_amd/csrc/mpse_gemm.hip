@@ -73,8 +73,6 @@ struct GemmArgs {
   unsigned long long* trace;        // debug timeline (mpse_ctx::gemm_trace), null normally
 };
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load in flight
-// (s_waitcnt vmcnt(0)): operand tiles prefetched across the barrier would be drained at each one.
 
 // (re, im) += conj(c) * y
 __device__ __forceinline__ void dot_acc(double& re, double& im, double2 c, double2 y) {
