@@ -4,6 +4,12 @@ evolve of the oracle (oracle/mps_oracle.py), same state, same 4 BLAS threads - t
 item 4 asks for (is the CPU stand-in timed on the GPU box representative of the real reference?).
 
     cd /tmp && python /root/repo/oracle/time_vs_reference.py [nmol=10] [D=64]
+    cd /tmp && python /root/repo/oracle/time_vs_reference.py site [Dl=256] [d=16] [Dr=256] [w=5]
+
+``site``: ONE local update at the headline shape - the effective Hamiltonian of a (Dl, d, Dr) centre between random
+environments with MPO bond w, propagated by the Krylov exponential - through the reference's hop_expr + expm_krylov
+and through the oracle's hop_apply + expm_krylov on the same arrays: the shape the cpu_baseline of bench.py is timed
+at, where the whole-evolve comparison above would take the reference several minutes.
 """
 import os
 import sys
@@ -22,6 +28,40 @@ from renormalizer.mps import Mps, Mpo  # noqa: E402
 from renormalizer.utils import Quantity, CompressConfig, CompressCriteria, EvolveConfig, EvolveMethod  # noqa: E402
 import numpy as np  # noqa: E402
 from oracle import mps_oracle as orc  # noqa: E402
+
+if len(sys.argv) > 1 and sys.argv[1] == "site":
+    from renormalizer.mps.hop_expr import hop_expr  # noqa: E402
+    from renormalizer.lib import expm_krylov  # noqa: E402
+    from renormalizer.mps.backend import xp  # noqa: E402
+    Dl, d, Dr, wb = [int(a) for a in (sys.argv[2:6] + ["256", "16", "256", "5"][len(sys.argv) - 2:])]
+    rng = np.random.default_rng(7)
+
+    def herm_env(D):
+        """(D, w, D) environment of a Hermitian operator: channel-wise A + A^H"""
+        a = rng.standard_normal((D, wb, D)) + 1j * rng.standard_normal((D, wb, D))
+        return (a + a.conj().transpose(2, 1, 0)) / np.sqrt(D)
+
+    ltensor, rtensor = herm_env(Dl), herm_env(Dr)
+    mo = rng.standard_normal((wb, d, d, wb))
+    mo = (mo + mo.transpose(0, 2, 1, 3)) / np.sqrt(d * wb)
+    c = rng.standard_normal((Dl, d, Dr)) + 1j * rng.standard_normal((Dl, d, Dr))
+    c /= np.linalg.norm(c)
+    dt = -0.05j
+    hop = hop_expr(ltensor.copy(), rtensor.copy(), [mo.copy()], c.shape)
+    hop(c)                                              # first call: contraction path search, BLAS thread start-up
+    orc.hop_apply(ltensor, rtensor, [mo], c)
+    t0 = time.perf_counter()
+    ref, j_ref = expm_krylov(lambda x: hop(x.reshape(c.shape)).ravel(), dt, xp.asarray(c.ravel()))
+    t_ref = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out, j_orc = orc.expm_krylov(lambda x: orc.hop_apply(ltensor, rtensor, [mo], x.reshape(c.shape)).ravel(), dt,
+                                 c.ravel(), return_stat=True)
+    t_orc = time.perf_counter() - t0
+    err = np.abs(np.asarray(ref) - out).max()
+    print(f"site update ({Dl}, {d}, {Dr}), MPO bond {wb}, complex128, 4 BLAS threads, {os.cpu_count()} vCPUs")
+    print(f"reference {t_ref:.2f} s (Krylov dim {j_ref})   oracle {t_orc:.2f} s (Krylov dim {j_orc})   "
+          f"ratio oracle/reference {t_orc / t_ref:.2f}   max |difference| {err:.1e}")
+    sys.exit(0)
 
 nmol = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
