@@ -264,13 +264,19 @@ def main():
         # collected from inside this process
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as fh:
-                kern = json.load(fh)["kernels"]
+            import glob
+            import hashlib
+            pmc_file = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1]   # latest round
+            with open(pmc_file, "rb") as fh:
+                raw = fh.read()
+            kern = json.loads(raw)["kernels"]
             key = next(k for k in kern if k.startswith("void k_gemm<true, true, true"))   # (+ the tile-shape argument)
             traffic = kern[key]["hbm_bytes_per_launch"]
-            traffic_src = ("profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                           "command, bench.py --init physical; counters cannot be read from inside the process)")
-        except (OSError, KeyError, ValueError, StopIteration):
+            traffic_src = (f"profiles/{os.path.basename(pmc_file)} sha256:{hashlib.sha256(raw).hexdigest()[:16]} "
+                           "(separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command with --init "
+                           "physical; a committed measurement, not one of this run: counters cannot be read from "
+                           "inside the process)")
+        except (OSError, KeyError, ValueError, StopIteration, IndexError):
             pass
         zz = prof["c128xc128"]
         sec = zz["ms"] * 1e-3
