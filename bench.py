@@ -297,10 +297,10 @@ def main():
                             "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                             "timed_calls": qq["launches"], "avg_call_ms": qq["ms"] / max(1, qq["launches"]),
                             "alg_flops_per_call": qq["flops"] / max(1, qq["launches"])})
-        for nm in ("c128xf64", "f64xc128"):
+        for nm, what in (("c128xf64", "small products with a real second operand"), ("f64xc128", "MPO step")):
             v = prof[nm]
             if v["ms"] > 0:
-                classes.append({"kernel": f"k_gemm<{nm}> (MPO step)", "bound": "hbm",
+                classes.append({"kernel": f"k_gemm<{nm}> ({what})", "bound": "hbm",
                                 "achieved": v["bytes"] / (v["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "timed_launches": v["launches"],
                                 "avg_launch_ms": v["ms"] / max(1, v["launches"])})

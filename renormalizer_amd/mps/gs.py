@@ -194,12 +194,17 @@ def single_sweep(mps, mpo, environ, percent, last_opt_e_idx, omega=None):
         # gs.py:245-247: small centres are diagonalised densely
         if int(np.prod(qn_mask.shape)) < 1000 or mps.optimize_config.algo == "direct":
             e, c, ncyc = eigh_direct(mps, qn_mask, ltensor, rtensor, cmo, omega is not None)
-            if nroots > 1:
-                while len(c) < nroots:              # fewer allowed states than roots: pad like the random guesses
-                    c.append(eng.asdevice((rng.random(qn_mask.shape) - 0.5) * qn_mask))
-                    e.append(e[-1])
         else:
             e, c, ncyc = eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, guess, omega is not None)
+        if nroots > 1:
+            # fewer allowed states than roots (dense solver), or a block Davidson that lost roots to linearly
+            # dependent guesses: pad like the random guesses so that the state average always sees nroots tensors
+            e, c = list(e), list(c)
+            if not c:
+                raise RuntimeError(f"DMRG centre {cidx}: the eigensolver returned no eigenpair")
+            while len(c) < nroots:
+                c.append(eng.asdevice(((rng.random(qn_mask.shape) - 0.5) * qn_mask).astype(c[0].dtype)))
+                e.append(e[-1])
         hops.append(ncyc)
         micro.append((e, cidx))
         if nroots == 1:

@@ -1426,7 +1426,22 @@ _CARRY = threading.local()
 def _carry_environ(mps, mpo, environ):
     ahead = "R" if mps.to_right else "L"
     environ.drop("L" if ahead == "R" else "R")
+    # the take-over test compares OBJECTS: an MPO site edited in place would go unnoticed, so the host arrays of a
+    # carried MPO become read-only (replacing a site, as try_swap_site does, is seen by the test)
+    for w in (mpo._mp if hasattr(mpo, "_mp") else []):
+        if isinstance(w, np.ndarray):
+            w.setflags(write=False)
     _CARRY.slot = (mpo, list(mpo._mp) if hasattr(mpo, "_mp") else None, ahead, environ, list(mps._mp))
+
+
+def clear_evolve_cache():
+    """Drop the environments the calling thread's last TDVP-PS step left for the next one (they pin one set of
+    environments and the site list in HBM until that thread evolves again).  ``MPSE_ENV_CARRY=0`` disables the
+    take-over altogether."""
+    _CARRY.slot = None
+
+
+Mps.clear_evolve_cache = staticmethod(clear_evolve_cache)
 
 
 def _carried_environ(mps, mpo, ahead):
