@@ -221,7 +221,7 @@ int mpse_prof_get(mpse_ctx* ctx, int variant, double* total_ms, double* total_fl
     unsigned long long n = 0;
     if (path && hipMemcpy(&n, ctx->gemm_trace, sizeof(n), hipMemcpyDeviceToHost) == hipSuccess) {
       if (n > GEMM_TRACE_CAP) n = GEMM_TRACE_CAP;
-      std::vector<unsigned long long> rec(size_t(n) * 8);
+      std::vector<unsigned long long> rec(size_t(n) * GEMM_TRACE_WORDS);
       if (n && hipMemcpy(rec.data(), ctx->gemm_trace + 1, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
         if (FILE* fh = fopen(path, "wb")) {
           fwrite(rec.data(), sizeof(unsigned long long), rec.size(), fh);

@@ -47,6 +47,8 @@ struct GemmArgs {
   int conjA, conjB;
   int use_beta;
   double alpha_re, alpha_im, beta_re, beta_im;
+  int skew;            // tile column = (column of the linear index + tile row) mod tiles_n
+  const int* perm;     // optional: linear tile index by launch position, tiles with the most K tiles first
   int ksplit;          // number of K slices (1 = none)
   int kt_per_split;    // k-tiles per slice
   double* ws;          // split-K partial sums: [batch][ksplit][M][N] compact, dtype of C
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   __shared__ double smem[(2 + (CA ? 1 : 0) + (CB ? 1 : 0)) * BK * LD];
   if (g.skip && *g.skip) return;   // workgroup-uniform
   const unsigned long long tr0 = g.trace ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long rt0 = g.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;   // device-wide 100 MHz clock
   unsigned long long tr1 = 0, tr2 = 0, tr3 = 0;
   double* sAr = smem;
   double* sAi = sAr + BK * LD;  // only meaningful if CA
@@ -124,9 +127,14 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   const int bs = bid / ntile;            // (batch, k-slice)
   const int b = bs / g.ksplit;
   const int ks_id = bs - b * g.ksplit;
-  const int t = bid - bs * ntile;
+  int t = bid - bs * ntile;
+  if (g.perm) t = g.perm[t];             // heaviest tiles first (k_tile_order)
   const int tm = t / g.tiles_n;
-  const int tn = t - tm * g.tiles_n;
+  int tn = t - tm * g.tiles_n;
+  // Workgroups go to the eight dies round robin (die = blockIdx mod 8) and the number of tile columns is a multiple
+  // of eight, so without the skew a die would own whole tile columns: with block-sparse operands (quantum-number
+  // sectors are column ranges) some dies got three times the K tiles of others (tools/gemm_balance.py).
+  if (g.skew && !g.perm) tn = (tn + tm) % g.tiles_n;
 
   const double* A = g.A + (long long)b * g.sbA * EA;
   const double* B = g.B + (long long)b * g.sbB * EB;
@@ -559,28 +567,32 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   if (g.trace) tr3 = __builtin_readcyclecounter();
   struct TraceEnd {     // the record is written when the workgroup leaves the kernel, whichever way
     const GemmArgs& g;
-    unsigned long long t0, &t1, &t2, &t3;
+    unsigned long long t0, rt0, &t1, &t2, &t3;
     int tid;
     int& ktd;
     __device__ ~TraceEnd() {
       if (g.trace && tid == 0) {
         const unsigned long long slot = atomicAdd(g.trace, 1ull);
         if (slot < GEMM_TRACE_CAP) {
-          unsigned long long* r = g.trace + 1 + slot * 8;
+          unsigned long long* r = g.trace + 1 + slot * GEMM_TRACE_WORDS;
           unsigned xcc = 0;
           r[0] = ((unsigned long long)gridDim.x << 32) | (unsigned long long)blockIdx.x;
           r[1] = ((unsigned long long)(CA ? 1 : 0) << 62) | ((unsigned long long)(CB ? 1 : 0) << 61) |
                  ((unsigned long long)g.ksplit << 40) | ((unsigned long long)(unsigned)g.K << 8) | xcc;
-          r[2] = (unsigned long long)ktd;
+          // where the workgroup ran: HW_ID (wave / SIMD / CU / SH / SE fields) and the die (XCC_ID)
+          const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+          r[2] = (unsigned long long)(unsigned)ktd | ((unsigned long long)(((xc & 0xf) << 16) | (hw & 0xffff)) << 32);
           r[3] = t0;
           r[4] = t1;
           r[5] = t2;
           r[6] = t3;
           r[7] = __builtin_readcyclecounter();
+          r[8] = rt0;
+          r[9] = __builtin_amdgcn_s_memrealtime();
         }
       }
     }
-  } trace_end{g, tr0, tr1, tr2, tr3, tid, kt_done};
+  } trace_end{g, tr0, rt0, tr1, tr2, tr3, tid, kt_done};
   if (g.kt_counter && tid == 0 && kt_done) atomicAdd(g.kt_counter, (unsigned long long)kt_done);
   if (g.cmask) {   // workgroup-uniform
     if (tid == 0) g.cmask[((long long)b * g.tiles_m + tm) * g.tiles_n + tn] = kt_done > 0 ? 1 : 0;
@@ -703,12 +715,58 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   if constexpr (WS == 2) {
     if (g.dot_y) {   // workgroup-uniform
       block_allsum2(dre, dim);
-      if (tid == 0) {
-        g.dot_part[2 * bid] = dre;
-        g.dot_part[2 * bid + 1] = dim;
+      if (tid == 0) {   // slot = the tile, not the launch position: the sum order does not depend on the tile order
+        const long long slot = (long long)bs * ntile + (long long)tm * g.tiles_n + tn;
+        g.dot_part[2 * slot] = dre;
+        g.dot_part[2 * slot + 1] = dim;
       }
     }
   }
+}
+
+// Launch order of the output tiles of a block-sparse product: tiles sorted by the number of K tiles both operands
+// occupy, most first.  The dispatcher hands workgroups to the dies round robin and to free slots in launch order, so
+// a sorted launch is longest-processing-time-first scheduling; in storage order the full tiles of a quantum-number
+// sector sit next to each other and pile up on the same compute units (tools/gemm_balance.py: 30 K tiles on the
+// fullest CU against 21 on average for the d = 16 A-step).  One workgroup, bitonic sort of <= 2048 keys in LDS.
+__global__ __launch_bounds__(1024) void k_tile_order(const unsigned long long* __restrict__ amask,
+                                                       const unsigned long long* __restrict__ bmask, int nkw, int nkt,
+                                                       int tiles_m, int tiles_n, int* __restrict__ perm,
+                                                       const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  __shared__ unsigned key[2048];
+  const int ntile = tiles_m * tiles_n, tid = threadIdx.x;
+  for (int i = tid; i < 2048; i += 1024) {
+    unsigned k = 0;
+    if (i < ntile) {
+      const int tm = i / tiles_n, tn = i - tm * tiles_n;
+      int cnt = 0;
+      for (int w = 0; w < nkw; ++w) {
+        unsigned long long x = 0x0101010101010101ull;
+        if (amask) x &= amask[(long long)tm * nkw + w];
+        if (bmask) x &= bmask[(long long)tn * nkw + w];
+        const int valid = nkt - 8 * w;                    // flag bytes past the last K tile are never written
+        if (valid < 8) x &= (1ull << (8 * valid)) - 1ull;
+        cnt += __popcll(x);
+      }
+      k = ((unsigned)cnt << 16) | (unsigned)(0xFFFF - i);
+    }
+    key[i] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= 2048; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      // 1024 compare-exchange pairs per step, one per thread
+      const int lo = 2 * tid - (tid & (stride - 1)), hi = lo + stride;
+      const bool desc = (lo & size) == 0;
+      const unsigned a = key[lo], b = key[hi];
+      if ((a < b) == desc) {
+        key[lo] = b;
+        key[hi] = a;
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < ntile; i += 1024) perm[i] = 0xFFFF - (int)(key[i] & 0xFFFFu);
 }
 
 // C(i,j) = alpha * sum_s ws[b][s][i][j] + beta * C(i,j); slices summed in fixed order.
@@ -981,13 +1039,16 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.nkw = 0;
   g.skip = ctx->skip_flag;
   g.cmask = nullptr;
+  static const int skew_on = [] { const char* e = getenv("MPSE_GEMM_SKEW"); return e ? atoi(e) : 1; }();
+  g.skew = skew_on;
+  g.perm = nullptr;
   g.dot_y = nullptr;
   g.dot_part = nullptr;
   if (!ctx->gemm_trace_checked) {
     ctx->gemm_trace_checked = true;
     if (getenv("MPSE_GEMM_TRACE")) {
       void* pt = nullptr;
-      if (hipMalloc(&pt, (1 + GEMM_TRACE_CAP * 8) * sizeof(unsigned long long)) == hipSuccess) {
+      if (hipMalloc(&pt, (1 + GEMM_TRACE_CAP * GEMM_TRACE_WORDS) * sizeof(unsigned long long)) == hipSuccess) {
         (void)hipMemsetAsync(pt, 0, sizeof(unsigned long long), ctx->stream);
         ctx->gemm_trace = static_cast<unsigned long long*>(pt);
       }
@@ -1057,6 +1118,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.kt_counter = prof_this && ctx->prof_ktiles ? ctx->prof_ktiles + variant : nullptr;
   if (amask_ext && !(is_single(g.kA) && is_single(g.kB)))
     return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_gemm: a producer's operand mask needs single-level K indices");
+  bool mask_a_stable = true, mask_b_stable = true;   // the mask (or its absence) outlives this call: cached or the solve's
   if ((skip_zero || amask_ext) && is_single(g.kA) && is_single(g.kB) && (nkt_all >= 2 || amask_ext) && d->batch <= 16384) {
     // tile occupancy of both operands (one small scan launch), then only K tiles with data on both sides are visited
     g.nkw = (nkt_all + 7) / 8;
@@ -1084,7 +1146,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
       return nullptr;
     };
     unsigned long long *am = nullptr, *bmk = nullptr;
-    bool scan_a = sa, scan_b = sb_;
+    bool scan_a = sa, scan_b = sb_, b_structural = false;
     mpse_ctx::OccKey ka, kb;
     const bool ca_ok = sa && cacheable(g.A), cb_ok = sb_ && cacheable(g.B);
     if (ca_ok) {
@@ -1101,8 +1163,11 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
       if (pb_ >= ctx->cmask.lo && pb_ < ctx->cmask.hi) {
         bmk = static_cast<unsigned long long*>(const_cast<void*>(ctx->cmask.ptr));
         scan_b = false;
+        b_structural = true;
       }
     }
+    mask_a_stable = sa ? ca_ok : amask_ext == nullptr;
+    mask_b_stable = !sb_ || cb_ok || b_structural;
     // storage: cached masks live until the solve ends, the others in a temporary of this call
     size_t tmp_words = 0;
     if (scan_a && !ca_ok) tmp_words += wa;
@@ -1140,6 +1205,34 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     }
     g.amask = sa ? am : static_cast<const unsigned long long*>(amask_ext);
     g.bmask = sb_ ? bmk : nullptr;
+  }
+  static const int order_on = [] { const char* e = getenv("MPSE_GEMM_ORDER"); return e ? atoi(e) : 1; }();
+  TmpBuf PERM(ctx);
+  const long long ntile_all = (long long)g.tiles_m * g.tiles_n;
+  if (order_on && !small && d->batch == 1 && (g.amask || g.bmask) && ntile_all * g.ksplit > 2 * n_cu &&
+      ntile_all <= 2048) {
+    // inside a Krylov solve both masks are the solve's (cached environment mask, structural centre mask): one sort
+    // serves every matvec of the solve
+    const bool keep = ctx->occ_cache_on && mask_a_stable && mask_b_stable;
+    int* pp = nullptr;
+    if (keep)
+      for (const auto& e : ctx->perm_cache)
+        if (e.amask == g.amask && e.bmask == g.bmask && e.tiles_m == g.tiles_m && e.tiles_n == g.tiles_n && e.nkt == nkt_all)
+          pp = static_cast<int*>(e.perm);
+    if (!pp) {
+      if (keep) {
+        void* pm = nullptr;
+        MPSE_TRY(mpse_malloc(ctx, size_t(ntile_all) * sizeof(int), &pm));
+        ctx->perm_cache.push_back({g.amask, g.bmask, g.tiles_m, g.tiles_n, nkt_all, pm});
+        pp = static_cast<int*>(pm);
+      } else {
+        MPSE_TRY(PERM.alloc(size_t(ntile_all) * sizeof(int)));
+        pp = PERM.as<int>();
+      }
+      hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, ctx->stream, g.amask, g.bmask, g.nkw, nkt_all, g.tiles_m,
+                         g.tiles_n, pp, ctx->skip_flag);
+    }
+    g.perm = pp;
   }
   // the fast kernel addresses its operands as uniform base + 32-bit lane offset: non-negative strides, spans < 4 GB
   auto span_ok = [](const IdxMap& m, const IdxMap& k, bool cplx) {

@@ -131,12 +131,19 @@ struct mpse_ctx {
   std::map<std::vector<long long>, hipGraphExec_t> qr_graphs;
   // Debug: per-workgroup timeline of the contraction kernel (MPSE_GEMM_TRACE=<file>): every workgroup appends one
   // record (grid, K tiles multiplied, s_memtime stamps of its phases); mpse_prof_get writes the file.
-  unsigned long long* gemm_trace = nullptr;   // [1 + GEMM_TRACE_CAP * 8] words: counter, then records
+  unsigned long long* gemm_trace = nullptr;   // [1 + GEMM_TRACE_CAP * GEMM_TRACE_WORDS] words: counter, then records
   bool gemm_trace_checked = false;
   bool occ_cache_on = false;
   const char* occ_lo[2] = {nullptr, nullptr};
   const char* occ_hi[2] = {nullptr, nullptr};
   std::vector<OccEntry> occ_cache;
+  // launch orders of block-sparse products (k_tile_order), kept like the masks they were computed from
+  struct PermEntry {
+    const void *amask, *bmask;
+    int tiles_m, tiles_n, nkt;
+    void* perm;
+  };
+  std::vector<PermEntry> perm_cache;
 };
 
 int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...);
@@ -239,7 +246,8 @@ struct QrBlk {
   long long row_off = 0, col_off = 0;   // block_qr: where the block's row / column index lists start (device lists)
 };
 constexpr int HH_BATCH_MAX_ROWS = 4096;
-constexpr unsigned long long GEMM_TRACE_CAP = 1ull << 21;
+constexpr unsigned long long GEMM_TRACE_CAP = 1ull << 21;   // records
+constexpr int GEMM_TRACE_WORDS = 10;                         // 64-bit words per record
 // ``blks_dev``: the same descriptors already on the device (else they are uploaded here)
 int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm, const QrBlk* blks_host, int nblk,
                   bool form_q, const QrBlk* blks_dev = nullptr);

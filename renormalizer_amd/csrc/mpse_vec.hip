@@ -701,6 +701,8 @@ struct OccScope {
     c->occ_cache_on = false;
     for (auto& e : c->occ_cache) mpse_free(c, e.mask);
     c->occ_cache.clear();
+    for (auto& e : c->perm_cache) mpse_free(c, e.perm);
+    c->perm_cache.clear();
     for (auto& e : c->wcsr_cache) {
       mpse_free(c, e.cnt);
       mpse_free(c, e.ent);

@@ -118,6 +118,8 @@ _SWITCHES = {
     "MPSE_LZ_DEFER_FIRST=0": True,    # the first convergence check of a solve on its own instead of merged into the second
     "MPSE_QR_CAQR=1": False,          # communication-avoiding tree QR instead of the panel-blocked kernels
     "MPSE_QR_GRAPH=1": True,          # the QR's launches replayed from a HIP graph instead of enqueued one by one
+    "MPSE_GEMM_SKEW=0": True,         # output tiles in storage order (a die then owns whole tile columns)
+    "MPSE_GEMM_ORDER=0": True,        # no heaviest-first launch order of the block-sparse products
     "MPSE_QR_LOOKAHEAD=0": False,     # panel and trailing update of the short blocks as two launches instead of one
 }
 

@@ -10,13 +10,13 @@ import sys
 
 import numpy as np
 
-r = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
+r = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 10)
 grid = (r[:, 0] >> np.uint64(32)).astype(np.int64)
 ca = ((r[:, 1] >> np.uint64(62)) & np.uint64(1)).astype(int)
 cb = ((r[:, 1] >> np.uint64(61)) & np.uint64(1)).astype(int)
 ks = ((r[:, 1] >> np.uint64(40)) & np.uint64(0xFFFF)).astype(int)
 K = ((r[:, 1] >> np.uint64(8)) & np.uint64(0xFFFFFFFF)).astype(np.int64)
-kt = r[:, 2].astype(np.int64)
+kt = (r[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
 t0, t1, t2, t3, t4 = (r[:, i].astype(np.int64) for i in range(3, 8))
 lines = ["| grid (WGs) | types | K | ksplit | workgroups | empty % | K tiles / WG (non-empty) | setup | first | loop | per K tile | epi | total (non-empty) | total (empty) |",
          "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
