@@ -48,6 +48,7 @@ struct GemmArgs {
   int use_beta;
   double alpha_re, alpha_im, beta_re, beta_im;
   int skew;            // tile column = (column of the linear index + tile row) mod tiles_n
+  int kbal;            // split-K: slices hold equal numbers of occupied K tiles instead of equal K ranges
   const int* perm;     // optional: linear tile index by launch position, tiles with the most K tiles first
   int ksplit;          // number of K slices (1 = none)
   int kt_per_split;    // k-tiles per slice
@@ -128,7 +129,9 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   const int b = bs / g.ksplit;
   const int ks_id = bs - b * g.ksplit;
   int t = bid - bs * ntile;
-  if (g.perm) t = g.perm[t];             // heaviest tiles first (k_tile_order)
+  // heaviest tiles first (k_tile_order); the odd slices of a split product run through the order backwards, so that
+  // the compute unit that receives a heavy tile's slice in one round receives a light one in the next
+  if (g.perm) t = g.perm[(ks_id & 1) ? ntile - 1 - t : t];
   const int tm = t / g.tiles_n;
   int tn = t - tm * g.tiles_n;
   // Workgroups go to the eight dies round robin (die = blockIdx mod 8) and the number of tile columns is a multiple
@@ -208,8 +211,8 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
     }
   };
   const int nkt_all = (g.K + BK - 1) / BK;
-  const int kt_begin = ks_id * g.kt_per_split;
-  const int kt_end = min(nkt_all, kt_begin + g.kt_per_split);
+  int kt_begin = ks_id * g.kt_per_split;
+  int kt_end = min(nkt_all, kt_begin + g.kt_per_split);
   // fast path (single-level K maps; the launcher guarantees non-negative strides and operand spans below 4 GB):
   // a uniform tile base (scalar registers, recomputed from the tile number) plus one 32-bit byte offset per lane and
   // staged element - the global_load saddr + voffset form: no per-lane 64-bit pointers to keep and to advance
@@ -330,6 +333,37 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
       }
       __syncthreads();
       mlds = true;
+      if (g.kbal && g.ksplit > 1) {
+        // K slices with equal numbers of OCCUPIED K tiles: with block-sparse operands the occupied tiles of an
+        // output tile cluster in part of the K range (K runs channel-major), and slices of equal length would give
+        // one workgroup everything.  Every thread walks the same flag words (uniform).
+        auto word_of = [&](int w) {
+          unsigned long long x = s_mask[0][w] & s_mask[1][w] & 0x0101010101010101ull;
+          const int valid = nkt_all - 8 * w;                 // flag bytes past the last K tile are never written
+          if (valid < 8) x &= (1ull << (8 * valid)) - 1ull;
+          return x;
+        };
+        int n = 0;
+        for (int w = 0; w < g.nkw; ++w) n += __popcll(word_of(w));
+        const int i0 = (int)((long long)ks_id * n / g.ksplit), i1 = (int)((long long)(ks_id + 1) * n / g.ksplit);
+        // position of the i-th occupied tile (i = n: the end of the range)
+        auto pos_of = [&](int i) {
+          if (i >= n) return nkt_all;
+          int seen = 0;
+          for (int w = 0; w < g.nkw; ++w) {
+            unsigned long long x = word_of(w);
+            const int c = __popcll(x);
+            if (seen + c > i) {
+              for (int skip = i - seen; skip > 0; --skip) x &= x - 1;   // drop the lowest set flags
+              return (w << 3) + (__builtin_ctzll(x) >> 3);
+            }
+            seen += c;
+          }
+          return nkt_all;
+        };
+        kt_begin = pos_of(i0);
+        kt_end = pos_of(i1);
+      }
     }
   }
   auto next_kt = [&](int from) -> int {
@@ -1042,6 +1076,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   static const int skew_on = [] { const char* e = getenv("MPSE_GEMM_SKEW"); return e ? atoi(e) : 1; }();
   g.skew = skew_on;
   g.perm = nullptr;
+  g.kbal = 0;
   g.dot_y = nullptr;
   g.dot_part = nullptr;
   if (!ctx->gemm_trace_checked) {
@@ -1077,6 +1112,21 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
       MPSE_TRY(WSB.alloc(size_t(d->batch) * g.ksplit * size_t(g.M) * size_t(g.N) * esz));
       g.ws = WSB.as<double>();
     }
+  }
+  const bool will_mask = (skip_zero || amask_ext) && is_single(g.kA) && is_single(g.kB) && (nkt_all >= 2 || amask_ext) &&
+                         d->batch <= 16384;
+  // A block-sparse product with one output tile per CU is as slow as its fullest tile (d = 16 C-step: 33 occupied K
+  // tiles against 21 on average): it is cut into slices of equal OCCUPIED tile counts, so that two workgroups share
+  // every CU and the fullest tile is halved.
+  static const int sk_bal = [] { const char* e = getenv("MPSE_SPLITK_BAL"); return e ? atoi(e) : 0; }();
+  if (sk_bal > 1 && !small && g.ksplit == 1 && d->batch == 1 && will_mask && (nkt_all + 7) / 8 <= 64 && !cmask_out &&
+      base_blocks >= tiles_limit && base_blocks < 2 * n_cu && nkt_all >= 16) {
+    g.ksplit = sk_bal;
+    g.kt_per_split = (nkt_all + sk_bal - 1) / sk_bal;
+    const size_t esz = (ca || cb) ? 16 : 8;
+    MPSE_TRY(WSB.alloc(size_t(d->batch) * g.ksplit * size_t(g.M) * size_t(g.N) * esz));
+    g.ws = WSB.as<double>();
+    g.kbal = 1;
   }
   long long nblk = base_blocks * g.ksplit;
   if (nblk > 0x7fffffffLL) return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpse_gemm: grid too large");
@@ -1209,7 +1259,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   static const int order_on = [] { const char* e = getenv("MPSE_GEMM_ORDER"); return e ? atoi(e) : 1; }();
   TmpBuf PERM(ctx);
   const long long ntile_all = (long long)g.tiles_m * g.tiles_n;
-  if (order_on && !small && d->batch == 1 && (g.amask || g.bmask) && ntile_all * g.ksplit > 2 * n_cu &&
+  if (order_on && !small && d->batch == 1 && (g.amask || g.bmask) && (ntile_all * g.ksplit > 2 * n_cu || g.kbal) &&
       ntile_all <= 2048) {
     // inside a Krylov solve both masks are the solve's (cached environment mask, structural centre mask): one sort
     // serves every matvec of the solve
