@@ -100,9 +100,13 @@ constexpr int BM = 64, BN = 64, BK = 16, LDK = BK + 1;   // BM x BN: granularity
 // WS: waves per side of the workgroup tile.  WS = 2: 256 threads own 64 x 64 (the workhorse); WS = 1: ONE wave owns
 // 32 x 32 - for products whose 64 x 64 tiles cannot fill the chip, four times as many workgroups instead of slicing K
 // into partial sums that a second kernel has to add up.
-template <bool CA, bool CB, bool KS, int WS>
-__global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) void k_gemm(const GemmArgs g) {
-  constexpr int TBM = 32 * WS, TBN = 32 * WS, NT = 64 * WS * WS;
+// WI: 16-row blocks of the output tile per wave.  2: four waves of 32 x 32 (the default).  1 (WS = 2 only): eight
+// waves of 16 x 32 on the same 64 x 64 tile - for launches that put ONE workgroup on a compute unit, so that every
+// SIMD still has two waves to overlap fragment reads, staging and address arithmetic with the other's MFMAs.
+template <bool CA, bool CB, bool KS, int WS, int WI = 2>
+__global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 : ((CA && CB) ? 2 : 3)) void k_gemm(const GemmArgs g) {
+  constexpr int TBM = 32 * WS, TBN = 32 * WS, NT = 64 * WS * WS * (2 / WI);
+  static_assert(WI == 2 || (WI == 1 && WS == 2), "eight-wave form only for 64 x 64 tiles");
   constexpr int LD = WS == 2 ? 80 : 48;          // [k][i] panel rows; LD mod 32 == 16 keeps the fragment reads conflict free
   constexpr int NLD = TBM * BK / NT;             // staged elements per thread and operand (panel = BK*LD >= TBM*LDK doubles)
   constexpr bool CC = CA || CB;
@@ -121,7 +125,8 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = WS == 2 ? wave >> 1 : 0, wn = WS == 2 ? wave & 1 : 0;
+  const int wm = WS == 2 ? wave >> 1 : 0, wn = WS == 2 ? wave & 1 : 0;   // WI == 1: wm = 0 .. 3
+  constexpr int WROWS = 16 * WI;         // rows of the output tile per wave
 
   const int ntile = g.tiles_m * g.tiles_n;
   const int bid = blockIdx.x;
@@ -303,9 +308,9 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   //   T1 = Ar Br, T2 = Ai Bi, T3 = (Ar + Ai)(Br + Bi)  =>  re = T1 - T2, im = T3 - T1 - T2
   // acc_re holds T1, acc_im holds T3, acc_t2 holds T2 until the epilogue combines them.
   constexpr bool M3 = CA && CB && MPSE_GEMM_3M;
-  v4d acc_re[2][2], acc_im[2][2], acc_t2[2][2];
+  v4d acc_re[WI][2], acc_im[WI][2], acc_t2[WI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       acc_re[i][j] = v4d{0, 0, 0, 0};
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   // LDS strides (in doubles) of element (i, k) of each panel
   const int sai = g.a_kfast ? LDK : 1, sak = g.a_kfast ? 1 : LD;
   const int sbj = g.b_kfast ? LDK : 1, sbk = g.b_kfast ? 1 : LD;
-  int wofa[NLD], wofb[NLD], rofa[2], rofb[2];
+  int wofa[NLD], wofb[NLD], rofa[WI], rofb[2];
 #pragma unroll
   for (int r = 0; r < NLD; ++r) {
     wofa[r] = ai[r] * sai + ak[r] * sak;
@@ -403,19 +408,21 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    rofa[i] = (wm * 32 + i * 16 + frow) * sai + fk * sak;
+    if (i < WI) rofa[i] = (wm * WROWS + i * 16 + frow) * sai + fk * sak;
     rofb[i] = (wn * 32 + i * 16 + frow) * sbj + fk * sbk;
   }
 
   // operand fragments of one k-group (4 of K): double buffered so that the ds_reads of group kk+1 are in
   // flight under the 16 MFMAs of group kk
-  double f_ar[2][2], f_ai[2][2], f_br[2][2], f_bi[2][2];
+  double f_ar[2][WI], f_ai[2][WI], f_br[2][2], f_bi[2][2];
   constexpr int lds_set = 0;
   auto read_frag = [&](int buf, int kk) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      f_ar[buf][i] = sAr[lds_set + rofa[i] + kk * 4 * sak];
-      if constexpr (CA) f_ai[buf][i] = sAi[lds_set + rofa[i] + kk * 4 * sak];
+      if (i < WI) {
+        f_ar[buf][i] = sAr[lds_set + rofa[i] + kk * 4 * sak];
+        if constexpr (CA) f_ai[buf][i] = sAi[lds_set + rofa[i] + kk * 4 * sak];
+      }
       f_br[buf][i] = sBr[lds_set + rofb[i] + kk * 4 * sbk];
       if constexpr (CB) f_bi[buf][i] = sBi[lds_set + rofb[i] + kk * 4 * sbk];
     }
@@ -440,14 +447,14 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   // the 16 (x3 / x4 / x2 / x1) MFMAs of k-group kk on fragment buffer cb
   auto mfma_group = [&](int cb) {
     if constexpr (M3) {
-      double as[2], bs[2];
+      double as[WI], bs[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        as[i] = f_ar[cb][i] + f_ai[cb][i];
+        if (i < WI) as[i] = f_ar[cb][i] + f_ai[cb][i];
         bs[i] = f_br[cb][i] + f_bi[cb][i];
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_br[cb][j], acc_re[i][j], 0, 0, 0);
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
         }
     } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f_ar[cb][i], f_br[cb][j], acc_re[i][j], 0, 0, 0);
@@ -476,16 +483,16 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   // the last k-group of a tile with the staging stores of the next tile between its MFMAs (one register of each
   // operand per output sub-tile; KS variants)
   auto mfma_group_staging = [&](int cb) {
-    double as[2], bs[2];
+    double as[WI], bs[2];
     if constexpr (M3) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        as[i] = f_ar[cb][i] + f_ai[cb][i];
+        if (i < WI) as[i] = f_ar[cb][i] + f_ai[cb][i];
         bs[i] = f_br[cb][i] + f_bi[cb][i];
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if constexpr (M3) {
@@ -634,7 +641,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   }
   if constexpr (M3) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         acc_im[i][j] = acc_im[i][j] - acc_re[i][j] - acc_t2[i][j];
@@ -650,10 +657,10 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
       const int gj = tn * TBN + wn * 32 + j * 16 + (lane & 15);
       if (gj >= g.N) continue;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int gi = tm * TBM + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+          const int gi = tm * TBM + wm * WROWS + i * 16 + (lane >> 4) + 4 * r;
           if (gi >= g.M) continue;
           double* p = wsb + ((long long)gi * g.N + gj) * EC;
           if constexpr (CC)
@@ -672,7 +679,7 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   // (complex x complex only: the mixed variants run three waves per SIMD on 168 registers, where the 128 registers
   // of the preloads spill; their beta / dot terms are read inside the store loop as before)
   constexpr bool PRE = CA && CB;
-  double2 pre_c[PRE ? 2 : 1][2][4], pre_y[PRE ? 2 : 1][2][4];
+  double2 pre_c[PRE ? WI : 1][2][4], pre_y[PRE ? WI : 1][2][4];
   const bool need_c = g.use_beta, need_y = g.dot_y != nullptr;
   if (PRE && (need_c || need_y)) {
 #pragma unroll
@@ -681,10 +688,10 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
       const long long coffn = idx_off(g.nC, gj);
       const long long cinn = g.Cin ? idx_off(g.nCin, gj) : 0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int gi = min(tm * TBM + wm * 32 + i * 16 + (lane >> 4) + 4 * r, g.M - 1);
+          const int gi = min(tm * TBM + wm * WROWS + i * 16 + (lane >> 4) + 4 * r, g.M - 1);
           const long long co = idx_off(g.mC, gi) + coffn;
           if (need_c) {
             const double* pin = g.Cin ? g.Cin + (idx_off(g.mCin, gi) + cinn) * EC : C + co * EC;
@@ -708,10 +715,10 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
     if (gj >= g.N) continue;
     const long long coffn = idx_off(g.nC, gj);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WI; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gi = tm * TBM + wm * 32 + i * 16 + (lane >> 4) + 4 * r;
+        const int gi = tm * TBM + wm * WROWS + i * 16 + (lane >> 4) + 4 * r;
         if (gi >= g.M) continue;
         const long long co = idx_off(g.mC, gi) + coffn;
         double* p = C + co * EC;
@@ -748,7 +755,21 @@ __global__ __launch_bounds__(64 * WS * WS, WS == 1 ? 1 : ((CA && CB) ? 2 : 3)) v
   }
   if constexpr (WS == 2) {
     if (g.dot_y) {   // workgroup-uniform
-      block_allsum2(dre, dim);
+      // (block-wide sum for NT threads, totals to every thread; fixed order)
+      __shared__ double s_dot[2 * (NT / 64)];
+      dre = wave_sum(dre);
+      dim = wave_sum(dim);
+      if (lane == 0) {
+        s_dot[2 * wave] = dre;
+        s_dot[2 * wave + 1] = dim;
+      }
+      __syncthreads();
+      dre = dim = 0.0;
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) {
+        dre += s_dot[2 * w];
+        dim += s_dot[2 * w + 1];
+      }
       if (tid == 0) {   // slot = the tile, not the launch position: the sum order does not depend on the tile order
         const long long slot = (long long)bs * ntile + (long long)tm * g.tiles_n + tn;
         g.dot_part[2 * slot] = dre;
@@ -1299,6 +1320,8 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   do {                                                                                                \
     if (ks && small)                                                                                  \
       hipLaunchKernelGGL((k_gemm<CA_, CB_, true, 1>), grid, block, 0, ctx->stream, g);                \
+    else if (ks && wide)                                                                              \
+      hipLaunchKernelGGL((k_gemm<CA_, CB_, true, 2, 1>), grid, dim3(512), 0, ctx->stream, g);         \
     else if (ks)                                                                                      \
       hipLaunchKernelGGL((k_gemm<CA_, CB_, true, 2>), grid, block, 0, ctx->stream, g);                \
     else if (small)                                                                                   \
@@ -1306,6 +1329,9 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     else                                                                                              \
       hipLaunchKernelGGL((k_gemm<CA_, CB_, false, 2>), grid, block, 0, ctx->stream, g);               \
   } while (0)
+  // one workgroup per compute unit (or fewer): eight waves on the tile instead of four
+  static const int wide_on = [] { const char* e = getenv("MPSE_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+  const bool wide = wide_on && !small && nblk <= (wide_on > 1 ? 2 * n_cu : n_cu) && nkt_all >= 2;
   if (ca && cb)
     MPSE_LAUNCH(true, true);
   else if (ca)
