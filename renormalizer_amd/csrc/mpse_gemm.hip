@@ -779,40 +779,19 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
   }
 }
 
-// Launch order of the output tiles of a block-sparse product: tiles sorted by the number of K tiles both operands
-// occupy, most first.  The dispatcher hands workgroups to the dies round robin and to free slots in launch order, so
-// a sorted launch is longest-processing-time-first scheduling; in storage order the full tiles of a quantum-number
-// sector sit next to each other and pile up on the same compute units (tools/gemm_balance.py: 30 K tiles on the
-// fullest CU against 21 on average for the d = 16 A-step).  One workgroup, bitonic sort of <= 2048 keys in LDS.
-__global__ __launch_bounds__(1024) void k_tile_order(const unsigned long long* __restrict__ amask,
-                                                       const unsigned long long* __restrict__ bmask, int nkw, int nkt,
-                                                       int tiles_m, int tiles_n, int* __restrict__ perm,
-                                                       const int* __restrict__ skip) {
-  if (skip && *skip) return;
-  __shared__ unsigned key[2048];
-  const int ntile = tiles_m * tiles_n, tid = threadIdx.x;
-  for (int i = tid; i < 2048; i += 1024) {
-    unsigned k = 0;
-    if (i < ntile) {
-      const int tm = i / tiles_n, tn = i - tm * tiles_n;
-      int cnt = 0;
-      for (int w = 0; w < nkw; ++w) {
-        unsigned long long x = 0x0101010101010101ull;
-        if (amask) x &= amask[(long long)tm * nkw + w];
-        if (bmask) x &= bmask[(long long)tn * nkw + w];
-        const int valid = nkt - 8 * w;                    // flag bytes past the last K tile are never written
-        if (valid < 8) x &= (1ull << (8 * valid)) - 1ull;
-        cnt += __popcll(x);
-      }
-      k = ((unsigned)cnt << 16) | (unsigned)(0xFFFF - i);
-    }
-    key[i] = k;
-  }
-  __syncthreads();
+// Launch order of the output tiles of a block-sparse product.  The dispatcher hands workgroups to the eight dies
+// round robin (die = launch position mod 8, checked with tools/gemm_balance.py) and to free slots in launch order.
+//  * Tiles are sorted by the number of K tiles both operands occupy, most first: longest-processing-time-first
+//    scheduling.  In storage order the full tiles of a quantum-number sector sit next to each other and pile up on
+//    the same dies and compute units (30 K tiles on the fullest CU against 21 on average for the d = 16 A-step).
+//  * Where the tile columns divide evenly among the dies, every die owns whole tile columns (chosen in a snake over
+//    the columns sorted by weight, so that the dies carry equal work): its L2 then holds the column panels of B it
+//    needs instead of streaming all of B (the plain sorted order raised the HBM-side traffic of the A-step by 2.5x).
+// One workgroup, bitonic sorts of <= 2048 keys in LDS.
+__device__ __forceinline__ void bitonic_desc_2048(unsigned* key, int tid) {
   for (int size = 2; size <= 2048; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      // 1024 compare-exchange pairs per step, one per thread
-      const int lo = 2 * tid - (tid & (stride - 1)), hi = lo + stride;
+      const int lo = 2 * tid - (tid & (stride - 1)), hi = lo + stride;   // 1024 compare-exchange pairs per step
       const bool desc = (lo & size) == 0;
       const unsigned a = key[lo], b = key[hi];
       if ((a < b) == desc) {
@@ -821,7 +800,61 @@ __global__ __launch_bounds__(1024) void k_tile_order(const unsigned long long* _
       }
       __syncthreads();
     }
-  for (int i = tid; i < ntile; i += 1024) perm[i] = 0xFFFF - (int)(key[i] & 0xFFFFu);
+}
+__global__ __launch_bounds__(1024) void k_tile_order(const unsigned long long* __restrict__ amask,
+                                                       const unsigned long long* __restrict__ bmask, int nkw, int nkt,
+                                                       int tiles_m, int tiles_n, int by_die, int* __restrict__ perm,
+                                                       const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  __shared__ unsigned key[2048], ckey[2048];
+  __shared__ int colw[2048];
+  __shared__ unsigned char die_of[2048];
+  const int ntile = tiles_m * tiles_n, tid = threadIdx.x;
+  const bool part = by_die && tiles_n % 8 == 0 && tiles_n <= 2048;
+  for (int c = tid; c < 2048; c += 1024) colw[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < 2048; i += 1024) {
+    unsigned cnt = 0;
+    if (i < ntile) {
+      const int tm = i / tiles_n, tn = i - tm * tiles_n;
+      for (int w = 0; w < nkw; ++w) {
+        unsigned long long x = 0x0101010101010101ull;
+        if (amask) x &= amask[(long long)tm * nkw + w];
+        if (bmask) x &= bmask[(long long)tn * nkw + w];
+        const int valid = nkt - 8 * w;                    // flag bytes past the last K tile are never written
+        if (valid < 8) x &= (1ull << (8 * valid)) - 1ull;
+        cnt += __popcll(x);
+      }
+      if (part) atomicAdd(&colw[tn], (int)cnt);
+    }
+    key[i] = cnt;      // (<= 512 K tiles)
+  }
+  __syncthreads();
+  if (part) {
+    for (int c = tid; c < 2048; c += 1024) ckey[c] = c < tiles_n ? ((unsigned)colw[c] << 11) | (unsigned)(2047 - c) : 0u;
+    __syncthreads();
+    bitonic_desc_2048(ckey, tid);
+    for (int r = tid; r < tiles_n; r += 1024) {
+      const int c = 2047 - (int)(ckey[r] & 2047u), r16 = r & 15;
+      die_of[c] = (unsigned char)(r16 < 8 ? r16 : 15 - r16);          // snake over the columns by weight
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 2048; i += 1024) {
+    unsigned k = 0;
+    if (i < ntile) {
+      const unsigned die = part ? die_of[i % tiles_n] : 0u;
+      k = (die << 28) | (key[i] << 16) | (unsigned)(0xFFFF - i);
+    }
+    key[i] = k;
+  }
+  __syncthreads();
+  bitonic_desc_2048(key, tid);
+  const int per_die = ntile / 8;           // part: every die owns tiles_n / 8 columns of tiles_m tiles
+  for (int i = tid; i < ntile; i += 1024) {
+    const int s = part ? (7 - (i & 7)) * per_die + (i >> 3) : i;
+    perm[i] = 0xFFFF - (int)(key[s] & 0xFFFFu);
+  }
 }
 
 // C(i,j) = alpha * sum_s ws[b][s][i][j] + beta * C(i,j); slices summed in fixed order.
@@ -1301,7 +1334,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
         pp = PERM.as<int>();
       }
       hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, ctx->stream, g.amask, g.bmask, g.nkw, nkt_all, g.tiles_m,
-                         g.tiles_n, pp, ctx->skip_flag);
+                         g.tiles_n, order_on > 1 ? 0 : 1, pp, ctx->skip_flag);
     }
     g.perm = pp;
   }

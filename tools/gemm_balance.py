@@ -50,7 +50,10 @@ for key, v in sorted(stats.items(), key=lambda kv: -sum(x[0] for x in kv[1]))[:1
     g, A, B, k, s = key
     lines.append(f"| {g} | {'c' if A else 'r'}x{'c' if B else 'r'} | {k} | {s} | {len(v)} | {m[0]:.0f} | {m[1] / (m[9] * m[0]):.2f} | {m[2]:.0f} | "
                  f"{m[3]:.0f} | {m[4]:.1f} | {m[2] / max(m[5], 1):.1f} | {m[6]:.1f} | {m[7]:.0f} / {m[8]:.0f} | {m[9]:.0f} |")
-out = "\n".join(lines) + f"\n\n{len(r)} workgroup records\n"
+bid = (r[:, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+big = grid >= 256
+rr = 100.0 * np.mean(xcc[big] == (bid[big] % 8)) if big.any() else 0.0
+out = "\n".join(lines) + f"\n\n{len(r)} workgroup records; die of a workgroup == blockIdx mod 8 for {rr:.1f} % of the workgroups of launches with >= 256 workgroups\n"
 print(out)
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(out)
