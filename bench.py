@@ -270,13 +270,15 @@ def main():
             with open(pmc_file, "rb") as fh:
                 raw = fh.read()
             kern = json.loads(raw)["kernels"]
-            key = next(k for k in kern if k.startswith("void k_gemm<true, true, true"))   # (+ the tile-shape argument)
-            traffic = kern[key]["hbm_bytes_per_launch"]
+            # every instantiation of the complex x complex contraction kernel (tile / wave-layout arguments differ),
+            # weighted by its launches
+            hits = [v for k, v in kern.items() if k.startswith("void k_gemm<true, true, true")]
+            traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / sum(v["launches"] for v in hits)
             traffic_src = (f"profiles/{os.path.basename(pmc_file)} sha256:{hashlib.sha256(raw).hexdigest()[:16]} "
                            "(separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command with --init "
                            "physical; a committed measurement, not one of this run: counters cannot be read from "
                            "inside the process)")
-        except (OSError, KeyError, ValueError, StopIteration, IndexError):
+        except (OSError, KeyError, ValueError, StopIteration, IndexError, ZeroDivisionError):
             pass
         zz = prof["c128xc128"]
         sec = zz["ms"] * 1e-3
