@@ -48,6 +48,8 @@ struct GemmArgs {
   int use_beta;
   double alpha_re, alpha_im, beta_re, beta_im;
   int skew;            // tile column = (column of the linear index + tile row) mod tiles_n
+  int die_group;       // 0: off, 1: a die owns whole tile rows, 2: whole tile columns (see the kernel)
+  int slice_fast;      // split-K, batch == 1: launch position = tile * ksplit + slice
   int kbal;            // split-K: slices hold equal numbers of occupied K tiles instead of equal K ranges
   const int* perm;     // optional: linear tile index by launch position, tiles with the most K tiles first
   int ksplit;          // number of K slices (1 = none)
@@ -130,19 +132,38 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
 
   const int ntile = g.tiles_m * g.tiles_n;
   const int bid = blockIdx.x;
-  const int bs = bid / ntile;            // (batch, k-slice)
+  // launch position -> (batch, K slice, tile): tile-fastest, or - split products of one batch element - slice-fastest:
+  // the die of a workgroup is its launch position mod 8, so with the slice running fastest a die works on one (or a
+  // few) K slices of every tile and its L2 sees 1/8 of both operands instead of most of them
+  int bs = bid / ntile;                  // (batch, k-slice)
+  int t = bid - bs * ntile;
+  if (g.slice_fast) {
+    t = bid / g.ksplit;
+    bs = bid - t * g.ksplit;
+  }
   const int b = bs / g.ksplit;
   const int ks_id = bs - b * g.ksplit;
-  int t = bid - bs * ntile;
   // heaviest tiles first (k_tile_order); the odd slices of a split product run through the order backwards, so that
   // the compute unit that receives a heavy tile's slice in one round receives a light one in the next
   if (g.perm) t = g.perm[(ks_id & 1) ? ntile - 1 - t : t];
-  const int tm = t / g.tiles_n;
+  int tm = t / g.tiles_n;
   int tn = t - tm * g.tiles_n;
+  // unsplit products without a sorted order: all tiles of a tile row (die_group 1) or tile column (2) on one die -
+  // position p runs on die p mod 8, so die x takes rows x, x + 8, .. with every column: the larger operand's panels are
+  // fetched into one L2 instead of into all eight
+  if (g.die_group == 1) {
+    const int x = t & 7, j = t >> 3;
+    tm = x + 8 * (j / g.tiles_n);
+    tn = j % g.tiles_n;
+  } else if (g.die_group == 2) {
+    const int x = t & 7, j = t >> 3;
+    tn = x + 8 * (j / g.tiles_m);
+    tm = j % g.tiles_m;
+  }
   // Workgroups go to the eight dies round robin (die = blockIdx mod 8) and the number of tile columns is a multiple
   // of eight, so without the skew a die would own whole tile columns: with block-sparse operands (quantum-number
   // sectors are column ranges) some dies got three times the K tiles of others (tools/gemm_balance.py).
-  if (g.skew && !g.perm) tn = (tn + tm) % g.tiles_n;
+  if (g.skew && !g.perm && !g.die_group) tn = (tn + tm) % g.tiles_n;
 
   const double* A = g.A + (long long)b * g.sbA * EA;
   const double* B = g.B + (long long)b * g.sbB * EB;
@@ -1131,6 +1152,8 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.skew = skew_on;
   g.perm = nullptr;
   g.kbal = 0;
+  g.slice_fast = 0;
+  g.die_group = 0;
   g.dot_y = nullptr;
   g.dot_part = nullptr;
   if (!ctx->gemm_trace_checked) {
@@ -1182,6 +1205,8 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     g.ws = WSB.as<double>();
     g.kbal = 1;
   }
+  static const int sf_on = [] { const char* e = getenv("MPSE_GEMM_SLICEFAST"); return e ? atoi(e) : 1; }();
+  g.slice_fast = sf_on && g.ksplit > 1 && d->batch == 1 && !g.kbal;
   long long nblk = base_blocks * g.ksplit;
   if (nblk > 0x7fffffffLL) return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpse_gemm: grid too large");
   if (cmask_out) {
@@ -1349,6 +1374,16 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     return (span(m) + span(k) + 1.0) * (cplx ? 16.0 : 8.0) < 4.0e9;
   };
   const bool ks = is_single(g.kA) && is_single(g.kB) && span_ok(g.mA, g.kA, ca) && span_ok(g.nB, g.kB, cb);
+  static const int dg_on = [] { const char* e = getenv("MPSE_GEMM_DIEGROUP"); return e ? atoi(e) : 1; }();
+  if (dg_on && !g.perm && g.ksplit == 1 && d->batch == 1 && !small && (long long)g.tiles_m * g.tiles_n >= 64) {
+    const double size_a = double(g.M) * (ca ? 2 : 1), size_b = double(g.N) * (cb ? 2 : 1);   // per unit of K
+    if (size_a >= size_b && g.tiles_m % 8 == 0)
+      g.die_group = 1;
+    else if (g.tiles_n % 8 == 0)
+      g.die_group = 2;
+    else if (g.tiles_m % 8 == 0)
+      g.die_group = 1;
+  }
 #define MPSE_LAUNCH(CA_, CB_)                                                                         \
   do {                                                                                                \
     if (ks && small)                                                                                  \
