@@ -480,7 +480,12 @@ __global__ __launch_bounds__(256) void k_hh_formq_b(double* q_base, const double
   constexpr int E = Cx<CPLX>::E;
   __shared__ double s_head[2];
   const QrBlk B = blks[blockIdx.y];
-  const int c = blockIdx.x;
+  // A workgroup runs on die (launch position mod 8).  Column c starts at panel c / 4 and walks down: neighbouring
+  // columns are at the same panel at the same time.  Every die therefore takes a contiguous range of columns, so
+  // that its workgroups read the same reflector panel while it is in that die's L2 (with the columns dealt round
+  // robin, a die held workgroups at 16 different panels and streamed the reflectors 456 MB per launch through).
+  int c = blockIdx.x;
+  if ((gridDim.x & 7) == 0) c = (c & 7) * (gridDim.x >> 3) + (c >> 3);
   if (c >= (B.nq > B.k ? B.nq : B.k)) return;
   const int mm = B.mm;
   const double* a = ws_base + B.ws_off * E;
@@ -726,7 +731,12 @@ __global__ __launch_bounds__(NT) void k_hh_formq_wy(double* q_base, const double
   constexpr int E = Cx<CPLX>::E;
   __shared__ double s_part[2][NT / 64][48];
   const QrBlk B = blks[blockIdx.y];
-  const int c = blockIdx.x;
+  // A workgroup runs on die (launch position mod 8).  Column c starts at panel c / 4 and walks down: neighbouring
+  // columns are at the same panel at the same time.  Every die therefore takes a contiguous range of columns, so
+  // that its workgroups read the same reflector panel while it is in that die's L2 (with the columns dealt round
+  // robin, a die held workgroups at 16 different panels and streamed the reflectors 456 MB per launch through).
+  int c = blockIdx.x;
+  if ((gridDim.x & 7) == 0) c = (c & 7) * (gridDim.x >> 3) + (c >> 3);
   if (c >= (B.nq > B.k ? B.nq : B.k)) return;
   const int mm = B.mm, tid = threadIdx.x;
   const double* a = ws_base + B.ws_off * E;
