@@ -1354,12 +1354,12 @@ class Mps:
             return eng.matmul(t.reshape(-1, t.shape[-1]), bond).reshape(t.shape[:-1] + (bond.shape[1],))
 
         # The calls that follow a local solve do not depend on WHEN it converges, only on the buffer its result lands
-        # in: with MPSE_DEFER=1 they are recorded ahead (Engine.recording) and issued by the engine the moment the
-        # solve has been enqueued to its end, so the GPU does not wait for the host language between a solve and its
-        # QR / absorption.  Off by default: on the headline run the idle time after a solve halves (41 -> 22 us) but
-        # the step time does not change within the noise.
+        # in: they are recorded ahead (Engine.recording) and issued by the engine the moment the solve has been enqueued
+        # to its end, so the GPU does not wait for the host language between a solve and its QR / absorption (56 us of
+        # idle time after every site solve otherwise).  Same tensors bit for bit; +1.1 % on the headline run since the
+        # contraction launches were rebalanced (neutral before: DESIGN.md section 5).  MPSE_DEFER=0: the plain loop.
         same_dtype = mps.is_complex or (evolve_dt.real == 0 and not mpo.is_complex)
-        pipelined = (cfg.ivp_solver == "krylov" and same_dtype and os.environ.get("MPSE_DEFER", "0") == "1"
+        pipelined = (cfg.ivp_solver == "krylov" and same_dtype and os.environ.get("MPSE_DEFER", "1") != "0"
                      and not os.environ.get("MPSE_VERIFY_UNIT"))
         try:
             for _ in range(2):

@@ -120,6 +120,7 @@ _SWITCHES = {
     "MPSE_QR_GRAPH=1": True,          # the QR's launches replayed from a HIP graph instead of enqueued one by one
     "MPSE_GEMM_SKEW=0": True,         # output tiles in storage order (a die then owns whole tile columns)
     "MPSE_GEMM_ORDER=0": True,        # no heaviest-first launch order of the block-sparse products
+    "MPSE_DEFER=0": True,             # QR / environment update / absorption issued from Python after each solve returns
     "MPSE_GEMM_SLICEFAST=0": True,    # split products launched tile-fastest (a die then reads most of both operands)
     "MPSE_GEMM_DIEGROUP=0": True,     # unsplit products without the die-wise grouping of tile rows / columns
     "MPSE_GEMM_WIDE=0": False,        # four waves per workgroup also where a workgroup has its compute unit to itself
