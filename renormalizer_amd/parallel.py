@@ -11,6 +11,7 @@ travels through a private file keyed by the launcher's process instance, single 
 stand-in of the same three operations that the world_size-2 tests use lives in ``tests/gloo_collective.py``."""
 import ctypes as C
 import os
+import sys
 import time
 
 import numpy as np
@@ -212,17 +213,115 @@ class RcclCollective:
                     pass
 
 
+class FileCollective:
+    """Single-node stand-in for the three operations of a run (barrier, max, one all-gather of a few KB) through
+    files in the private rendezvous directory: rank r publishes ``<tag>.fc.<seq>.<r>`` (written aside, renamed into
+    place) and polls for the other ranks' files of the same sequence number.  Not a data-path collective - there is
+    none - and slow (milliseconds per operation); it exists so that a job whose RCCL communicator cannot be created
+    still gathers its observables and times its steps instead of dying at start-up (``make_collective``)."""
+    kind = "file"
+
+    def __init__(self, rank: int, world: int, timeout_s: float = 600.0, tag: str = "fc"):
+        self.rank, self.world, self.timeout_s = int(rank), int(world), float(timeout_s)
+        self._base = _rendezvous_path() + "." + tag
+        self._seq = 0
+        self._t_start = _process_start_time()
+
+    def _name(self, seq, rank):
+        return f"{self._base}.{seq}.{rank}"
+
+    def _exchange(self, row: np.ndarray) -> np.ndarray:
+        row = np.ascontiguousarray(row, dtype=np.float64).ravel()
+        seq = self._seq
+        self._seq += 1
+        tmp = self._name(seq, self.rank) + ".tmp"
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        with os.fdopen(fd, "wb") as fh:
+            fh.write(np.int64(row.size).tobytes() + row.tobytes())
+        os.replace(tmp, self._name(seq, self.rank))
+        # every rank that writes sequence number s has read all files of s - 1, hence every rank has written s - 1,
+        # hence finished reading s - 2: this rank's file of s - 2 can go
+        try:
+            os.remove(self._name(seq - 2, self.rank))
+        except OSError:
+            pass
+        out = np.empty((self.world, row.size))
+        t0 = time.time()
+        for r in range(self.world):
+            while True:
+                try:
+                    with open(self._name(seq, r), "rb") as fh:
+                        if os.fstat(fh.fileno()).st_mtime < self._t_start - 120.0:
+                            raise FileNotFoundError          # left by an earlier launch with the same tag
+                        raw = fh.read()
+                    n = int(np.frombuffer(raw[:8], dtype=np.int64)[0]) if len(raw) >= 8 else -1
+                    if n == row.size and len(raw) == 8 + 8 * n:
+                        out[r] = np.frombuffer(raw[8:], dtype=np.float64)
+                        break
+                    if n >= 0 and n != row.size:
+                        raise RuntimeError(f"rank {self.rank}: rank {r} sent {n} values where {row.size} were expected")
+                except FileNotFoundError:
+                    pass
+                if time.time() - t0 > self.timeout_s:
+                    raise TimeoutError(f"rank {self.rank}: no message {seq} from rank {r} within {self.timeout_s} s "
+                                       f"({self._name(seq, r)})")
+                time.sleep(0.0005)
+        return out
+
+    def barrier(self):
+        self._exchange(np.zeros(1))
+
+    def allreduce_max(self, value: float) -> float:
+        return float(self._exchange(np.array([value])).max())
+
+    def allgather(self, row: np.ndarray) -> np.ndarray:
+        return self._exchange(row)
+
+    def close(self):
+        self.barrier()                      # nobody is still reading what is removed below
+        for seq in range(max(0, self._seq - 3), self._seq - 1):
+            try:
+                os.remove(self._name(seq, self.rank))
+            except OSError:
+                pass
+        # (the last file stays until the directory is cleaned: another rank may still be reading it)
+
+
 def make_collective(eng=None, backend=None):
     """Collective of this process from the launcher's environment (RANK / WORLD_SIZE as set by
-    torch.distributed.run): serial for one process, RCCL (ctypes) otherwise."""
+    torch.distributed.run): serial for one process, RCCL (ctypes) otherwise.  Whether RCCL is used is decided by
+    ALL ranks together (a vote through ``FileCollective``): if the communicator cannot be created on any rank -
+    library missing, rendezvous or ``ncclCommInitRank`` timing out (``MPSE_RCCL_TIMEOUT``, default 120 s) - every rank
+    falls back to the file collective and says so; ``backend="rccl"`` (or MPSE_COLLECTIVE=rccl) forbids the fallback,
+    MPSE_COLLECTIVE=file skips RCCL."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world == 1 and backend != "rccl":
+    want = backend or os.environ.get("MPSE_COLLECTIVE", "")
+    if world == 1 and want != "rccl":
         return SerialCollective()
+    if want == "file":
+        return FileCollective(rank, world)
     if eng is None:
         from .engine import get_engine
         eng = get_engine()
-    return RcclCollective(eng, rank, world)
+    timeout = float(os.environ.get("MPSE_RCCL_TIMEOUT", "120"))
+    if want == "rccl" or world == 1:
+        return RcclCollective(eng, rank, world, timeout_s=timeout)
+    vote = FileCollective(rank, world, timeout_s=timeout + 300.0, tag="vote")
+    rc, err = None, None
+    try:
+        rc = RcclCollective(eng, rank, world, timeout_s=timeout)
+    except (TimeoutError, RuntimeError, OSError) as e:       # (OSError: librccl.so not loadable)
+        err = e
+    failed = vote.allreduce_max(0.0 if rc is not None else 1.0) > 0.0
+    if not failed:
+        vote.close()
+        return rc
+    sys.stderr.write(f"[rank {rank}] RCCL communicator not available on every rank"
+                     f"{' (' + str(err) + ')' if err else ''}: barrier / gather through files instead\n")
+    sys.stderr.flush()
+    vote.close()
+    return FileCollective(rank, world)       # (a communicator this rank did create is abandoned, not used)
 
 
 def max_over_ranks(coll, value: float) -> float:

@@ -297,6 +297,48 @@ def test_rccl_collective_through_ctypes(tmp_path, monkeypatch):
     assert not os.path.exists(parallel._rendezvous_path())
 
 
+def test_collective_falls_back_to_files_when_rccl_cannot_start(tmp_path):
+    """Two ranks on ONE GPU: RCCL refuses (or never completes) a communicator with two ranks on the same device.  All
+    ranks vote, fall back to the file collective together and still gather their rows - a job does not die at
+    start-up because its communicator cannot be created (parallel.make_collective)."""
+    import subprocess
+    import sys
+    import textwrap
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {repo!r})
+        import numpy as np
+        from renormalizer_amd.engine import get_engine
+        from renormalizer_amd.parallel import make_collective, gather_observables, units_of_rank
+        eng = get_engine()
+        coll = make_collective(eng)
+        rank = coll.rank
+        units = units_of_rank(4, rank, coll.world)
+        rows = gather_observables(coll, np.array([[float(u), 2.0 * u] for u in units]), units, 4)
+        assert np.array_equal(rows[:, 0], np.arange(4.0)) and np.array_equal(rows[:, 1], 2.0 * np.arange(4.0))
+        coll.barrier()
+        print("KIND", coll.kind, rank)
+        coll.close()
+    """))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MPSE_RCCL_TIMEOUT="25",
+                   MPSE_RENDEZVOUS_DIR=str(tmp_path), MPSE_RENDEZVOUS_TAG="fallback", MASTER_PORT="29671")
+        env.pop("MPSE_COLLECTIVE", None)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    kinds = []
+    for p in procs:
+        out, err = p.communicate(timeout=400)
+        assert p.returncode == 0, err[-2000:]
+        kinds += [ln.split()[1] for ln in out.splitlines() if ln.startswith("KIND")]
+    # both ranks agree; on one device that is the file collective (a box whose RCCL accepts the shared device would
+    # say rccl twice - equally fine)
+    assert len(kinds) == 2 and kinds[0] == kinds[1] and kinds[0] in ("file", "rccl"), kinds
+
+
 def test_asynchronous_lanczos_guesses_and_fallbacks(eng):
     """The solve that runs ahead of its convergence decision (vectors longer than 256 elements): Krylov dimension and
     result equal the oracle's when the run-ahead guess (dimension of the previous solve of the same size) is too

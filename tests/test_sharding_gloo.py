@@ -97,3 +97,41 @@ def test_stale_rendezvous_file_is_ignored(tmp_path):
         fh.write(b"\x02" * 64)
     with pytest.raises(TimeoutError):
         parallel.await_id(path, 0.2, rank=1)
+
+
+def test_file_collective_two_processes(tmp_path):
+    """The fallback collective of a job whose RCCL communicator cannot be created (parallel.make_collective): two
+    processes, barrier / max / all-gather through files in the private rendezvous directory, same results as any
+    other collective; a stale file of an earlier launch with the same tag is ignored."""
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, time
+        sys.path.insert(0, {REPO!r})
+        import numpy as np
+        from renormalizer_amd.parallel import make_collective, gather_observables, max_over_ranks, units_of_rank
+        coll = make_collective()                               # MPSE_COLLECTIVE=file
+        assert coll.kind == "file" and coll.world == 2
+        rank = coll.rank
+        units = units_of_rank(5, rank, 2)
+        obs = np.array([[10.0 + u, u * 0.5] for u in units])
+        for _ in range(3):                                     # several rounds: files of old sequence numbers go away
+            allobs = gather_observables(coll, obs, units, 5)
+            coll.barrier()
+        t = max_over_ranks(coll, float(rank + 1))
+        assert allobs.shape == (5, 2) and np.array_equal(allobs[:, 0], 10.0 + np.arange(5)) and t == 2.0
+        coll.close()
+        print("OK", rank)
+    """))
+    stale = tmp_path / "mpse_rccl_fctest.id.fc.0.1"          # what a crashed launch with the same tag would leave
+    stale.write_bytes(b"\0" * 24)
+    os.utime(stale, (1.0e9, 1.0e9))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MPSE_COLLECTIVE="file", MPSE_RENDEZVOUS_DIR=str(tmp_path),
+                   MPSE_RENDEZVOUS_TAG="fctest")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for rank, p in enumerate(procs):
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err[-2000:]
+        assert f"OK {{rank}}".format(rank=rank) in out
