@@ -44,7 +44,8 @@ class SerialCollective:
 
 
 class _ncclUniqueId(C.Structure):
-    _fields_ = [("internal", C.c_char * 128)]
+    # (unsigned bytes: a c_char array would read back as a Python bytes object cut at the first zero byte)
+    _fields_ = [("internal", C.c_ubyte * 128)]
 
 
 _NCCL_FLOAT64, _NCCL_SUM, _NCCL_MAX = 8, 0, 2
@@ -136,6 +137,26 @@ def await_id(path: str, timeout_s: float, rank: int = -1) -> bytes:
         time.sleep(0.01)
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on the C stdout of the process; a job's stdout carries one JSON line.  While the
+    communicator is created, file descriptor 1 points at stderr, and the C buffers are flushed before it is restored."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            C.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class RcclCollective:
     """RCCL over xGMI through ctypes; one communicator per process, collectives on the engine's stream."""
     kind = "rccl"
@@ -153,31 +174,32 @@ class RcclCollective:
         uid = _ncclUniqueId()
         path = _rendezvous_path()
         self._path = path if self.rank == 0 else None
-        if self.rank == 0:
-            self._ok(L.ncclGetUniqueId(C.byref(uid)))
-            publish_id(path, bytes(uid.internal))
-        else:
-            C.memmove(C.byref(uid), await_id(path, timeout_s, self.rank), 128)
-        eng.sync()                                     # binds this thread to the engine's device (the comm's device)
-        self.comm = C.c_void_p()
-        # ncclCommInitRank blocks until every rank has called it with the same id: a mismatched id (or a rank that
-        # died) must end in an error, not in a hang
-        import threading
-        res = {}
+        with _StdoutToStderr():
+            if self.rank == 0:
+                self._ok(L.ncclGetUniqueId(C.byref(uid)))
+                publish_id(path, C.string_at(C.addressof(uid), 128))        # all 128 bytes, zeros included
+            else:
+                C.memmove(C.byref(uid), await_id(path, timeout_s, self.rank), 128)
+            eng.sync()                                 # binds this thread to the engine's device (the comm's device)
+            self.comm = C.c_void_p()
+            # ncclCommInitRank blocks until every rank has called it with the same id: a mismatched id (or a rank
+            # that died) must end in an error, not in a hang
+            import threading
+            res = {}
 
-        def init():
-            eng.sync()                                 # the HIP device is per thread: bind this one as well
-            res["st"] = L.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
+            def init():
+                eng.sync()                             # the HIP device is per thread: bind this one as well
+                res["st"] = L.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
 
-        if self.world > 1:
-            th = threading.Thread(target=init, daemon=True)
-            th.start()
-            th.join(timeout_s)
-            if th.is_alive():
-                raise TimeoutError(f"rank {self.rank}: ncclCommInitRank did not return within {timeout_s} s "
-                                   f"({self.world} ranks expected; id file {path})")
-        else:
-            init()
+            if self.world > 1:
+                th = threading.Thread(target=init, daemon=True)
+                th.start()
+                th.join(timeout_s)
+                if th.is_alive():
+                    raise TimeoutError(f"rank {self.rank}: ncclCommInitRank did not return within {timeout_s} s "
+                                       f"({self.world} ranks expected; id file {path})")
+            else:
+                init()
         self._ok(res["st"])
 
     def _ok(self, st):

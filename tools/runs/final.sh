@@ -17,5 +17,6 @@ rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_mfma
 for t in 2 4; do python bench.py --cpu-updates 0 --steps 3 --traj-per-gpu $t 2>/dev/null >> $O/multi_traj.jsonl; done
 MPSE_ENV_CARRY=0 python bench.py --cpu-updates 0 --steps 5 --warmup 2 --state-file /tmp/state.npz > $O/bench_nocarry.json 2>/dev/null
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --share-gpu --dist-backend gloo --steps 1 --warmup 0 --cpu-updates 0 > $O/bench_2rank_shared.json 2> $O/bench_2rank.err
+MPSE_RCCL_TIMEOUT=40 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --share-gpu --steps 1 --warmup 0 --cpu-updates 0 > $O/bench_2rank_fallback.json 2> $O/bench_2rank_fallback.err
 (timeout 900 python tools/config_times.py $O/config_times.md > /dev/null) 2> $O/config_times.err
 cut -c1-200 $O/bench_20steps.json; ls -la $O
