@@ -19,7 +19,15 @@
 //   * split-K with a fixed-order reduction kernel when there are fewer output tiles than CUs.
 //   * optional structural-zero skipping: a scan kernel flags the 64 x 16 operand tiles that hold data, the K loop
 //     visits only K tiles with data on both sides (block-sparse tensors of the quantum-number-conserving sweeps).
-//   * accumulation order over k is fixed => bitwise reproducible results.
+//   * launches with at most one workgroup per compute unit put eight waves on the tile (16 x 32 per wave) so that
+//     every SIMD has a second wave to fill its MFMA gaps.
+//   * workgroups are placed by die: the dispatcher deals launch positions to the eight dies (XCDs, one L2 each) round
+//     robin - die = blockIdx mod 8 - so the position -> (tile, K slice) map decides what each L2 has to hold and how
+//     evenly block-sparse work spreads.  Split products run slice-fastest (a die = a K range of both operands);
+//     unsplit ones give a die whole tile rows or columns of the larger operand; block-sparse ones with more tiles than
+//     slots are launched in a die-aware, heaviest-first order computed from the occupancy masks (k_tile_order), the
+//     others with their tile columns skewed by the tile row.  (tools/gemm_balance.py on MPSE_GEMM_TRACE timelines.)
+//   * accumulation order over k is fixed and independent of the launch order => bitwise reproducible results.
 #include <cstdlib>
 
 #include "mpse_device.h"
