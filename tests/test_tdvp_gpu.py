@@ -279,8 +279,8 @@ def test_config4_full_size_invariants():
     TDVP-PS with dt = 160 a.u., two disorder realisations with their own seeds (what each GPU of the 8-trajectory job
     runs).  Size-independent properties: norm and exciton number conserved, <H> conserved by the unitary step, the
     physical (not the tilde) modes pick up energy, bonds and quantum numbers consistent, trajectories distinct; the
-    zero-disorder run is compared with its own T -> 0 limit only through those invariants (the reduced-size runs of
-    test_thermofield_tdvp_matches_reference carry the reference pin)."""
+    the reduced-size runs of test_thermofield_tdvp_matches_reference carry the reference pin; one full-size step of
+    the first realisation is compared with the oracle from the same tensors."""
     import importlib.util
     from renormalizer_amd.mps.mps import Mps
     from renormalizer_amd.parallel import trajectory_seed
@@ -302,8 +302,26 @@ def test_config4_full_size_invariants():
         e0 = psi.expectation(mpo)
         occ0 = np.asarray(psi.e_occupations)
         assert abs(occ0[3] - 1) < 1e-9 and abs(e0) < 1e-9
-        for _ in range(2):
-            psi = psi.evolve(mpo, 160.0)
+        psi = psi.evolve(mpo, 160.0)
+        if unit == 0:
+            # the second step of the first realisation also runs through the oracle, from the same tensors: configs[3]
+            # at its full size against the CPU restatement (occupations, <H>, integer bookkeeping, solve count)
+            ost = orc.MpsState(psi.to_arrays(), [q.copy() for q in psi.qn], psi.qnidx, psi.qntot.copy(), psi.to_right,
+                               [np.array(b.sigmaqn) for b in model.basis], complex(psi.coeff))
+            w_host = [mpo[i] for i in range(len(mpo))]
+            ost = orc.tdvp_ps_step(ost, w_host, 160.0)
+        psi = psi.evolve(mpo, 160.0)
+        if unit == 0:
+            occ_orc = np.array([orc.expectation(ost.sites, [m[i] for i in range(len(m))]).real
+                                for m in model.mpos["e_occupations"]])
+            assert np.abs(np.asarray(psi.e_occupations) - occ_orc).max() < 1e-8
+            assert abs(psi.expectation(mpo) - orc.expectation(ost.sites, w_host)) < 1e-8
+            assert list(psi.bond_dims) == list(ost.bond_dims) and psi.qnidx == ost.qnidx and psi.to_right == ost.to_right
+            for qa, qb in zip(psi.qn, ost.qn):
+                assert np.array_equal(np.sort(np.asarray(qa).ravel()), np.sort(np.asarray(qb).ravel()))
+            assert psi.evolve_config.stat["nobs"] == len(ost.krylov_dims)
+            ov = orc.mps_dot([x.conj() for x in ost.sites], psi.to_arrays())
+            assert abs(abs(ov) - 1.0) < 1e-8, abs(ov)
         occ = np.asarray(psi.e_occupations)
         assert abs(psi.mp_norm - 1) < 1e-12
         assert abs(occ.sum() - 1) < 1e-9 and occ.min() > -1e-12
