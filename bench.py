@@ -59,7 +59,7 @@ def _roctx():
 DISORDER_AU = 50.0 * 4.556335e-6   # static diagonal disorder of the trajectories beyond the first: sigma = 50 cm^-1
 
 
-def build_workload(nmol, pdim, bond_dim, seed, init, unit=0, state_file=None):
+def build_workload(nmol, pdim, bond_dim, seed, init, unit=0, state_file=None, scheme="tdvp_ps"):
     from renormalizer_amd import (HolsteinModel, Phonon, Mol, Quantity, Mpo, CompressConfig, CompressCriteria,
                                   EvolveConfig, EvolveMethod)
     from renormalizer_amd.mps.mps import Mps
@@ -91,7 +91,7 @@ def build_workload(nmol, pdim, bond_dim, seed, init, unit=0, state_file=None):
     if state_file and not os.path.exists(state_file):
         mps.dump(state_file)
     mps.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=bond_dim)
-    mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
+    mps.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps2 if scheme == "tdvp_ps2" else EvolveMethod.tdvp_ps)
     return model, mpo, mps
 
 
@@ -142,6 +142,10 @@ def main():
     ap.add_argument("--bond-dim", type=int, default=256)
     ap.add_argument("--dt", type=float, default=10.0)
     ap.add_argument("--init", default="physical", choices=["physical", "random"])
+    ap.add_argument("--scheme", default="tdvp_ps", choices=["tdvp_ps", "tdvp_ps2"],
+                    help="tdvp_ps = the headline (one-site projector splitting, block QR per site); tdvp_ps2 = two-site "
+                         "TDVP on the same chain: every bond is truncated through the blocked one-sided Jacobi SVD "
+                         "(mps/mps.py:1406-1517) - the profile of that kernel at the headline bond size")
     ap.add_argument("--traj-per-gpu", type=int, default=1,
                     help="independent trajectories sharing each GPU (threads with their own stream); 1 = headline")
     ap.add_argument("--cpu-updates", type=int, default=9, help="site updates in the CPU baseline sample (0 = skip)")
@@ -195,7 +199,8 @@ def main():
             use_engine(engines[t])
             model, mpo, mps = build_workload(args.nmol, args.pdim, args.bond_dim, seed=1234 + rank * T + t,
                                              init=args.init, unit=rank * T + t,
-                                             state_file=args.state_file if (T == 1 and world == 1) else None)
+                                             state_file=args.state_file if (T == 1 and world == 1) else None,
+                                             scheme=args.scheme)
             for _ in range(args.warmup):
                 mps = mps.evolve(mpo, args.dt)
             engines[t].prof_reset()
@@ -299,6 +304,16 @@ def main():
                             "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                             "timed_calls": qq["launches"], "avg_call_ms": qq["ms"] / max(1, qq["launches"]),
                             "alg_flops_per_call": qq["flops"] / max(1, qq["launches"])})
+        ss = prof.get("block_svd", {"ms": 0})
+        if ss["ms"] > 0:
+            gbs = ss["bytes"] / (ss["ms"] * 1e-3) / 1e9
+            classes.append({"kernel": "block SVD (batched one-sided Jacobi, whole mpse_block_svd calls: gather, sweeps, "
+                                      "Householder completion, scatter)", "bound": "hbm (L2-resident column pairs)",
+                            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "achieved_tflops": ss["flops"] / (ss["ms"] * 1e-3) / 1e12,
+                            "timed_calls": ss["launches"], "avg_call_ms": ss["ms"] / max(1, ss["launches"]),
+                            "sweeps_per_call": ss["sweeps"] / max(1, ss["launches"]),
+                            "note": "bytes / flops count every column pair of every sweep (upper bound: converged pairs are not rotated)"})
         for nm, what in (("c128xf64", "small products with a real second operand"), ("f64xc128", "MPO step")):
             v = prof[nm]
             if v["ms"] > 0:
@@ -307,9 +322,12 @@ def main():
                                 "frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "timed_launches": v["launches"],
                                 "avg_launch_ms": v["ms"] / max(1, v["launches"])})
         out = {
-            "metric": "TDVP-PS sweep site-updates/sec at (Nsite=%d, Dbond=%d, dphys=2/%d)" % (nsite, args.bond_dim, args.pdim),
-            "value": world * T * args.steps * 2 * nsite / elapsed,
-            "unit": "site-updates/s",
+            "metric": ("TDVP-PS sweep site-updates/sec at (Nsite=%d, Dbond=%d, dphys=2/%d)" if args.scheme == "tdvp_ps" else
+                       "TDVP-PS2 (two-site) sweep bond-updates/sec at (Nsite=%d, Dbond=%d, dphys=2/%d)")
+                      % (nsite, args.bond_dim, args.pdim),
+            # tdvp_ps: 2 N one-site forward solves per evolve; tdvp_ps2: 2 (N - 1) two-site solves, each followed by the block SVD
+            "value": world * T * args.steps * (2 * nsite if args.scheme == "tdvp_ps" else 2 * (nsite - 1)) / elapsed,
+            "unit": "site-updates/s" if args.scheme == "tdvp_ps" else "bond-updates/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,

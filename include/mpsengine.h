@@ -71,6 +71,10 @@ int mpse_device_info(mpse_ctx* ctx, char* name, size_t name_len, int* n_cu, void
  * variant (0-3) actually multiplied - with structural-zero skipping fewer than the dense count; the MFMA work issued
  * is ktiles x 65536 MACs x {2, 4, 4, 6} real flops (complex x complex uses three real products per complex one). */
 int mpse_prof_get_ktiles(mpse_ctx* ctx, int variant, int64_t* ktiles);
+/* variant 6 of mpse_prof_get = whole batched mpse_block_svd[_full] calls (one-sided Jacobi): total_bytes / total_flops are
+ * the traffic and the arithmetic of sweeps x all column pairs (an upper bound: converged pairs are not rotated);
+ * mpse_prof_get_svd_sweeps: Jacobi sweeps summed over the timed calls. */
+int mpse_prof_get_svd_sweeps(mpse_ctx* ctx, int64_t* sweeps);
 int mpse_prof_enable(mpse_ctx* ctx, int on);
 int mpse_prof_reset(mpse_ctx* ctx);
 int mpse_prof_get(mpse_ctx* ctx, int variant, double* total_ms, double* total_flops, double* total_bytes,

@@ -104,7 +104,8 @@ void prof_drain(mpse_ctx* ctx) {
 }
 
 bool prof_begin(mpse_ctx* ctx, int variant, double flops, double bytes, mpse_ctx::ProfRec* rec) {
-  if (!ctx->prof_on || (ctx->prof_counter++ % ctx->prof_stride != 0)) return false;
+  // (whole block-SVD calls, variant 6, last milliseconds and are few: every one of them is timed)
+  if (!ctx->prof_on || (variant != 6 && ctx->prof_counter++ % ctx->prof_stride != 0)) return false;
   auto get_event = [&](hipEvent_t* e) {
     if (!ctx->prof_free_events.empty()) {
       *e = ctx->prof_free_events.back();
@@ -192,6 +193,7 @@ int mpse_prof_reset(mpse_ctx* ctx) {
     ctx->prof_ms[i] = ctx->prof_flops[i] = ctx->prof_bytes[i] = 0;
     ctx->prof_launches[i] = 0;
   }
+  ctx->prof_svd_sweeps = 0;
   if (ctx->prof_ktiles) {
     MPSE_HIP(ctx, hipMemsetAsync(ctx->prof_ktiles, 0, 4 * sizeof(unsigned long long), ctx->stream));
     MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -208,6 +210,12 @@ int mpse_prof_get_ktiles(mpse_ctx* ctx, int variant, int64_t* ktiles) {
   MPSE_HIP(ctx, hipMemcpyAsync(v, ctx->prof_ktiles, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *ktiles = (int64_t)v[variant];
+  return MPSE_OK;
+}
+
+int mpse_prof_get_svd_sweeps(mpse_ctx* ctx, int64_t* sweeps) {
+  if (!ctx || !sweeps) return MPSE_ERR_ARG;
+  *sweeps = ctx->prof_svd_sweeps;
   return MPSE_OK;
 }
 

@@ -663,6 +663,10 @@ int block_svd_batched(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t nco
     blks.push_back(B);
   }
   const int nblk = (int)blks.size();
+  // whole-call timing for bench.py (variant 6): the algorithmic bytes depend on the sweep count, filled in below
+  mpse_ctx::ProfRec srec;
+  const bool spt = prof_begin(ctx, 6, 0.0, 0.0, &srec);
+  int sweeps_done = 0;
   MPSE_TRY(mpse_memset_zero(ctx, U, size_t(nrow * KU) * es));
   MPSE_TRY(mpse_memset_zero(ctx, Vt, size_t(KV * ncol) * es));
   const int64_t nri = row_off[nblocks], nci = col_off[nblocks];
@@ -719,6 +723,7 @@ int block_svd_batched(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t nco
       }
       all = true;
       for (int b = 0; b < nblk; ++b) all = all && hdone[b];
+      ++sweeps_done;
     }
     if (!all) return mpse_fail(ctx, MPSE_ERR_NOCONV, "block_svd: Jacobi did not converge within 60 sweeps");
   }
@@ -756,6 +761,22 @@ int block_svd_batched(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t nco
     hipLaunchKernelGGL((k_scatter_null_b<CPLX>), dim3(gx, nblk), dim3(256), 0, ctx->stream, (double*)U, (double*)Vt,
                        (const double*)Q.as<double>(), (long long)KU, (long long)ncol, drows, dcols, dblk);
   MPSE_HIP(ctx, hipGetLastError());
+  if (spt) {
+    // one sweep = nn (nn - 1) / 2 pairs; a pair reads its two columns of A (Gram entries), reads and writes them again
+    // (rotation), and does the same on the nn-row columns of V: 3 passes over 2 (mm + nn) elements.  Rotations that are
+    // skipped (converged pairs, null columns) make the real traffic smaller: an upper bound, like the flops
+    // (dots 3 x 8 + rotation 2 x 12 real flops per complex row pair).
+    double bytes = 0.0, flops = 0.0;
+    for (const SvdBlk& B : blks) {
+      const double pairs = 0.5 * B.nn * (B.nn - 1.0) * sweeps_done, rows = double(B.mm) + B.nn;
+      bytes += pairs * 3.0 * 2.0 * rows * double(es);
+      flops += pairs * rows * (CPLX ? 48.0 : 12.0);
+    }
+    srec.bytes = bytes;
+    srec.flops = flops;
+    ctx->prof_svd_sweeps += sweeps_done;
+    prof_end(ctx, srec);
+  }
   (void)E;
   return MPSE_OK;
 }

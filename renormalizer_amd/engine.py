@@ -89,6 +89,7 @@ _SIGNATURES = {
     "mpse_prof_reset": [C.c_void_p],
     "mpse_prof_get": [C.c_void_p, C.c_int, _dblp, _dblp, _dblp, C.POINTER(C.c_int64)],
     "mpse_prof_get_ktiles": [C.c_void_p, C.c_int, C.POINTER(C.c_int64)],
+    "mpse_prof_get_svd_sweeps": [C.c_void_p, C.POINTER(C.c_int64)],
     "mpse_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
     "mpse_free": [C.c_void_p, C.c_void_p],
     "mpse_pool_trim": [C.c_void_p],
@@ -395,7 +396,7 @@ class Engine:
 
     def prof_get(self):
         """{variant: dict(ms, flops, bytes, launches)} for the contraction kernel variants."""
-        names = {0: "f64xf64", 1: "c128xf64", 2: "f64xc128", 3: "c128xc128", 4: "lanczos_vec", 5: "block_qr"}
+        names = {0: "f64xf64", 1: "c128xf64", 2: "f64xc128", 3: "c128xc128", 4: "lanczos_vec", 5: "block_qr", 6: "block_svd"}
         issued_per_mac = {0: 2.0, 1: 4.0, 2: 4.0, 3: 6.0}     # real flops the MFMA units execute per multiply-add
         out = {}
         for v, nm in names.items():
@@ -407,6 +408,9 @@ class Engine:
                 self._check(self.lib.mpse_prof_get_ktiles(self.ctx, v, C.byref(kt)))
                 out[nm]["ktiles"] = kt.value
                 out[nm]["issued_flops"] = kt.value * 65536.0 * issued_per_mac[v]
+        sw = C.c_int64()
+        self._check(self.lib.mpse_prof_get_svd_sweeps(self.ctx, C.byref(sw)))
+        out["block_svd"]["sweeps"] = sw.value
         return out
 
     # -- tensor factories
