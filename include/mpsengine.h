@@ -238,6 +238,14 @@ typedef struct {
 
 int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, void* out);
 
+/* Optional: tells the engine the values of a real MPO site W (wl, d, d, wr) that lives at W_dev, from a host copy
+ * (row major, the same numbers).  The engine keeps the block structure W[b, :, :, f] (which channel pairs are non-zero,
+ * which are the identity) and, for large one-site centres on that site, absorbs the MPO step of mpse_heff_apply /
+ * mpse_expm_lanczos / mpse_davidson into the operands of the two large products instead of running it as a step of
+ * its own (same result: the reference's single expression mps/hop_expr.py:75-79).  The contents of W_dev must not
+ * change while the hint stands; mpse_free(W_dev) or a call with W_host == NULL drops it.  No device work. */
+int mpse_mpo_site_hint(mpse_ctx* ctx, const void* W_dev, const double* W_host_f64, int64_t wl, int64_t d, int64_t wr);
+
 /* Two-layer effective Hamiltonian of the (H - omega)^2 functional, replaces the twolayer=True closures of
  * mps/hop_expr.py:24-52 (1-site abcd,befg,cfhi,jgik,aej->dhk ; 2-site abcd,befg,cfhi,gjkl,ikmn,olnp,aejo->dhmp).
  *   L (Dl, wl, wl, Dl), R (Dr, wr, wr, Dr); W0 / W1 serve both layers; no ancilla; nsite in {1, 2}; the unit-channel

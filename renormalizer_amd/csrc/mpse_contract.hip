@@ -1,6 +1,8 @@
 // Hot-path contractions: environment update and effective-Hamiltonian matvec.
 // The index algebra lives in mpse_plans.h (a list of strided-GEMM steps); this file
 // executes a plan on the device with the FP64-MFMA contraction kernel.
+#include <deque>
+
 #include "mpse_internal.h"
 #include "mpse_plans.h"
 
@@ -55,53 +57,6 @@ __global__ __launch_bounds__(256) void k_unit_deviation(const double* env, int D
     }
     __syncthreads();
   }
-}
-
-// ---- MPO step of the masked one-site chain (mpse_plans.h: K_WSTEP)
-constexpr int WS_MAXE = 128;   // most (b, e) pairs feeding one (d, f): wl * d, checked on the host
-
-struct WsEntry {
-  int be;        // b * d + e
-  int pad;
-  double val;
-};
-
-// sparse form of the MPO site: for every (d, f) the list of (b, e) with W[b, d, e, f] != 0, stored compactly:
-// cnt[o], ptr[o] (o = d * wr + f) and ent[ptr[o] ..]; cnt[d * wr] = total number of entries.  One workgroup.
-__global__ __launch_bounds__(256) void k_w_csr(const double* __restrict__ W, int wl, int d, int wr, int* __restrict__ cnt,
-                                               WsEntry* __restrict__ ent) {
-  __shared__ int s_cnt[1024], s_ptr[1025];
-  const int no = d * wr;
-  for (int o = threadIdx.x; o < no; o += blockDim.x) {
-    const int dd = o / wr, f = o - dd * wr;
-    int c = 0;
-    for (int b = 0; b < wl; ++b)
-      for (int e = 0; e < d; ++e)
-        if (W[(((long long)b * d + dd) * d + e) * wr + f] != 0.0) ++c;
-    s_cnt[o] = c;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int o = 0; o < no; ++o) {
-      s_ptr[o] = acc;
-      acc += s_cnt[o];
-    }
-    s_ptr[no] = acc;
-  }
-  __syncthreads();
-  for (int o = threadIdx.x; o < no; o += blockDim.x) {
-    const int dd = o / wr, f = o - dd * wr;
-    int c = s_ptr[o];
-    for (int b = 0; b < wl; ++b)
-      for (int e = 0; e < d; ++e) {
-        const double v = W[(((long long)b * d + dd) * d + e) * wr + f];
-        if (v != 0.0) ent[c++] = WsEntry{b * d + e, 0, v};
-      }
-    cnt[o] = s_cnt[o];
-    cnt[no + 1 + o] = s_ptr[o];
-  }
-  if (threadIdx.x == 0) cnt[no] = s_ptr[no];
 }
 
 // ---- MPO step of a small site (wl d <= 16 inputs, d wr <= 16 outputs per bond state and trailing index: the d = 2
@@ -163,171 +118,107 @@ __global__ __launch_bounds__(256) void k_wsmall(const WsmArgs g) {
   }
 }
 
-struct WsArgs {
-  const double* T1;
-  const double* X0;       // centre tensor (unit channel of the left environment), or null
-  double* T2;
-  const int* cnt;
-  const WsEntry* ent;
-  const unsigned char* m1_lo;   // tile flags of T1's producers: channels below / above the unit channel
-  const unsigned char* m1_hi;
-  unsigned char* m2_lo;         // tile masks of T2 for its consumers: f below / above the right unit channel
-  unsigned char* m2_hi;
-  int Da, d, wl, wr, Dk;
-  int l_unit, r_unit;
-  int t1_tiles_n, nkw_lo, nkw_hi;
+// ---- elementwise MPO step of the folded one-site matvec (mpse_plans.h: K_WMIX):
+//   dst_j[a, dd, k] = sum_terms sum_e W[b_t, dd, e, f_t] src_t[a, e, k]
+// A thread owns one (a, k) and WM_CHUNK consecutive dd (lanes run along k: every load / store of a wave is 1 KB
+// contiguous; the chunks of one (a, k) sit in neighbouring waves and share their loads in L2); it reads only the
+// columns e its rows touch ([e_lo, e_hi) per term and chunk, from the host copy of the site: a tridiagonal block
+// costs six loads per chunk, an identity block is a plain add).  Non-identity blocks sit in LDS as dense d x d matrices.
+struct WmixTermDev {
+  const double* src;
+  long long s_a, s_d;
+  int b, f, ident, slot;
+  unsigned char e_lo[WM_MAXCHUNKS], e_hi[WM_MAXCHUNKS];
+};
+struct WmixDstDev {
+  double* dst;
+  long long s_a, s_d;
+  int nterm, pad;
+  WmixTermDev term[WM_MAXTERM];
+};
+struct WmixArgs {
+  WmixDstDev dst[WM_MAXDST];
+  const double* W;
+  int ndst, Da, d, wr, Dk, nchunk, nslot;
   const int* skip;
 };
 
-// One workgroup per (64 rows of the (a, d) index = 64 / d values of a, 64 consecutive k); lane = k.
-//   1. the producers' tile flags of all input rows (b, a, e) of the tile and the sparse MPO site go to LDS;
-//   2. which f receive anything in this tile (flags only) -> consumer masks;
-//   3. per a: the flagged input rows X[b][a][e][k0 .. k0 + 63] are staged in LDS, eight independent coalesced 1 KB
-//      loads in flight per wave (the kernel must be bandwidth bound, not a chain of dependent loads), then every
-//      wave forms its share of the d x wr output rows from LDS and stores them (1 KB each).
-// A flagged f is stored for ALL rows of the tile, zeros included, so that a flagged tile is completely defined.
-constexpr int WS_MAXROWS = 96;    // wl * d rows of 64 elements staged per a: 96 KB (complex) of LDS
-constexpr int WS_LDS_ENT = 1024;  // sparse MPO entries kept in LDS (more: read from global memory)
-
 template <bool CPLX>
-__global__ __launch_bounds__(256) void k_wstep(const WsArgs g) {
+__global__ __launch_bounds__(256) void k_wmix(const WmixArgs g) {
   if (g.skip && *g.skip) return;
   constexpr int E = CPLX ? 2 : 1;
-  extern __shared__ double s_x[];                   // [wl * d][64][E]
-  __shared__ unsigned char s_flag[WS_MAXROWS * 64]; // [b * d + e][ai]  (ai = a - a0 < 64 / d)
-  __shared__ WsEntry s_ent[WS_LDS_ENT];
-  __shared__ int s_cnt[1024], s_ptr[1024];
-  __shared__ int s_rows[WS_MAXROWS];
-  __shared__ int s_n;
-  __shared__ unsigned int s_any[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
-  const int k0 = blockIdx.x * 64, k = k0 + lane;
-  const int tm = blockIdx.y;
-  const int d = g.d, wr = g.wr, wl = g.wl;
-  const int na = 64 / d;                          // d divides 64 (checked on the host)
-  const int a0 = tm * na;
-  const int nrow = wl * d, no = d * wr;
-  // ---- 1. flags and sparse MPO site
-  for (int t = tid; t < nrow * na; t += 256) {
-    const int be = t / na, ai = t - be * na;
-    const int b = be / d, e = be - b * d;
-    const int a = a0 + ai;
-    unsigned char f = 0;
-    if (a < g.Da) {
-      if (b == g.l_unit) {
-        f = 1;
-      } else {
-        const bool low = g.l_unit < 0 || b < g.l_unit;
-        const int b0 = low ? 0 : g.l_unit + 1;
-        const long long row = (long long)(b - b0) * g.Da + a;
-        const long long tn = ((long long)e * g.Dk + k0) >> 6;
-        f = (low ? g.m1_lo : g.m1_hi)[(row >> 6) * g.t1_tiles_n + tn];
+  extern __shared__ double s_blk[];               // [slot][dd][e]
+  const int d = g.d, dd2 = d * d;
+  for (int j = 0; j < g.ndst; ++j)
+    for (int t = 0; t < g.dst[j].nterm; ++t) {
+      const WmixTermDev& tm = g.dst[j].term[t];
+      if (tm.ident) continue;
+      for (int r = threadIdx.x; r < dd2; r += 256) {
+        const int x = r / d, e = r - x * d;
+        s_blk[tm.slot * dd2 + r] = g.W[(((long long)tm.b * d + x) * d + e) * g.wr + tm.f];
       }
     }
-    s_flag[be * 64 + ai] = f;
-  }
-  const int nnz = g.cnt[no];
-  const bool ent_lds = nnz <= WS_LDS_ENT;
-  for (int o = tid; o < no; o += 256) {
-    s_cnt[o] = g.cnt[o];
-    s_ptr[o] = g.cnt[no + 1 + o];
-  }
-  if (ent_lds)
-    for (int i = tid; i < nnz; i += 256) s_ent[i] = g.ent[i];
-  const WsEntry* ents = ent_lds ? s_ent : g.ent;
   __syncthreads();
-  // ---- 2. which f receive anything: outputs (ai, dd, f), one per thread and pass
-  unsigned int anyf = 0;
-  for (int t = tid; t < na * d * wr; t += 256) {
-    const int f = t % wr, rest = t / wr;
-    const int dd = rest % d, ai = rest / d;
-    if (a0 + ai >= g.Da) continue;
-    const int o = dd * wr + f, c = s_cnt[o];
-    const WsEntry* en = ents + s_ptr[o];
-    for (int i = 0; i < c; ++i)
-      if (s_flag[en[i].be * 64 + ai]) {
-        anyf |= 1u << f;
-        break;
-      }
-  }
-  for (int o = 32; o > 0; o >>= 1) anyf |= __shfl_xor(anyf, o, 64);
-  if (lane == 0) s_any[wave] = anyf;
-  __syncthreads();
-  anyf = s_any[0] | s_any[1] | s_any[2] | s_any[3];
-  if (tid < wr * 4) {   // consumer masks: one byte per (f, 16 k); this workgroup owns the four bytes of its 64 k
-    const int f = tid >> 2, sub = tid & 3;
-    if (f != g.r_unit) {
-      const bool low = g.r_unit < 0 || f < g.r_unit;
-      const int f0 = low ? 0 : g.r_unit + 1;
-      const long long kt = ((long long)(f - f0) * g.Dk + k0) / 16 + sub;
-      unsigned char* m = low ? g.m2_lo : g.m2_hi;
-      const long long nkw = low ? g.nkw_lo : g.nkw_hi;
-      m[(long long)tm * nkw * 8 + kt] = (anyf >> f) & 1u;
-    }
-  }
-  if (g.r_unit >= 0) anyf |= 1u << g.r_unit;
-  if (anyf == 0) return;
-  // ---- 3. per a: stage flagged rows, then compute
-  for (int ai = 0; ai < na; ++ai) {
-    const int a = a0 + ai;
-    if (a >= g.Da) break;
-    if (tid == 0) s_n = 0;
-    __syncthreads();                                // previous a's rows fully consumed; counter reset
-    if (tid < nrow && s_flag[tid * 64 + ai]) s_rows[atomicAdd(&s_n, 1)] = tid;
-    __syncthreads();
-    const int nr = s_n;
-    for (int base = wave * 8; base < nr; base += 32) {
-      double2 v[8];
-      int bes[8];
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)g.Da * g.nchunk * g.Dk) return;
+  const int k = (int)(idx % g.Dk);
+  const long long rest = idx / g.Dk;
+  const int q = (int)(rest % g.nchunk), a = (int)(rest / g.nchunk);
+  const int x0 = q * WM_CHUNK;
+  for (int j = 0; j < g.ndst; ++j) {
+    const WmixDstDev& D = g.dst[j];
+    double ar[WM_CHUNK], ai[WM_CHUNK];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u;
-        bes[u] = idx < nr ? s_rows[idx] : -1;
-        v[u] = make_double2(0.0, 0.0);
-        if (bes[u] >= 0) {
-          const int b = bes[u] / d, e = bes[u] - b * d;
-          const double* src = (b == g.l_unit) ? g.X0 + (((long long)a * d + e) * g.Dk + k) * E
-                                              : g.T1 + ((((long long)b * g.Da + a) * d + e) * g.Dk + k) * E;
-          if (CPLX)
-            v[u] = *reinterpret_cast<const double2*>(src);
-          else
-            v[u].x = src[0];
-        }
-      }
+    for (int i = 0; i < WM_CHUNK; ++i) ar[i] = 0.0, ai[i] = 0.0;
+    for (int t = 0; t < D.nterm; ++t) {
+      const WmixTermDev& tm = D.term[t];
+      const double* src = tm.src + ((long long)a * tm.s_a + k) * E;
+      if (tm.ident) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (bes[u] >= 0) {
-          if (CPLX)
-            reinterpret_cast<double2*>(s_x)[bes[u] * 64 + lane] = v[u];
-          else
-            s_x[bes[u] * 64 + lane] = v[u].x;
-        }
-    }
-    __syncthreads();
-    for (int t = wave; t < no; t += 4) {
-      const int f = t % wr;
-      if (!((anyf >> f) & 1u)) continue;
-      const int dd = t / wr;
-      const int c = s_cnt[t];
-      const WsEntry* en = ents + s_ptr[t];
-      double xr = 0.0, xi = 0.0;
-      for (int i = 0; i < c; ++i) {
-        const WsEntry w = en[i];
-        if (!s_flag[w.be * 64 + ai]) continue;
-        if (CPLX) {
-          const double2 x = reinterpret_cast<const double2*>(s_x)[w.be * 64 + lane];
-          xr += w.val * x.x;
-          xi += w.val * x.y;
-        } else {
-          xr += w.val * s_x[w.be * 64 + lane];
-        }
+        for (int i = 0; i < WM_CHUNK; ++i)
+          if (x0 + i < d) {
+            const double* p = src + (long long)(x0 + i) * tm.s_d * E;
+            ar[i] += p[0];
+            if constexpr (CPLX) ai[i] += p[1];
+          }
+        continue;
       }
-      double* dst = g.T2 + ((((long long)a * d + dd) * wr + f) * g.Dk + k) * E;
-      if (CPLX)
-        *reinterpret_cast<double2*>(dst) = make_double2(xr, xi);
-      else
-        dst[0] = xr;
+      const double* blk = s_blk + tm.slot * dd2;
+      const int lo = tm.e_lo[q], hi = tm.e_hi[q];
+      for (int e0 = lo; e0 < hi; e0 += 8) {
+        double vr[8], vi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {      // the loads of a batch are issued together
+          vr[u] = 0.0, vi[u] = 0.0;
+          if (e0 + u < hi) {
+            const double* p = src + (long long)(e0 + u) * tm.s_d * E;
+            vr[u] = p[0];
+            if constexpr (CPLX) vi[u] = p[1];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (e0 + u < hi) {
+#pragma unroll
+            for (int i = 0; i < WM_CHUNK; ++i)
+              if (x0 + i < d) {
+                const double w = blk[(x0 + i) * d + e0 + u];
+                ar[i] += w * vr[u];
+                if constexpr (CPLX) ai[i] += w * vi[u];
+              }
+          }
+      }
     }
+    double* dst = D.dst + ((long long)a * D.s_a + k) * E;
+#pragma unroll
+    for (int i = 0; i < WM_CHUNK; ++i)
+      if (x0 + i < d) {
+        double* p = dst + (long long)(x0 + i) * D.s_d * E;
+        if constexpr (CPLX)
+          *reinterpret_cast<double2*>(p) = make_double2(ar[i], ai[i]);
+        else
+          p[0] = ar[i];
+      }
   }
 }
 
@@ -367,9 +258,6 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
     MPSE_TRY(t3.alloc(size_t(p.tmp_elems[2]) * es));
     bufs[B_T3] = t3.p;
   }
-  TmpBuf msk[M_COUNT] = {TmpBuf(ctx), TmpBuf(ctx), TmpBuf(ctx), TmpBuf(ctx)};
-  for (int i = 0; i < M_COUNT; ++i)
-    if (p.mask_bytes[i] > 0) MPSE_TRY(msk[i].alloc(size_t(p.mask_bytes[i]) + 64));
   // MPSE_WSMALL=0: the MPO step of small sites as a batched MFMA product like the large ones
   static const bool wsmall_on = [] {
     const char* e = getenv("MPSE_WSMALL");
@@ -394,67 +282,106 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
       MPSE_HIP(ctx, hipGetLastError());
       continue;
     }
-    if (s.kind == K_WSTEP) {
-      const WStepDesc& w = s.ws;
-      if (w.wl * w.d > WS_MAXROWS || w.wr > 32 || 64 % w.d != 0 || w.d * w.wr > 1024)
-        return mpse_fail(ctx, MPSE_ERR_SHAPE, "masked MPO step: MPO site outside the supported range");
-      // sparse form of the MPO site: built once per Krylov solve (the site does not change), else per call
-      TmpBuf CNT(ctx), ENT(ctx);
-      int* cntp = nullptr;
-      WsEntry* entp = nullptr;
-      if (ctx->occ_cache_on)
-        for (const auto& e : ctx->wcsr_cache)
-          if (e.w == bufs[s.b] && e.wl == w.wl && e.d == w.d && e.wr == w.wr) {
-            cntp = static_cast<int*>(e.cnt);
-            entp = static_cast<WsEntry*>(e.ent);
-          }
-      if (!cntp) {
-        const size_t cb = size_t(2 * w.d * w.wr + 2) * sizeof(int), eb = size_t(w.wl * w.d * w.d * w.wr) * sizeof(WsEntry);
-        if (ctx->occ_cache_on) {
-          void *pc = nullptr, *pe = nullptr;
-          MPSE_TRY(mpse_malloc(ctx, cb, &pc));
-          MPSE_TRY(mpse_malloc(ctx, eb, &pe));
-          ctx->wcsr_cache.push_back({bufs[s.b], w.wl, w.d, w.wr, pc, pe});
-          cntp = static_cast<int*>(pc), entp = static_cast<WsEntry*>(pe);
-        } else {
-          MPSE_TRY(CNT.alloc(cb));
-          MPSE_TRY(ENT.alloc(eb));
-          cntp = CNT.as<int>(), entp = ENT.as<WsEntry>();
-        }
-        // (not subject to the skip flag: a cached table must be complete whenever it is used)
-        hipLaunchKernelGGL(k_w_csr, dim3(1), dim3(256), 0, ctx->stream, (const double*)bufs[s.b], (int)w.wl, (int)w.d,
-                           (int)w.wr, cntp, entp);
-      }
-      WsArgs g;
-      g.T1 = (const double*)bufs[B_T1];
-      g.X0 = (const double*)bufs[s.a];
-      g.T2 = (double*)const_cast<void*>(bufs[s.c]);
-      g.cnt = cntp;
-      g.ent = entp;
-      g.m1_lo = msk[M_T1_LO].as<unsigned char>();
-      g.m1_hi = msk[M_T1_HI].as<unsigned char>();
-      g.m2_lo = msk[M_T2_LO].as<unsigned char>();
-      g.m2_hi = msk[M_T2_HI].as<unsigned char>();
-      g.Da = (int)w.Da, g.d = (int)w.d, g.wl = (int)w.wl, g.wr = (int)w.wr, g.Dk = (int)w.Dk;
-      g.l_unit = (int)w.l_unit, g.r_unit = (int)w.r_unit;
-      g.t1_tiles_n = (int)w.t1_tiles_n, g.nkw_lo = (int)w.nkw_lo, g.nkw_hi = (int)w.nkw_hi;
+    if (s.kind == K_WMIX) {
+      if (!bufs[s.b]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing buffer");
+      WmixArgs g;
+      memset(&g, 0, sizeof(g));
+      g.W = (const double*)bufs[s.b];
+      g.ndst = (int)s.mix.size();
+      g.Da = (int)s.wp_Da, g.d = (int)s.wp_d, g.wr = (int)s.wp_wr, g.Dk = (int)s.wp_Dk;
+      g.nchunk = (g.d + WM_CHUNK - 1) / WM_CHUNK;
       g.skip = ctx->skip_flag;
-      const dim3 grid((unsigned)(w.Dk / 64), (unsigned)((w.Da * w.d + 63) / 64));
-      const size_t lds = size_t(w.wl * w.d) * 64 * dtype_size(dtype);
-      static const bool lds_attr = [] {   // beyond the default 64 KB of dynamic LDS (the CU has 160 KB)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wstep<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  WS_MAXROWS * 64 * 16);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wstep<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  WS_MAXROWS * 64 * 16);
-        (void)hipGetLastError();
-        return true;
-      }();
-      (void)lds_attr;
+      int nslot = 0;
+      for (int j = 0; j < g.ndst; ++j) {
+        const WMixDst& q = s.mix[j];
+        if (!bufs[q.dst]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing buffer");
+        g.dst[j].dst = (double*)((char*)const_cast<void*>(bufs[q.dst]) + size_t(q.dst_off) * es);
+        g.dst[j].s_a = q.s_a, g.dst[j].s_d = q.s_d, g.dst[j].nterm = q.nterm;
+        for (int t = 0; t < q.nterm; ++t) {
+          const WMixTerm& tm = q.term[t];
+          if (!bufs[tm.src]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing buffer");
+          WmixTermDev& o = g.dst[j].term[t];
+          o.src = (const double*)((const char*)bufs[tm.src] + size_t(tm.src_off) * es);
+          o.s_a = tm.s_a, o.s_d = tm.s_d, o.b = tm.b, o.f = tm.f, o.ident = tm.ident ? 1 : 0;
+          o.slot = tm.ident ? 0 : nslot++;
+          memcpy(o.e_lo, tm.e_lo, sizeof(o.e_lo));
+          memcpy(o.e_hi, tm.e_hi, sizeof(o.e_hi));
+        }
+      }
+      g.nslot = nslot;
+      const size_t lds = size_t(nslot > 0 ? nslot : 1) * g.d * g.d * sizeof(double);
+      if (lds > 64 * 1024) return mpse_fail(ctx, MPSE_ERR_SHAPE, "plan: MPO blocks of the elementwise step exceed the LDS");
+      const long long total = (long long)s.wp_Da * g.nchunk * s.wp_Dk;
+      const dim3 grid((unsigned)((total + 255) / 256));
       if (dtype == MPSE_C128)
-        hipLaunchKernelGGL((k_wstep<true>), grid, dim3(256), lds, ctx->stream, g);
+        hipLaunchKernelGGL((k_wmix<true>), grid, dim3(256), lds, ctx->stream, g);
       else
-        hipLaunchKernelGGL((k_wstep<false>), grid, dim3(256), lds, ctx->stream, g);
+        hipLaunchKernelGGL((k_wmix<false>), grid, dim3(256), lds, ctx->stream, g);
       MPSE_HIP(ctx, hipGetLastError());
+      continue;
+    }
+    if (s.kind == K_GGEMM) {
+      GroupedDesc gd;
+      gd.dta = s.dta, gd.dtb = s.dtb;
+      gd.ma = s.ma, gd.ka = s.ka, gd.kb = s.kb, gd.nb = s.nb, gd.mc = s.mc, gd.nc = s.nc;
+      gd.ngrp = (int)s.groups.size();
+      // occupancy of the operands: the environments by a scan that the solve keeps (one scan serves every channel),
+      // the centre tensor by the structural mask of the solve - pushed through the MPO block for prepared operands
+      TmpBuf MA(ctx), MB(ctx);
+      const unsigned char *fa = nullptr, *fb = nullptr;
+      bool stable = true;
+      if (s.scan_a.on && bufs[s.scan_a.buf]) {
+        bool st = false;
+        MPSE_TRY(occ_mask_get(ctx, (const char*)bufs[s.scan_a.buf] + size_t(s.scan_a.off) * dtype_size(s.scan_a.dt),
+                              s.scan_a.dt, s.scan_a.r, s.scan_a.k, MA, &fa, &gd.am_pitch, &st));
+        stable = stable && st;
+      }
+      if (s.scan_b.on && bufs[s.scan_b.buf]) {
+        bool st = false;
+        MPSE_TRY(occ_mask_get(ctx, (const char*)bufs[s.scan_b.buf] + size_t(s.scan_b.off) * dtype_size(s.scan_b.dt),
+                              s.scan_b.dt, s.scan_b.r, s.scan_b.k, MB, &fb, &gd.bm_pitch, &st));
+        stable = stable && st;
+      }
+      // structural mask of the centre (B_C) as operand B: K = its left bond, columns = (e, k)
+      const unsigned char* cm = nullptr;
+      int cm_pitch = 0;
+      {
+        const char* pc = (const char*)bufs[B_C];
+        const int64_t K = s.kb.ext, N = s.nb.ext;
+        const int64_t nkw = ((K + 15) / 16 + 7) / 8, ntn = (N + 63) / 64;
+        if (ctx->cmask.ptr && pc && pc >= ctx->cmask.lo && pc < ctx->cmask.hi && ctx->cmask.bytes == ntn * nkw * 8) {
+          cm = static_cast<const unsigned char*>(ctx->cmask.ptr);
+          cm_pitch = (int)(nkw * 8);
+        }
+      }
+      for (int i = 0; i < gd.ngrp; ++i) {
+        const GGroupPlan& g = s.groups[i];
+        GroupedGrp& o = gd.grp[i];
+        if (!bufs[g.cbuf]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing buffer");
+        o.C = (char*)const_cast<void*>(bufs[g.cbuf]) + size_t(g.c_off) * es;
+        o.nseg = g.nseg;
+        o.beta = g.beta;
+        for (int q = 0; q < g.nseg; ++q) {
+          const GSegPlan& sg = g.seg[q];
+          if (!bufs[sg.abuf] || !bufs[sg.bbuf]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing buffer");
+          o.seg[q].A = (const char*)bufs[sg.abuf] + size_t(sg.a_off) * dtype_size(s.dta);
+          o.seg[q].B = (const char*)bufs[sg.bbuf] + size_t(sg.b_off) * dtype_size(s.dtb);
+          if (fa && sg.am_row0 >= 0) o.seg[q].am = fa + size_t(sg.am_row0) * gd.am_pitch;
+          if (sg.bm_kind == BM_SCAN && fb) {
+            o.seg[q].bm = fb + sg.bm_kt0;
+          } else if (sg.bm_kind == BM_CENTRE && cm) {
+            o.seg[q].bm = cm;
+            gd.bm_pitch = cm_pitch;
+          }
+        }
+      }
+      gd.masks_stable = stable;
+      // the last step completes the result: it carries the caller's dot request
+      if (ctx->dot_req.y && &s == &p.steps.back() && gd.ngrp == 1 && s.groups[0].cbuf == B_OUT && s.groups[0].c_off == 0)
+        ctx->dot_now = true;
+      const int st = gemm_grouped(ctx, gd);
+      ctx->dot_now = false;
+      MPSE_TRY(st);
       continue;
     }
     const char* a = (const char*)bufs[s.a] + size_t(s.a_off) * dtype_size(s.dta);
@@ -470,7 +397,7 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
     }
     // the last step completes the result: it takes the caller's dot request along when it is a plain product into
     // the whole of `out`
-    if (ctx->dot_req.y && &s == &p.steps.back() && s.c == B_OUT && s.c_off == 0 && s.batch == 1 && s.cmask_slot < 0)
+    if (ctx->dot_req.y && &s == &p.steps.back() && s.c == B_OUT && s.c_off == 0 && s.batch == 1)
       ctx->dot_now = true;
     if (s.cin >= 0) {
       if (!bufs[s.cin]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing beta source");
@@ -479,9 +406,7 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
       ctx->cin_req.n = s.ncin;
     }
     const int st = gemm_call(ctx, s.dta, s.dtb, s.conja, s.conjb, s.ma, s.ka, s.kb, s.nb, s.mc, s.nc, s.batch, s.sba,
-                             s.sbb, s.sbc, a, b, c, 1.0, s.beta, s.skip_zero,
-                             s.amask_slot >= 0 ? msk[s.amask_slot].p : nullptr,
-                             s.cmask_slot >= 0 ? msk[s.cmask_slot].p : nullptr);
+                             s.sbb, s.sbc, a, b, c, 1.0, s.beta, s.skip_zero);
     // requests the call did not take (degenerate product, error) must not reach a later one
     ctx->cin_req = mpse_ctx::CinReq();
     ctx->dot_now = false;
@@ -495,7 +420,13 @@ extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, con
   MPSE_BIND(ctx);
   if (dtype != MPSE_C128 && (h->l_dtype == MPSE_C128 || h->r_dtype == MPSE_C128 || h->w_dtype == MPSE_C128))
     return mpse_fail(ctx, MPSE_ERR_ARG, "heff_apply: real centre with complex operator parts");
-  Plan p = plan_heff(dtype, *h);
+  std::shared_ptr<void> wi_keep;     // (the map is also touched by mpse_free, possibly from another thread)
+  if (h->nsite == 1 && h->W0) {
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    auto it = ctx->wsite_info.find(h->W0);
+    if (it != ctx->wsite_info.end()) wi_keep = it->second;
+  }
+  Plan p = plan_heff(dtype, *h, static_cast<const WSiteInfo*>(wi_keep.get()));
   const void* bufs[B_COUNT] = {nullptr};
   bufs[B_L] = h->L;
   bufs[B_R] = h->R;
@@ -504,6 +435,21 @@ extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, con
   bufs[B_C] = C;
   bufs[B_OUT] = out;
   return run_plan(ctx, dtype, p, bufs);
+}
+
+extern "C" int mpse_mpo_site_hint(mpse_ctx* ctx, const void* W_dev, const double* W_host, int64_t wl, int64_t d,
+                                  int64_t wr) {
+  if (!ctx || !W_dev) return MPSE_ERR_ARG;
+  if (!W_host) {
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    ctx->wsite_info.erase(W_dev);
+    return MPSE_OK;
+  }
+  if (wl <= 0 || d <= 0 || wr <= 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpo_site_hint: empty MPO site");
+  std::shared_ptr<void> info = std::make_shared<WSiteInfo>(analyse_mpo_site(W_host, wl, d, wr));
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
+  ctx->wsite_info[W_dev] = info;
+  return MPSE_OK;
 }
 
 extern "C" int mpse_env_update(mpse_ctx* ctx, int dtype, int domain, const mpse_dims* dims, const void* env,

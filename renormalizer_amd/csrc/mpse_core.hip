@@ -319,9 +319,6 @@ int mpse_ctx_destroy(mpse_ctx* ctx) {
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->stage) (void)hipHostFree(ctx->stage);
-  for (auto& kv : ctx->qr_graphs) (void)hipGraphExecDestroy(kv.second);
-  for (void* b : ctx->qr_buf)
-    if (b) (void)hipFree(b);
   if (ctx->dscratch) (void)hipFree(ctx->dscratch);
   if (ctx->prof_ktiles) (void)hipFree(ctx->prof_ktiles);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -394,6 +391,7 @@ int mpse_free(mpse_ctx* ctx, void* dptr) {
   std::lock_guard<std::mutex> lock(ctx->pool_mu);
   auto it = ctx->live.find(dptr);
   if (it == ctx->live.end()) return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_free: unknown pointer %p", dptr);
+  if (!ctx->wsite_info.empty()) ctx->wsite_info.erase(dptr);   // a described MPO site (mpse_mpo_site_hint) goes with its buffer
   if (ctx->defer_hold) {   // a recorded call may still read this block: released after the replay
     ctx->defer_frees.push_back(dptr);
     return MPSE_OK;

@@ -42,6 +42,29 @@ struct IdxMap {
   int ext, lo;
 };
 
+// Grouped launch (folded one-site matvec, mpse_plans.h): the tile rows of the launch are divided among up to GMAX_GRP
+// groups of equal height; a group has its own result and up to GMAX_SEG (A, B) operand pairs whose products are summed
+// - the K loop runs over the segments one after the other.  All pairs share the index maps of GemmArgs (M = rows of
+// one group, K = length of one segment).  am / bm: byte flags of the 64 x 16 tiles of the segment's operands (row of
+// tile t at t * pitch), null = all occupied.
+constexpr int GMAX_GRP = 8, GMAX_SEG = 4;
+struct GSeg {
+  const double* A;
+  const double* B;
+  const unsigned char* am;
+  const unsigned char* bm;
+};
+struct GGrp {
+  GSeg seg[GMAX_SEG];
+  double* C;
+  int nseg;
+  int use_beta;
+};
+struct GemmGroups {
+  GGrp g[GMAX_GRP];
+  int ngrp, tiles_m_grp, nkt_seg, am_pitch, bm_pitch;
+};
+
 struct GemmArgs {
   const double* A;
   const double* B;
@@ -58,7 +81,6 @@ struct GemmArgs {
   int skew;            // tile column = (column of the linear index + tile row) mod tiles_n
   int die_group;       // 0: off, 1: a die owns whole tile rows, 2: whole tile columns (see the kernel)
   int slice_fast;      // split-K, batch == 1: launch position = tile * ksplit + slice
-  int kbal;            // split-K: slices hold equal numbers of occupied K tiles instead of equal K ranges
   const int* perm;     // optional: linear tile index by launch position, tiles with the most K tiles first
   int ksplit;          // number of K slices (1 = none)
   int kt_per_split;    // k-tiles per slice
@@ -72,8 +94,6 @@ struct GemmArgs {
   int nkw;
   unsigned long long* kt_counter;   // profiling only: every workgroup adds the number of K tiles it multiplied
   const int* skip;                  // optional device flag: non-zero -> the launch does nothing (mpse_ctx::skip_flag)
-  unsigned char* cmask;             // optional: flag per output tile (1 = K tiles were multiplied into it); tiles
-                                    // without any are NOT stored - the consumer reads the flags (masked chain)
   // optional (batch == 1): the kernel that stores the final values of C also accumulates sum conj(C) . y over its
   // share of C (y laid out like C) and stores one (re, im) partial per workgroup at dot_part - the Lanczos
   // coefficient alpha_j = <H v_j, v_j> without a pass of its own over the two vectors
@@ -84,6 +104,7 @@ struct GemmArgs {
   const double* Cin;
   IdxMap mCin, nCin;
   unsigned long long* trace;        // debug timeline (mpse_ctx::gemm_trace), null normally
+  GemmGroups gg;                    // GRP instantiations only
 };
 
 
@@ -113,8 +134,10 @@ constexpr int BM = 64, BN = 64, BK = 16, LDK = BK + 1;   // BM x BN: granularity
 // WI: 16-row blocks of the output tile per wave.  2: four waves of 32 x 32 (the default).  1 (WS = 2 only): eight
 // waves of 16 x 32 on the same 64 x 64 tile - for launches that put ONE workgroup on a compute unit, so that every
 // SIMD still has two waves to overlap fragment reads, staging and address arithmetic with the other's MFMAs.
-template <bool CA, bool CB, bool KS, int WS, int WI = 2>
+// GRP: grouped launch (GemmGroups; batch == 1, unsplit, KS, K a multiple of BK, M a multiple of the tile height).
+template <bool CA, bool CB, bool KS, int WS, int WI = 2, bool GRP = false>
 __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 : ((CA && CB) ? 2 : 3)) void k_gemm(const GemmArgs g) {
+  static_assert(!GRP || (KS && WS == 2), "grouped launches use the single-level 64 x 64 kernel");
   constexpr int TBM = 32 * WS, TBN = 32 * WS, NT = 64 * WS * WS * (2 / WI);
   static_assert(WI == 2 || (WI == 1 && WS == 2), "eight-wave form only for 64 x 64 tiles");
   constexpr int LD = WS == 2 ? 80 : 48;          // [k][i] panel rows; LD mod 32 == 16 keeps the fragment reads conflict free
@@ -173,9 +196,16 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
   // sectors are column ranges) some dies got three times the K tiles of others (tools/gemm_balance.py).
   if (g.skew && !g.perm && !g.die_group) tn = (tn + tm) % g.tiles_n;
 
-  const double* A = g.A + (long long)b * g.sbA * EA;
-  const double* B = g.B + (long long)b * g.sbB * EB;
-  double* C = g.C + (long long)b * g.sbC * EC;
+  // grouped launch: the tile row picks the group, the rest of the kernel sees the group's own rows
+  int grp = 0;
+  if constexpr (GRP) {
+    grp = tm / g.gg.tiles_m_grp;
+    tm -= grp * g.gg.tiles_m_grp;
+  }
+  const GGrp& gp = g.gg.g[grp];          // (kernel-argument memory; touched by GRP instantiations only)
+  const double* A = GRP ? gp.seg[0].A : g.A + (long long)b * g.sbA * EA;
+  const double* B = GRP ? gp.seg[0].B : g.B + (long long)b * g.sbB * EB;
+  double* C = GRP ? gp.C : g.C + (long long)b * g.sbC * EC;
 
   // ---- per-thread staging coordinates (4 elements of each operand tile)
   int ai[NLD], ak[NLD], bj[NLD], bk[NLD];
@@ -244,9 +274,10 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
       }
     }
   };
-  const int nkt_all = (g.K + BK - 1) / BK;
-  int kt_begin = ks_id * g.kt_per_split;
-  int kt_end = min(nkt_all, kt_begin + g.kt_per_split);
+  const int nkt_seg = GRP ? g.gg.nkt_seg : 0;
+  const int nkt_all = GRP ? gp.nseg * nkt_seg : (g.K + BK - 1) / BK;
+  int kt_begin = GRP ? 0 : ks_id * g.kt_per_split;
+  int kt_end = GRP ? nkt_all : min(nkt_all, kt_begin + g.kt_per_split);
   // fast path (single-level K maps; the launcher guarantees non-negative strides and operand spans below 4 GB):
   // a uniform tile base (scalar registers, recomputed from the tile number) plus one 32-bit byte offset per lane and
   // staged element - the global_load saddr + voffset form: no per-lane 64-bit pointers to keep and to advance
@@ -277,6 +308,20 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
     step_a = (long long)BK * g.kA.s_lo * EA * 8;   // bytes per K tile
     step_b = (long long)BK * g.kB.s_lo * EB * 8;
   }
+  // grouped launch: tile bases of every segment's operands (uniform), selected by the segment a K tile falls into
+  const char* seg_a[GMAX_SEG];
+  const char* seg_b[GMAX_SEG];
+  if constexpr (GRP) {
+#pragma unroll
+    for (int q = 0; q < GMAX_SEG; ++q) {
+      const int qq = q < gp.nseg ? q : 0;
+      seg_a[q] = a_row0 + (reinterpret_cast<const char*>(gp.seg[qq].A) - reinterpret_cast<const char*>(A));
+      seg_b[q] = b_col0 + (reinterpret_cast<const char*>(gp.seg[qq].B) - reinterpret_cast<const char*>(B));
+    }
+  }
+  auto seg_pick = [&](const char* const(&arr)[GMAX_SEG], int q) {
+    return q == 0 ? arr[0] : q == 1 ? arr[1] : q == 2 ? arr[2] : arr[3];
+  };
   // FULL: every k of the tile is < K.  Otherwise (at most the last K tile of a GEMM) lanes past K skip the
   // load and stage zeros.
   auto load_ks = [&](int kt, bool full) {
@@ -305,6 +350,11 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
   auto load_full = [&](int kt) {
     const char* at = a_row0 + (long long)kt * step_a;
     const char* bt = b_col0 + (long long)kt * step_b;
+    if constexpr (GRP) {
+      const int q = kt / nkt_seg, l = kt - q * nkt_seg;
+      at = seg_pick(seg_a, q) + (long long)l * step_a;
+      bt = seg_pick(seg_b, q) + (long long)l * step_b;
+    }
 #pragma unroll
     for (int r = 0; r < NLD; ++r) {
       if constexpr (CA) {
@@ -322,7 +372,9 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
     }
   };
   auto load_tile = [&](int kt) {
-    if constexpr (KS) {
+    if constexpr (GRP) {
+      load_full(kt);
+    } else if constexpr (KS) {
       if ((kt + 1) * BK <= g.K)
         load_full(kt);
       else
@@ -356,7 +408,28 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
   const unsigned long long* bm = nullptr;
   bool mlds = false;   // the flag words are in LDS (read with ds_read: a generic pointer would make every look-up a
                        // flat load, whose wait drains the operand loads in flight as well)
-  if constexpr (KS) {
+  if constexpr (GRP) {
+    // flags of the concatenated K range of this tile, assembled from the segments' operand masks (g.nkw = words of
+    // that range when any segment has a mask, else 0)
+    if (g.nkw > 0 && g.nkw <= MASKW) {
+      unsigned char* f0 = reinterpret_cast<unsigned char*>(s_mask[0]);
+      for (int t = tid; t < g.nkw * 8; t += NT) {
+        unsigned char v = 0;
+        if (t < nkt_all) {
+          const int q = t / nkt_seg, l = t - q * nkt_seg;
+          const GSeg& sg = gp.seg[q];
+          v = 1;
+          if (sg.am) v &= sg.am[(long long)tm * g.gg.am_pitch + l];
+          if (sg.bm) v &= sg.bm[(long long)tn * g.gg.bm_pitch + l];
+        }
+        f0[t] = v;
+      }
+      if (tid < g.nkw) s_mask[1][tid] = 0x0101010101010101ull;
+      __syncthreads();
+      mlds = true;
+      am = s_mask[0];       // (non-null: look-ups go through the LDS copy)
+    }
+  } else if constexpr (KS) {
     // masks are kept per 64 rows / columns whatever the workgroup tile
     if (g.amask) am = g.amask + ((long long)b * g.mtiles_m + (tm * TBM) / BM) * g.nkw;
     if (g.bmask) bm = g.bmask + ((long long)b * g.mtiles_n + (tn * TBN) / BN) * g.nkw;
@@ -367,37 +440,6 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
       }
       __syncthreads();
       mlds = true;
-      if (g.kbal && g.ksplit > 1) {
-        // K slices with equal numbers of OCCUPIED K tiles: with block-sparse operands the occupied tiles of an
-        // output tile cluster in part of the K range (K runs channel-major), and slices of equal length would give
-        // one workgroup everything.  Every thread walks the same flag words (uniform).
-        auto word_of = [&](int w) {
-          unsigned long long x = s_mask[0][w] & s_mask[1][w] & 0x0101010101010101ull;
-          const int valid = nkt_all - 8 * w;                 // flag bytes past the last K tile are never written
-          if (valid < 8) x &= (1ull << (8 * valid)) - 1ull;
-          return x;
-        };
-        int n = 0;
-        for (int w = 0; w < g.nkw; ++w) n += __popcll(word_of(w));
-        const int i0 = (int)((long long)ks_id * n / g.ksplit), i1 = (int)((long long)(ks_id + 1) * n / g.ksplit);
-        // position of the i-th occupied tile (i = n: the end of the range)
-        auto pos_of = [&](int i) {
-          if (i >= n) return nkt_all;
-          int seen = 0;
-          for (int w = 0; w < g.nkw; ++w) {
-            unsigned long long x = word_of(w);
-            const int c = __popcll(x);
-            if (seen + c > i) {
-              for (int skip = i - seen; skip > 0; --skip) x &= x - 1;   // drop the lowest set flags
-              return (w << 3) + (__builtin_ctzll(x) >> 3);
-            }
-            seen += c;
-          }
-          return nkt_all;
-        };
-        kt_begin = pos_of(i0);
-        kt_end = pos_of(i1);
-      }
     }
   }
   auto next_kt = [&](int from) -> int {
@@ -664,10 +706,6 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
     }
   } trace_end{g, tr0, rt0, tr1, tr2, tr3, tid, kt_done};
   if (g.kt_counter && tid == 0 && kt_done) atomicAdd(g.kt_counter, (unsigned long long)kt_done);
-  if (g.cmask) {   // workgroup-uniform
-    if (tid == 0) g.cmask[((long long)b * g.tiles_m + tm) * g.tiles_n + tn] = kt_done > 0 ? 1 : 0;
-    if (kt_done == 0) return;
-  }
   if constexpr (M3) {
 #pragma unroll
     for (int i = 0; i < WI; ++i)
@@ -709,7 +747,7 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
   // of the preloads spill; their beta / dot terms are read inside the store loop as before)
   constexpr bool PRE = CA && CB;
   double2 pre_c[PRE ? WI : 1][2][4], pre_y[PRE ? WI : 1][2][4];
-  const bool need_c = g.use_beta, need_y = g.dot_y != nullptr;
+  const bool need_c = GRP ? gp.use_beta != 0 : g.use_beta != 0, need_y = g.dot_y != nullptr;
   if (PRE && (need_c || need_y)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -833,7 +871,7 @@ __device__ __forceinline__ void bitonic_desc_2048(unsigned* key, int tid) {
 __global__ __launch_bounds__(1024) void k_tile_order(const unsigned long long* __restrict__ amask,
                                                        const unsigned long long* __restrict__ bmask, int nkw, int nkt,
                                                        int tiles_m, int tiles_n, int by_die, int* __restrict__ perm,
-                                                       const int* __restrict__ skip) {
+                                                       const int* __restrict__ skip, const GemmGroups gg) {
   if (skip && *skip) return;
   __shared__ unsigned key[2048], ckey[2048];
   __shared__ int colw[2048];
@@ -846,13 +884,25 @@ __global__ __launch_bounds__(1024) void k_tile_order(const unsigned long long* _
     unsigned cnt = 0;
     if (i < ntile) {
       const int tm = i / tiles_n, tn = i - tm * tiles_n;
-      for (int w = 0; w < nkw; ++w) {
-        unsigned long long x = 0x0101010101010101ull;
-        if (amask) x &= amask[(long long)tm * nkw + w];
-        if (bmask) x &= bmask[(long long)tn * nkw + w];
-        const int valid = nkt - 8 * w;                    // flag bytes past the last K tile are never written
-        if (valid < 8) x &= (1ull << (8 * valid)) - 1ull;
-        cnt += __popcll(x);
+      if (gg.ngrp > 0) {   // grouped launch: the segments of the tile row's group, byte flags per operand
+        const int grp = tm / gg.tiles_m_grp, tml = tm - grp * gg.tiles_m_grp;
+        const GGrp& G = gg.g[grp];
+        for (int q = 0; q < G.nseg; ++q)
+          for (int l = 0; l < gg.nkt_seg; ++l) {
+            unsigned v = 1;
+            if (G.seg[q].am) v &= G.seg[q].am[(long long)tml * gg.am_pitch + l];
+            if (G.seg[q].bm) v &= G.seg[q].bm[(long long)tn * gg.bm_pitch + l];
+            cnt += v;
+          }
+      } else {
+        for (int w = 0; w < nkw; ++w) {
+          unsigned long long x = 0x0101010101010101ull;
+          if (amask) x &= amask[(long long)tm * nkw + w];
+          if (bmask) x &= bmask[(long long)tn * nkw + w];
+          const int valid = nkt - 8 * w;                    // flag bytes past the last K tile are never written
+          if (valid < 8) x &= (1ull << (8 * valid)) - 1ull;
+          cnt += __popcll(x);
+        }
       }
       if (part) atomicAdd(&colw[tn], (int)cnt);
     }
@@ -1088,8 +1138,7 @@ __global__ __launch_bounds__(256) void k_transpose_inner(double* out, const doub
 
 }  // namespace
 
-static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C, int skip_zero,
-                     const void* amask_ext = nullptr, void* cmask_out = nullptr) {
+static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C, int skip_zero) {
   if (!ctx || !d) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
   if ((d->dtype_a != MPSE_F64 && d->dtype_a != MPSE_C128) || (d->dtype_b != MPSE_F64 && d->dtype_b != MPSE_C128))
@@ -1115,16 +1164,11 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.K = g.kA.ext;
   g.mtiles_m = (g.M + BM - 1) / BM;
   g.mtiles_n = (g.N + BN - 1) / BN;
-  // workgroup tile: 64 x 64 (four waves).  A 32 x 32 one-wave tile for products whose 64 x 64 tiles cannot fill the
-  // chip (four times the workgroups before K has to be sliced) exists behind MPSE_SMALL_TILES=1; measured on the
-  // headline run it loses to split-K by 17 % (one wave walking the whole K is a longer latency chain than many
-  // workgroups walking two K tiles each plus a reduction pass), so it is off.
-  static const bool small_ok = [] { const char* e = getenv("MPSE_SMALL_TILES"); return e && e[0] == '1'; }();
-  const int n_cu0 = ctx->n_cu > 0 ? ctx->n_cu : 256;
-  const bool small = small_ok && !cmask_out && (long long)g.mtiles_m * g.mtiles_n * d->batch < n_cu0;
-  const int TB = small ? 32 : 64;
-  g.tiles_m = (g.M + TB - 1) / TB;
-  g.tiles_n = (g.N + TB - 1) / TB;
+  // workgroup tile: 64 x 64.  (A 32 x 32 one-wave tile for products whose 64 x 64 tiles cannot fill the chip lost to
+  // split-K by 17 % on the headline run - one wave walking the whole K is a longer latency chain than many workgroups
+  // walking two K tiles each plus a reduction pass - and was removed.)
+  g.tiles_m = g.mtiles_m;
+  g.tiles_n = g.mtiles_n;
   auto fast = [](const IdxMap& m) { return m.ext <= 1 ? (long long)1 << 60 : (m.s_lo < 0 ? -m.s_lo : m.s_lo); };
   g.a_kfast = fast(g.kA) <= fast(g.mA);
   g.b_kfast = fast(g.kB) <= fast(g.nB);
@@ -1155,11 +1199,9 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.amask = g.bmask = nullptr;
   g.nkw = 0;
   g.skip = ctx->skip_flag;
-  g.cmask = nullptr;
-  static const int skew_on = [] { const char* e = getenv("MPSE_GEMM_SKEW"); return e ? atoi(e) : 1; }();
-  g.skew = skew_on;
+  g.skew = 1;
   g.perm = nullptr;
-  g.kbal = 0;
+  g.gg.ngrp = 0;
   g.slice_fast = 0;
   g.die_group = 0;
   g.dot_y = nullptr;
@@ -1177,12 +1219,8 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   g.trace = ctx->prof_on ? ctx->gemm_trace : nullptr;    // only inside the profiled (timed) region
   TmpBuf WSB(ctx), MSK(ctx);
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-  // tuning knobs of the split-K policy (environment, read once): output tiles below which K is sliced, and how many
-  // workgroups the slicing aims at
-  static const int sk_tiles = [] { const char* e = getenv("MPSE_SPLITK_TILES"); return e ? atoi(e) : 0; }();
-  static const int sk_target = [] { const char* e = getenv("MPSE_SPLITK_TARGET"); return e ? atoi(e) : 0; }();
-  const int tiles_limit = sk_tiles > 0 ? sk_tiles : n_cu;
-  const long long wg_target = sk_target > 0 ? sk_target : n_cu;   // one workgroup per CU (sweep of the headline run)
+  const int tiles_limit = n_cu;
+  const long long wg_target = n_cu;   // one workgroup per CU (policy sweeps of the headline run)
   if (base_blocks < tiles_limit && nkt_all >= 4) {
     // fewer output tiles than CUs: slice K until ~1 workgroup per CU exists (2 per CU: equal to 1.7 % slower on the
     // headline run depending on the box - the reduction pass reads twice the slices; 3 per CU: -3 %; 0.5 per CU: -7 %).  (One tile per CU runs as fast
@@ -1198,37 +1236,16 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
       g.ws = WSB.as<double>();
     }
   }
-  const bool will_mask = (skip_zero || amask_ext) && is_single(g.kA) && is_single(g.kB) && (nkt_all >= 2 || amask_ext) &&
-                         d->batch <= 16384;
-  // A block-sparse product with one output tile per CU is as slow as its fullest tile (d = 16 C-step: 33 occupied K
-  // tiles against 21 on average): it is cut into slices of equal OCCUPIED tile counts, so that two workgroups share
-  // every CU and the fullest tile is halved.
-  static const int sk_bal = [] { const char* e = getenv("MPSE_SPLITK_BAL"); return e ? atoi(e) : 0; }();
-  if (sk_bal > 1 && !small && g.ksplit == 1 && d->batch == 1 && will_mask && (nkt_all + 7) / 8 <= 64 && !cmask_out &&
-      base_blocks >= tiles_limit && base_blocks < 2 * n_cu && nkt_all >= 16) {
-    g.ksplit = sk_bal;
-    g.kt_per_split = (nkt_all + sk_bal - 1) / sk_bal;
-    const size_t esz = (ca || cb) ? 16 : 8;
-    MPSE_TRY(WSB.alloc(size_t(d->batch) * g.ksplit * size_t(g.M) * size_t(g.N) * esz));
-    g.ws = WSB.as<double>();
-    g.kbal = 1;
-  }
-  static const int sf_on = [] { const char* e = getenv("MPSE_GEMM_SLICEFAST"); return e ? atoi(e) : 1; }();
-  g.slice_fast = sf_on && g.ksplit > 1 && d->batch == 1 && !g.kbal;
+  g.slice_fast = g.ksplit > 1 && d->batch == 1;
   long long nblk = base_blocks * g.ksplit;
   if (nblk > 0x7fffffffLL) return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpse_gemm: grid too large");
-  if (cmask_out) {
-    if (g.ksplit != 1 || g.use_beta)
-      return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_gemm: output tile flags need an unsplit, non-accumulating product");
-    g.cmask = static_cast<unsigned char*>(cmask_out);
-  }
 
   // dot request of the caller (mpse_ctx::dot_req, armed by run_plan for the step that completes the result)
   const bool want_dot = ctx->dot_now;
   ctx->dot_now = false;
   long long rgx = (g.N + 255) / 256 > 64 ? 64 : (g.N + 255) / 256;
   long long rgy = (long long)g.M * d->batch > 32768 ? 32768 : (long long)g.M * d->batch;
-  if (want_dot && !small && d->batch == 1 && !cmask_out) {
+  if (want_dot && d->batch == 1) {
     long long producers = base_blocks;
     if (g.ksplit > 1) {
       const long long cap_y = ctx->dot_req.cap / rgx;
@@ -1242,7 +1259,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     }
   }
 
-  dim3 grid((unsigned)nblk), block(small ? 64 : 256);
+  dim3 grid((unsigned)nblk), block(256);
   mpse_ctx::ProfRec rec;
   const int variant = (ca ? 1 : 0) + (cb ? 2 : 0);
   const double mnk = double(g.M) * double(g.N) * double(g.K) * double(d->batch);
@@ -1253,15 +1270,13 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
                           double(g.M) * g.N * ((ca || cb) ? 16 : 8) * (g.use_beta ? 2 : 1)),
       &rec);
   g.kt_counter = prof_this && ctx->prof_ktiles ? ctx->prof_ktiles + variant : nullptr;
-  if (amask_ext && !(is_single(g.kA) && is_single(g.kB)))
-    return mpse_fail(ctx, MPSE_ERR_ARG, "mpse_gemm: a producer's operand mask needs single-level K indices");
   bool mask_a_stable = true, mask_b_stable = true;   // the mask (or its absence) outlives this call: cached or the solve's
-  if ((skip_zero || amask_ext) && is_single(g.kA) && is_single(g.kB) && (nkt_all >= 2 || amask_ext) && d->batch <= 16384) {
+  if (skip_zero && is_single(g.kA) && is_single(g.kB) && nkt_all >= 2 && d->batch <= 16384) {
     // tile occupancy of both operands (one small scan launch), then only K tiles with data on both sides are visited
     g.nkw = (nkt_all + 7) / 8;
     const size_t wa = size_t(d->batch) * g.mtiles_m * g.nkw, wb = size_t(d->batch) * g.mtiles_n * g.nkw;
     // skip_zero bit 0: scan A, bit 1: scan B (an operand that is as large as the product itself is not worth a pass)
-    const bool sa = (skip_zero & 1) && !amask_ext, sb_ = skip_zero & 2;
+    const bool sa = skip_zero & 1, sb_ = skip_zero & 2;
     // Inside a Krylov solve the environments do not change: their masks are computed once and kept (mpse_internal.h)
     auto cacheable = [&](const void* p) {
       if (!ctx->occ_cache_on) return false;
@@ -1303,7 +1318,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
         b_structural = true;
       }
     }
-    mask_a_stable = sa ? ca_ok : amask_ext == nullptr;
+    mask_a_stable = !sa || ca_ok;
     mask_b_stable = !sb_ || cb_ok || b_structural;
     // storage: cached masks live until the solve ends, the others in a temporary of this call
     size_t tmp_words = 0;
@@ -1340,14 +1355,12 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
       const dim3 og((nkt_all + 3) / 4, tmax, (unsigned)(2 * d->batch));
       hipLaunchKernelGGL(k_tile_occ, og, dim3(256), 0, ctx->stream, oa, ob, g.K, g.nkw, (int)d->batch, ctx->skip_flag);
     }
-    g.amask = sa ? am : static_cast<const unsigned long long*>(amask_ext);
+    g.amask = sa ? am : nullptr;
     g.bmask = sb_ ? bmk : nullptr;
   }
-  static const int order_on = [] { const char* e = getenv("MPSE_GEMM_ORDER"); return e ? atoi(e) : 1; }();
   TmpBuf PERM(ctx);
   const long long ntile_all = (long long)g.tiles_m * g.tiles_n;
-  if (order_on && !small && d->batch == 1 && (g.amask || g.bmask) && (ntile_all * g.ksplit > 2 * n_cu || g.kbal) &&
-      ntile_all <= 2048) {
+  if (d->batch == 1 && (g.amask || g.bmask) && ntile_all * g.ksplit > 2 * n_cu && ntile_all <= 2048) {
     // inside a Krylov solve both masks are the solve's (cached environment mask, structural centre mask): one sort
     // serves every matvec of the solve
     const bool keep = ctx->occ_cache_on && mask_a_stable && mask_b_stable;
@@ -1367,7 +1380,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
         pp = PERM.as<int>();
       }
       hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, ctx->stream, g.amask, g.bmask, g.nkw, nkt_all, g.tiles_m,
-                         g.tiles_n, order_on > 1 ? 0 : 1, pp, ctx->skip_flag);
+                         g.tiles_n, 1, pp, ctx->skip_flag, GemmGroups());
     }
     g.perm = pp;
   }
@@ -1382,8 +1395,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     return (span(m) + span(k) + 1.0) * (cplx ? 16.0 : 8.0) < 4.0e9;
   };
   const bool ks = is_single(g.kA) && is_single(g.kB) && span_ok(g.mA, g.kA, ca) && span_ok(g.nB, g.kB, cb);
-  static const int dg_on = [] { const char* e = getenv("MPSE_GEMM_DIEGROUP"); return e ? atoi(e) : 1; }();
-  if (dg_on && !g.perm && g.ksplit == 1 && d->batch == 1 && !small && (long long)g.tiles_m * g.tiles_n >= 64) {
+  if (!g.perm && g.ksplit == 1 && d->batch == 1 && (long long)g.tiles_m * g.tiles_n >= 64) {
     const double size_a = double(g.M) * (ca ? 2 : 1), size_b = double(g.N) * (cb ? 2 : 1);   // per unit of K
     if (size_a >= size_b && g.tiles_m % 8 == 0)
       g.die_group = 1;
@@ -1394,20 +1406,15 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   }
 #define MPSE_LAUNCH(CA_, CB_)                                                                         \
   do {                                                                                                \
-    if (ks && small)                                                                                  \
-      hipLaunchKernelGGL((k_gemm<CA_, CB_, true, 1>), grid, block, 0, ctx->stream, g);                \
-    else if (ks && wide)                                                                              \
+    if (ks && wide)                                                                                   \
       hipLaunchKernelGGL((k_gemm<CA_, CB_, true, 2, 1>), grid, dim3(512), 0, ctx->stream, g);         \
     else if (ks)                                                                                      \
       hipLaunchKernelGGL((k_gemm<CA_, CB_, true, 2>), grid, block, 0, ctx->stream, g);                \
-    else if (small)                                                                                   \
-      hipLaunchKernelGGL((k_gemm<CA_, CB_, false, 1>), grid, block, 0, ctx->stream, g);               \
     else                                                                                              \
       hipLaunchKernelGGL((k_gemm<CA_, CB_, false, 2>), grid, block, 0, ctx->stream, g);               \
   } while (0)
   // one workgroup per compute unit (or fewer): eight waves on the tile instead of four
-  static const int wide_on = [] { const char* e = getenv("MPSE_GEMM_WIDE"); return e ? atoi(e) : 1; }();
-  const bool wide = wide_on && !small && nblk <= (wide_on > 1 ? 2 * n_cu : n_cu) && nkt_all >= 2;
+  const bool wide = nblk <= n_cu && nkt_all >= 2;
   if (ca && cb)
     MPSE_LAUNCH(true, true);
   else if (ca)
@@ -1429,6 +1436,188 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   return MPSE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Tile-occupancy flags of one operand (rows through `r`, K through `k`, both from `ptr`): from the cache of the
+// running Krylov solve, else scanned now - into the cache when the operand lies inside the solve's environment
+// ranges, into `tmp` otherwise.  flags[t * pitch + kt], 64 rows per tile t.
+int occ_mask_get(mpse_ctx* ctx, const void* ptr, int dtype, mpse_index r, mpse_index k, TmpBuf& tmp,
+                 const unsigned char** flags, int* pitch, bool* stable) {
+  IdxMap rm, km;
+  if (!to_map(r, &rm) || !to_map(k, &km) || !is_single(km))
+    return mpse_fail(ctx, MPSE_ERR_SHAPE, "occupancy scan: K index must be single level");
+  const int K = km.ext, nrows = rm.ext, nkt = (K + BK - 1) / BK, nkw = (nkt + 7) / 8, tiles = (nrows + BM - 1) / BM;
+  const bool cplx = dtype == MPSE_C128;
+  auto fastest = [](const IdxMap& m) { return m.ext <= 1 ? (long long)1 << 60 : (m.s_lo < 0 ? -m.s_lo : m.s_lo); };
+  const int kfast = fastest(km) <= fastest(rm);
+  mpse_ctx::OccKey key;
+  memset(&key, 0, sizeof(key));
+  key.ptr = ptr;
+  key.r_ext = rm.ext, key.r_lo = rm.lo, key.r_shi = rm.s_hi, key.r_slo = rm.s_lo;
+  key.k_ext = km.ext, key.k_lo = km.lo, key.k_shi = km.s_hi, key.k_slo = km.s_lo;
+  key.sb = 0, key.nrows = nrows, key.tiles = tiles, key.nkw = nkw, key.batch = 1, key.K = K, key.cplx = cplx ? 1 : 0;
+  const char* c = reinterpret_cast<const char*>(ptr);
+  const bool cacheable = ctx->occ_cache_on && ((c >= ctx->occ_lo[0] && c < ctx->occ_hi[0]) ||
+                                               (c >= ctx->occ_lo[1] && c < ctx->occ_hi[1]));
+  *pitch = nkw * 8;
+  *stable = cacheable;
+  if (cacheable)
+    for (const auto& e : ctx->occ_cache)
+      if (memcmp(&e.key, &key, sizeof(key)) == 0) {
+        *flags = static_cast<const unsigned char*>(e.mask);
+        return MPSE_OK;
+      }
+  void* pm = nullptr;
+  const size_t bytes = size_t(tiles) * nkw * 8;
+  if (cacheable) {
+    MPSE_TRY(mpse_malloc(ctx, bytes, &pm));
+    ctx->occ_cache.push_back({key, pm});
+  } else {
+    MPSE_TRY(tmp.alloc(bytes));
+    pm = tmp.p;
+  }
+  OccOperand oa{static_cast<const double*>(ptr), rm, km, nrows, tiles, cplx ? 1 : 0, kfast, 0, static_cast<unsigned char*>(pm)};
+  OccOperand ob = oa;
+  ob.tiles = 0;
+  hipLaunchKernelGGL(k_tile_occ, dim3((nkt + 3) / 4, tiles, 2), dim3(256), 0, ctx->stream, oa, ob, K, nkw, 1, ctx->skip_flag);
+  MPSE_HIP(ctx, hipGetLastError());
+  *flags = static_cast<const unsigned char*>(pm);
+  return MPSE_OK;
+}
+
+// Grouped launch of the contraction kernel (mpse_internal.h GroupedDesc; folded one-site matvec of mpse_plans.h).
+int gemm_grouped(mpse_ctx* ctx, const GroupedDesc& d) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  if (d.ngrp < 1 || d.ngrp > GMAX_GRP) return mpse_fail(ctx, MPSE_ERR_ARG, "grouped product: 1 .. %d groups", GMAX_GRP);
+  if (!to_map(d.ma, &g.mA) || !to_map(d.ka, &g.kA) || !to_map(d.kb, &g.kB) || !to_map(d.nb, &g.nB) ||
+      !to_map(d.mc, &g.mC) || !to_map(d.nc, &g.nC))
+    return mpse_fail(ctx, MPSE_ERR_SHAPE, "grouped product: extent out of range");
+  g.M = g.mA.ext, g.N = g.nB.ext, g.K = g.kA.ext;
+  if (g.M != g.mC.ext || g.N != g.nC.ext || g.K != g.kB.ext) return mpse_fail(ctx, MPSE_ERR_SHAPE, "grouped product: extents disagree");
+  if (g.M == 0 || g.N == 0) return MPSE_OK;
+  const bool ca = d.dta == MPSE_C128, cb = d.dtb == MPSE_C128;
+  auto span_ok = [](const IdxMap& m, const IdxMap& k, bool cplx) {
+    if (m.s_hi < 0 || m.s_lo < 0 || k.s_hi < 0 || k.s_lo < 0) return false;
+    auto span = [](const IdxMap& x) {
+      if (x.ext <= 1) return 0.0;
+      if (x.lo == 0x7fffffff) return double(x.ext - 1) * double(x.s_lo);
+      return double((x.ext - 1) / x.lo) * double(x.s_hi) + double(x.lo - 1) * double(x.s_lo);
+    };
+    return (span(m) + span(k) + 1.0) * (cplx ? 16.0 : 8.0) < 4.0e9;
+  };
+  if (!is_single(g.kA) || !is_single(g.kB) || !span_ok(g.mA, g.kA, ca) || !span_ok(g.nB, g.kB, cb) || g.K % BK != 0 ||
+      g.K < BK || (d.ngrp > 1 && g.M % BM != 0) || !cb)
+    return mpse_fail(ctx, MPSE_ERR_SHAPE, "grouped product: needs single-level K indices, K a multiple of %d, group "
+                     "heights a multiple of %d and a complex second operand", BK, BM);
+  g.mtiles_m = (g.M + BM - 1) / BM;
+  g.mtiles_n = (g.N + BN - 1) / BN;
+  g.tiles_m = g.mtiles_m * d.ngrp;
+  g.tiles_n = g.mtiles_n;
+  auto fast = [](const IdxMap& m) { return m.ext <= 1 ? (long long)1 << 60 : (m.s_lo < 0 ? -m.s_lo : m.s_lo); };
+  g.a_kfast = fast(g.kA) <= fast(g.mA);
+  g.b_kfast = fast(g.kB) <= fast(g.nB);
+  g.alpha_re = 1.0, g.beta_re = 1.0;
+  g.ksplit = 1;
+  g.skip = ctx->skip_flag;
+  g.skew = 1;
+  g.trace = ctx->prof_on ? ctx->gemm_trace : nullptr;
+  GemmGroups& gg = g.gg;
+  gg.ngrp = d.ngrp, gg.tiles_m_grp = g.mtiles_m, gg.nkt_seg = g.K / BK;
+  gg.am_pitch = d.am_pitch, gg.bm_pitch = d.bm_pitch;
+  int max_seg = 0;
+  bool any_mask = false, any_beta = false;
+  for (int i = 0; i < d.ngrp; ++i) {
+    const GroupedGrp& s = d.grp[i];
+    if (s.nseg < 1 || s.nseg > GMAX_SEG || !s.C) return mpse_fail(ctx, MPSE_ERR_ARG, "grouped product: bad group");
+    gg.g[i].C = static_cast<double*>(s.C);
+    gg.g[i].nseg = s.nseg;
+    gg.g[i].use_beta = s.beta != 0.0 ? 1 : 0;
+    if (s.beta != 0.0 && s.beta != 1.0) return mpse_fail(ctx, MPSE_ERR_ARG, "grouped product: beta must be 0 or 1");
+    any_beta = any_beta || s.beta != 0.0;
+    for (int q = 0; q < s.nseg; ++q) {
+      if (!s.seg[q].A || !s.seg[q].B) return mpse_fail(ctx, MPSE_ERR_ARG, "grouped product: null operand");
+      gg.g[i].seg[q] = GSeg{static_cast<const double*>(s.seg[q].A), static_cast<const double*>(s.seg[q].B), s.seg[q].am, s.seg[q].bm};
+      any_mask = any_mask || s.seg[q].am || s.seg[q].bm;
+    }
+    max_seg = s.nseg > max_seg ? s.nseg : max_seg;
+  }
+  g.A = gg.g[0].seg[0].A, g.B = gg.g[0].seg[0].B, g.C = gg.g[0].C;
+  g.use_beta = any_beta;
+  const int nkt_max = max_seg * gg.nkt_seg;
+  g.nkw = (any_mask && (nkt_max + 7) / 8 <= 64) ? (nkt_max + 7) / 8 : 0;
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  const long long ntile = (long long)g.tiles_m * g.tiles_n;
+  if (ntile > 0x7fffffffLL) return mpse_fail(ctx, MPSE_ERR_SHAPE, "grouped product: grid too large");
+  // the caller's dot request (the launch that completes a matvec result): one group only
+  const bool want_dot = ctx->dot_now;
+  ctx->dot_now = false;
+  if (want_dot && d.ngrp == 1 && ntile >= 1 && ntile <= ctx->dot_req.cap) {
+    g.dot_y = static_cast<const double*>(ctx->dot_req.y);
+    g.dot_part = ctx->dot_req.part;
+    ctx->dot_req.nb_out = (int)ntile;
+  }
+  mpse_ctx::ProfRec rec;
+  const int variant = (ca ? 1 : 0) + (cb ? 2 : 0);
+  double segs = 0;
+  for (int i = 0; i < d.ngrp; ++i) segs += d.grp[i].nseg;
+  const double mnk = double(g.M) * double(g.N) * double(g.K) * segs;
+  const bool prof_this = prof_begin(ctx, variant, mnk * ((ca && cb) ? 8.0 : 4.0),
+                                    segs * (double(g.M) * g.K * (ca ? 16 : 8) + double(g.K) * g.N * 16.0) +
+                                        double(d.ngrp) * double(g.M) * g.N * 16.0 * (any_beta ? 2 : 1),
+                                    &rec);
+  g.kt_counter = prof_this && ctx->prof_ktiles ? ctx->prof_ktiles + variant : nullptr;
+  TmpBuf PERM(ctx);
+  if (g.nkw > 0 && ntile > 2 * n_cu && ntile <= 2048) {
+    int* pp = nullptr;
+    const void *ka = gg.g[0].seg[0].am, *kb = gg.g[0].seg[0].bm;
+    const int nkt_key = nkt_max + 1000 * d.ngrp;       // (grouped entries never collide with plain ones)
+    const bool keep = ctx->occ_cache_on && d.masks_stable;
+    if (keep)
+      for (const auto& e : ctx->perm_cache)
+        if (e.amask == ka && e.bmask == kb && e.tiles_m == g.tiles_m && e.tiles_n == g.tiles_n && e.nkt == nkt_key)
+          pp = static_cast<int*>(e.perm);
+    if (!pp) {
+      if (keep) {
+        void* pm = nullptr;
+        MPSE_TRY(mpse_malloc(ctx, size_t(ntile) * sizeof(int), &pm));
+        ctx->perm_cache.push_back({ka, kb, g.tiles_m, g.tiles_n, nkt_key, pm});
+        pp = static_cast<int*>(pm);
+      } else {
+        MPSE_TRY(PERM.alloc(size_t(ntile) * sizeof(int)));
+        pp = PERM.as<int>();
+      }
+      hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)nullptr,
+                         (const unsigned long long*)nullptr, 0, nkt_max, g.tiles_m, g.tiles_n, 1, pp, ctx->skip_flag, gg);
+    }
+    g.perm = pp;
+  }
+  if (!g.perm && ntile >= 64) {
+    const double size_a = double(g.M) * d.ngrp * (ca ? 2 : 1), size_b = double(g.N) * 2;
+    if (size_a >= size_b && g.tiles_m % 8 == 0)
+      g.die_group = 1;
+    else if (g.tiles_n % 8 == 0)
+      g.die_group = 2;
+    else if (g.tiles_m % 8 == 0)
+      g.die_group = 1;
+  }
+  const dim3 grid((unsigned)ntile);
+  const bool wide = ntile <= n_cu;
+  if (ca) {
+    if (wide)
+      hipLaunchKernelGGL((k_gemm<true, true, true, 2, 1, true>), grid, dim3(512), 0, ctx->stream, g);
+    else
+      hipLaunchKernelGGL((k_gemm<true, true, true, 2, 2, true>), grid, dim3(256), 0, ctx->stream, g);
+  } else {
+    if (wide)
+      hipLaunchKernelGGL((k_gemm<false, true, true, 2, 1, true>), grid, dim3(512), 0, ctx->stream, g);
+    else
+      hipLaunchKernelGGL((k_gemm<false, true, true, 2, 2, true>), grid, dim3(256), 0, ctx->stream, g);
+  }
+  if (prof_this) prof_end(ctx, rec);
+  MPSE_HIP(ctx, hipGetLastError());
+  return MPSE_OK;
+}
+
 extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, const void* B, void* C) {
   if (ctx && d && MPSE_RECORDING(ctx)) {
     const mpse_gemm_desc dc = *d;
@@ -1440,8 +1629,7 @@ extern "C" int mpse_gemm(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, 
 
 int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index ma, mpse_index ka, mpse_index kb,
               mpse_index nb, mpse_index mc, mpse_index nc, int64_t batch, int64_t sba, int64_t sbb, int64_t sbc,
-              const void* A, const void* B, void* C, double alpha, double beta, int skip_zero, const void* amask_ext,
-              void* cmask_out) {
+              const void* A, const void* B, void* C, double alpha, double beta, int skip_zero) {
   mpse_gemm_desc d;
   d.dtype_a = dta;
   d.dtype_b = dtb;
@@ -1462,7 +1650,7 @@ int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index 
   d.beta_re = beta;
   d.beta_im = 0.0;
   d.skip_zero_tiles = skip_zero;
-  return gemm_impl(ctx, &d, A, B, C, skip_zero, amask_ext, cmask_out);
+  return gemm_impl(ctx, &d, A, B, C, skip_zero);
 }
 
 extern "C" int mpse_transpose_inner(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t d0, int64_t d1,

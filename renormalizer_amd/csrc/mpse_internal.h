@@ -9,6 +9,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -82,15 +83,9 @@ struct mpse_ctx {
   const int* skip_flag = nullptr;
   // Krylov dimension of the last solve per problem class (number of sites, vector length): how far to run ahead
   std::unordered_map<unsigned long long, int> lz_hint;
-  // sparse forms of MPO sites built for the masked one-site chain (mpse_contract.hip), kept like the occupancy
-  // masks for the duration of a Krylov solve
-  struct WCsr {
-    const void* w;
-    long long wl, d, wr;
-    void* cnt;
-    void* ent;
-  };
-  std::vector<WCsr> wcsr_cache;
+  // Block structure of MPO sites the caller has described (mpse_mpo_site_hint), by device pointer: large one-site
+  // matvecs on such a site take the folded plan (mpse_plans.h).  Dropped when the buffer is freed.
+  std::unordered_map<const void*, std::shared_ptr<void>> wsite_info;   // -> mpse_plan::WSiteInfo
   // Deferred calls (mpse_defer_*): mpse_gemm / mpse_block_qr / mpse_env_update issued while a list is being recorded
   // are stored with copies of their arguments; an armed list runs at the end of the next mpse_expm_lanczos, right
   // after the solve has been enqueued to its end.  While a list is recorded or waiting, freed device blocks are held
@@ -124,12 +119,6 @@ struct mpse_ctx {
     const void* ptr = nullptr;
     mpse_index m{}, n{};
   } cin_req;
-  // Block QR as HIP graphs (mpse_qr.hip): the panel / update / Q-formation launches of a decomposition are captured
-  // once per launch signature and replayed - the d = 2 sites' kernels take 4-5 us, less than the host needs to enqueue
-  // one.  The kernels' operands live in persistent buffers (a graph bakes the pointers in); growing one drops the graphs.
-  void* qr_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // index lists + descriptors | workspaces | Q | reflector parameters
-  size_t qr_cap[4] = {0, 0, 0, 0};
-  std::map<std::vector<long long>, hipGraphExec_t> qr_graphs;
   // Debug: per-workgroup timeline of the contraction kernel (MPSE_GEMM_TRACE=<file>): every workgroup appends one
   // record (grid, K tiles multiplied, s_memtime stamps of its phases); mpse_prof_get writes the file.
   unsigned long long* gemm_trace = nullptr;   // [1 + GEMM_TRACE_CAP * GEMM_TRACE_WORDS] words: counter, then records
@@ -212,7 +201,34 @@ static inline mpse_index idx2(int64_t hi_ext, int64_t lo_ext, int64_t s_hi, int6
 int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index ma, mpse_index ka,
               mpse_index kb, mpse_index nb, mpse_index mc, mpse_index nc, int64_t batch, int64_t sba,
               int64_t sbb, int64_t sbc, const void* A, const void* B, void* C, double alpha = 1.0,
-              double beta = 0.0, int skip_zero = 0, const void* amask_ext = nullptr, void* cmask_out = nullptr);
+              double beta = 0.0, int skip_zero = 0);
+
+// Grouped launch of the contraction kernel (mpse_gemm.hip): up to 8 groups of equal height dividing the tile rows, each
+// with its own result C (same index maps) and up to 4 (A, B) operand pairs whose products are summed (+ beta C, beta 0
+// or 1).  am / bm: tile-occupancy flags of the operands (occ_mask_get layout, row pitches below), null = dense.
+struct GroupedSeg {
+  const void* A = nullptr;
+  const void* B = nullptr;
+  const unsigned char* am = nullptr;
+  const unsigned char* bm = nullptr;
+};
+struct GroupedGrp {
+  GroupedSeg seg[4];
+  void* C = nullptr;
+  int nseg = 0;
+  double beta = 0.0;
+};
+struct GroupedDesc {
+  int dta = MPSE_F64, dtb = MPSE_F64;
+  mpse_index ma{}, ka{}, kb{}, nb{}, mc{}, nc{};
+  int ngrp = 0;
+  GroupedGrp grp[8];
+  int am_pitch = 0, bm_pitch = 0;
+  bool masks_stable = false;   // the flags live as long as the running solve's caches: the launch order is kept with them
+};
+int gemm_grouped(mpse_ctx* ctx, const GroupedDesc& d);
+int occ_mask_get(mpse_ctx* ctx, const void* ptr, int dtype, mpse_index r, mpse_index k, TmpBuf& tmp,
+                 const unsigned char** flags, int* pitch, bool* stable);
 
 // Low-latency read-back of a few device doubles: a one-wave kernel copies them into the mapped pinned buffer
 // and then publishes a sequence number; the host spins on that number instead of going through a copy-engine
@@ -252,11 +268,5 @@ constexpr int GEMM_TRACE_WORDS = 10;                         // 64-bit words per
 // ``blks_dev``: the same descriptors already on the device (else they are uploaded here)
 int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm, const QrBlk* blks_host, int nblk,
                   bool form_q, const QrBlk* blks_dev = nullptr);
-// Communication-avoiding QR of the same blocks (mpse_caqr.hip): TSQR panels of 16 columns over chunks of 256 rows.
-// No per-reflector parameters; R in the upper triangle of the workspaces, the leading max(nq, k) columns of Q in q.
-constexpr int CAQR_MAX_ROWS = 4096;
-bool caqr_enabled();   // MPSE_QR_CAQR=1 (measured slower than the panel-blocked kernels of mpse_qr2.hip: off by default)
-int caqr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, const QrBlk* blks_host, int nblk, bool form_q,
-                 const QrBlk* blks_dev = nullptr);
 // zero fill of two ranges in one launch (8-byte aligned)
 int device_zero2(mpse_ctx* ctx, void* a, size_t abytes, void* b, size_t bbytes);

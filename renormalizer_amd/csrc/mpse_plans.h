@@ -24,19 +24,92 @@ namespace mpse_plan {
 enum Buf { B_L = 0, B_R, B_W0, B_W1, B_C, B_BRA, B_OUT, B_T1, B_T2, B_T3, B_W2, B_W3, B_COUNT };
 inline int w_buf(int layer) { return layer == 0 ? B_W0 : layer == 1 ? B_W1 : layer == 2 ? B_W2 : B_W3; }
 
-enum Kind { K_GEMM = 0, K_COPY = 1, K_WSTEP = 2 };
-enum Mask { M_T1_LO = 0, M_T1_HI, M_T2_LO, M_T2_HI, M_COUNT };
+enum Kind { K_GEMM = 0, K_COPY = 1, K_WMIX = 2, K_GGEMM = 3 };
 
-// MPO step of the masked one-site chain (K_WSTEP): T2[a,d,f,k] = sum_{b,e} W[b,d,e,f] X[b][a,e,k] with X[b] = T1[b]
-// (channel-outer intermediate of the first GEMMs) or, for the unit channel of the left environment, the centre tensor
-// itself.  Tiles of T1 into which nothing was multiplied were never stored: they are recognised by the producers'
-// tile flags and never read; tiles of T2 that stay empty are not stored either and flagged for the consumer GEMMs.
-struct WStepDesc {
-  int64_t Da = 0, d = 0, wl = 0, wr = 0, Dk = 0;
-  int64_t l_unit = -1;        // 0-based channel of X that is the centre tensor (buffer a), -1: none
-  int64_t r_unit = -1;        // 0-based channel f that is always stored (the consumer copies it), -1: none
-  int64_t t1_tiles_n = 0;     // tile columns of the producers' flag arrays (ceil(d Dk / 64))
-  int64_t nkw_lo = 0, nkw_hi = 0;   // 64-bit words per tile row of the consumers' masks (f < r_unit / f > r_unit)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Folded one-site matvec: the MPO step shrinks to what the block structure of the MPO site needs, so most of the
+// intermediates T1 = L . C and T2 = W T1 (Dl wl d Dr elements each) and the launches that only move them (MPO step as a
+// batched product, unit-channel copy) disappear.
+//   out[a,dd,l] = sum_f P_f[a,dd,k] R[l,f,k],   P_f = sum_b W[b,dd,:,f] (L[:,b,:] . C)
+// An MPO site is a sparse matrix of d x d blocks W[b,:,:,f]; for sum-of-products Hamiltonians most non-zero blocks are
+// the identity (channels that pass through the site).
+//   * a channel b whose only block is an identity into a channel f that receives nothing else: the product
+//     L[:,b,:] . C IS the plane P_f - written there directly;
+//   * the other channels b write temporary planes T_b = L[:,b,:] . C, and one elementwise pass (K_WMIX) forms every
+//     remaining plane P_f = sum_b W[b,:,:,f] T_b, with the centre tensor itself in the place of T_b for the unit channel
+//     of L (d x d blocks out of LDS; an identity block is a plain add);
+//   * a plane that is only the unit channel's identity block is the centre tensor itself (no copy), and the plane of
+//     R's unit channel is `out`;
+//   * all products L[:,b,:] . C of a site are ONE grouped launch (K_GGEMM: a group = the tile rows of one channel), and
+//     out (+)= sum_{f != ru} P_f . R[:,f,:]^T is one more: one group whose K loop runs over the channels (segments).
+// Every channel keeps its own product, so the quantum-number zero blocks of L[:,b,:] stay whole empty tiles.
+constexpr int G_MAXGRP = 8, G_MAXSEG = 4, WM_MAXDST = 4, WM_MAXTERM = 4;
+
+struct WBlock {
+  int b, f;
+  bool ident;   // W[b, :, :, f] is the d x d identity
+};
+struct WSiteInfo {
+  int64_t wl = 0, d = 0, wr = 0;
+  std::vector<WBlock> blocks;   // the non-zero blocks, ordered by (f, b)
+  std::vector<double> w;        // the site itself (wl, d, d, wr), row major
+};
+inline WSiteInfo analyse_mpo_site(const double* w, int64_t wl, int64_t d, int64_t wr) {
+  WSiteInfo r;
+  r.wl = wl, r.d = d, r.wr = wr;
+  r.w.assign(w, w + wl * d * d * wr);
+  for (int64_t f = 0; f < wr; ++f)
+    for (int64_t b = 0; b < wl; ++b) {
+      bool any = false, ident = true;
+      for (int64_t x = 0; x < d; ++x)
+        for (int64_t e = 0; e < d; ++e) {
+          const double v = w[((b * d + x) * d + e) * wr + f];
+          if (v != 0.0) any = true;
+          if (v != (x == e ? 1.0 : 0.0)) ident = false;
+        }
+      if (any) r.blocks.push_back(WBlock{(int)b, (int)f, ident});
+    }
+  return r;
+}
+
+// K_WMIX: dst[a, dd, k] = sum_terms sum_e W[b, dd, e, f] src[a, e, k]; element (a, x, k) of a tensor at off + a s_a + x s_d + k
+constexpr int WM_CHUNK = 4, WM_MAXCHUNKS = 8;     // a thread forms WM_CHUNK consecutive dd; d <= 32
+struct WMixTerm {
+  int b = 0, f = 0;
+  bool ident = false;
+  int src = 0;
+  int64_t src_off = 0, s_a = 0, s_d = 0;
+  unsigned char e_lo[WM_MAXCHUNKS] = {0}, e_hi[WM_MAXCHUNKS] = {0};   // columns e the rows of a chunk need: [e_lo, e_hi)
+};
+struct WMixDst {
+  int dst = 0;
+  int64_t dst_off = 0, s_a = 0, s_d = 0;
+  int nterm = 0;
+  WMixTerm term[WM_MAXTERM];
+};
+enum BMaskKind { BM_NONE = 0, BM_SCAN = 1, BM_CENTRE = 2 };
+struct GSegPlan {
+  int abuf = 0;
+  int64_t a_off = 0;
+  int bbuf = 0;
+  int64_t b_off = 0;
+  int64_t am_row0 = -1;   // >= 0: occupancy of A from the step's scan_a: first tile row of this segment there
+  int bm_kind = BM_NONE;  // BM_SCAN: from scan_b, K tiles from bm_kt0 on; BM_CENTRE: B is the centre tensor (structural
+  int64_t bm_kt0 = 0;     // mask of the solve)
+};
+struct GGroupPlan {
+  int nseg = 0;
+  GSegPlan seg[G_MAXSEG];
+  int cbuf = 0;
+  int64_t c_off = 0;
+  double beta = 0.0;
+};
+struct ScanDesc {   // an operand whose tile occupancy is scanned once for all segments that read parts of it
+  bool on = false;
+  int buf = 0, dt = MPSE_F64;
+  int64_t off = 0;
+  mpse_index r{}, k{};
 };
 
 struct Step {
@@ -49,14 +122,15 @@ struct Step {
   int kind = K_GEMM;           // K_COPY: C(i,j) = A(i,j) with A indexed by (ma, ka), C by (mc, nc); b unused
   double beta = 0.0;           // K_GEMM: C = A.B + beta C
   int skip_zero = 0;           // K_GEMM: scan both operands for all-zero tiles and skip them (block-sparse sweeps)
-  int cmask_slot = -1;         // K_GEMM: byte flag per 64 x 64 output tile into this mask buffer (1 = something was
-                               // multiplied into it); tiles with nothing are NOT stored (consumer: K_WSTEP)
-  int amask_slot = -1;         // K_GEMM: tile-occupancy mask of operand A written by a K_WSTEP producer (no scan)
-  WStepDesc ws;                // K_WSTEP (a = centre tensor, b = W site, c = T2; T1 is B_T1)
   // K_GEMM steps written by push_w also carry the sizes of the MPO step they are (Da = batch of bond states, N =
   // trailing block): the executor runs small ones (d = 2 sites) through an elementwise kernel instead of MFMA tiles
   bool is_wstep = false;
   int64_t w_Da = 0, w_wl = 0, w_d = 0, w_wr = 0, w_N = 0;
+  // K_WMIX / K_GGEMM (folded one-site matvec, above)
+  std::vector<WMixDst> mix;    // K_WMIX: b = MPO site; tensors (wp_Da, wp_d, wp_Dk)
+  int64_t wp_Da = 0, wp_d = 0, wp_Dk = 0, wp_wr = 0;
+  std::vector<GGroupPlan> groups;   // K_GGEMM: ma .. nc describe ONE segment's product (rows of one group, K of one segment)
+  ScanDesc scan_a, scan_b;
   int cin = -1;                // K_GEMM with beta != 0: buffer the beta term is read from (-1: C itself) ...
   int64_t cin_off = 0;         // ... at this element offset, through these index maps
   mpse_index mcin{}, ncin{};
@@ -65,7 +139,6 @@ struct Step {
 struct Plan {
   std::vector<Step> steps;
   int64_t tmp_elems[3] = {0, 0, 0};  // T1, T2, T3 sizes (elements of the working dtype)
-  int64_t mask_bytes[M_COUNT] = {0, 0, 0, 0};   // tile-flag buffers of the masked chain
   const char* error = nullptr;
 };
 
@@ -189,91 +262,15 @@ inline void push_w(Plan& p, int wbuf, int w_dtype, int tin, int tout, int t_dtyp
   s.w_Da = na, s.w_wl = wl, s.w_d = d, s.w_wr = wr, s.w_N = N;
 }
 
-// One-site matvec whose intermediates never carry their structural zeros through HBM (large centres only):
-//   A: T1[b] = L[:, b, :] C for the channels that are not the left unit channel; output tiles into which no K tile
-//      was multiplied are flagged and not stored;
-//   W: custom MPO step (K_WSTEP) reading the flagged tiles of T1 and the centre itself for the unit channel, writing
-//      the non-empty parts of T2 and their tile mask;
-//   C: out = T2 . R with the mask of T2 (from W) and the scanned mask of R.
-inline int64_t& masked_chain_min() {   // smallest M1 * N (elements of T1 per channel) that takes this path
-  static int64_t v = [] {                // off unless MPSE_MASKED_CHAIN=1: measured slower than the dense chain, DESIGN.md
-    const char* e = getenv("MPSE_MASKED_CHAIN");
-    return (e && e[0] == '1') ? (int64_t(1) << 20) : (int64_t(1) << 62);
-  }();
-  return v;
-}
-inline bool masked_chain_ok(int dtype, const mpse_heff& h) {
-  const mpse_dims& s = h.dims;
-  const int64_t Dl = s.Dl_ket, Dr = s.Dr_ket, d = s.d0;
-  const int64_t Dlb = s.Dl_bra > 0 ? s.Dl_bra : Dl, Drb = s.Dr_bra > 0 ? s.Dr_bra : Dr;
-  if (h.nsite != 1 || (s.danc > 1) || h.w_dtype != MPSE_F64) return false;
-  if (Dr % 64 != 0 || (Dlb * d) % 64 != 0 || Dlb % 64 != 0) return false;
-  if (64 % d != 0 || s.wl * d > 96 || s.wr > 32) return false;     // limits of the MPO-step kernel (LDS staging)
-  if (Dlb * d * Dr < masked_chain_min()) return false;
-  (void)dtype;
-  (void)Drb;
-  return true;
-}
-
-inline Plan plan_heff1_masked(int dtype, const mpse_heff& h) {
-  Plan p;
-  const mpse_dims& s = h.dims;
-  const int64_t Dl = s.Dl_ket, Dr = s.Dr_ket, wl = s.wl, wr = s.wr, d = s.d0;
-  const int64_t Dlb = s.Dl_bra > 0 ? s.Dl_bra : Dl, Drb = s.Dr_bra > 0 ? s.Dr_bra : Dr;
-  const int64_t N = d * Dr;
-  p.tmp_elems[0] = Dlb * wl * N;
-  p.tmp_elems[1] = Dlb * d * wr * Dr;
-  const int64_t lu = (h.l_unit >= 1 && h.l_unit <= wl && Dlb == Dl) ? h.l_unit - 1 : -1;
-  const int64_t ru = (h.r_unit >= 1 && h.r_unit <= wr && Drb == Dr) ? h.r_unit - 1 : -1;
-  const int64_t tiles_n1 = (N + 63) / 64;
-  // A: channels below / above the unit channel (all of them when there is none)
-  const int64_t lo[2] = {0, lu + 1}, hi[2] = {lu >= 0 ? lu : wl, lu >= 0 ? wl : 0};
-  for (int r = 0; r < 2; ++r) {
-    const int64_t b0 = lo[r], nb = hi[r] - lo[r];
-    if (nb <= 0) continue;
-    push(p, B_L, b0 * Dl, h.l_dtype, 0, B_C, 0, dtype, 0, B_T1, b0 * Dlb * N, i2(nb, Dlb, Dl, wl * Dl), i1(Dl, 1),
-         i1(Dl, N), i1(N, 1), i1(nb * Dlb, N), i1(N, 1));
-    p.steps.back().skip_zero = 3;
-    p.steps.back().cmask_slot = r == 0 ? M_T1_LO : M_T1_HI;
-    p.mask_bytes[r == 0 ? M_T1_LO : M_T1_HI] = ((nb * Dlb + 63) / 64) * tiles_n1;
-  }
-  // W
-  Step w{B_C, B_W0, B_T2, 0, 0, 0, dtype, h.w_dtype, 0, 0, {}, {}, {}, {}, {}, {}, 1, 0, 0, 0};
-  w.kind = K_WSTEP;
-  w.ws.Da = Dlb, w.ws.d = d, w.ws.wl = wl, w.ws.wr = wr, w.ws.Dk = Dr;
-  w.ws.l_unit = lu, w.ws.r_unit = ru, w.ws.t1_tiles_n = tiles_n1;
-  const int64_t nf_lo = ru >= 0 ? ru : wr, nf_hi = ru >= 0 ? wr - ru - 1 : 0;
-  w.ws.nkw_lo = ((nf_lo * Dr + 15) / 16 + 7) / 8;
-  w.ws.nkw_hi = ((nf_hi * Dr + 15) / 16 + 7) / 8;
-  const int64_t tiles_m2 = (Dlb * d + 63) / 64;
-  p.mask_bytes[M_T2_LO] = tiles_m2 * w.ws.nkw_lo * 8;
-  p.mask_bytes[M_T2_HI] = tiles_m2 * w.ws.nkw_hi * 8;
-  p.steps.push_back(w);
-  // C
-  double beta = 0.0;
-  if (ru >= 0) {
-    push_copy(p, B_T2, ru * Dr, B_OUT, 0, dtype, i2(Dlb * d, 1, wr * Dr, Dr), i1(Dr, 1), i1(Dlb * d, Drb), i1(Drb, 1));
-    beta = 1.0;
-  }
-  const int64_t flo[2] = {0, ru + 1}, fhi[2] = {ru >= 0 ? ru : wr, ru >= 0 ? wr : 0};
-  for (int r = 0; r < 2; ++r) {
-    const int64_t f0 = flo[r], nf = fhi[r] - flo[r];
-    if (nf <= 0) continue;
-    push(p, B_T2, f0 * Dr, dtype, 0, B_R, f0 * Dr, h.r_dtype, 0, B_OUT, 0, i1(Dlb * d, wr * Dr), i1(nf * Dr, 1),
-         i1(nf * Dr, 1), i1(Drb, wr * Dr), i1(Dlb * d, Drb), i1(Drb, 1));
-    p.steps.back().beta = beta;
-    p.steps.back().skip_zero = 2;
-    p.steps.back().amask_slot = r == 0 ? M_T2_LO : M_T2_HI;
-    beta = 1.0;
-  }
-  return p;
-}
-
 // Effective Hamiltonian matvec, mps/hop_expr.py:57-115.  The bra-side bonds (rows of L / R, bonds of `out`) may
 // differ from the ket-side bonds (columns of L / R, bonds of C): that is the projection of H C onto another
 // state's bond spaces used by the variational compression (mps/mp.py:513-650); the Krylov / Davidson drivers
 // require them equal.
-inline Plan plan_heff(int dtype, const mpse_heff& h) {
+inline Plan plan_heff1_fold(int dtype, const mpse_heff& h, const WSiteInfo& wi);
+
+// `wi`: block structure of the MPO site where the caller knows it (mpse_mpo_site_hint): large one-site centres then
+// take the folded plan
+inline Plan plan_heff(int dtype, const mpse_heff& h, const WSiteInfo* wi = nullptr) {
   Plan p;
   const mpse_dims& s = h.dims;
   const int64_t Dl = s.Dl_ket, Dr = s.Dr_ket, wl = s.wl, wr = s.wr;
@@ -291,7 +288,10 @@ inline Plan plan_heff(int dtype, const mpse_heff& h) {
     return p;
   }
   if (h.nsite == 1) {
-    if (masked_chain_ok(dtype, h)) return plan_heff1_masked(dtype, h);
+    if (wi) {
+      Plan f = plan_heff1_fold(dtype, h, *wi);
+      if (!f.error) return f;
+    }
     // abc,bdef,lfk,cek->adl (hop_expr.py:75-79); ancilla cegk->adgl (87-91)
     const int64_t d = s.d0, N = d * anc * Dr, Nb = anc * Dr;
     p.tmp_elems[0] = Dlb * wl * N;
@@ -330,6 +330,186 @@ inline Plan plan_heff(int dtype, const mpse_heff& h) {
     return p;
   }
   p.error = "heff: nsite must be 0, 1 or 2";
+  return p;
+}
+
+
+// smallest Dl * d * Dr * Dl (multiply-adds of one channel's product) from which the folded plan is used
+inline int64_t& fold_min() {
+  static int64_t v = [] {
+    const char* e = getenv("MPSE_WFOLD");      // MPSE_WFOLD=0: the three-step chain everywhere
+    return (e && e[0] == '0') ? (int64_t(1) << 62) : (int64_t(1) << 28);
+  }();
+  return v;
+}
+
+inline int64_t& fold_align() {   // bra-bond multiple the device needs (a 64-row tile = one channel); a test hook lowers it
+  static int64_t v = 64;
+  return v;
+}
+
+// Folded one-site matvec (see above); p.error is set when the site does not qualify and the caller takes plan_heff.
+inline Plan plan_heff1_fold(int dtype, const mpse_heff& h, const WSiteInfo& wi) {
+  Plan p;
+  const mpse_dims& s = h.dims;
+  const int64_t Dl = s.Dl_ket, Dr = s.Dr_ket, wl = s.wl, wr = s.wr, d = s.d0;
+  const int64_t Dlb = s.Dl_bra > 0 ? s.Dl_bra : Dl, Drb = s.Dr_bra > 0 ? s.Dr_bra : Dr;
+  if (h.nsite != 1 || s.danc > 1 || h.w_dtype != MPSE_F64 || wi.wl != wl || wi.d != d || wi.wr != wr ||
+      ((dtype != MPSE_C128 || h.r_dtype != MPSE_C128) && fold_align() == 64)) {   // (the grouped kernel is built for a
+                                                    // complex second operand: centre and R; host emulation: any)
+    p.error = "fold: not a plain complex one-site centre with a real MPO site";
+    return p;
+  }
+  if (Dlb % fold_align() != 0 || Dl % std::min<int64_t>(16, fold_align()) != 0 ||
+      Dr % std::min<int64_t>(16, fold_align()) != 0 || d > WM_CHUNK * WM_MAXCHUNKS || Dl * d * Dr * Dlb < fold_min()) {
+    p.error = "fold: centre too small or not tile aligned";
+    return p;
+  }
+  const int64_t lu = (h.l_unit >= 1 && h.l_unit <= wl && Dlb == Dl) ? h.l_unit - 1 : -1;
+  const int64_t ru = (h.r_unit >= 1 && h.r_unit <= wr && Drb == Dr) ? h.r_unit - 1 : -1;
+  const int64_t N = d * Dr, plane = Dlb * N;
+  std::vector<std::vector<const WBlock*>> by_f(wr), by_b(wl);
+  for (const WBlock& k : wi.blocks) by_f[k.f].push_back(&k), by_b[k.b].push_back(&k);
+  // where the product of channel b goes: straight into the plane of its channel f, or into a temporary
+  std::vector<int64_t> direct_f(wl, -1), tmp_of(wl, -1);
+  int64_t ntmp = 0, ngemm = 0;
+  for (int64_t b = 0; b < wl; ++b) {
+    if (b == lu || by_b[b].empty()) continue;
+    ++ngemm;
+    if (by_b[b].size() == 1 && by_b[b][0]->ident && by_f[by_b[b][0]->f].size() == 1)
+      direct_f[b] = by_b[b][0]->f;
+    else
+      tmp_of[b] = ntmp++;
+  }
+  if (ngemm > G_MAXGRP) {
+    p.error = "fold: too many channels";
+    return p;
+  }
+  // planes: storage for every channel f != ru that is not the centre tensor itself
+  std::vector<int64_t> plane_of(wr, -1);
+  std::vector<char> alias(wr, 0), present(wr, 0);
+  int64_t nplanes = 0;
+  for (int64_t f = 0; f < wr; ++f) {
+    if (by_f[f].empty()) continue;
+    present[f] = 1;
+    if (f == ru) continue;
+    if (by_f[f].size() == 1 && by_f[f][0]->b == lu && by_f[f][0]->ident)
+      alias[f] = 1;
+    else
+      plane_of[f] = nplanes++;
+  }
+  auto dest = [&](int64_t f, int* buf, int64_t* off) {
+    if (f == ru)
+      *buf = B_OUT, *off = 0;
+    else
+      *buf = B_T2, *off = plane_of[f] * plane;
+  };
+  // A: all products L[:, b, :] . C in one grouped launch
+  Step ga{};
+  ga.kind = K_GGEMM;
+  ga.dta = h.l_dtype, ga.dtb = dtype;
+  ga.ma = i1(Dlb, wl * Dl), ga.ka = i1(Dl, 1), ga.kb = i1(Dl, N), ga.nb = i1(N, 1), ga.mc = i1(Dlb, N), ga.nc = i1(N, 1);
+  ga.batch = 1;
+  ga.scan_a.on = true;        // L as (channel | bra bond) rows: every 64-row tile belongs to one channel
+  ga.scan_a.buf = B_L, ga.scan_a.dt = h.l_dtype, ga.scan_a.off = 0;
+  ga.scan_a.r = i2(wl, Dlb, Dl, wl * Dl), ga.scan_a.k = i1(Dl, 1);
+  for (int64_t b = 0; b < wl; ++b) {
+    if (direct_f[b] < 0 && tmp_of[b] < 0) continue;
+    GGroupPlan g;
+    g.nseg = 1;
+    g.seg[0].abuf = B_L, g.seg[0].a_off = b * Dl, g.seg[0].am_row0 = b * (Dlb / 64);
+    g.seg[0].bbuf = B_C, g.seg[0].b_off = 0, g.seg[0].bm_kind = BM_CENTRE;
+    if (direct_f[b] >= 0)
+      dest(direct_f[b], &g.cbuf, &g.c_off);
+    else
+      g.cbuf = B_T1, g.c_off = tmp_of[b] * plane;
+    ga.groups.push_back(g);
+  }
+  // W: the planes that are sums of blocks
+  Step mix{};
+  mix.kind = K_WMIX;
+  mix.b = B_W0;
+  mix.dta = dtype, mix.dtb = h.w_dtype;
+  mix.wp_Da = Dlb, mix.wp_d = d, mix.wp_Dk = Dr, mix.wp_wr = wr;
+  const int64_t nchunk = (d + WM_CHUNK - 1) / WM_CHUNK;
+  for (int64_t f = 0; f < wr; ++f) {
+    if (!present[f] || alias[f]) continue;
+    bool is_direct = false;
+    for (const WBlock* k : by_f[f])
+      if (k->b != lu && direct_f[k->b] == f) is_direct = true;
+    if (is_direct) continue;
+    if ((int)mix.mix.size() >= WM_MAXDST || (int)by_f[f].size() > WM_MAXTERM) {
+      p.error = "fold: too many blocks per channel";
+      return p;
+    }
+    WMixDst q;
+    dest(f, &q.dst, &q.dst_off);
+    q.s_a = N, q.s_d = Dr;
+    for (const WBlock* k : by_f[f]) {
+      WMixTerm& t = q.term[q.nterm++];
+      t.b = k->b, t.f = k->f, t.ident = k->ident;
+      if (k->b == lu)
+        t.src = B_C, t.src_off = 0;
+      else
+        t.src = B_T1, t.src_off = tmp_of[k->b] * plane;
+      t.s_a = N, t.s_d = Dr;
+      for (int64_t c = 0; c < nchunk; ++c) {
+        int64_t lo = d, hi = 0;
+        for (int64_t x = c * WM_CHUNK; x < std::min<int64_t>(d, (c + 1) * WM_CHUNK); ++x)
+          for (int64_t e = 0; e < d; ++e)
+            if (wi.w[((k->b * d + x) * d + e) * wr + k->f] != 0.0) lo = std::min(lo, e), hi = std::max(hi, e + 1);
+        t.e_lo[c] = (unsigned char)(hi > lo ? lo : 0), t.e_hi[c] = (unsigned char)(hi > lo ? hi : 0);
+      }
+    }
+    mix.mix.push_back(q);
+  }
+  {
+    int64_t nslot = 0;
+    for (const WMixDst& q : mix.mix)
+      for (int t = 0; t < q.nterm; ++t) nslot += q.term[t].ident ? 0 : 1;
+    if (nslot * d * d > 8192) {          // 64 KB of LDS for the dense blocks
+      p.error = "fold: blocks too large for the elementwise pass";
+      return p;
+    }
+  }
+  // C: out (+)= sum_{f != ru} P_f . R[:, f, :]^T, one group, at most G_MAXSEG channels per launch
+  Step gc{};
+  gc.kind = K_GGEMM;
+  gc.dta = dtype, gc.dtb = h.r_dtype;
+  gc.ma = i1(Dlb * d, Dr), gc.ka = i1(Dr, 1), gc.kb = i1(Dr, 1), gc.nb = i1(Drb, wr * Dr), gc.mc = i1(Dlb * d, Drb),
+  gc.nc = i1(Drb, 1);
+  gc.batch = 1;
+  gc.scan_b.on = true;        // R as (bra bond) x (channel | ket bond)
+  gc.scan_b.buf = B_R, gc.scan_b.dt = h.r_dtype, gc.scan_b.off = 0;
+  gc.scan_b.r = i1(Drb, wr * Dr), gc.scan_b.k = i1(wr * Dr, 1);
+  std::vector<GSegPlan> csegs;
+  for (int64_t f = 0; f < wr; ++f) {
+    if (!present[f] || f == ru) continue;
+    GSegPlan sg;
+    sg.abuf = alias[f] ? B_C : B_T2, sg.a_off = alias[f] ? 0 : plane_of[f] * plane;
+    sg.bbuf = B_R, sg.b_off = f * Dr;
+    sg.bm_kind = BM_SCAN, sg.bm_kt0 = f * (Dr / 16);
+    csegs.push_back(sg);
+  }
+  bool out_init = ru >= 0 && present[ru];
+  if (csegs.empty() && !out_init) {
+    p.error = "fold: the MPO site is zero";
+    return p;
+  }
+  p.tmp_elems[0] = ntmp * plane;
+  p.tmp_elems[1] = nplanes * plane;
+  if (!ga.groups.empty()) p.steps.push_back(ga);
+  if (!mix.mix.empty()) p.steps.push_back(mix);
+  for (size_t i = 0; i < csegs.size(); i += G_MAXSEG) {
+    Step st = gc;
+    GGroupPlan g;
+    g.cbuf = B_OUT, g.c_off = 0;
+    g.beta = out_init ? 1.0 : 0.0;
+    for (size_t j = i; j < csegs.size() && j < i + G_MAXSEG; ++j) g.seg[g.nseg++] = csegs[j];
+    st.groups.push_back(g);
+    p.steps.push_back(st);
+    out_init = true;
+  }
   return p;
 }
 

@@ -324,44 +324,17 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   memcpy(host.data(), row_idx, size_t(nri) * sizeof(int64_t));
   memcpy(host.data() + size_t(nri) * sizeof(int64_t), col_idx, size_t(nci) * sizeof(int64_t));
   memcpy(host.data() + ib, blks.data(), db);
-  // operands of the factorisation kernels: persistent buffers when the launches are replayed from a graph
-  // (opt-in, MPSE_QR_GRAPH=1: replaying the launches from a graph measured no gain - 0.411 vs 0.414 ms per d = 2
-  // decomposition, 321.0 vs 320.5 site-updates/s - the ~4 us between the dependent panel / update kernels are spent on
-  // the device, not by the host enqueuing them)
-  static const bool graphs_on = [] {
-    const char* e = getenv("MPSE_QR_GRAPH");
-    return e && e[0] == '1';
-  }();
+  // (replaying the launch sequence from a HIP graph measured no gain - 0.411 vs 0.414 ms per d = 2 decomposition: the
+  // ~4 us between the dependent panel / update kernels are spent on the device, not by the host - and was removed)
   const bool batched = max_mm <= HH_BATCH_MAX_ROWS;
-  const bool use_caqr = max_mm <= CAQR_MAX_ROWS && caqr_enabled();
-  const bool use_graph = graphs_on && batched && !use_caqr && !MPSE_RECORDING(ctx);
   TmpBuf IDX(ctx), WS(ctx), Q(ctx), PRM(ctx);
   void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
   const size_t need[4] = {ib + db, size_t(ws_tot) * es, size_t(q_tot) * es, size_t(ktot + 1) * sizeof(HhParam)};
-  if (use_graph) {
-    for (int i = 0; i < 4; ++i) {
-      if (need[i] > ctx->qr_cap[i]) {
-        // grow (x 1.5, 64 KB granules); the graphs hold the old pointers: drop them.  The stream may still read the
-        // old buffer: wait for it before the memory goes back.
-        MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (auto& kv : ctx->qr_graphs) (void)hipGraphExecDestroy(kv.second);
-        ctx->qr_graphs.clear();
-        if (ctx->qr_buf[i]) MPSE_HIP(ctx, hipFree(ctx->qr_buf[i]));
-        ctx->qr_buf[i] = nullptr;
-        ctx->qr_cap[i] = 0;
-        const size_t cap = ((need[i] + need[i] / 2) + 65535) & ~size_t(65535);
-        MPSE_HIP(ctx, hipMalloc(&ctx->qr_buf[i], cap));
-        ctx->qr_cap[i] = cap;
-      }
-      bufs[i] = ctx->qr_buf[i];
-    }
-  } else {
-    MPSE_TRY(IDX.alloc(need[0]));
-    MPSE_TRY(WS.alloc(need[1]));
-    MPSE_TRY(Q.alloc(need[2]));
-    MPSE_TRY(PRM.alloc(need[3]));
-    bufs[0] = IDX.p, bufs[1] = WS.p, bufs[2] = Q.p, bufs[3] = PRM.p;
-  }
+  MPSE_TRY(IDX.alloc(need[0]));
+  MPSE_TRY(WS.alloc(need[1]));
+  MPSE_TRY(Q.alloc(need[2]));
+  MPSE_TRY(PRM.alloc(need[3]));
+  bufs[0] = IDX.p, bufs[1] = WS.p, bufs[2] = Q.p, bufs[3] = PRM.p;
   MPSE_TRY(stage_h2d(ctx, bufs[0], host.data(), ib + db));
   const long long* drows = static_cast<const long long*>(bufs[0]);
   const long long* dcols = drows + nri;
@@ -372,43 +345,7 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   constexpr int E = CPLX ? 2 : 1;
   hipLaunchKernelGGL((k_gather_blocks<CPLX>), dim3(ew_blocks(max_el), (unsigned)blks.size()), dim3(256), 0, ctx->stream, ws,
                      (const double*)coef, (long long)ncol, drows, dcols, dblk, herm);
-  if (use_caqr) {
-    MPSE_TRY(caqr_batched(ctx, CPLX, ws, q, blks.data(), (int)blks.size(), true, dblk));
-  } else if (use_graph) {
-    // the launch sequence of hh_qr_batched depends on these numbers only (and on the operand addresses)
-    int max_nn = 0, max_k = 0, max_q = 0;
-    for (const QrBlk& B : blks) {
-      max_nn = B.nn > max_nn ? B.nn : max_nn;
-      max_k = B.k > max_k ? B.k : max_k;
-      const int nq = B.nq > B.k ? B.nq : B.k;
-      max_q = nq > max_q ? nq : max_q;
-    }
-    const std::vector<long long> key = {CPLX ? 1 : 0, (long long)blks.size(), max_mm, max_nn, max_k, max_q,
-                                        (long long)(intptr_t)ws, (long long)(intptr_t)q, (long long)(intptr_t)prm,
-                                        (long long)(intptr_t)dblk};
-    auto it = ctx->qr_graphs.find(key);
-    if (it == ctx->qr_graphs.end()) {
-      hipGraph_t graph = nullptr;
-      MPSE_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-      const int st = hh_qr_batched(ctx, CPLX, ws, q, prm, blks.data(), (int)blks.size(), true, dblk);
-      const hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
-      if (st != MPSE_OK) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return st;
-      }
-      MPSE_HIP(ctx, ce);
-      hipGraphExec_t exec = nullptr;
-      const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      MPSE_HIP(ctx, ie);
-      if (ctx->qr_graphs.size() >= 512) {   // bounded: an unusual run with many shapes starts over
-        for (auto& kv : ctx->qr_graphs) (void)hipGraphExecDestroy(kv.second);
-        ctx->qr_graphs.clear();
-      }
-      it = ctx->qr_graphs.emplace(key, exec).first;
-    }
-    MPSE_HIP(ctx, hipGraphLaunch(it->second, ctx->stream));
-  } else if (batched) {
+  if (batched) {
     MPSE_TRY(hh_qr_batched(ctx, CPLX, ws, q, prm, blks.data(), (int)blks.size(), true, dblk));
   } else {
     for (const QrBlk& B : blks) {

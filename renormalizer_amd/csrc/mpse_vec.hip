@@ -703,11 +703,6 @@ struct OccScope {
     c->occ_cache.clear();
     for (auto& e : c->perm_cache) mpse_free(c, e.perm);
     c->perm_cache.clear();
-    for (auto& e : c->wcsr_cache) {
-      mpse_free(c, e.cnt);
-      mpse_free(c, e.ent);
-    }
-    c->wcsr_cache.clear();
   }
 };
 

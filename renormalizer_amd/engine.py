@@ -90,6 +90,7 @@ _SIGNATURES = {
     "mpse_prof_get": [C.c_void_p, C.c_int, _dblp, _dblp, _dblp, C.POINTER(C.c_int64)],
     "mpse_prof_get_ktiles": [C.c_void_p, C.c_int, C.POINTER(C.c_int64)],
     "mpse_prof_get_svd_sweeps": [C.c_void_p, C.POINTER(C.c_int64)],
+    "mpse_mpo_site_hint": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64],
     "mpse_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
     "mpse_free": [C.c_void_p, C.c_void_p],
     "mpse_pool_trim": [C.c_void_p],
@@ -385,6 +386,17 @@ class Engine:
 
     def free_all_blocks(self):
         self._check(self.lib.mpse_pool_trim(self.ctx))
+
+    def mpo_site_hint(self, dev, host):
+        """Describe a real MPO site to the engine (``mpse_mpo_site_hint``): ``dev`` is the device copy of ``host``
+        (wl, d, d, wr).  Large one-site matvecs on that site then take the folded plan.  The hint goes with the
+        buffer; the device copy must not be written to afterwards."""
+        host = np.asarray(host)
+        if host.ndim != 4 or np.iscomplexobj(host) or dev.is_complex or dev.offset != 0:
+            return
+        w = np.ascontiguousarray(host, dtype=np.float64)
+        self._check(self.lib.mpse_mpo_site_hint(self.ctx, dev.ptr, w.ctypes.data, *[int(x) for x in w.shape[:2]],
+                                                int(w.shape[3])))
 
     # -- kernel profiling (HIP events on the engine stream)
     def prof_enable(self, on=True):

@@ -31,6 +31,8 @@ class Hop:
             assert nsite in (1, 2) and self.l.ndim == 4 and self.r.ndim == 4
             assert self.l.shape[1] == self.l.shape[2] and self.r.shape[1] == self.r.shape[2]
         self.cmo = [eng.asdevice(w) for w in cmo]
+        if nsite == 1 and isinstance(cmo[0], np.ndarray):
+            eng.mpo_site_hint(self.cmo[0], cmo[0])
         if nsite == 2 and self.cmo[0].is_complex != self.cmo[1].is_complex:
             self.cmo = [w.to_complex() for w in self.cmo]
         h = mpse_heff()

@@ -391,6 +391,7 @@ class Mpo:
         key = (i, id(eng))
         if key not in self._dev:
             self._dev[key] = eng.asdevice(self._mp[i])
+            eng.mpo_site_hint(self._dev[key], self._mp[i])     # block structure of the site for the folded matvec
         return self._dev[key]
 
     def try_swap_site(self, new_model, swap_jw: bool = False, tol: float = 1e-13):

@@ -69,39 +69,52 @@ static int run(int dtype, const Plan& p, const void* bufs_in[B_COUNT]) {
   for (const Step& s : p.steps) {
     const size_t ea = s.dta == MPSE_C128 ? 16 : 8, eb = s.dtb == MPSE_C128 ? 16 : 8;
     const int dtc = (s.dta == MPSE_C128 || s.dtb == MPSE_C128) ? MPSE_C128 : MPSE_F64;
-    if (dtc != dtype) return MPSE_ERR_ARG;
-    if (s.kind == K_WSTEP) {   // dense restatement of the masked MPO step (tile flags play no role on the host)
-      const WStepDesc& w = s.ws;
-      const cd* X0c = (const cd*)bufs[s.a];
-      const double* X0r = (const double*)bufs[s.a];
+    if (dtc != dtype && s.kind != K_WMIX) return MPSE_ERR_ARG;
+    if (s.kind == K_WMIX) {   // dst[a, dd, k] = sum_terms sum_e W[b, dd, e, f] src[a, e, k]
       const double* W = (const double*)bufs[s.b];
-      const void* T1 = bufs[B_T1];
-      void* T2 = const_cast<void*>(bufs[s.c]);
-      for (int64_t a = 0; a < w.Da; ++a)
-        for (int64_t dd = 0; dd < w.d; ++dd)
-          for (int64_t f = 0; f < w.wr; ++f)
-            for (int64_t k = 0; k < w.Dk; ++k) {
+      const int64_t nchunk = (s.wp_d + WM_CHUNK - 1) / WM_CHUNK;
+      for (const WMixDst& q : s.mix)
+        for (int64_t a = 0; a < s.wp_Da; ++a)
+          for (int64_t dd = 0; dd < s.wp_d; ++dd)
+            for (int64_t k = 0; k < s.wp_Dk; ++k) {
               cd acc = 0;
-              for (int64_t b = 0; b < w.wl; ++b)
-                for (int64_t e = 0; e < w.d; ++e) {
-                  const double v = W[((b * w.d + dd) * w.d + e) * w.wr + f];
-                  if (v == 0.0) continue;
-                  cd x;
-                  if (b == w.l_unit) {
-                    const int64_t o = (a * w.d + e) * w.Dk + k;
-                    x = dtype == MPSE_C128 ? X0c[o] : cd(X0r[o], 0.0);
-                  } else {
-                    const int64_t o = ((b * w.Da + a) * w.d + e) * w.Dk + k;
-                    x = dtype == MPSE_C128 ? ((const cd*)T1)[o] : cd(((const double*)T1)[o], 0.0);
-                  }
-                  acc += v * x;
+              for (int t = 0; t < q.nterm; ++t) {
+                const WMixTerm& tm = q.term[t];
+                const int64_t c = dd / WM_CHUNK;
+                if (c >= nchunk) return MPSE_ERR_ARG;
+                // only the columns the plan declares for this chunk are read - as on the device
+                for (int64_t e = tm.e_lo[c]; e < tm.e_hi[c]; ++e) {
+                  const double v = tm.ident ? (e == dd ? 1.0 : 0.0) : W[((tm.b * s.wp_d + dd) * s.wp_d + e) * s.wp_wr + tm.f];
+                  if (v != 0.0) acc += v * ld(bufs[tm.src], dtype, tm.src_off + a * tm.s_a + e * tm.s_d + k, 0);
                 }
-              const int64_t o = ((a * w.d + dd) * w.wr + f) * w.Dk + k;
+              }
+              const int64_t o = q.dst_off + a * q.s_a + dd * q.s_d + k;
               if (dtype == MPSE_C128)
-                ((cd*)T2)[o] = acc;
+                ((cd*)const_cast<void*>(bufs[q.dst]))[o] = acc;
               else
-                ((double*)T2)[o] = acc.real();
+                ((double*)const_cast<void*>(bufs[q.dst]))[o] = acc.real();
             }
+      continue;
+    }
+    if (s.kind == K_GGEMM) {   // every group: C = sum over its segments of A_seg . B_seg (+ beta C)
+      for (const GGroupPlan& g : s.groups) {
+        void* Cg = const_cast<void*>(bufs[g.cbuf]);
+        for (int64_t i = 0; i < s.ma.ext; ++i)
+          for (int64_t jn = 0; jn < s.nb.ext; ++jn) {
+            cd acc = 0;
+            for (int q = 0; q < g.nseg; ++q) {
+              const GSegPlan& sg = g.seg[q];
+              for (int64_t k = 0; k < s.ka.ext; ++k)
+                acc += ld(bufs[sg.abuf], s.dta, sg.a_off + off(s.ma, i) + off(s.ka, k), 0) *
+                       ld(bufs[sg.bbuf], s.dtb, sg.b_off + off(s.kb, k) + off(s.nb, jn), 0);
+            }
+            const int64_t o = g.c_off + off(s.mc, i) + off(s.nc, jn);
+            if (dtype == MPSE_C128)
+              ((cd*)Cg)[o] = acc + (g.beta != 0.0 ? g.beta * ((const cd*)Cg)[o] : cd(0));
+            else
+              ((double*)Cg)[o] = acc.real() + (g.beta != 0.0 ? g.beta * ((const double*)Cg)[o] : 0.0);
+          }
+      }
       continue;
     }
     if (s.kind == K_COPY) {
@@ -167,5 +180,22 @@ extern "C" int emu_heff_apply2(int dtype, const mpse_heff* h, const void* C, voi
 }
 
 extern "C" void emu_set_unit_threshold(long long macs) { unit_threshold() = macs; }
-extern "C" void emu_set_masked_chain_min(long long elems) { masked_chain_min() = elems; }
+// one-site matvec through the folded plan (the block structure of the MPO site read from the host copy of W);
+// returns MPSE_ERR_SHAPE when the site does not qualify.  *nsteps receives the number of plan steps.
+extern "C" int emu_heff_apply_fold(int dtype, const mpse_heff* h, const void* C, void* out, int* nsteps) {
+  const WSiteInfo wi = analyse_mpo_site((const double*)h->W0, h->dims.wl, h->dims.d0, h->dims.wr);
+  Plan p = plan_heff1_fold(dtype, *h, wi);
+  if (nsteps) *nsteps = (int)p.steps.size();
+  const void* bufs[B_COUNT] = {nullptr};
+  bufs[B_L] = h->L;
+  bufs[B_R] = h->R;
+  bufs[B_W0] = h->W0;
+  bufs[B_C] = C;
+  bufs[B_OUT] = out;
+  return run(dtype, p, bufs);
+}
+extern "C" void emu_set_fold_min(long long macs, long long align) {
+  fold_min() = macs;
+  fold_align() = align;
+}
 extern "C" void emu_set_beta_source(int on) { beta_source_flag() = on != 0; }

@@ -372,17 +372,12 @@ def test_block_qr_rank_deficient_and_shapes(eng, cplx):
             assert np.abs(iso.conj().T @ iso - np.eye(iso.shape[1])).max() < 1e-13
 
 
-@pytest.mark.parametrize("caqr", ["0", "1"])
 @pytest.mark.parametrize("cplx", [False, True])
-def test_block_qr_many_ragged_blocks_tree_shapes(eng, cplx, caqr, monkeypatch):
-    # (MPSE_QR_GRAPH is read once per process: the graph replay of the default kernels is exercised by
-    # test_headline_switch_ab[MPSE_QR_GRAPH=1] in its own process)
-    """Several quantum-number blocks of different heights in ONE decomposition, chosen around the chunk (256 rows) and
-    panel (16 columns) boundaries of the communication-avoiding QR: single chunk, chunk + a few rows, many chunks,
-    the full 4096-row tree, blocks with fewer rows than columns, one-row and one-column blocks; interleaved row /
-    column order.  Reconstruction, isometry, and the triangular shape of every block's R.  Both implementations:
-    the panel-blocked kernels (default) and the communication-avoiding tree (MPSE_QR_CAQR=1)."""
-    monkeypatch.setenv("MPSE_QR_CAQR", caqr)
+def test_block_qr_many_ragged_blocks_tree_shapes(eng, cplx):
+    """Several quantum-number blocks of different heights in ONE decomposition, chosen around the row-slot (256 / 512
+    threads x rows per thread) and panel boundaries of the batched Householder kernels: blocks of 255 .. 4096 rows,
+    blocks with fewer rows than columns, one-row and one-column blocks; interleaved row / column order.
+    Reconstruction, isometry, and the triangular shape of every block's R."""
     rng = np.random.default_rng(21)
     heights = [255, 256, 257, 511, 17, 1, 4096, 1300, 16, 15, 33]
     widths = [40, 16, 130, 17, 33, 5, 256, 48, 16, 31, 1]
@@ -550,21 +545,39 @@ def test_device_copies_all_alignments(eng):
             assert np.array_equal(dst.to_host(), a[1:])
 
 
+def _holstein_like_site(rng, d):
+    """(wl, wr) = (5, 4) MPO site with the block structure of a phonon site of a Holstein chain: channels that pass
+    through (identity blocks), one diagonal and one tridiagonal block into the last channel."""
+    w = np.zeros((5, d, d, 4))
+    eye = np.eye(d)
+    w[0, :, :, 0] = eye
+    w[0, :, :, 3] = np.diag(rng.standard_normal(d))
+    w[1, :, :, 1] = eye
+    w[2, :, :, 2] = eye
+    w[3, :, :, 3] = np.diag(rng.standard_normal(d - 1), 1) + np.diag(rng.standard_normal(d - 1), -1)
+    w[4, :, :, 3] = eye
+    return w
+
+
 @pytest.mark.parametrize("cplx", [True, False])
-def test_masked_one_site_chain_block_sparse_vs_oracle(eng, cplx):
-    """The one-site matvec whose intermediates skip their structural zeros (tile-flagged T1 / T2, custom MPO step,
-    mpse_plans.h plan_heff1_masked) at a size that takes that path (D = 256, d = 16): block-sparse operands with two
-    bond sectors that do not align with the 64-wide tiles, with and without unit channels, against the oracle."""
+def test_folded_one_site_matvec_block_sparse_vs_oracle(eng, cplx):
+    """The one-site matvec with the MPO step absorbed into the operands of the two large products (mpse_plans.h
+    plan_heff1_fold: prepared operands, grouped launches with K segments) at a size that takes that path (D = 256,
+    d = 16): block-sparse operands with two bond sectors that do not align with the 64-wide tiles, with and without
+    unit channels, against the oracle; then the same product inside a Lanczos solve with the structural mask of the
+    centre (masks of the prepared operands derived from it) against the solve without it."""
+    from renormalizer_amd.lib.krylov import expm_krylov
+    from renormalizer_amd.mps.hop_expr import centre_tile_mask
     rng = np.random.default_rng(31)
     D, d, wl, wr = 256, 16, 5, 4
     sec = np.array([0] * 100 + [1] * 156)
-    dl = np.array([0, 0, 1, -1, 0])                       # charge carried by the channels of L
+    dl = np.array([0, 1, -1, 0, 0])                       # charge carried by the channels of L
     dr = np.array([0, 1, -1, 0])
     l = _rand(rng, (D, wl, D), cplx) * (sec[:, None, None] - sec[None, None, :] == dl[None, :, None])
     r = _rand(rng, (D, wr, D), cplx) * (sec[:, None, None] - sec[None, None, :] == dr[None, :, None])
-    w = rng.standard_normal((wl, d, d, wr)) * (rng.random((wl, d, d, wr)) < 0.05)
+    w = _holstein_like_site(rng, d)
     c = _rand(rng, (D, d, D), cplx) * (sec[:, None, None] == sec[None, None, :])
-    for lu, ru in ((0, 0), (1, wr)):
+    for lu, ru in ((0, 0), (1, wr), (1, 0), (0, wr)):
         l2, r2 = l.copy(), r.copy()
         if lu:
             l2[:, lu - 1, :] = np.eye(D)
@@ -572,13 +585,25 @@ def test_masked_one_site_chain_block_sparse_vs_oracle(eng, cplx):
             r2[:, ru - 1, :] = np.eye(D)
         ld, rd = eng.asdevice(l2), eng.asdevice(r2)
         ld.unit, rd.unit = lu, ru
-        hop = hop_expr(ld, rd, [eng.asdevice(w)], c.shape)
+        hop = hop_expr(ld, rd, [w], c.shape)              # a host MPO site: its block structure goes to the engine
         out = hop(eng.asdevice(c)).to_host()
         ref = orc.hop_apply(l2, r2, [w], c)
         assert _relerr(out.ravel(), ref.ravel()) < 1e-12, (lu, ru)
-        # an all-zero centre passes through the flags untouched
         z = hop(eng.zeros(c.shape, c.dtype)).to_host()
         assert np.abs(z).max() == 0.0
+    # (the operator is not Hermitian: with a tiny step both solves stop at their second estimate, and they run the
+    # same recurrence on the same numbers - only the tile masks differ)
+    ld, rd = eng.asdevice(l2), eng.asdevice(r2)
+    ld.unit, rd.unit = 0, wr
+    hop = hop_expr(ld, rd, [w], c.shape)
+    v0 = eng.asdevice(c.astype(complex))
+    plain, n0 = expm_krylov(hop, -1e-7j, v0)
+    qn_l = np.repeat(sec[:, None], d, axis=1).reshape(D * d, 1)          # phonon levels carry no charge
+    hop.cmask = centre_tile_mask(eng, qn_l, -sec[:, None], np.array([0]), c.shape)
+    assert hop.cmask is not None
+    masked, n1 = expm_krylov(hop, -1e-7j, v0)
+    assert n0 == n1
+    assert _relerr(masked.to_host().ravel(), plain.to_host().ravel()) < 1e-13
 
 
 def test_eigh_qn_density_matrix_blocks(eng):

@@ -109,23 +109,11 @@ def _run_variant(state, out, env_extra):
 
 # switch -> True: the alternative path is designed to give the same bits; False: same state to rounding
 _SWITCHES = {
-    "MPSE_CENTRE_MASK=0": True,       # scan every Krylov vector instead of the quantum-number tile mask
+    "MPSE_CENTRE_MASK=0": True,       # no quantum-number tile mask of the Krylov vectors (more tiles multiplied, all zeros)
     "MPSE_ENV_CARRY=0": True,         # rebuild the environments at every step
-    "MPSE_BETA_SOURCE=0": True,       # copy the unit-channel slice, then accumulate onto it
-    "MPSE_DOT_FUSED=0": False,        # Lanczos coefficient by its own reduction kernel (other summation order)
-    "MPSE_WSMALL=0": False,           # MPO step of the d = 2 sites as an MFMA product
     "MPSE_LANCZOS_ASYNC=0": False,    # host-side eigen-decomposition of the tridiagonal matrix
-    "MPSE_LZ_DEFER_FIRST=0": True,    # the first convergence check of a solve on its own instead of merged into the second
-    "MPSE_QR_CAQR=1": False,          # communication-avoiding tree QR instead of the panel-blocked kernels
-    "MPSE_QR_GRAPH=1": True,          # the QR's launches replayed from a HIP graph instead of enqueued one by one
-    "MPSE_GEMM_SKEW=0": True,         # output tiles in storage order (a die then owns whole tile columns)
-    "MPSE_GEMM_ORDER=0": True,        # no heaviest-first launch order of the block-sparse products
     "MPSE_DEFER=0": True,             # QR / environment update / absorption issued from Python after each solve returns
-    "MPSE_GEMM_SLICEFAST=0": True,    # split products launched tile-fastest (a die then reads most of both operands)
-    "MPSE_GEMM_DIEGROUP=0": True,     # unsplit products without the die-wise grouping of tile rows / columns
-    "MPSE_GEMM_WIDE=0": False,        # four waves per workgroup also where a workgroup has its compute unit to itself
-    "MPSE_SPLITK_BAL=2": False,       # one-tile-per-CU block-sparse products cut into two slices of equal occupied K tiles
-    "MPSE_QR_LOOKAHEAD=0": False,     # panel and trailing update of the short blocks as two launches instead of one
+    "MPSE_WFOLD=0": False,            # one-site matvec as the three-step chain (L.C, MPO step, .R) instead of the folded plan
 }
 
 

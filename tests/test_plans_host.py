@@ -371,31 +371,79 @@ def test_stacked_mpo_plans_vs_golden(emu, golden_dir):
         assert np.abs(outz[..., 1, :] - 2 * g("out")).max() < 1e-10 * max(1, np.abs(g("out")).max())
 
 
-def test_masked_one_site_chain_plan(emu):
-    """plan_heff1_masked (tile-flagged intermediates, custom MPO step): the same numbers as the oracle, with and
-    without unit channels on either side, square and projected (bra bonds != ket bonds)."""
-    emu.emu_set_masked_chain_min.argtypes = [C.c_longlong]
-    emu.emu_set_masked_chain_min(1)
+def _fold_w(rng, wl, d, wr, kind):
+    """MPO sites with the block structure the folded plan distinguishes: identity blocks (channels that pass through),
+    general blocks, empty channels."""
+    w = np.zeros((wl, d, d, wr))
+    if kind == "holstein":        # (wl, wr) = (5, 4): I->I, I->done (diag), a->a, b->b, x->done (general), done->done
+        assert (wl, wr) == (5, 4)
+        eye = np.eye(d)
+        w[0, :, :, 0] = eye
+        w[0, :, :, 3] = np.diag(rng.standard_normal(d))
+        w[1, :, :, 1] = eye
+        w[2, :, :, 2] = eye
+        w[3, :, :, 3] = np.diag(rng.standard_normal(d - 1), 1) + np.diag(rng.standard_normal(d - 1), -1)
+        w[4, :, :, 3] = eye
+    elif kind == "mixed":         # identity blocks that are not alone in their channel, a scaled identity, an empty channel
+        eye = np.eye(d)
+        for b in range(wl):
+            w[b, :, :, b % (wr - 1)] = eye if b % 2 == 0 else 0.5 * eye
+        w[0, :, :, 0] += rng.standard_normal((d, d))
+    else:                         # dense: every block general
+        w = rng.standard_normal((wl, d, d, wr))
+    return w
+
+
+def test_folded_one_site_plan(emu):
+    """plan_heff1_fold (MPO step absorbed into the operands of the two large products, mpse_plans.h): the same
+    numbers as the dense contraction with and without unit channels on either side, for pass-through, mixed and dense
+    MPO sites; a site with more blocks per channel than the elementwise pass takes is refused (the caller takes the
+    three-step chain)."""
+    emu.emu_heff_apply_fold.argtypes = [C.c_int, C.POINTER(E.mpse_heff), C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    emu.emu_set_fold_min.argtypes = [C.c_longlong, C.c_longlong]
+    emu.emu_set_fold_min(1, 4)          # (the device needs bonds in multiples of 64: tile = channel; not the host loops)
     try:
-        rng = np.random.default_rng(17)
+        rng = np.random.default_rng(23)
         for cplx in (False, True):
-            for (Dl, Dr, d, wl, wr, Dlb, Drb) in ((64, 64, 2, 3, 4, 64, 64), (64, 64, 1, 2, 3, 128, 64)):
-                l = _rand(rng, (Dlb, wl, Dl), cplx)
-                r = _rand(rng, (Drb, wr, Dr), cplx)
-                w0 = _rand(rng, (wl, d, d, wr), False) * (rng.random((wl, d, d, wr)) < 0.4)
-                c = _rand(rng, (Dl, d, Dr), cplx)
-                ref = np.einsum("abc,bdef,lfk,cek->adl", l, w0, r, c)
-                out = emu_heff(emu, l, r, [w0], c)
-                assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max()
-                if Dl == Dlb and Dr == Drb:
-                    for lu, ru in ((1, 0), (0, wr), (2, 1)):
-                        l2, r2 = l.copy(), r.copy()
-                        if lu:
-                            l2[:, lu - 1, :] = np.eye(Dl)
-                        if ru:
-                            r2[:, ru - 1, :] = np.eye(Dr)
-                        ref = np.einsum("abc,bdef,lfk,cek->adl", l2, w0, r2, c)
-                        out = emu_heff(emu, l2, r2, [w0], c, l_unit=lu, r_unit=ru)
-                        assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max(), (lu, ru)
+            for (D, d, wl, wr, kind) in ((12, 4, 5, 4, "holstein"), (8, 3, 4, 4, "mixed"), (8, 2, 2, 2, "dense")):
+                w0 = _fold_w(rng, wl, d, wr, kind)
+                c = _rand(rng, (D, d, D), cplx)
+                for lu, ru in ((0, 0), (1, wr), (1, 0), (0, wr), (wl, 1)):
+                    l = _rand(rng, (D, wl, D), cplx)
+                    r = _rand(rng, (D, wr, D), cplx)
+                    if lu:
+                        l[:, lu - 1, :] = np.eye(D)
+                    if ru:
+                        r[:, ru - 1, :] = np.eye(D)
+                    ref = np.einsum("abc,bdef,lfk,cek->adl", l, w0, r, c)
+                    h = E.mpse_heff()
+                    h.nsite, h.l_unit, h.r_unit = 1, lu, ru
+                    dm = h.dims
+                    dm.Dl_ket = dm.Dl_bra = dm.Dr_ket = dm.Dr_bra = D
+                    dm.danc, dm.wl, dm.wr, dm.d0, dm.d1, dm.wm = 1, wl, wr, d, 1, 1
+                    keep = [_c(l), _c(r), _c(w0), _c(c)]
+                    h.L, h.l_dtype = keep[0].ctypes.data, E.dtype_code(keep[0].dtype)
+                    h.R, h.r_dtype = keep[1].ctypes.data, E.dtype_code(keep[1].dtype)
+                    h.W0, h.w_dtype = keep[2].ctypes.data, E.F64
+                    out = np.full(c.shape, np.nan, dtype=c.dtype)
+                    nsteps = C.c_int(0)
+                    st = emu.emu_heff_apply_fold(E.C128 if cplx else E.F64, C.byref(h), keep[3].ctypes.data,
+                                                 out.ctypes.data, C.byref(nsteps))
+                    assert st == 0, (kind, lu, ru)
+                    assert nsteps.value <= 3
+                    assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max(), (kind, lu, ru)
+        # six channels into one: refused
+        w0 = rng.standard_normal((6, 2, 2, 1))
+        l, r, c = _rand(rng, (8, 6, 8), False), _rand(rng, (8, 1, 8), False), _rand(rng, (8, 2, 8), False)
+        h = E.mpse_heff()
+        h.nsite = 1
+        dm = h.dims
+        dm.Dl_ket = dm.Dl_bra = dm.Dr_ket = dm.Dr_bra = 8
+        dm.danc, dm.wl, dm.wr, dm.d0, dm.d1, dm.wm = 1, 6, 1, 2, 1, 1
+        keep = [_c(l), _c(r), _c(w0), _c(c)]
+        h.L, h.l_dtype, h.R, h.r_dtype = keep[0].ctypes.data, E.F64, keep[1].ctypes.data, E.F64
+        h.W0, h.w_dtype = keep[2].ctypes.data, E.F64
+        out = np.zeros_like(c)
+        assert emu.emu_heff_apply_fold(E.F64, C.byref(h), keep[3].ctypes.data, out.ctypes.data, None) != 0
     finally:
-        emu.emu_set_masked_chain_min(1 << 20)
+        emu.emu_set_fold_min(1 << 28, 64)
