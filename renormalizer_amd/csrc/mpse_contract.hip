@@ -376,6 +376,11 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
         }
       }
       gd.masks_stable = stable;
+      if (gd.ngrp == 1 && s.groups[0].split2) {
+        if (!bufs[B_OUT2]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing second result");
+        gd.split2 = true;
+        gd.c2 = const_cast<void*>(bufs[B_OUT2]);
+      }
       // the last step completes the result: it carries the caller's dot request
       if (ctx->dot_req.y && &s == &p.steps.back() && gd.ngrp == 1 && s.groups[0].cbuf == B_OUT && s.groups[0].c_off == 0)
         ctx->dot_now = true;
@@ -426,7 +431,11 @@ extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, con
     auto it = ctx->wsite_info.find(h->W0);
     if (it != ctx->wsite_info.end()) wi_keep = it->second;
   }
-  Plan p = plan_heff(dtype, *h, static_cast<const WSiteInfo*>(wi_keep.get()));
+  // a caller that takes the result in two parts (mpse_ctx::y2_req, the Lanczos solve) lets the last product run as
+  // halved tiles; `used` tells it whether the second part holds anything
+  mpse_ctx::Y2Req& y2 = ctx->y2_req;
+  Plan p = plan_heff(dtype, *h, static_cast<const WSiteInfo*>(wi_keep.get()), y2.ptr != nullptr);
+  y2.used = p.two_results;
   const void* bufs[B_COUNT] = {nullptr};
   bufs[B_L] = h->L;
   bufs[B_R] = h->R;
@@ -434,6 +443,7 @@ extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, con
   bufs[B_W1] = h->W1;
   bufs[B_C] = C;
   bufs[B_OUT] = out;
+  bufs[B_OUT2] = y2.ptr;
   return run_plan(ctx, dtype, p, bufs);
 }
 

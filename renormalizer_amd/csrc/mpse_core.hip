@@ -1,5 +1,6 @@
 // Context, pooled device memory and host<->device transfers of libmpsengine.so.
 #include "mpse_internal.h"
+#include "mpse_plans.h"
 
 int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...) {
   if (ctx) {
@@ -264,6 +265,7 @@ int mpse_ctx_create(int device, mpse_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
     ctx->n_cu = prop.multiProcessorCount;
+    if (ctx->n_cu > 0) mpse_plan::fold_cus() = ctx->n_cu;
     snprintf(ctx->dev_name, sizeof(ctx->dev_name), "%s (%s)", prop.name, prop.gcnArchName);
   }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||

@@ -63,6 +63,15 @@ struct GGrp {
 struct GemmGroups {
   GGrp g[GMAX_GRP];
   int ngrp, tiles_m_grp, nkt_seg, am_pitch, bm_pitch;
+  // split2: every output tile is computed by TWO workgroups, each over half of the tile's OCCUPIED K tiles: the first
+  // half (with the beta term) is stored to C, the second to C2, laid out like C - the CONSUMER of the result adds the
+  // two (the Lanczos update reads both; floating-point atomics onto one result measured slower than the launch they
+  // were to speed up: 16 K eight-byte atomics per workgroup).  For block-sparse products with one tile per compute
+  // unit: such a launch is as slow as its fullest tile, and a lone workgroup leaves the matrix pipe idle between its
+  // MFMAs; the halves of heavy and light tiles are paired per compute unit through the launch order (cpd = compute
+  // units per die, perm = tiles by decreasing weight).  DESIGN.md 4.1.
+  int split2, cpd;
+  double* C2;
 };
 
 struct GemmArgs {
@@ -168,6 +177,25 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
   // few) K slices of every tile and its L2 sees 1/8 of both operands instead of most of them
   int bs = bid / ntile;                  // (batch, k-slice)
   int t = bid - bs * ntile;
+  int half = 0;                          // grouped launch with split2: which half of the tile's K tiles
+  if constexpr (GRP) {
+    if (g.gg.split2) {
+      // Launch position -> (tile, half).  Positions go to the dies round robin and, on a die, to its compute units in
+      // order: the first cpd positions of a die get a unit each, the next cpd join them.  The 2 m halves of the die's m
+      // tiles, by decreasing weight, are laid out so that the unit that receives the q-th heaviest half in the first
+      // round receives the q-th lightest in the second.
+      if ((ntile & 7) == 0) {
+        const int m2 = 2 * (ntile >> 3), r = bid >> 3, cpd = g.gg.cpd;
+        const int q = (r < cpd || m2 <= cpd) ? r : (m2 - 1) - (r - cpd);
+        half = q & 1;
+        t = ((q >> 1) << 3) | (bid & 7);
+      } else {
+        half = bid & 1;
+        t = bid >> 1;
+      }
+      bs = half;       // (slot of the dot partials: half * tiles + tile)
+    }
+  }
   if (g.slice_fast) {
     t = bid / g.ksplit;
     bs = bid - t * g.ksplit;
@@ -205,7 +233,8 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
   const GGrp& gp = g.gg.g[grp];          // (kernel-argument memory; touched by GRP instantiations only)
   const double* A = GRP ? gp.seg[0].A : g.A + (long long)b * g.sbA * EA;
   const double* B = GRP ? gp.seg[0].B : g.B + (long long)b * g.sbB * EB;
-  double* C = GRP ? gp.C : g.C + (long long)b * g.sbC * EC;
+  // (halved tiles: the second half of every tile goes to the second result, without the beta term)
+  double* C = GRP ? (half ? g.gg.C2 : gp.C) : g.C + (long long)b * g.sbC * EC;
 
   // ---- per-thread staging coordinates (4 elements of each operand tile)
   int ai[NLD], ak[NLD], bj[NLD], bk[NLD];
@@ -428,6 +457,39 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
       __syncthreads();
       mlds = true;
       am = s_mask[0];       // (non-null: look-ups go through the LDS copy)
+    }
+    if (g.gg.split2) {
+      // this workgroup's half: occupied K tiles [n half / 2, n (half + 1) / 2) of the tile (every thread walks the
+      // same flag words); without masks the K range itself is halved
+      if (mlds) {
+        auto word_of = [&](int w) {
+          unsigned long long x = s_mask[0][w] & 0x0101010101010101ull;
+          const int valid = nkt_all - 8 * w;
+          if (valid < 8) x &= valid > 0 ? (1ull << (8 * valid)) - 1ull : 0ull;
+          return x;
+        };
+        int n = 0;
+        for (int w = 0; w < g.nkw; ++w) n += __popcll(word_of(w));
+        auto pos_of = [&](int i) {      // position of the i-th occupied tile (i >= n: the end of the range)
+          if (i >= n) return nkt_all;
+          int seen = 0;
+          for (int w = 0; w < g.nkw; ++w) {
+            unsigned long long x = word_of(w);
+            const int c = __popcll(x);
+            if (seen + c > i) {
+              for (int skip = i - seen; skip > 0; --skip) x &= x - 1;
+              return (w << 3) + (__builtin_ctzll(x) >> 3);
+            }
+            seen += c;
+          }
+          return nkt_all;
+        };
+        kt_begin = half == 0 ? 0 : pos_of(n / 2);
+        kt_end = half == 0 ? pos_of(n / 2) : nkt_all;
+      } else {
+        kt_begin = half == 0 ? 0 : nkt_all / 2;
+        kt_end = half == 0 ? nkt_all / 2 : nkt_all;
+      }
     }
   } else if constexpr (KS) {
     // masks are kept per 64 rows / columns whatever the workgroup tile
@@ -747,7 +809,7 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
   // of the preloads spill; their beta / dot terms are read inside the store loop as before)
   constexpr bool PRE = CA && CB;
   double2 pre_c[PRE ? WI : 1][2][4], pre_y[PRE ? WI : 1][2][4];
-  const bool need_c = GRP ? gp.use_beta != 0 : g.use_beta != 0, need_y = g.dot_y != nullptr;
+  const bool need_c = GRP ? (gp.use_beta != 0 && half == 0) : g.use_beta != 0, need_y = g.dot_y != nullptr;
   if (PRE && (need_c || need_y)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1524,6 +1586,11 @@ int gemm_grouped(mpse_ctx* ctx, const GroupedDesc& d) {
   GemmGroups& gg = g.gg;
   gg.ngrp = d.ngrp, gg.tiles_m_grp = g.mtiles_m, gg.nkt_seg = g.K / BK;
   gg.am_pitch = d.am_pitch, gg.bm_pitch = d.bm_pitch;
+  gg.split2 = d.split2 ? 1 : 0;
+  gg.C2 = static_cast<double*>(d.c2);
+  gg.cpd = (ctx->n_cu > 0 ? ctx->n_cu : 256) / 8;
+  if (d.split2 && (d.ngrp != 1 || !d.c2 || g.M % BM != 0))
+    return mpse_fail(ctx, MPSE_ERR_ARG, "grouped product: halved tiles need one group, whole tile rows and a second result");
   int max_seg = 0;
   bool any_mask = false, any_beta = false;
   for (int i = 0; i < d.ngrp; ++i) {
@@ -1551,10 +1618,11 @@ int gemm_grouped(mpse_ctx* ctx, const GroupedDesc& d) {
   // the caller's dot request (the launch that completes a matvec result): one group only
   const bool want_dot = ctx->dot_now;
   ctx->dot_now = false;
-  if (want_dot && d.ngrp == 1 && ntile >= 1 && ntile <= ctx->dot_req.cap) {
+  const long long nwg = ntile * (d.split2 ? 2 : 1);
+  if (want_dot && d.ngrp == 1 && nwg >= 1 && nwg <= ctx->dot_req.cap) {
     g.dot_y = static_cast<const double*>(ctx->dot_req.y);
     g.dot_part = ctx->dot_req.part;
-    ctx->dot_req.nb_out = (int)ntile;
+    ctx->dot_req.nb_out = (int)nwg;
   }
   mpse_ctx::ProfRec rec;
   const int variant = (ca ? 1 : 0) + (cb ? 2 : 0);
@@ -1567,7 +1635,9 @@ int gemm_grouped(mpse_ctx* ctx, const GroupedDesc& d) {
                                     &rec);
   g.kt_counter = prof_this && ctx->prof_ktiles ? ctx->prof_ktiles + variant : nullptr;
   TmpBuf PERM(ctx);
-  if (g.nkw > 0 && ntile > 2 * n_cu && ntile <= 2048) {
+  // launch order by weight: products with more tiles than slots (heaviest first, die aware), and halved products (their
+  // position -> (tile, half) map pairs heavy and light halves per compute unit through it; plain sorted order)
+  if (g.nkw > 0 && (ntile > 2 * n_cu || d.split2) && ntile <= 2048) {
     int* pp = nullptr;
     const void *ka = gg.g[0].seg[0].am, *kb = gg.g[0].seg[0].bm;
     const int nkt_key = nkt_max + 1000 * d.ngrp;       // (grouped entries never collide with plain ones)
@@ -1587,7 +1657,8 @@ int gemm_grouped(mpse_ctx* ctx, const GroupedDesc& d) {
         pp = PERM.as<int>();
       }
       hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)nullptr,
-                         (const unsigned long long*)nullptr, 0, nkt_max, g.tiles_m, g.tiles_n, 1, pp, ctx->skip_flag, gg);
+                         (const unsigned long long*)nullptr, 0, nkt_max, g.tiles_m, g.tiles_n, d.split2 ? 0 : 1, pp,
+                         ctx->skip_flag, gg);
     }
     g.perm = pp;
   }
@@ -1600,8 +1671,8 @@ int gemm_grouped(mpse_ctx* ctx, const GroupedDesc& d) {
     else if (g.tiles_m % 8 == 0)
       g.die_group = 1;
   }
-  const dim3 grid((unsigned)ntile);
-  const bool wide = ntile <= n_cu;
+  const dim3 grid((unsigned)nwg);
+  const bool wide = nwg <= n_cu;
   if (ca) {
     if (wide)
       hipLaunchKernelGGL((k_gemm<true, true, true, 2, 1, true>), grid, dim3(512), 0, ctx->stream, g);

@@ -105,6 +105,12 @@ struct mpse_ctx {
     int nb_out = 0;
   } dot_req;
   bool dot_now = false;   // set by run_plan for the one GEMM launch that completes the result
+  // A caller of mpse_heff_apply that can take the result as the SUM of two tensors (the Lanczos update reads both)
+  // offers a second buffer of the result's size; `used` reports whether the plan wrote a part of the result there
+  struct Y2Req {
+    void* ptr = nullptr;
+    bool used = false;
+  } y2_req;
   // Tile-occupancy mask of the centre tensor as operand B of the first products of a matvec, supplied by the caller
   // (mpse_expm_centre_mask: the structural pattern of the quantum numbers, the same for every Krylov vector).
   // `pending` holds what the caller set for the next solve; during that solve lo / hi delimit the Krylov vectors.
@@ -225,6 +231,10 @@ struct GroupedDesc {
   GroupedGrp grp[8];
   int am_pitch = 0, bm_pitch = 0;
   bool masks_stable = false;   // the flags live as long as the running solve's caches: the launch order is kept with them
+  // one group only: two workgroups per output tile, each over half of its occupied K tiles; the first half (+ beta C)
+  // goes to C, the second to c2 (laid out like C): the consumer adds them
+  bool split2 = false;
+  void* c2 = nullptr;
 };
 int gemm_grouped(mpse_ctx* ctx, const GroupedDesc& d);
 int occ_mask_get(mpse_ctx* ctx, const void* ptr, int dtype, mpse_index r, mpse_index k, TmpBuf& tmp,

@@ -21,7 +21,7 @@
 
 namespace mpse_plan {
 
-enum Buf { B_L = 0, B_R, B_W0, B_W1, B_C, B_BRA, B_OUT, B_T1, B_T2, B_T3, B_W2, B_W3, B_COUNT };
+enum Buf { B_L = 0, B_R, B_W0, B_W1, B_C, B_BRA, B_OUT, B_T1, B_T2, B_T3, B_W2, B_W3, B_OUT2, B_COUNT };
 inline int w_buf(int layer) { return layer == 0 ? B_W0 : layer == 1 ? B_W1 : layer == 2 ? B_W2 : B_W3; }
 
 enum Kind { K_GEMM = 0, K_COPY = 1, K_WMIX = 2, K_GGEMM = 3 };
@@ -104,6 +104,9 @@ struct GGroupPlan {
   int cbuf = 0;
   int64_t c_off = 0;
   double beta = 0.0;
+  // split2 (single-group steps): two workgroups per output tile, each over half of the tile's occupied K tiles; the
+  // first half (+ beta C) is stored to C, the second to B_OUT2, laid out like C: the caller of the plan adds the two
+  bool split2 = false;
 };
 struct ScanDesc {   // an operand whose tile occupancy is scanned once for all segments that read parts of it
   bool on = false;
@@ -139,6 +142,7 @@ struct Step {
 struct Plan {
   std::vector<Step> steps;
   int64_t tmp_elems[3] = {0, 0, 0};  // T1, T2, T3 sizes (elements of the working dtype)
+  bool two_results = false;          // the result is B_OUT + B_OUT2 (GGroupPlan::split2)
   const char* error = nullptr;
 };
 
@@ -266,11 +270,12 @@ inline void push_w(Plan& p, int wbuf, int w_dtype, int tin, int tout, int t_dtyp
 // differ from the ket-side bonds (columns of L / R, bonds of C): that is the projection of H C onto another
 // state's bond spaces used by the variational compression (mps/mp.py:513-650); the Krylov / Davidson drivers
 // require them equal.
-inline Plan plan_heff1_fold(int dtype, const mpse_heff& h, const WSiteInfo& wi);
+inline Plan plan_heff1_fold(int dtype, const mpse_heff& h, const WSiteInfo& wi, bool two_results);
 
 // `wi`: block structure of the MPO site where the caller knows it (mpse_mpo_site_hint): large one-site centres then
-// take the folded plan
-inline Plan plan_heff(int dtype, const mpse_heff& h, const WSiteInfo* wi = nullptr) {
+// take the folded plan.  `two_results`: the caller accepts the result as the sum of B_OUT and B_OUT2 (Plan::two_results
+// says whether the plan made use of it).
+inline Plan plan_heff(int dtype, const mpse_heff& h, const WSiteInfo* wi = nullptr, bool two_results = false) {
   Plan p;
   const mpse_dims& s = h.dims;
   const int64_t Dl = s.Dl_ket, Dr = s.Dr_ket, wl = s.wl, wr = s.wr;
@@ -289,7 +294,7 @@ inline Plan plan_heff(int dtype, const mpse_heff& h, const WSiteInfo* wi = nullp
   }
   if (h.nsite == 1) {
     if (wi) {
-      Plan f = plan_heff1_fold(dtype, h, *wi);
+      Plan f = plan_heff1_fold(dtype, h, *wi, two_results);
       if (!f.error) return f;
     }
     // abc,bdef,lfk,cek->adl (hop_expr.py:75-79); ancilla cegk->adgl (87-91)
@@ -343,13 +348,28 @@ inline int64_t& fold_min() {
   return v;
 }
 
+inline int64_t& fold_cus() {    // compute units of the device (mpse_ctx_create sets it): products with at most one
+  static int64_t v = 256;       // 64 x 64 tile per unit are halved along K (GGroupPlan::split2)
+  return v;
+}
+inline bool& fold_split2() {
+  static bool v = [] {
+    const char* e = getenv("MPSE_SPLIT2");     // MPSE_SPLIT2=0: one workgroup per tile
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+inline int64_t& fold_split2_min_kt() {   // fewest K tiles of a product worth halving (test hook)
+  static int64_t v = 8;
+  return v;
+}
 inline int64_t& fold_align() {   // bra-bond multiple the device needs (a 64-row tile = one channel); a test hook lowers it
   static int64_t v = 64;
   return v;
 }
 
 // Folded one-site matvec (see above); p.error is set when the site does not qualify and the caller takes plan_heff.
-inline Plan plan_heff1_fold(int dtype, const mpse_heff& h, const WSiteInfo& wi) {
+inline Plan plan_heff1_fold(int dtype, const mpse_heff& h, const WSiteInfo& wi, bool two_results = false) {
   Plan p;
   const mpse_dims& s = h.dims;
   const int64_t Dl = s.Dl_ket, Dr = s.Dr_ket, wl = s.wl, wr = s.wr, d = s.d0;
@@ -398,6 +418,14 @@ inline Plan plan_heff1_fold(int dtype, const mpse_heff& h, const WSiteInfo& wi) 
     else
       plane_of[f] = nplanes++;
   }
+  // The products with R as halved tiles (split2) when the caller takes the result in two parts, they have at most one
+  // tile per compute unit and fit one launch.
+  int64_t ncseg = 0;
+  for (int64_t f = 0; f < wr; ++f)
+    if (present[f] && f != ru) ++ncseg;
+  const int64_t ctiles = ((Dlb * d + 63) / 64) * ((Drb + 63) / 64);
+  const bool split2 = two_results && fold_split2() && ncseg >= 1 && ncseg <= G_MAXSEG && ctiles <= fold_cus() && ncseg * ((Dr + 15) / 16) >= fold_split2_min_kt() &&
+                      (Dlb * d) % 64 == 0 && Drb == Dr && dtype == MPSE_C128;
   auto dest = [&](int64_t f, int* buf, int64_t* off) {
     if (f == ru)
       *buf = B_OUT, *off = 0;
@@ -505,6 +533,7 @@ inline Plan plan_heff1_fold(int dtype, const mpse_heff& h, const WSiteInfo& wi) 
     GGroupPlan g;
     g.cbuf = B_OUT, g.c_off = 0;
     g.beta = out_init ? 1.0 : 0.0;
+    if (split2) g.split2 = true, p.two_results = true;
     for (size_t j = i; j < csegs.size() && j < i + G_MAXSEG; ++j) g.seg[g.nseg++] = csegs[j];
     st.groups.push_back(g);
     p.steps.push_back(st);

@@ -228,8 +228,10 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update(double* __restri
 // s_{j-1}^2 = 1 / *prev2 (recorded one step earlier).  Partials of |w|^2 go to `partial` (a different area than
 // cur_partial: blocks read all of those before any block of the NEXT step overwrites them).
 template <bool VEC>
+// y2 (optional): the matvec result arrives as y + y2 (a product whose tiles were halved, mpse_gemm.hip split2)
 __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __restrict__ u_next,
                                                                   const double* __restrict__ y,
+                                                                  const double* __restrict__ y2,
                                                                   const double* __restrict__ u1,
                                                                   const double* __restrict__ u0, long long n_doubles,
                                                                   const double* __restrict__ a_partial, int a_nb,
@@ -259,14 +261,20 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
     const long long n2 = n_doubles >> 1;
     double2* o2 = reinterpret_cast<double2*>(u_next);
     const double2* py = reinterpret_cast<const double2*>(y);
+    const double2* py2 = reinterpret_cast<const double2*>(y2);
     const double2* p1 = reinterpret_cast<const double2*>(u1);
     const double2* p0 = reinterpret_cast<const double2*>(u0);
     const double2 zz = make_double2(0.0, 0.0);
     for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n2; i += 2 * stride) {
       const long long i1 = i + stride;
       const bool h1 = i1 < n2;
-      const double2 ya = py[i], va = p1[i], ua = u0 ? p0[i] : zz;
-      const double2 yb = h1 ? py[i1] : zz, vb = h1 ? p1[i1] : zz, ub = (h1 && u0) ? p0[i1] : zz;
+      double2 ya = py[i], yb = h1 ? py[i1] : zz;
+      if (y2) {
+        const double2 ta = py2[i], tb = h1 ? py2[i1] : zz;
+        ya.x += ta.x, ya.y += ta.y, yb.x += tb.x, yb.y += tb.y;
+      }
+      const double2 va = p1[i], ua = u0 ? p0[i] : zz;
+      const double2 vb = h1 ? p1[i1] : zz, ub = (h1 && u0) ? p0[i1] : zz;
       const double2 xa = make_double2(c_y * ya.x - (c_1 * va.x + c_0 * ua.x), c_y * ya.y - (c_1 * va.y + c_0 * ua.y));
       const double2 xb = make_double2(c_y * yb.x - (c_1 * vb.x + c_0 * ub.x), c_y * yb.y - (c_1 * vb.y + c_0 * ub.y));
       o2[i] = xa;
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
     for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n_doubles; i += stride) {
       double t = c_1 * u1[i];
       if (u0) t += c_0 * u0[i];
-      const double x = c_y * y[i] - t;
+      const double x = c_y * (y2 ? y[i] + y2[i] : y[i]) - t;
       u_next[i] = x;
       s += x * x;
     }
@@ -727,9 +735,10 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
 
   int cap = hint + 4 > 16 ? hint + 4 : 16;
   if (cap > limit + 1) cap = limit + 1;
-  TmpBuf V(ctx), W(ctx), RES(ctx), SCAL(ctx);
+  TmpBuf V(ctx), W(ctx), W2(ctx), RES(ctx), SCAL(ctx);
   MPSE_TRY(V.alloc(size_t(cap) * n * es));
   MPSE_TRY(W.alloc(size_t(n) * es));
+  MPSE_TRY(W2.alloc(size_t(n) * es));   // second part of a matvec result (mpse_ctx::y2_req)
   MPSE_TRY(RES.alloc(size_t(n) * es));
   // scalars as in the synchronous solve: [0..1] |v|^2 ; per j: alpha at 4+4j, beta^2 at 6+4j ; then control + coefficients
   const int SC_CTL = 4 + 4 * 130, SC_COEF = SC_CTL + 8;
@@ -801,25 +810,28 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
   for (int j = 0;; ++j) {
     // <H U_j, U_j> rides on the launch that completes H U_j (mpse_ctx::dot_req); plans that cannot take it leave
     // nb_out = 0 and the reduction runs as a pass of its own
-    static const bool dot_fused = [] {
-      const char* e = getenv("MPSE_DOT_FUSED");
-      return !(e && e[0] == '0');
-    }();
-    if (dot_fused) {
-      ctx->dot_req.y = vec(j);
-      ctx->dot_req.part = part_a;
-      ctx->dot_req.cap = 2 * RED_MAX_BLOCKS;
-      ctx->dot_req.nb_out = 0;
-    }
+    ctx->dot_req.y = vec(j);
+    ctx->dot_req.part = part_a;
+    ctx->dot_req.cap = 2 * RED_MAX_BLOCKS;
+    ctx->dot_req.nb_out = 0;
     ctx->cmask.lo = V.as<char>();
     ctx->cmask.hi = V.as<char>() + size_t(cap) * n * es;
+    // the result may come as W + W2 (the update below reads both): the last product of a large one-site matvec then
+    // runs as halved tiles, two workgroups per compute unit
+    ctx->y2_req.ptr = W2.p;
+    ctx->y2_req.used = false;
     const int st_mv = mpse_heff_apply(ctx, dtype, h, vec(j), W.p);
+    const bool two = ctx->y2_req.used;
+    ctx->y2_req = mpse_ctx::Y2Req();
     const bool dot_done = ctx->dot_req.nb_out > 0;
     const int a_nb = dot_done ? ctx->dot_req.nb_out : nb;
     ctx->dot_req = mpse_ctx::DotReq();
     ctx->dot_now = false;
     MPSE_TRY(st_mv);
-    if (!dot_done) dot_partials(W.p, vec(j), part_a);
+    if (!dot_done) {
+      if (two) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: a two-part matvec result without its dot partials");
+      dot_partials(W.p, vec(j), part_a);
+    }
     if (j + 2 > cap) {      // room for U_{j+1}
       int ncap = cap * 2 < limit + 1 ? cap * 2 : limit + 1;
       TmpBuf V2(ctx);
@@ -833,16 +845,16 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
     double* new_part = part_b2[(j + 1) & 1];
     double* cur_out = j == 0 ? scal : scal + 6 + 4 * (j - 1);
     const double* prev2 = j == 0 ? scal : (j == 1 ? scal : scal + 6 + 4 * (j - 2));
-    bracket((j > 0 ? 4.0 : 3.0) * vbytes, [&] {
+    bracket((j > 0 ? 4.0 : 3.0) * vbytes + (two ? vbytes : 0.0), [&] {
       if (vec16)
         hipLaunchKernelGGL(k_lanczos_update_u<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
-                           W.as<const double>(), (const double*)vec(j),
+                           W.as<const double>(), two ? W2.as<const double>() : (const double*)nullptr, (const double*)vec(j),
                            j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
                            (const double*)part_a, a_nb, scal + 4 + 4 * j, (const double*)cur_part, nb, cur_out, prev2,
                            new_part, done);
       else
         hipLaunchKernelGGL(k_lanczos_update_u<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
-                           W.as<const double>(), (const double*)vec(j),
+                           W.as<const double>(), two ? W2.as<const double>() : (const double*)nullptr, (const double*)vec(j),
                            j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
                            (const double*)part_a, a_nb, scal + 4 + 4 * j, (const double*)cur_part, nb, cur_out, prev2,
                            new_part, done);

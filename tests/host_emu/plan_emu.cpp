@@ -109,6 +109,13 @@ static int run(int dtype, const Plan& p, const void* bufs_in[B_COUNT]) {
                        ld(bufs[sg.bbuf], s.dtb, sg.b_off + off(s.kb, k) + off(s.nb, jn), 0);
             }
             const int64_t o = g.c_off + off(s.mc, i) + off(s.nc, jn);
+            // split2: the second result receives a part of the sum (here: nothing), the caller adds the two
+            if (g.split2) {
+              if (dtype == MPSE_C128)
+                ((cd*)const_cast<void*>(bufs[B_OUT2]))[o] = 0.25 * acc, acc *= 0.75;
+              else
+                ((double*)const_cast<void*>(bufs[B_OUT2]))[o] = 0.25 * acc.real(), acc *= 0.75;
+            }
             if (dtype == MPSE_C128)
               ((cd*)Cg)[o] = acc + (g.beta != 0.0 ? g.beta * ((const cd*)Cg)[o] : cd(0));
             else
@@ -184,18 +191,28 @@ extern "C" void emu_set_unit_threshold(long long macs) { unit_threshold() = macs
 // returns MPSE_ERR_SHAPE when the site does not qualify.  *nsteps receives the number of plan steps.
 extern "C" int emu_heff_apply_fold(int dtype, const mpse_heff* h, const void* C, void* out, int* nsteps) {
   const WSiteInfo wi = analyse_mpo_site((const double*)h->W0, h->dims.wl, h->dims.d0, h->dims.wr);
-  Plan p = plan_heff1_fold(dtype, *h, wi);
-  if (nsteps) *nsteps = (int)p.steps.size();
+  // the result in two parts where the plan makes use of it (complex centres whose rows fill whole tiles)
+  Plan p = plan_heff1_fold(dtype, *h, wi, true);
+  if (nsteps) *nsteps = (int)p.steps.size() + (p.two_results ? 100 : 0);
+  const size_t es = dtype == MPSE_C128 ? 16 : 8;
+  const int64_t n = (h->dims.Dl_bra > 0 ? h->dims.Dl_bra : h->dims.Dl_ket) * h->dims.d0 *
+                    (h->dims.Dr_bra > 0 ? h->dims.Dr_bra : h->dims.Dr_ket);
+  std::vector<char> out2(size_t(n) * es + 16, 0x7f);
   const void* bufs[B_COUNT] = {nullptr};
   bufs[B_L] = h->L;
   bufs[B_R] = h->R;
   bufs[B_W0] = h->W0;
   bufs[B_C] = C;
   bufs[B_OUT] = out;
-  return run(dtype, p, bufs);
+  bufs[B_OUT2] = out2.data();
+  const int st = run(dtype, p, bufs);
+  if (st == MPSE_OK && p.two_results)
+    for (int64_t i = 0; i < n * (int64_t)(es / 8); ++i) ((double*)out)[i] += ((const double*)out2.data())[i];
+  return st;
 }
-extern "C" void emu_set_fold_min(long long macs, long long align) {
+extern "C" void emu_set_fold_min(long long macs, long long align, long long split2_min_kt) {
   fold_min() = macs;
   fold_align() = align;
+  fold_split2_min_kt() = split2_min_kt;
 }
 extern "C" void emu_set_beta_source(int on) { beta_source_flag() = on != 0; }

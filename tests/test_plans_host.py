@@ -400,12 +400,14 @@ def test_folded_one_site_plan(emu):
     MPO sites; a site with more blocks per channel than the elementwise pass takes is refused (the caller takes the
     three-step chain)."""
     emu.emu_heff_apply_fold.argtypes = [C.c_int, C.POINTER(E.mpse_heff), C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
-    emu.emu_set_fold_min.argtypes = [C.c_longlong, C.c_longlong]
-    emu.emu_set_fold_min(1, 4)          # (the device needs bonds in multiples of 64: tile = channel; not the host loops)
+    emu.emu_set_fold_min.argtypes = [C.c_longlong, C.c_longlong, C.c_longlong]
+    emu.emu_set_fold_min(1, 4, 1)       # (the device needs bonds in multiples of 64: tile = channel; not the host loops)
     try:
         rng = np.random.default_rng(23)
         for cplx in (False, True):
-            for (D, d, wl, wr, kind) in ((12, 4, 5, 4, "holstein"), (8, 3, 4, 4, "mixed"), (8, 2, 2, 2, "dense")):
+            # (D d a multiple of 64 with a complex centre: the products with R as halved tiles adding into a zeroed result)
+            for (D, d, wl, wr, kind) in ((12, 4, 5, 4, "holstein"), (16, 4, 5, 4, "holstein"), (8, 3, 4, 4, "mixed"),
+                                         (8, 2, 2, 2, "dense")):
                 w0 = _fold_w(rng, wl, d, wr, kind)
                 c = _rand(rng, (D, d, D), cplx)
                 for lu, ru in ((0, 0), (1, wr), (1, 0), (0, wr), (wl, 1)):
@@ -430,7 +432,8 @@ def test_folded_one_site_plan(emu):
                     st = emu.emu_heff_apply_fold(E.C128 if cplx else E.F64, C.byref(h), keep[3].ctypes.data,
                                                  out.ctypes.data, C.byref(nsteps))
                     assert st == 0, (kind, lu, ru)
-                    assert nsteps.value <= 3
+                    assert nsteps.value % 100 <= 3
+                    assert (nsteps.value >= 100) == (cplx and (D * d) % 64 == 0)      # the result in two parts
                     assert np.abs(out - ref).max() < 1e-11 * np.abs(ref).max(), (kind, lu, ru)
         # six channels into one: refused
         w0 = rng.standard_normal((6, 2, 2, 1))
@@ -446,4 +449,4 @@ def test_folded_one_site_plan(emu):
         out = np.zeros_like(c)
         assert emu.emu_heff_apply_fold(E.F64, C.byref(h), keep[3].ctypes.data, out.ctypes.data, None) != 0
     finally:
-        emu.emu_set_fold_min(1 << 28, 64)
+        emu.emu_set_fold_min(1 << 28, 64, 8)
