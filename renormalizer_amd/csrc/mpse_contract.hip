@@ -433,9 +433,10 @@ extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, con
   }
   // a caller that takes the result in two parts (mpse_ctx::y2_req, the Lanczos solve) lets the last product run as
   // halved tiles; `used` tells it whether the second part holds anything
-  mpse_ctx::Y2Req& y2 = ctx->y2_req;
-  Plan p = plan_heff(dtype, *h, static_cast<const WSiteInfo*>(wi_keep.get()), y2.ptr != nullptr);
-  y2.used = p.two_results;
+  mpse_ctx::PartsReq& pr = ctx->parts_req;
+  const bool two_ok = pr.ptr != nullptr && pr.cap_elems >= 2 * pr.n;
+  Plan p = plan_heff(dtype, *h, static_cast<const WSiteInfo*>(wi_keep.get()), two_ok);
+  pr.used = 0;
   const void* bufs[B_COUNT] = {nullptr};
   bufs[B_L] = h->L;
   bufs[B_R] = h->R;
@@ -443,8 +444,12 @@ extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, con
   bufs[B_W1] = h->W1;
   bufs[B_C] = C;
   bufs[B_OUT] = out;
-  bufs[B_OUT2] = y2.ptr;
-  return run_plan(ctx, dtype, p, bufs);
+  // halved tiles: part 0 is `out` itself (it holds the beta term), part 1 the second slot of the caller's buffer;
+  // split products: all parts in the caller's buffer (mpse_gemm.hip sets `used`)
+  if (p.two_results) bufs[B_OUT2] = static_cast<char*>(pr.ptr) + size_t(pr.n) * dtype_size(dtype);
+  const int st = run_plan(ctx, dtype, p, bufs);
+  if (st == MPSE_OK && p.two_results) pr.used = -2;     // (out, part 1)
+  return st;
 }
 
 extern "C" int mpse_mpo_site_hint(mpse_ctx* ctx, const void* W_dev, const double* W_host, int64_t wl, int64_t d,

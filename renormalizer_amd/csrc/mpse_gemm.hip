@@ -72,6 +72,9 @@ struct GemmGroups {
   // units per die, perm = tiles by decreasing weight).  DESIGN.md 4.1.
   int split2, cpd;
   double* C2;
+  // optional: the flags of every tile's concatenated K range, assembled once (k_tile_order, kept with the launch order
+  // for the solve): nkw words per tile, tile = (group's tile row, tile column) in launch-independent order
+  const unsigned long long* flags;
 };
 
 struct GemmArgs {
@@ -440,7 +443,15 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
   if constexpr (GRP) {
     // flags of the concatenated K range of this tile, assembled from the segments' operand masks (g.nkw = words of
     // that range when any segment has a mask, else 0)
-    if (g.nkw > 0 && g.nkw <= MASKW) {
+    if (g.nkw > 0 && g.nkw <= MASKW && g.gg.flags) {
+      if (tid < g.nkw) {
+        s_mask[0][tid] = g.gg.flags[((long long)(grp * g.gg.tiles_m_grp + tm) * g.tiles_n + tn) * g.nkw + tid];
+        s_mask[1][tid] = 0x0101010101010101ull;
+      }
+      __syncthreads();
+      mlds = true;
+      am = s_mask[0];
+    } else if (g.nkw > 0 && g.nkw <= MASKW) {
       unsigned char* f0 = reinterpret_cast<unsigned char*>(s_mask[0]);
       for (int t = tid; t < g.nkw * 8; t += NT) {
         unsigned char v = 0;
@@ -862,7 +873,7 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
             if constexpr (PRE)
               c0 = pre_c[i][j][r];
             else
-              c0 = *reinterpret_cast<const double2*>(g.Cin ? g.Cin + (idx_off(g.mCin, gi) + idx_off(g.nCin, gj)) * EC : p);
+              c0 = *reinterpret_cast<const double2*>(g.Cin ? g.Cin + (idx_off(g.mCin, gi) + idx_off(g.nCin, gj)) * EC : C + co * EC);
             o.x += g.beta_re * c0.x - g.beta_im * c0.y;
             o.y += g.beta_re * c0.y + g.beta_im * c0.x;
           }
@@ -933,7 +944,8 @@ __device__ __forceinline__ void bitonic_desc_2048(unsigned* key, int tid) {
 __global__ __launch_bounds__(1024) void k_tile_order(const unsigned long long* __restrict__ amask,
                                                        const unsigned long long* __restrict__ bmask, int nkw, int nkt,
                                                        int tiles_m, int tiles_n, int by_die, int* __restrict__ perm,
-                                                       const int* __restrict__ skip, const GemmGroups gg) {
+                                                       const int* __restrict__ skip, const GemmGroups gg,
+                                                       unsigned char* __restrict__ flags_out, int flags_pitch) {
   if (skip && *skip) return;
   __shared__ unsigned key[2048], ckey[2048];
   __shared__ int colw[2048];
@@ -955,7 +967,10 @@ __global__ __launch_bounds__(1024) void k_tile_order(const unsigned long long* _
             if (G.seg[q].am) v &= G.seg[q].am[(long long)tml * gg.am_pitch + l];
             if (G.seg[q].bm) v &= G.seg[q].bm[(long long)tn * gg.bm_pitch + l];
             cnt += v;
+            if (flags_out) flags_out[(long long)i * flags_pitch + q * gg.nkt_seg + l] = (unsigned char)v;
           }
+        if (flags_out)
+          for (int l = G.nseg * gg.nkt_seg; l < flags_pitch; ++l) flags_out[(long long)i * flags_pitch + l] = 0;
       } else {
         for (int w = 0; w < nkw; ++w) {
           unsigned long long x = 0x0101010101010101ull;
@@ -1293,6 +1308,9 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
     if (S > 1) {
       g.kt_per_split = (nkt_all + S - 1) / S;
       g.ksplit = (nkt_all + g.kt_per_split - 1) / g.kt_per_split;
+      // (Leaving the slices to the consumer of a matvec result - the Lanczos update adding them while it reads -
+      // instead of the reduction launch measured 1.4 % slower on the headline run: every slice's workgroups then load
+      // the dot partner, and the update kernel streams 16 slices with a fraction of the reduction kernel's blocks.)
       const size_t esz = (ca || cb) ? 16 : 8;
       MPSE_TRY(WSB.alloc(size_t(d->batch) * g.ksplit * size_t(g.M) * size_t(g.N) * esz));
       g.ws = WSB.as<double>();
@@ -1442,7 +1460,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
         pp = PERM.as<int>();
       }
       hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, ctx->stream, g.amask, g.bmask, g.nkw, nkt_all, g.tiles_m,
-                         g.tiles_n, 1, pp, ctx->skip_flag, GemmGroups());
+                         g.tiles_n, 1, pp, ctx->skip_flag, GemmGroups(), (unsigned char*)nullptr, 0);
     }
     g.perm = pp;
   }
@@ -1646,21 +1664,24 @@ int gemm_grouped(mpse_ctx* ctx, const GroupedDesc& d) {
       for (const auto& e : ctx->perm_cache)
         if (e.amask == ka && e.bmask == kb && e.tiles_m == g.tiles_m && e.tiles_n == g.tiles_n && e.nkt == nkt_key)
           pp = static_cast<int*>(e.perm);
+    // (one buffer: the launch order, then the assembled flags of every tile - 8-byte aligned)
+    const size_t perm_bytes = (size_t(ntile) * sizeof(int) + 7) & ~size_t(7), flag_pitch = size_t(g.nkw) * 8;
     if (!pp) {
       if (keep) {
         void* pm = nullptr;
-        MPSE_TRY(mpse_malloc(ctx, size_t(ntile) * sizeof(int), &pm));
+        MPSE_TRY(mpse_malloc(ctx, perm_bytes + size_t(ntile) * flag_pitch, &pm));
         ctx->perm_cache.push_back({ka, kb, g.tiles_m, g.tiles_n, nkt_key, pm});
         pp = static_cast<int*>(pm);
       } else {
-        MPSE_TRY(PERM.alloc(size_t(ntile) * sizeof(int)));
+        MPSE_TRY(PERM.alloc(perm_bytes + size_t(ntile) * flag_pitch));
         pp = PERM.as<int>();
       }
       hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, ctx->stream, (const unsigned long long*)nullptr,
                          (const unsigned long long*)nullptr, 0, nkt_max, g.tiles_m, g.tiles_n, d.split2 ? 0 : 1, pp,
-                         ctx->skip_flag, gg);
+                         ctx->skip_flag, gg, reinterpret_cast<unsigned char*>(pp) + perm_bytes, (int)flag_pitch);
     }
     g.perm = pp;
+    g.gg.flags = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(pp) + perm_bytes);
   }
   if (!g.perm && ntile >= 64) {
     const double size_a = double(g.M) * d.ngrp * (ca ? 2 : 1), size_b = double(g.N) * 2;

@@ -105,12 +105,15 @@ struct mpse_ctx {
     int nb_out = 0;
   } dot_req;
   bool dot_now = false;   // set by run_plan for the one GEMM launch that completes the result
-  // A caller of mpse_heff_apply that can take the result as the SUM of two tensors (the Lanczos update reads both)
-  // offers a second buffer of the result's size; `used` reports whether the plan wrote a part of the result there
-  struct Y2Req {
+  // A caller of mpse_heff_apply that can take the result as the SUM of several tensors (the Lanczos update adds them
+  // while it reads) offers a buffer of cap_elems elements of the working dtype, n of them per part: the last product
+  // of the plan may then leave its K slices there instead of reducing them (mpse_gemm.hip: split products, halved
+  // tiles).  used = number of parts written at ptr, ptr + n, .. (0: the result is complete in `out`, as usual).
+  struct PartsReq {
     void* ptr = nullptr;
-    bool used = false;
-  } y2_req;
+    long long cap_elems = 0, n = 0;
+    int used = 0;
+  } parts_req;
   // Tile-occupancy mask of the centre tensor as operand B of the first products of a matvec, supplied by the caller
   // (mpse_expm_centre_mask: the structural pattern of the quantum numbers, the same for every Krylov vector).
   // `pending` holds what the caller set for the next solve; during that solve lo / hi delimit the Krylov vectors.

@@ -228,10 +228,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update(double* __restri
 // s_{j-1}^2 = 1 / *prev2 (recorded one step earlier).  Partials of |w|^2 go to `partial` (a different area than
 // cur_partial: blocks read all of those before any block of the NEXT step overwrites them).
 template <bool VEC>
-// y2 (optional): the matvec result arrives as y + y2 (a product whose tiles were halved, mpse_gemm.hip split2)
+// The matvec result arrives as the sum of nparts tensors y, y + part_stride, .. (doubles): the K slices of a split
+// product or the halves of halved tiles (mpse_gemm.hip), added here in slice order instead of by a launch of their own
 __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __restrict__ u_next,
-                                                                  const double* __restrict__ y,
-                                                                  const double* __restrict__ y2,
+                                                                  const double* __restrict__ y, int nparts,
+                                                                  long long part_stride,
                                                                   const double* __restrict__ u1,
                                                                   const double* __restrict__ u0, long long n_doubles,
                                                                   const double* __restrict__ a_partial, int a_nb,
@@ -261,7 +262,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
     const long long n2 = n_doubles >> 1;
     double2* o2 = reinterpret_cast<double2*>(u_next);
     const double2* py = reinterpret_cast<const double2*>(y);
-    const double2* py2 = reinterpret_cast<const double2*>(y2);
     const double2* p1 = reinterpret_cast<const double2*>(u1);
     const double2* p0 = reinterpret_cast<const double2*>(u0);
     const double2 zz = make_double2(0.0, 0.0);
@@ -269,8 +269,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
       const long long i1 = i + stride;
       const bool h1 = i1 < n2;
       double2 ya = py[i], yb = h1 ? py[i1] : zz;
-      if (y2) {
-        const double2 ta = py2[i], tb = h1 ? py2[i1] : zz;
+      for (int s = 1; s < nparts; ++s) {
+        const double2* ps = py + s * (part_stride >> 1);
+        const double2 ta = ps[i], tb = h1 ? ps[i1] : zz;
         ya.x += ta.x, ya.y += ta.y, yb.x += tb.x, yb.y += tb.y;
       }
       const double2 va = p1[i], ua = u0 ? p0[i] : zz;
@@ -288,7 +289,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
     for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n_doubles; i += stride) {
       double t = c_1 * u1[i];
       if (u0) t += c_0 * u0[i];
-      const double x = c_y * (y2 ? y[i] + y2[i] : y[i]) - t;
+      double yv = y[i];
+      for (int s = 1; s < nparts; ++s) yv += y[s * part_stride + i];
+      const double x = c_y * yv - t;
       u_next[i] = x;
       s += x * x;
     }
@@ -735,10 +738,11 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
 
   int cap = hint + 4 > 16 ? hint + 4 : 16;
   if (cap > limit + 1) cap = limit + 1;
-  TmpBuf V(ctx), W(ctx), W2(ctx), RES(ctx), SCAL(ctx);
+  TmpBuf V(ctx), W(ctx), RES(ctx), SCAL(ctx);
   MPSE_TRY(V.alloc(size_t(cap) * n * es));
-  MPSE_TRY(W.alloc(size_t(n) * es));
-  MPSE_TRY(W2.alloc(size_t(n) * es));   // second part of a matvec result (mpse_ctx::y2_req)
+  // the matvec result, with room for a second part (mpse_ctx::parts_req: halved tiles)
+  const long long wcap = 2 * n;
+  MPSE_TRY(W.alloc(size_t(wcap) * es));
   MPSE_TRY(RES.alloc(size_t(n) * es));
   // scalars as in the synchronous solve: [0..1] |v|^2 ; per j: alpha at 4+4j, beta^2 at 6+4j ; then control + coefficients
   const int SC_CTL = 4 + 4 * 130, SC_COEF = SC_CTL + 8;
@@ -818,11 +822,15 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
     ctx->cmask.hi = V.as<char>() + size_t(cap) * n * es;
     // the result may come as W + W2 (the update below reads both): the last product of a large one-site matvec then
     // runs as halved tiles, two workgroups per compute unit
-    ctx->y2_req.ptr = W2.p;
-    ctx->y2_req.used = false;
+    ctx->parts_req.ptr = W.p;
+    ctx->parts_req.cap_elems = wcap;
+    ctx->parts_req.n = n;
+    ctx->parts_req.used = 0;
     const int st_mv = mpse_heff_apply(ctx, dtype, h, vec(j), W.p);
-    const bool two = ctx->y2_req.used;
-    ctx->y2_req = mpse_ctx::Y2Req();
+    const int used = ctx->parts_req.used;
+    const int nparts = used > 0 ? used : (used == -2 ? 2 : 1);
+    const bool two = nparts > 1;
+    ctx->parts_req = mpse_ctx::PartsReq();
     const bool dot_done = ctx->dot_req.nb_out > 0;
     const int a_nb = dot_done ? ctx->dot_req.nb_out : nb;
     ctx->dot_req = mpse_ctx::DotReq();
@@ -845,16 +853,16 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
     double* new_part = part_b2[(j + 1) & 1];
     double* cur_out = j == 0 ? scal : scal + 6 + 4 * (j - 1);
     const double* prev2 = j == 0 ? scal : (j == 1 ? scal : scal + 6 + 4 * (j - 2));
-    bracket((j > 0 ? 4.0 : 3.0) * vbytes + (two ? vbytes : 0.0), [&] {
+    bracket((j > 0 ? 4.0 : 3.0) * vbytes + (nparts - 1) * vbytes, [&] {
       if (vec16)
         hipLaunchKernelGGL(k_lanczos_update_u<true>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
-                           W.as<const double>(), two ? W2.as<const double>() : (const double*)nullptr, (const double*)vec(j),
+                           W.as<const double>(), nparts, (long long)nd, (const double*)vec(j),
                            j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
                            (const double*)part_a, a_nb, scal + 4 + 4 * j, (const double*)cur_part, nb, cur_out, prev2,
                            new_part, done);
       else
         hipLaunchKernelGGL(k_lanczos_update_u<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
-                           W.as<const double>(), two ? W2.as<const double>() : (const double*)nullptr, (const double*)vec(j),
+                           W.as<const double>(), nparts, (long long)nd, (const double*)vec(j),
                            j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
                            (const double*)part_a, a_nb, scal + 4 + 4 * j, (const double*)cur_part, nb, cur_out, prev2,
                            new_part, done);
