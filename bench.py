@@ -59,6 +59,36 @@ def _roctx():
 DISORDER_AU = 50.0 * 4.556335e-6   # static diagonal disorder of the trajectories beyond the first: sigma = 50 cm^-1
 
 
+def _pci_bus_id(device):
+    """PCI bus id of a HIP device as one integer (domain << 24 | bus << 16 | device << 8 | function), -1 if unknown:
+    the JSON line shows that N ranks ran on N distinct devices."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+            return -1
+        dom, bus, rest = buf.value.decode().split(":")
+        dev, fn = rest.split(".")
+        return (int(dom, 16) << 24) | (int(bus, 16) << 16) | (int(dev, 16) << 8) | int(fn, 16)
+    except (OSError, ValueError, AttributeError):
+        return -1
+
+
+def _kernel_source_sha():
+    """Fingerprint of the contraction kernel's sources: a committed PMC traffic figure is quoted as `roofline.traffic`
+    only while it was measured on these very sources (tools/pmc_traffic.py stores the same fingerprint)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("mpse_gemm.hip", "mpse_plans.h", "mpse_contract.hip"):
+        try:
+            with open(os.path.join(REPO, "renormalizer_amd", "csrc", name), "rb") as fh:
+                h.update(fh.read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
+
+
 def build_workload(nmol, pdim, bond_dim, seed, init, unit=0, state_file=None, scheme="tdvp_ps"):
     from renormalizer_amd import (HolsteinModel, Phonon, Mol, Quantity, Mpo, CompressConfig, CompressCriteria,
                                   EvolveConfig, EvolveMethod)
@@ -177,7 +207,15 @@ def main():
         from gloo_collective import GlooCollective
         coll = GlooCollective()
     else:
-        coll = make_collective(eng)
+        # A scaling run must not print a number obtained without RCCL: unless the file collective was asked for
+        # (MPSE_COLLECTIVE=file), a communicator that cannot be created on every rank ends the job on every rank
+        from renormalizer_amd.parallel import CollectiveUnavailable
+        try:
+            coll = make_collective(eng, strict=world > 1 and os.environ.get("MPSE_COLLECTIVE", "") != "file")
+        except CollectiveUnavailable as exc:
+            # no result line; leave at once (a thread stuck inside ncclCommInitRank would keep the process from ending)
+            print(f"bench.py: CollectiveUnavailable: {exc}", file=sys.stderr, flush=True)
+            os._exit(3)
     if world > 1:
         print(f"[rank {rank}] device {local_rank}: {eng.device_name}; {coll.kind} communicator of {coll.world} ranks",
               file=sys.stderr, flush=True)
@@ -255,10 +293,17 @@ def main():
     elapsed = max_over_ranks(coll, elapsed)
     # the only collective of the whole job besides the barriers: all-gather of the per-trajectory observables (KBs)
     # (each row: the electronic populations of the rank's trajectory, then the device ordinal the rank ran on)
-    row = np.concatenate([np.asarray(mps.e_occupations, dtype=np.float64), [float(local_rank)]])
+    # (each row: the populations, then what identifies the rank's device - ordinal, PCI bus id - and what the RCCL
+    # communicator itself reports for the rank: ranks in the communicator, the rank's number there, its device)
+    comm_info = coll.describe() if hasattr(coll, "describe") else (-1, -1, -1)
+    row = np.concatenate([np.asarray(mps.e_occupations, dtype=np.float64),
+                          [float(local_rank), float(_pci_bus_id(local_rank))], [float(x) for x in comm_info]])
     table = gather_observables(coll, row[None, :], [rank], world)
     assert table.shape[0] == world
-    occ_table, rank_devices = table[:, :-1], [int(x) for x in table[:, -1]]
+    occ_table, rank_devices = table[:, :-5], [int(x) for x in table[:, -5]]
+    rank_pci = ["%04x:%02x:%02x.%x" % ((int(x) >> 24) & 0xFFFF, (int(x) >> 16) & 0xFF, (int(x) >> 8) & 0xFF, int(x) & 0xFF)
+                if x >= 0 else None for x in table[:, -4]]
+    comm_count, comm_rank, comm_dev = ([int(x) for x in table[:, k]] for k in (-3, -2, -1))
     distinct = len({tuple(np.round(r, 10)) for r in occ_table})
     if world > 1 and rank == 0:
         print(f"[rank 0] gathered populations of {world} trajectories, {distinct} distinct", file=sys.stderr, flush=True)
@@ -274,15 +319,20 @@ def main():
             pmc_file = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc_traffic.json")))[-1]   # latest round
             with open(pmc_file, "rb") as fh:
                 raw = fh.read()
-            kern = json.loads(raw)["kernels"]
+            pmc = json.loads(raw)
+            kern = pmc["kernels"]
             # every instantiation of the complex x complex contraction kernel (tile / wave-layout arguments differ),
             # weighted by its launches
             hits = [v for k, v in kern.items() if k.startswith("void k_gemm<true, true, true")]
-            traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / sum(v["launches"] for v in hits)
+            traffic_ref = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hits) / sum(v["launches"] for v in hits)
+            fresh = pmc.get("kernel_source_sha") is not None and pmc.get("kernel_source_sha") == _kernel_source_sha()
+            traffic = traffic_ref if fresh else None       # a figure measured on other kernel sources is not this kernel's
             traffic_src = (f"profiles/{os.path.basename(pmc_file)} sha256:{hashlib.sha256(raw).hexdigest()[:16]} "
                            "(separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command with --init "
                            "physical; a committed measurement, not one of this run: counters cannot be read from "
-                           "inside the process)")
+                           "inside the process); kernel sources "
+                           + ("unchanged since that pass" if fresh else
+                              f"CHANGED since that pass: traffic withheld, the stale figure was {traffic_ref:.4g} bytes/launch"))
         except (OSError, KeyError, ValueError, StopIteration, IndexError, ZeroDivisionError):
             pass
         zz = prof["c128xc128"]
@@ -346,7 +396,9 @@ def main():
                        "nsite": nsite, "bond_dim": args.bond_dim, "dphys": [2, args.pdim], "mpo_bond": max(mpo.bond_dims),
                        "dt": args.dt, "init": args.init, "mean_krylov_dim": float(np.mean(kry)),
                        "device": eng.device_name, "collective": coll.kind, "ranks": coll.world,
-                       "rank_devices": rank_devices, "distinct_trajectories": distinct,
+                       "rank_devices": rank_devices, "rank_pci_bus_ids": rank_pci,
+                       "rccl_comm_count": comm_count, "rccl_comm_user_rank": comm_rank, "rccl_comm_device": comm_dev,
+                       "distinct_trajectories": distinct,
                        "bond_dims": [int(d) for d in mps.bond_dims],
                        "environments": ("rebuilt at every step (MPSE_ENV_CARRY=0)" if os.environ.get("MPSE_ENV_CARRY") == "0"
                                         else "those ahead of the first half sweep are taken over from the previous step "

@@ -180,11 +180,15 @@ def _expm_tridiag(alpha, beta, V, v_norm, dt):
     return V.T @ coef, coef
 
 
-def expm_krylov(Afunc, dt, vstart, block_size=50, rtol=1e-5, atol=1e-8, return_stat=False):
+def expm_krylov(Afunc, dt, vstart, block_size=50, rtol=1e-5, atol=1e-8, return_stat=False, margins=None):
     """Krylov approximation of expm(dt*A) v for Hermitian A.
     lib/krylov/krylov.py:27-82: no re-orthogonalisation, growth by blocks of
     ``block_size``, breakdown if beta < 100*n*eps, convergence test = successive
-    approximations ``allclose`` on every even j > 3."""
+    approximations ``allclose`` on every even j > 3.
+
+    ``margins`` (test instrumentation, not in the reference): a list that receives, per convergence test, the largest
+    ``|res - new_res| / (atol + rtol |new_res|)`` - the test passes where it is <= 1, so values near 1 mark solves whose
+    Krylov dimension hinges on rounding."""
     dt = complex(dt)
     if dt.imag == 0:
         dt = dt.real
@@ -214,6 +218,8 @@ def expm_krylov(Afunc, dt, vstart, block_size=50, rtol=1e-5, atol=1e-8, return_s
             return _expm_tridiag(alpha[: j + 1], beta[:j], V[: j + 1], nrmv, dt)[0], j + 1
         if 3 < j and j % 2 == 0:
             new_res = _expm_tridiag(alpha[: j + 1], beta[:j], V[: j + 1], nrmv, dt)[0]
+            if margins is not None and res is not None:
+                margins.append(float(np.max(np.abs(res - new_res) / (atol + rtol * np.abs(new_res)))))
             if res is not None and np.allclose(res, new_res, rtol=rtol, atol=atol):
                 return new_res, j + 1
             res = new_res
@@ -398,6 +404,7 @@ class MpsState:
     sigmaqn: List[np.ndarray]         # per site (d, qn_size)
     coeff: complex = 1.0
     krylov_dims: List[int] = field(default_factory=list)
+    krylov_margins: List[list] = field(default_factory=list)     # per solve: expm_krylov's ``margins``
 
     def copy(self):
         return MpsState([s.copy() for s in self.sites], [np.array(q).copy() for q in self.qn],
@@ -513,11 +520,17 @@ def tdvp_ps_step(state: MpsState, mpo, dt, normalize_after=True, max_updates=Non
     n = st.nsite
     env = build_environ(st.sites, mpo, env_domain)
     dims = []
+    margins = []
     done = 0
+
+    def _m():
+        margins.append([])
+        return margins[-1]
+
     for _ in range(2):
         for i in st.iter_idx_list(full=True):
             if max_updates is not None and done >= max_updates:
-                st.krylov_dims = dims
+                st.krylov_dims, st.krylov_margins = dims, margins
                 return st
             done += 1
             _t0 = _time.perf_counter()
@@ -527,7 +540,7 @@ def tdvp_ps_step(state: MpsState, mpo, dt, normalize_after=True, max_updates=Non
             shape = st.sites[i].shape
             w = mpo[i]
             c, k = expm_krylov(lambda y: hop_apply(l, r, [w], y.reshape(shape)).ravel(),
-                               -1j * dt / 2, st.sites[i].ravel())
+                               -1j * dt / 2, st.sites[i].ravel(), margins=_m())
             dims.append(k)
             c = c.reshape(shape)
             qnbigl, qnbigr, _ = get_big_qn(st.qn[i], st.qn[i + 1], [st.sigmaqn[i]], st.to_right)
@@ -541,7 +554,7 @@ def tdvp_ps_step(state: MpsState, mpo, dt, normalize_after=True, max_updates=Non
                 r = contract_one_site(r, st.sites[i], w, "R")
                 env[("R", i)] = r
                 b, k = expm_krylov(lambda y: hop_apply(l, r, [], y.reshape(u.shape)).ravel(),
-                                   1j * dt / 2, u.ravel())
+                                   1j * dt / 2, u.ravel(), margins=_m())
                 dims.append(k)
                 st.sites[i - 1] = np.tensordot(st.sites[i - 1], b.reshape(u.shape), axes=(-1, 0))
             elif st.to_right and i != n - 1:
@@ -551,7 +564,7 @@ def tdvp_ps_step(state: MpsState, mpo, dt, normalize_after=True, max_updates=Non
                 l = contract_one_site(l, st.sites[i], w, "L")
                 env[("L", i)] = l
                 b, k = expm_krylov(lambda y: hop_apply(l, r, [], y.reshape(vt.shape)).ravel(),
-                                   1j * dt / 2, vt.ravel())
+                                   1j * dt / 2, vt.ravel(), margins=_m())
                 dims.append(k)
                 st.sites[i + 1] = np.tensordot(b.reshape(vt.shape), st.sites[i + 1], axes=(1, 0))
             else:
@@ -559,6 +572,7 @@ def tdvp_ps_step(state: MpsState, mpo, dt, normalize_after=True, max_updates=Non
             if timings is not None:
                 timings.append((i, tuple(shape), _time.perf_counter() - _t0))
         st.switch_direction()
+    st.krylov_margins = margins
     st.krylov_dims = dims
     if normalize_after:
         normalize(st, "mps_and_coeff" if imag_time else "mps_only")

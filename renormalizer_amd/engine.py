@@ -244,6 +244,38 @@ class DeviceTensor:
     def is_complex(self):
         return self.dtype == np.complex128
 
+    # shape helpers of the reference's Matrix (mps/matrix.py:66-91): a site tensor is (left bond, physical.., right bond)
+    @property
+    def pdim(self):
+        return self.shape[1:-1]
+
+    @property
+    def pdim_prod(self):
+        return int(np.prod(self.shape[1:-1]))
+
+    @property
+    def bond_dim(self):
+        return self.shape[0], self.shape[-1]
+
+    @property
+    def r_combine_shape(self):
+        return self.shape[0], int(np.prod(self.shape[1:]))
+
+    @property
+    def l_combine_shape(self):
+        return int(np.prod(self.shape[:-1])), self.shape[-1]
+
+    def r_combine(self):
+        return self.reshape(self.r_combine_shape)
+
+    def l_combine(self):
+        return self.reshape(self.l_combine_shape)
+
+    @property
+    def array(self):
+        """Host copy (the reference's ``Matrix.array``)."""
+        return self.to_host()
+
     def __repr__(self):
         return f"DeviceTensor(shape={self.shape}, dtype={self.dtype})"
 

@@ -3,7 +3,9 @@
 Mirrors the names a Renormalizer user touches in renormalizer/mps/backend.py:97-216
 (``backend.real_dtype``, ``canonical_atol``, ``sync()``, ``free_all_blocks()`` ...).  There
 is no array-module alias ``xp`` here: tensors are ``DeviceTensor`` handles owned by the HIP
-engine and all arithmetic goes through its C ABI."""
+engine and all arithmetic goes through its C ABI; the functional counterparts of the ``xp.*``
+calls the sweep code makes (``tensordot``, ``asnumpy`` / ``asxp``, ``multi_tensor_contract``,
+``Matrix``) are in ``renormalizer_amd.mps.matrix``."""
 import logging
 import os
 
@@ -14,6 +16,7 @@ from ..engine import DeviceMemoryError, DeviceTensor, get_engine
 logger = logging.getLogger("renormalizer_amd")
 
 USE_GPU = True
+OE_BACKEND = "mpsengine"     # who contracts the einsum-like expressions (reference: "numpy" / "cupy", backend.py:77-84)
 MEMORY_ERRORS = (DeviceMemoryError, MemoryError)
 ARRAY_TYPES = (DeviceTensor, np.ndarray)
 

@@ -1426,12 +1426,18 @@ _CARRY = threading.local()
 def _carry_environ(mps, mpo, environ):
     ahead = "R" if mps.to_right else "L"
     environ.drop("L" if ahead == "R" else "R")
-    # the take-over test compares OBJECTS: an MPO site edited in place would go unnoticed, so the host arrays of a
-    # carried MPO become read-only (replacing a site, as try_swap_site does, is seen by the test)
-    for w in (mpo._mp if hasattr(mpo, "_mp") else []):
-        if isinstance(w, np.ndarray):
-            w.setflags(write=False)
-    _CARRY.slot = (mpo, list(mpo._mp) if hasattr(mpo, "_mp") else None, ahead, environ, list(mps._mp))
+    # the take-over test compares the MPO sites as OBJECTS and by a fingerprint of their contents: a site replaced (as
+    # try_swap_site does) or edited in place (a time-dependent Hamiltonian) drops the carried environments - the
+    # caller's arrays are left as they are
+    sites = list(mpo._mp) if hasattr(mpo, "_mp") else None
+    _CARRY.slot = (mpo, sites, ahead, environ, list(mps._mp), _mpo_fingerprint(sites))
+
+
+def _mpo_fingerprint(sites):
+    if sites is None:
+        return None
+    import zlib
+    return tuple(zlib.crc32(np.ascontiguousarray(w).view(np.uint8)) if isinstance(w, np.ndarray) else id(w) for w in sites)
 
 
 def clear_evolve_cache():
@@ -1449,11 +1455,11 @@ def _carried_environ(mps, mpo, ahead):
     _CARRY.slot = None
     if slot is None or os.environ.get("MPSE_ENV_CARRY", "1") == "0":
         return None
-    cmpo, cmpo_sites, cahead, environ, csites = slot
+    cmpo, cmpo_sites, cahead, environ, csites, cprint = slot
     n = len(mps)
     if cmpo is not mpo or cmpo_sites is None or cahead != ahead or len(csites) != n or len(cmpo_sites) != n:
         return None
-    if any(a is not b for a, b in zip(mpo._mp, cmpo_sites)):
+    if any(a is not b for a, b in zip(mpo._mp, cmpo_sites)) or _mpo_fingerprint(list(mpo._mp)) != cprint:
         return None
     # R(i) depends on the sites i .. n-1 (needed for i >= 1), L(i) on 0 .. i (needed for i <= n-2); the centre site
     # (rescaled by normalize) is in neither

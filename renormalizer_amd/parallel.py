@@ -157,6 +157,30 @@ class _StdoutToStderr:
         return False
 
 
+_HARD_EXIT = []
+
+
+def _exit_hard_at_end():
+    """A thread of this process is stuck inside ncclCommInitRank (two ranks on one device, a rank that never came):
+    the interpreter would finish its work and then hang in the runtime's teardown, waiting for that thread.  From
+    now on the process leaves through os._exit once Python's own exit handlers have run - with the status it would
+    have had (1 after an uncaught exception)."""
+    if _HARD_EXIT:
+        return
+    _HARD_EXIT.append(True)
+    import atexit
+
+    def bye():
+        for fh in (sys.stdout, sys.stderr):
+            try:
+                fh.flush()
+            except (OSError, ValueError):
+                pass
+        os._exit(1 if getattr(sys, "last_value", None) is not None else 0)
+
+    atexit.register(bye)
+
+
 class RcclCollective:
     """RCCL over xGMI through ctypes; one communicator per process, collectives on the engine's stream."""
     kind = "rccl"
@@ -171,6 +195,8 @@ class RcclCollective:
         L.ncclCommDestroy.argtypes = [C.c_void_p]
         L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        for name in ("ncclCommCount", "ncclCommUserRank", "ncclCommCuDevice"):
+            getattr(L, name).argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         uid = _ncclUniqueId()
         path = _rendezvous_path()
         self._path = path if self.rank == 0 else None
@@ -188,19 +214,35 @@ class RcclCollective:
             res = {}
 
             def init():
-                eng.sync()                             # the HIP device is per thread: bind this one as well
-                res["st"] = L.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
+                try:
+                    eng.sync()                         # the HIP device is per thread: bind this one as well
+                    res["st"] = L.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
+                except BaseException as exc:           # noqa: BLE001 - re-raised on the calling thread below
+                    res["exc"] = exc
 
             if self.world > 1:
                 th = threading.Thread(target=init, daemon=True)
                 th.start()
                 th.join(timeout_s)
                 if th.is_alive():
+                    _exit_hard_at_end()
                     raise TimeoutError(f"rank {self.rank}: ncclCommInitRank did not return within {timeout_s} s "
                                        f"({self.world} ranks expected; id file {path})")
             else:
                 init()
-        self._ok(res["st"])
+        if "exc" in res:
+            raise RuntimeError(f"rank {self.rank}: creating the RCCL communicator failed: {res['exc']!r}") from res["exc"]
+        self._ok(res.get("st", -1))
+
+    def describe(self):
+        """What the communicator itself says about this rank: (ranks in the communicator, this rank's number there, its
+        device ordinal) - whether RCCL saw N ranks on N devices is answerable from these."""
+        out = []
+        for name in ("ncclCommCount", "ncclCommUserRank", "ncclCommCuDevice"):
+            v = C.c_int(-1)
+            self._ok(getattr(self.lib, name)(self.comm, C.byref(v)))
+            out.append(int(v.value))
+        return tuple(out)
 
     def _ok(self, st):
         if st != 0:
@@ -248,6 +290,17 @@ class FileCollective:
         self._base = _rendezvous_path() + "." + tag
         self._seq = 0
         self._t_start = _process_start_time()
+        # Every message carries the launch's nonce: a file an earlier launch with the same tag left behind (same name,
+        # same sequence number, possibly only seconds old) can never be taken for one of this launch.  Rank 0 draws it
+        # and publishes it like the RCCL id (exclusive create + rename; readers insist on a file no older than they are).
+        npath = self._base + ".nonce"
+        if self.rank == 0:
+            raw = os.urandom(8) + b"\0" * 120
+            publish_id(npath, raw)
+        else:
+            raw = await_id(npath, self.timeout_s, self.rank)
+        self._nonce = raw[:8]
+        self._mine = []
 
     def _name(self, seq, rank):
         return f"{self._base}.{seq}.{rank}"
@@ -259,13 +312,15 @@ class FileCollective:
         tmp = self._name(seq, self.rank) + ".tmp"
         fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
         with os.fdopen(fd, "wb") as fh:
-            fh.write(np.int64(row.size).tobytes() + row.tobytes())
+            fh.write(self._nonce + np.int64(row.size).tobytes() + row.tobytes())
         os.replace(tmp, self._name(seq, self.rank))
+        self._mine.append(self._name(seq, self.rank))
         # every rank that writes sequence number s has read all files of s - 1, hence every rank has written s - 1,
         # hence finished reading s - 2: this rank's file of s - 2 can go
         try:
             os.remove(self._name(seq - 2, self.rank))
-        except OSError:
+            self._mine.remove(self._name(seq - 2, self.rank))
+        except (OSError, ValueError):
             pass
         out = np.empty((self.world, row.size))
         t0 = time.time()
@@ -273,9 +328,10 @@ class FileCollective:
             while True:
                 try:
                     with open(self._name(seq, r), "rb") as fh:
-                        if os.fstat(fh.fileno()).st_mtime < self._t_start - 120.0:
-                            raise FileNotFoundError          # left by an earlier launch with the same tag
                         raw = fh.read()
+                    if raw[:8] != self._nonce:
+                        raise FileNotFoundError              # left by another launch with the same tag
+                    raw = raw[8:]
                     n = int(np.frombuffer(raw[:8], dtype=np.int64)[0]) if len(raw) >= 8 else -1
                     if n == row.size and len(raw) == 8 + 8 * n:
                         out[r] = np.frombuffer(raw[8:], dtype=np.float64)
@@ -300,22 +356,36 @@ class FileCollective:
         return self._exchange(row)
 
     def close(self):
-        self.barrier()                      # nobody is still reading what is removed below
-        for seq in range(max(0, self._seq - 3), self._seq - 1):
-            try:
-                os.remove(self._name(seq, self.rank))
-            except OSError:
-                pass
-        # (the last file stays until the directory is cleaned: another rank may still be reading it)
+        # two barriers: whoever leaves the second one knows that every rank has WRITTEN its file of the second, hence
+        # finished reading the first - so everything up to the first can go now; this rank's file of the second may
+        # still be read by a slower rank and stays (a few dozen bytes; it carries the nonce, so no later launch with the
+        # same tag mistakes it for one of its own)
+        self.barrier()
+        self.barrier()
+        last = self._name(self._seq - 1, self.rank)
+        for name in list(self._mine):
+            if name != last:
+                try:
+                    os.remove(name)
+                except OSError:
+                    pass
+                self._mine.remove(name)
 
 
-def make_collective(eng=None, backend=None):
+class CollectiveUnavailable(RuntimeError):
+    """The RCCL communicator could not be created on every rank and the caller did not allow the file fallback."""
+
+
+def make_collective(eng=None, backend=None, strict=False):
     """Collective of this process from the launcher's environment (RANK / WORLD_SIZE as set by
     torch.distributed.run): serial for one process, RCCL (ctypes) otherwise.  Whether RCCL is used is decided by
     ALL ranks together (a vote through ``FileCollective``): if the communicator cannot be created on any rank -
     library missing, rendezvous or ``ncclCommInitRank`` timing out (``MPSE_RCCL_TIMEOUT``, default 120 s) - every rank
     falls back to the file collective and says so; ``backend="rccl"`` (or MPSE_COLLECTIVE=rccl) forbids the fallback,
-    MPSE_COLLECTIVE=file skips RCCL."""
+    MPSE_COLLECTIVE=file skips RCCL.  ``strict=True`` (a scaling run: ``bench.py --gpus N``): the vote still takes place
+    - so that every rank learns the outcome and none is left waiting - but a failed vote raises
+    ``CollectiveUnavailable`` on EVERY rank instead of degrading: a run that was to measure RCCL over xGMI must not
+    print a number obtained without it."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     want = backend or os.environ.get("MPSE_COLLECTIVE", "")
@@ -339,6 +409,11 @@ def make_collective(eng=None, backend=None):
     if not failed:
         vote.close()
         return rc
+    if strict:
+        vote.close()
+        raise CollectiveUnavailable(f"rank {rank}: the RCCL communicator is not available on every rank"
+                                    f"{' (' + str(err) + ')' if err else ''}; set MPSE_COLLECTIVE=file to run with "
+                                    "the file-based barrier / gather instead")
     sys.stderr.write(f"[rank {rank}] RCCL communicator not available on every rank"
                      f"{' (' + str(err) + ')' if err else ''}: barrier / gather through files instead\n")
     sys.stderr.flush()

@@ -436,3 +436,29 @@ def test_deferred_calls_run_after_the_armed_solve():
         with pytest.raises(Exception):
             expm_krylov(hop, -0.3j, cd)
     eng.defer_discard()
+
+
+def test_bench_two_ranks_fail_loudly_without_rccl(tmp_path):
+    """The driver's N = 2 command line (torch.distributed.run, one rank per GPU) with both ranks forced onto ONE device,
+    which RCCL does not accept: a scaling run whose communicator cannot be created must END - non-zero exit on every
+    rank, no JSON line, an error that names the way out - instead of printing a number obtained through the file
+    collective (verdict round 3, item 4).  (A box whose RCCL accepts two ranks on one device prints a line with
+    "collective": "rccl" and the communicator's own rank / device report - equally fine.)"""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPSE_RCCL_TIMEOUT="25", MPSE_RENDEZVOUS_DIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MPSE_COLLECTIVE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29677", os.path.join(repo, "bench.py"), "--gpus", "2", "--share-gpu",
+           "--steps", "1", "--warmup", "0", "--cpu-updates", "0", "--nmol", "3", "--pdim", "4", "--bond-dim", "16"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=repo)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode == 0:
+        d = json.loads(lines[-1])
+        assert d["config"]["collective"] == "rccl" and d["config"]["rccl_comm_count"] == [2, 2]
+        assert d["config"]["rccl_comm_user_rank"] == [0, 1]
+        return
+    assert not lines, "a failed scaling run must not print a result line"
+    assert "CollectiveUnavailable" in r.stderr and "MPSE_COLLECTIVE=file" in r.stderr, r.stderr[-1500:]

@@ -606,6 +606,57 @@ def test_folded_one_site_matvec_block_sparse_vs_oracle(eng, cplx):
     assert _relerr(masked.to_host().ravel(), plain.to_host().ravel()) < 1e-13
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_matrix_module_tensordot_and_paths(eng, cplx):
+    """renormalizer_amd.mps.matrix (the module-level names of SURVEY 8(b)): tensordot over device tensors against numpy
+    for single, multiple, permuted and interleaved contracted axes (two-level strided indices, host loops beyond),
+    multi_tensor_contract on the reference's own contract_one_site paths (mps/lib.py:200-243), asnumpy / asxp."""
+    from renormalizer_amd.mps import matrix as mx
+    from renormalizer_amd.mps.backend import OE_BACKEND
+    assert OE_BACKEND == "mpsengine"
+    rng = np.random.default_rng(5)
+    cases = [((6, 5, 4), (4, 7), ([2], [0])), ((6, 5, 4), (5, 6, 3), ([0, 1], [1, 0])),
+             ((3, 4, 5, 6), (5, 2, 3), ([2, 0], [0, 2])), ((2, 3, 4, 5), (5, 3, 7), ([1, 3], [1, 0])),
+             ((4, 3, 2, 5, 6), (6, 2, 3), ([4, 2], [0, 1])), ((5, 4), (5, 4), ([0, 1], [0, 1])), ((7,), (7,), ([0], [0])),
+             ((3, 4, 5, 2, 6), (2, 4, 7, 5), ([3, 1, 2], [0, 1, 3]))]
+    for sa, sb, axes in cases:
+        a, b = _rand(rng, sa, cplx), _rand(rng, sb, cplx and len(sb) > 1)
+        got = mx.tensordot(mx.asxp(a), b, axes)
+        ref = np.tensordot(a, b, axes)
+        assert got.shape == (ref.shape if ref.shape else (1,)) or got.shape == ref.shape
+        assert _relerr(mx.asnumpy(got).ravel(), np.asarray(ref).ravel()) < 1e-13, (sa, sb, axes)
+    assert mx.asnumpy(None) is None and mx.asxp(None) is None
+    # environment update through the reference's path strings, against the engine's own plan
+    D, d, w = 12, 3, 4
+    ms, mo = _rand(rng, (D, d, D), cplx), rng.standard_normal((w, d, d, w))
+    env = _rand(rng, (D, w, D), cplx)
+    path = [([0, 1], "fda, abc -> fdbc"), ([2, 0], "fdbc, gdeb -> fcge"), ([1, 0], "fcge, hec -> fgh")]
+    out = mx.multi_tensor_contract(path, ms.conj(), env, mo, ms)
+    ref = orc.contract_one_site(env, ms, mo, "R")
+    assert _relerr(mx.asnumpy(out).ravel(), ref.ravel()) < 1e-12
+    m = mx.Matrix(ms)
+    assert m.pdim == (d,) and m.bond_dim == (D, D) and m.l_combine().shape == (D * d, D) and m.r_combine().shape == (D, d * D)
+
+
+def test_truncate_select_vs_oracle_through_cabi(eng):
+    """select_basis (mps/lib.py:253-322) through the C ABI - mpse_truncate_select, host-side integer logic inside the
+    library - against the oracle: equal quotas per quantum-number block, remaining slots by weight, stable on ties,
+    for percent = 0 / 0.2 / 1 and selections smaller and larger than the candidate set (the CPU suite
+    holds the same comparison for the Python wrapper)."""
+    from renormalizer_amd.mps.basis_select import select_basis_indices
+    rng = np.random.default_rng(3)
+    for n, nq in ((30, 3), (257, 5), (1, 1)):
+        s = rng.random(n)
+        if n > 10:
+            s[4] = s[9]                                   # a tie
+            s[7] = 0.0
+        qn = rng.integers(0, nq, (n, 1)).tolist()
+        for percent in (0, 0.2, 1.0):
+            for mmax in (1, 5, 17, n, n + 50):
+                assert select_basis_indices(s, qn, mmax, percent) == orc.select_basis_indices(s, qn, mmax, percent), \
+                    (n, percent, mmax)
+
+
 def test_eigh_qn_density_matrix_blocks(eng):
     """svd_qn.eigh_qn (mps/svd_qn.py:243-302): block eigen-decomposition of a reduced density matrix against LAPACK."""
     from renormalizer_amd.mps import svd_qn

@@ -75,11 +75,36 @@ def test_headline_one_evolve_vs_oracle(headline):
         assert np.array_equal(_sorted_rows(a), _sorted_rows(b))
     st = dev.evolve_config.stat
     assert st["nobs"] == len(ost.krylov_dims) == 2 * (2 * len(mps) - 1)
-    # the Krylov dimension of a solve depends on the gauge of the local tensor where a stopping test is marginal:
-    # the counts agree, the dimensions agree on average
-    assert abs(st["mean"] - float(np.mean(ost.krylov_dims))) < 0.5
+    # solve by solve: the same Krylov dimension, except where the oracle's own stopping test was marginal (largest
+    # |res - new_res| / (atol + rtol |new_res|) within 10 % of 1 at one of its checks: there the outcome hinges on
+    # rounding and on the gauge of the local tensor) - such a solve may differ by one check (2 vectors)
+    dev_dims, orc_dims = list(st["steps"]), list(ost.krylov_dims)
+    assert len(dev_dims) == len(orc_dims) == len(ost.krylov_margins)
+    marginal = [any(0.9 <= m <= 1.1 for m in ms) for ms in ost.krylov_margins]
+    differ = [i for i, (a, b) in enumerate(zip(dev_dims, orc_dims)) if a != b]
+    assert all(marginal[i] and abs(dev_dims[i] - orc_dims[i]) <= 2 for i in differ), \
+        [(i, dev_dims[i], orc_dims[i], ost.krylov_margins[i]) for i in differ]
+    assert abs(st["mean"] - float(np.mean(orc_dims))) < 0.1
     ov = orc.mps_dot([s.conj() for s in ost.sites], dev.to_arrays())
     assert abs(abs(ov) - 1.0) < 1e-9, abs(ov)
+
+
+def test_headline_five_evolves_conserve(headline):
+    """Five consecutive evolves at the headline size (the bench runs twenty): <H> drifts by less than 1e-6 relative to
+    the band width, the electronic populations sum to 1 to 1e-9 at every step, the norm stays 1, and the bond
+    dimensions stay where the fixed-bond scheme keeps them."""
+    model, mpo, mps, _ = headline
+    e0 = mps.expectation(mpo)
+    dims0 = list(mps.bond_dims)
+    cur = mps
+    for step in range(5):
+        cur = cur.evolve(mpo, 10.0)
+        occ = np.asarray(cur.e_occupations)
+        assert abs(occ.sum() - 1.0) < 1e-9, (step, occ.sum())
+        assert occ.min() > -1e-12
+        assert abs(cur.mp_norm - 1.0) < 1e-11, (step, cur.mp_norm)
+        assert abs(cur.expectation(mpo) - e0) < 1e-6 * 0.12, (step, cur.expectation(mpo) - e0)   # 4 J = 0.12 a.u.
+        assert list(cur.bond_dims) == dims0
 
 
 _VARIANT = r"""

@@ -815,11 +815,17 @@ def test_environments_carried_between_tdvp_ps_steps(golden_dir, monkeypatch):
             nb = len(built)
             after = other.evolve(mpo, 10.0)
             assert len(built) == nb + 1
-            # a carried MPO's host arrays are read-only (an in-place edit could not be seen by the identity test) ...
+            # an MPO site edited in place is noticed by its fingerprint (the caller's arrays stay writable): rebuild ...
             w0 = mpo[0]
             if isinstance(w0, np.ndarray):
-                with pytest.raises(ValueError):
-                    w0[...] = 0.0
+                assert w0.flags.writeable
+                saved = w0.copy()
+                w0[...] = 2.0 * saved
+                nb = len(built)
+                after.evolve(mpo, 10.0)
+                assert len(built) == nb + 1
+                w0[...] = saved
+                after = other.evolve(mpo, 10.0)
             # ... and the slot can be dropped by hand: the next step rebuilds
             type(after).clear_evolve_cache()
             nb = len(built)

@@ -7,10 +7,23 @@ Both counters are reported in KB by rocprofv3.  MI355X_MICROARCH.md (HBM section
 128-byte requests as 64 bytes for wide coalesced reads, so the fetch figure is doubled; WRITE_SIZE is taken as is.
 The passes are separate runs of the same command (FETCH_SIZE and WRITE_SIZE do not fit one pass), launches are
 matched by kernel name and averaged."""
+import hashlib
 import json
+import os
 import re
 import sqlite3
 import sys
+
+
+def kernel_source_sha():
+    """Fingerprint of the contraction kernel's sources at the time of the counter passes (bench.py quotes the figure
+    as `roofline.traffic` only while the sources still match)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "renormalizer_amd", "csrc")
+    h = hashlib.sha256()
+    for name in ("mpse_gemm.hip", "mpse_plans.h", "mpse_contract.hip"):
+        with open(os.path.join(root, name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(path, counter):
@@ -33,7 +46,8 @@ def main():
             continue
         res[k] = dict(launches=f["launches"], fetch_raw_bytes=f["avg_kb"] * 1024.0, write_bytes=w["avg_kb"] * 1024.0,
                       hbm_bytes_per_launch=2.0 * f["avg_kb"] * 1024.0 + w["avg_kb"] * 1024.0)
-    json.dump(dict(note="avg per launch; hbm_bytes = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE", kernels=res),
+    json.dump(dict(note="avg per launch; hbm_bytes = 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE",
+                   kernel_source_sha=kernel_source_sha(), kernels=res),
               open(sys.argv[3], "w"), indent=1)
     lines = ["| kernel | launches | FETCH_SIZE raw MB | WRITE_SIZE MB | HBM MB / launch (2 x fetch + write) |", "|---|---|---|---|---|"]
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"]):
