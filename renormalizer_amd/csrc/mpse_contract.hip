@@ -258,13 +258,8 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
     MPSE_TRY(t3.alloc(size_t(p.tmp_elems[2]) * es));
     bufs[B_T3] = t3.p;
   }
-  // MPSE_WSMALL=0: the MPO step of small sites as a batched MFMA product like the large ones
-  static const bool wsmall_on = [] {
-    const char* e = getenv("MPSE_WSMALL");
-    return !(e && e[0] == '0');
-  }();
   for (const Step& s : p.steps) {
-    if (s.kind == K_GEMM && s.is_wstep && wsmall_on && s.dta == MPSE_F64 && s.a_off == 0 && s.b_off == 0 &&
+    if (s.kind == K_GEMM && s.is_wstep && s.dta == MPSE_F64 && s.a_off == 0 && s.b_off == 0 &&
         s.c_off == 0 && s.beta == 0.0 && s.w_wl * s.w_d <= 16 && s.w_d * s.w_wr <= 16) {
       if (!bufs[s.a] || !bufs[s.b] || !bufs[s.c]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing buffer");
       WsmArgs g;

@@ -283,8 +283,7 @@ int mpse_ctx_create(int device, mpse_ctx** out) {
   (void)hipStreamSynchronize(ctx->stream);
   if (hipHostGetDevicePointer((void**)&ctx->pinned_dev, ctx->pinned, 0) != hipSuccess) ctx->pinned_dev = nullptr;
   {
-    const char* e = getenv("MPSE_STAGE_KERNEL");
-    if ((e && e[0] == '0') || hipHostGetDevicePointer((void**)&ctx->stage_dev, ctx->stage, 0) != hipSuccess)
+    if (hipHostGetDevicePointer((void**)&ctx->stage_dev, ctx->stage, 0) != hipSuccess)
       ctx->stage_dev = nullptr;
     (void)hipGetLastError();
   }
@@ -453,9 +452,6 @@ int mpse_mem_info(mpse_ctx* ctx, size_t* pool_bytes, size_t* in_use_bytes, size_
                   size_t* device_total) {
   if (!ctx) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
-  if (getenv("MPSE_POOL_STATS"))
-    fprintf(stderr, "[mpsengine] pool %zu B, in use %zu B, hipMalloc calls %llu, held frees %zu\n", ctx->pool_bytes,
-            ctx->in_use_bytes, ctx->n_device_allocs, ctx->defer_frees.size());
   if (pool_bytes) *pool_bytes = ctx->pool_bytes;
   if (in_use_bytes) *in_use_bytes = ctx->in_use_bytes;
   size_t f = 0, t = 0;

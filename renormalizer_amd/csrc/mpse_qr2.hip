@@ -19,8 +19,7 @@
 // its register ring), so the applying workgroups only reduce V^H x.  Blocks of at most 1024 rows run one launch
 // per panel (k_hh_step: the panel's workgroup first gives its columns the previous panel's reflectors, the trailing
 // update of that panel runs beside it); taller blocks keep the two launches: there the update of the four panel
-// columns alone fills its compute unit's FP64 pipe for longer than the second launch costs (MPSE_QR_LOOKAHEAD=0:
-// two launches everywhere).  Conventions are LAPACK's (?geqr2 / ?ung2r):
+// columns alone fills its compute unit's FP64 pipe for longer than the second launch costs.  Conventions are LAPACK's (?geqr2 / ?ung2r):
 // H_j = I - tau_j v_j v_j^H, v_j = (0.., 1, scale_j * tail_j), tails stored UNSCALED below the
 // diagonal, R on and above it.
 #include <cstdlib>
@@ -811,13 +810,7 @@ __global__ __launch_bounds__(NT) void k_hh_formq_wy(double* q_base, const double
   }
 }
 
-inline bool qr_use_wy() {
-  static const bool on = [] {
-    const char* e = getenv("MPSE_QR_WY");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+inline bool qr_use_wy() { return true; }
 
 template <bool CPLX>
 int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk* dblk, int nblk, int max_mm,
@@ -828,12 +821,8 @@ int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk*
   // tall blocks prefer more rows per thread over more waves (cycle breakdown by s_memtime).
   // Rows per thread follow the tallest block (256 x 1..4 up to 1024 rows, 512 x 5..8 above 2048): the panel is bound
   // by the FP64 vector work of its CU, and row slots that do not exist still cost their share of it (headline: 400
-  // rows -> 256 x 2 instead of 256 x 4: -16 % per d = 2 QR; 3200 rows -> 512 x 7).  MPSE_QR_FIT=0: the three
-  // coarse configurations only.
-  static const bool fit = [] {
-    const char* e = getenv("MPSE_QR_FIT");
-    return !(e && e[0] == '0');
-  }();
+  // rows -> 256 x 2 instead of 256 x 4: -16 % per d = 2 QR; 3200 rows -> 512 x 7).
+  constexpr bool fit = true;
   const int cfg = max_mm <= 1024 ? 0 : max_mm <= 2048 ? 1 : 2;
   const int rpt = !fit ? (cfg == 2 ? 8 : 4) : cfg == 0 ? (max_mm + 255) / 256 : cfg == 2 ? (max_mm + 511) / 512 : 4;
   const int nb = 4;
@@ -852,10 +841,7 @@ int run_batched(mpse_ctx* ctx, double* ws, double* q, HhParam* prm, const QrBlk*
     case 7: hipLaunchKernelGGL((KERNEL<CPLX, 512, 7 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(512), 0, ctx->stream, ARGS); break; \
     default: hipLaunchKernelGGL((KERNEL<CPLX, 512, 8 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(512), 0, ctx->stream, ARGS);       \
   }
-  static const bool look = [] {
-    const char* e = getenv("MPSE_QR_LOOKAHEAD");
-    return !(e && e[0] == '0');
-  }();
+  constexpr bool look = true;
   if (look && wy && cfg == 0) {
     // the extra step after the last panel only carries the trailing update of blocks wider than their rank
     for (int j0 = 0; j0 < max_k + (max_tail > 0 ? nb : 0); j0 += nb) {

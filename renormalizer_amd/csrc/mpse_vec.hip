@@ -871,11 +871,8 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
     const bool last = (j + 1 >= limit);
     // The first check of a solve (j = 4) cannot stop it - there is no earlier estimate to compare with - so it is
     // evaluated together with the second one (j = 6): one pass over the basis forms both estimates, and a solve has
-    // three small launches and ~25 us of dependent latency less (MPSE_LZ_DEFER_FIRST=0: every check on its own).
-    static const bool defer_first = [] {
-      const char* e = getenv("MPSE_LZ_DEFER_FIRST");
-      return !(e && e[0] == '0');
-    }();
+    // three small launches and ~25 us of dependent latency less.
+    constexpr bool defer_first = true;
     bool merged = false;
     if (defer_first && check && !prev && j == 4 && j + 3 < limit) check = false;   // (its turn comes at j = 6)
     if (defer_first && check && !prev && j == 6) merged = true;
@@ -919,20 +916,6 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
   }
   ctx->lz_hint[key] = hc.nvec;
   if (nvec) *nvec = hc.nvec;
-  if (getenv("MPSE_LZ_STATS")) fprintf(stderr, "[lzs] nsite %d n %lld hint %d nvec %d\n", h->nsite, (long long)n, hint, hc.nvec);
-  if (getenv("MPSE_LZ_DEBUG")) {
-    std::vector<double> hs(size_t(SC_COEF + 2 * LZ_MAXM));
-    (void)hipMemcpy(hs.data(), scal, hs.size() * sizeof(double), hipMemcpyDeviceToHost);
-    const int m = hc.nvec;
-    std::vector<double> al, be;
-    for (int i = 0; i < m; ++i) al.push_back(hs[4 + 4 * i]), be.push_back(sqrt(hs[6 + 4 * i]));
-    Coefs c;
-    expm_coefs(m, al, be, sqrt(hs[0]), dt, &c);
-    double err = 0;
-    for (int i = 0; i < m; ++i) err = fmax(err, hypot(c.re[i] - hs[SC_COEF + i], c.im[i] - hs[SC_COEF + LZ_MAXM + i]));
-    fprintf(stderr, "[lz] nvec %d which %d hint %d wait_from %d coef err %.3e (c0 %.6f %.6f dev %.6f %.6f)\n", hc.nvec, hc.which,
-            hint, wait_from, err, c.re[0], c.im[0], hs[SC_COEF], hs[SC_COEF + LZ_MAXM]);
-  }
   return MPSE_OK;
 }
 

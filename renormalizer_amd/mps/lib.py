@@ -90,7 +90,7 @@ def contract_one_site(environ, ms, mo, domain, ms_conj=None, canonical_mo_host=N
         if canonical_mo_host is not None and ms.ndim == 3 and environ.unit > 0:
             # the chain of predictions starts at the sentinel and is carried through small bonds as well
             out.unit = predict_unit_channel(canonical_mo_host, domain, environ.unit)
-            if os.environ.get("MPSE_VERIFY_UNIT") and oshape[0] >= UNIT_MIN_BOND and not deferred:
+            if VERIFY_UNIT and oshape[0] >= UNIT_MIN_BOND and not deferred:
                 measured = find_unit_channel(out)
                 assert measured == out.unit, f"unit channel predicted {out.unit}, measured {measured}"
         elif oshape[0] >= UNIT_MIN_BOND and not deferred:
@@ -145,6 +145,9 @@ UNIT_TOL = 1e-12
 # (mpse_plans.h unit_pays: D^2 x d D for a one-site matvec): below D = 128 no physical dimension reaches that, and the
 # detection - a small kernel plus a host round trip per environment update - would be pure latency.
 UNIT_MIN_BOND = 128
+# debug (tests): every predicted unit channel is also measured on the device and compared; the sweep then runs the
+# plain loop (a recorded update cannot be measured before it has run)
+VERIFY_UNIT = False
 
 
 def find_unit_channel(env):

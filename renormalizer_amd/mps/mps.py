@@ -19,6 +19,7 @@ from ..model import Model, Op, OpSum
 from ..utils import CompressConfig, CompressCriteria, EvolveConfig, EvolveMethod, OptimizeConfig
 from . import svd_qn
 from .hop_expr import centre_tile_mask, hop_expr
+from . import lib as _lib
 from .lib import Environ, contract_one_site
 from .mpo import Mpo
 from .svd_qn import add_outer, get_qn_mask
@@ -1360,7 +1361,7 @@ class Mps:
         # contraction launches were rebalanced (neutral before: DESIGN.md section 5).  MPSE_DEFER=0: the plain loop.
         same_dtype = mps.is_complex or (evolve_dt.real == 0 and not mpo.is_complex)
         pipelined = (cfg.ivp_solver == "krylov" and same_dtype and os.environ.get("MPSE_DEFER", "1") != "0"
-                     and not os.environ.get("MPSE_VERIFY_UNIT"))
+                     and not _lib.VERIFY_UNIT)
         try:
             for _ in range(2):
                 order = list(mps.iter_idx_list(full=True))

@@ -187,7 +187,7 @@ class RcclCollective:
 
     def __init__(self, eng, rank: int, world: int, timeout_s: float = 300.0):
         self.eng, self.rank, self.world = eng, int(rank), int(world)
-        self.lib = C.CDLL(os.environ.get("MPSE_RCCL_LIB", "librccl.so"))
+        self.lib = C.CDLL("librccl.so")
         L = self.lib
         L.ncclGetErrorString.restype = C.c_char_p
         L.ncclGetUniqueId.argtypes = [C.POINTER(_ncclUniqueId)]

@@ -255,9 +255,10 @@ def test_headline_size_invariants(monkeypatch):
     """BASELINE headline size (50 sites, dphys 2/16, Dbond 256): properties that do not need the oracle -
     norm and particle number conserved, energy conserved by the unitary step, mirror symmetry of the chain.  The
     unit channels that the sweep predicts on the host for environments built from freshly orthogonalised sites are
-    verified here against the measurement on the device (MPSE_VERIFY_UNIT)."""
+    verified here against the measurement on the device (mps.lib.VERIFY_UNIT)."""
     import bench
-    monkeypatch.setenv("MPSE_VERIFY_UNIT", "1")
+    import renormalizer_amd.mps.lib as _mlib
+    monkeypatch.setattr(_mlib, "VERIFY_UNIT", True)
     model, mpo, mps = bench.build_workload(25, 16, 256, 0, "physical")
     assert max(mps.bond_dims) == 256 and len(mps) == 50
     e0 = mps.expectation(mpo)
