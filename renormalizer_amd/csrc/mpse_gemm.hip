@@ -928,18 +928,26 @@ __global__ __launch_bounds__(64 * WS * WS * (2 / WI), WS == 1 ? 1 : WI == 1 ? 4 
 //    the columns sorted by weight, so that the dies carry equal work): its L2 then holds the column panels of B it
 //    needs instead of streaming all of B (the plain sorted order raised the HBM-side traffic of the A-step by 2.5x).
 // One workgroup, bitonic sorts of <= 2048 keys in LDS.
-__device__ __forceinline__ void bitonic_desc_2048(unsigned* key, int tid) {
-  for (int size = 2; size <= 2048; size <<= 1)
+// (n: power of two <= 2048, the keys beyond the data are zero; 1024 threads, n / 2 compare-exchange pairs per step)
+__device__ __forceinline__ void bitonic_desc(unsigned* key, int tid, int n) {
+  for (int size = 2; size <= n; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const int lo = 2 * tid - (tid & (stride - 1)), hi = lo + stride;   // 1024 compare-exchange pairs per step
-      const bool desc = (lo & size) == 0;
-      const unsigned a = key[lo], b = key[hi];
-      if ((a < b) == desc) {
-        key[lo] = b;
-        key[hi] = a;
+      if (tid < (n >> 1)) {
+        const int lo = 2 * tid - (tid & (stride - 1)), hi = lo + stride;
+        const bool desc = (lo & size) == 0;
+        const unsigned a = key[lo], b = key[hi];
+        if ((a < b) == desc) {
+          key[lo] = b;
+          key[hi] = a;
+        }
       }
       __syncthreads();
     }
+}
+__device__ __forceinline__ int pow2_at_least(int x) {
+  int n = 2;
+  while (n < x) n <<= 1;
+  return n;
 }
 __global__ __launch_bounds__(1024) void k_tile_order(const unsigned long long* __restrict__ amask,
                                                        const unsigned long long* __restrict__ bmask, int nkw, int nkt,
@@ -989,7 +997,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const unsigned long long* _
   if (part) {
     for (int c = tid; c < 2048; c += 1024) ckey[c] = c < tiles_n ? ((unsigned)colw[c] << 11) | (unsigned)(2047 - c) : 0u;
     __syncthreads();
-    bitonic_desc_2048(ckey, tid);
+    bitonic_desc(ckey, tid, pow2_at_least(tiles_n));
     for (int r = tid; r < tiles_n; r += 1024) {
       const int c = 2047 - (int)(ckey[r] & 2047u), r16 = r & 15;
       die_of[c] = (unsigned char)(r16 < 8 ? r16 : 15 - r16);          // snake over the columns by weight
@@ -1005,7 +1013,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const unsigned long long* _
     key[i] = k;
   }
   __syncthreads();
-  bitonic_desc_2048(key, tid);
+  bitonic_desc(key, tid, pow2_at_least(ntile));
   const int per_die = ntile / 8;           // part: every die owns tiles_n / 8 columns of tiles_m tiles
   for (int i = tid; i < ntile; i += 1024) {
     const int s = part ? (7 - (i & 7)) * per_die + (i >> 3) : i;

@@ -138,6 +138,7 @@ _SWITCHES = {
     "MPSE_ENV_CARRY=0": True,         # rebuild the environments at every step
     "MPSE_LANCZOS_ASYNC=0": False,    # host-side eigen-decomposition of the tridiagonal matrix
     "MPSE_DEFER=0": True,             # QR / environment update / absorption issued from Python after each solve returns
+    "MPSE_SPLIT2=0": False,           # products with R as one workgroup per tile (other summation order)
     "MPSE_WFOLD=0": False,            # one-site matvec as the three-step chain (L.C, MPO step, .R) instead of the folded plan
 }
 
