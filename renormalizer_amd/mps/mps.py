@@ -269,19 +269,31 @@ class Mps:
 
     @classmethod
     def load(cls, model, fname: str):
-        """Read protocol 0.3 / 0.4 files (mps/mps.py:352-386)."""
+        """Read dump files of every protocol version the reference reads (mps/mps.py:352-386): 0.3 / 0.4 carry
+        ``to_right`` and ``coeff``; 0.2 carries ``to_right`` and the coefficient as the last entry of the (otherwise
+        obsolete) time-dependent-Hartree part; 0.1 calls the direction ``left`` and has no coefficient."""
         z = np.load(fname, allow_pickle=True)
         version = str(z["version"])
-        if version not in ("0.3", "0.4"):
-            raise ValueError(f"Unknown dump version: {version}")
         n = int(z["nsites"])
         arrays = [z[f"mt_{i}"] for i in range(n)]
         if f"subqn_{n}" in z.files:
             qn = [np.asarray(z[f"subqn_{i}"]).astype(int) for i in range(n + 1)]
         else:
             qn = [np.asarray(q).astype(int) for q in z["qn"]]
-        return cls.from_arrays(model, arrays, qn, int(z["qnidx"]), np.asarray(z["qntot"]).astype(int),
-                               bool(z["to_right"]), z["coeff"].item(0))
+        if version == "0.1":
+            logger.warning("Using old dump/load protocol. TD Hartree part will be lost")
+            to_right, coeff = bool(z["left"]), 1
+        elif version == "0.2":
+            logger.warning("Using old dump/load protocol. TD Hartree part will be lost")
+            to_right, coeff = bool(z["to_right"]), np.asarray(z["tdh_wfns"], dtype=object)[-1]
+            coeff = complex(np.asarray(coeff).item(0)) if np.iscomplexobj(coeff) else float(np.asarray(coeff).item(0))
+        elif version in ("0.3", "0.4"):
+            to_right, coeff = bool(z["to_right"]), z["coeff"].item(0)
+        else:
+            raise ValueError(f"Unknown dump version: {version}")
+        qn = [q.reshape(len(q), -1) for q in qn]            # (protocols before 0.4 stored one number per state)
+        return cls.from_arrays(model, arrays, qn, int(z["qnidx"]), np.asarray(z["qntot"]).astype(int).reshape(-1),
+                               to_right, coeff)
 
     def _get_sigmaqn(self, idx):
         return np.array(self.model.basis[idx].sigmaqn)

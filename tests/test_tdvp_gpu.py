@@ -225,6 +225,22 @@ def test_checkpoint_wire_format(golden_dir, tmp_path):
         assert np.array_equal(a[k], b[k]), k
     again = Mps.load(model, out)
     assert abs(again.expectation(Mpo(model)) - float(exp["energy"])) < 1e-12
+    # the older protocols the reference still reads (mps/mps.py:369-380): 0.2 keeps the coefficient as the last entry
+    # of the time-dependent-Hartree list, 0.1 calls the direction "left" and has no coefficient
+    base = {k: b[k] for k in b.files if k not in ("version", "coeff", "to_right")}
+    v02 = str(tmp_path / "v02.npz")
+    np.savez(v02, version="0.2", to_right=b["to_right"], tdh_wfns=np.array([0.5 + 0.25j]), **base)
+    old = Mps.load(model, v02)
+    assert old.coeff == 0.5 + 0.25j and old.to_right == bool(b["to_right"])
+    assert abs(old.expectation(Mpo(model)) - float(exp["energy"])) < 1e-12
+    v01 = str(tmp_path / "v01.npz")
+    np.savez(v01, version="0.1", left=b["to_right"], **base)
+    older = Mps.load(model, v01)
+    assert older.coeff == 1 and older.to_right == bool(b["to_right"])
+    assert np.abs(older.e_occupations - exp["occ"]).max() < 1e-12
+    with pytest.raises(ValueError):
+        np.savez(v01, version="9.9", **base)
+        Mps.load(model, v01)
 
 
 def test_imaginary_time_tdvp_real_dtype():
