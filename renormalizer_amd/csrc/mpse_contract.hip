@@ -69,6 +69,12 @@ struct WsmArgs {
   const double* W;
   int Da, d, wl, wr, N;
   const int* skip;
+  // channels [b_lo, b_hi) of T1 arrive as `nslices` K slices of the product that forms them (slice s of channel b, row
+  // a at slices + s * slice_stride + (((b - b_lo) * Da + a) * d + e) * N + n): added here instead of by a launch of
+  // their own (nslices == 0: everything is read from T1)
+  const double* slices;
+  long long slice_stride;
+  int nslices, b_lo, b_hi;
 };
 
 template <bool CPLX>
@@ -97,9 +103,18 @@ __global__ __launch_bounds__(256) void k_wsmall(const WsmArgs g) {
     xi[be] = 0.0;
     if (be < nrow) {
       const int b = be / g.d, e = be - b * g.d;
-      const double* src = g.T1 + ((((long long)b * g.Da + a) * g.d + e) * g.N + n) * E;
-      xr[be] = src[0];
-      if constexpr (CPLX) xi[be] = src[1];
+      if (g.nslices > 0 && b >= g.b_lo && b < g.b_hi) {
+        const double* src = g.slices + ((((long long)(b - g.b_lo) * g.Da + a) * g.d + e) * g.N + n) * E;
+        for (int sl = 0; sl < g.nslices; ++sl) {      // slice order: the same sum as the reduction launch forms
+          xr[be] += src[0];
+          if constexpr (CPLX) xi[be] += src[1];
+          src += g.slice_stride * E;
+        }
+      } else {
+        const double* src = g.T1 + ((((long long)b * g.Da + a) * g.d + e) * g.N + n) * E;
+        xr[be] = src[0];
+        if constexpr (CPLX) xi[be] = src[1];
+      }
     }
   }
 #pragma unroll
@@ -258,9 +273,33 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
     MPSE_TRY(t3.alloc(size_t(p.tmp_elems[2]) * es));
     bufs[B_T3] = t3.p;
   }
+  // The elementwise MPO step of a small site adds the K slices of the ONE product that forms its input channels itself
+  // (no reduction launch between them): which step that is, and where its slices go
+  auto small_wstep = [](const Step& s) {
+    return s.kind == K_GEMM && s.is_wstep && s.dta == MPSE_F64 && s.a_off == 0 && s.b_off == 0 && s.c_off == 0 &&
+           s.beta == 0.0 && s.w_wl * s.w_d <= 16 && s.w_d * s.w_wr <= 16;
+  };
+  const Step* slice_producer = nullptr;
+  const Step* slice_consumer = nullptr;
+  {
+    int n_t1 = 0;
+    const Step* prod = nullptr;
+    const Step* cons = nullptr;
+    for (const Step& s : p.steps) {
+      if (small_wstep(s) && s.b == B_T1 && !cons) cons = &s;
+      if (!cons && s.kind == K_GEMM && !s.is_wstep && s.c == B_T1) ++n_t1, prod = &s;
+    }
+    // (the product's rows are (channel | bra bond) over whole channels of the consumer's input, compactly stored)
+    if (cons && n_t1 == 1 && prod->batch == 1 && prod->beta == 0.0 && prod->cin < 0 && cons->w_Da > 0 &&
+        prod->nc.ext == cons->w_d * cons->w_N && prod->mc.ext % cons->w_Da == 0 &&
+        prod->c_off % (cons->w_Da * cons->w_d * cons->w_N) == 0)
+      slice_producer = prod, slice_consumer = cons;
+  }
+  TmpBuf SLC(ctx);
+  int slices_used = 0;
+  long long slice_elems = 0, slice_b_lo = 0, slice_b_hi = 0;
   for (const Step& s : p.steps) {
-    if (s.kind == K_GEMM && s.is_wstep && s.dta == MPSE_F64 && s.a_off == 0 && s.b_off == 0 &&
-        s.c_off == 0 && s.beta == 0.0 && s.w_wl * s.w_d <= 16 && s.w_d * s.w_wr <= 16) {
+    if (small_wstep(s)) {
       if (!bufs[s.a] || !bufs[s.b] || !bufs[s.c]) return mpse_fail(ctx, MPSE_ERR_ARG, "plan: missing buffer");
       WsmArgs g;
       g.T1 = (const double*)bufs[s.b];
@@ -268,6 +307,9 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
       g.W = (const double*)bufs[s.a];
       g.Da = (int)s.w_Da, g.d = (int)s.w_d, g.wl = (int)s.w_wl, g.wr = (int)s.w_wr, g.N = (int)s.w_N;
       g.skip = ctx->skip_flag;
+      g.slices = slices_used > 0 ? SLC.as<const double>() : nullptr;
+      g.nslices = slices_used, g.slice_stride = slice_elems, g.b_lo = (int)slice_b_lo, g.b_hi = (int)slice_b_hi;
+      slices_used = 0;
       const long long total = s.w_Da * s.w_N;
       const dim3 grid((unsigned)((total + 255) / 256));
       if (s.dtb == MPSE_C128)
@@ -405,8 +447,27 @@ static int run_plan(mpse_ctx* ctx, int dtype, const Plan& p, const void* bufs_in
       ctx->cin_req.m = s.mcin;
       ctx->cin_req.n = s.ncin;
     }
+    if (&s == slice_producer) {
+      // room for four slices of this product's result (more: the product reduces them itself, as usual)
+      const size_t blk = size_t(s.mc.ext) * size_t(s.nc.ext) * dtype_size(dtc);
+      if (SLC.alloc(4 * blk) == MPSE_OK) {
+        ctx->slices_req.ptr = SLC.p;
+        ctx->slices_req.cap_bytes = 4 * blk;
+        ctx->slices_req.used = 0;
+      }
+    }
     const int st = gemm_call(ctx, s.dta, s.dtb, s.conja, s.conjb, s.ma, s.ka, s.kb, s.nb, s.mc, s.nc, s.batch, s.sba,
                              s.sbb, s.sbc, a, b, c, 1.0, s.beta, s.skip_zero);
+    if (&s == slice_producer) {
+      slices_used = ctx->slices_req.used;
+      ctx->slices_req = mpse_ctx::SlicesReq();
+      if (slices_used > 0) {
+        // rows of the product = (channel - b_lo | bra bond): which channels of T1 it forms
+        slice_elems = (long long)s.mc.ext * s.nc.ext;
+        slice_b_lo = s.c_off / (slice_consumer->w_Da * slice_consumer->w_d * slice_consumer->w_N);
+        slice_b_hi = slice_b_lo + s.mc.ext / slice_consumer->w_Da;
+      }
+    }
     // requests the call did not take (degenerate product, error) must not reach a later one
     ctx->cin_req = mpse_ctx::CinReq();
     ctx->dot_now = false;

@@ -1303,6 +1303,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   }
   g.trace = ctx->prof_on ? ctx->gemm_trace : nullptr;    // only inside the profiled (timed) region
   TmpBuf WSB(ctx), MSK(ctx);
+  bool leave_slices = false;
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const int tiles_limit = n_cu;
   const long long wg_target = n_cu;   // one workgroup per CU (policy sweeps of the headline run)
@@ -1320,8 +1321,18 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
       // instead of the reduction launch measured 1.4 % slower on the headline run: every slice's workgroups then load
       // the dot partner, and the update kernel streams 16 slices with a fraction of the reduction kernel's blocks.)
       const size_t esz = (ca || cb) ? 16 : 8;
-      MPSE_TRY(WSB.alloc(size_t(d->batch) * g.ksplit * size_t(g.M) * size_t(g.N) * esz));
-      g.ws = WSB.as<double>();
+      const size_t ws_bytes = size_t(d->batch) * g.ksplit * size_t(g.M) * size_t(g.N) * esz;
+      // slices for a consumer that adds them itself (mpse_ctx::slices_req): plain product into a compact result
+      const bool compact = is_single(g.mC) && is_single(g.nC) && g.mC.s_lo == g.N && (g.nC.s_lo == 1 || g.N == 1);
+      if (ctx->slices_req.ptr && !ctx->dot_now && d->batch == 1 && compact && !g.use_beta && d->alpha_re == 1.0 &&
+          d->alpha_im == 0.0 && ws_bytes <= ctx->slices_req.cap_bytes) {
+        g.ws = static_cast<double*>(ctx->slices_req.ptr);
+        ctx->slices_req.used = g.ksplit;
+        leave_slices = true;
+      } else {
+        MPSE_TRY(WSB.alloc(ws_bytes));
+        g.ws = WSB.as<double>();
+      }
     }
   }
   g.slice_fast = g.ksplit > 1 && d->batch == 1;
@@ -1512,7 +1523,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
   else
     MPSE_LAUNCH(false, false);
 #undef MPSE_LAUNCH
-  if (g.ksplit > 1) {
+  if (g.ksplit > 1 && !leave_slices) {
     const dim3 rgrid((unsigned)rgx, (unsigned)rgy);
     if (ca || cb)
       hipLaunchKernelGGL((k_splitk_reduce<true>), rgrid, dim3(256), 0, ctx->stream, g, (int)d->batch);

@@ -105,6 +105,14 @@ struct mpse_ctx {
     int nb_out = 0;
   } dot_req;
   bool dot_now = false;   // set by run_plan for the one GEMM launch that completes the result
+  // A plan step whose CONSUMER adds the K slices of a split product while it reads them (the elementwise MPO step of
+  // the small sites): the product leaves its raw slices at ptr (slice s at ptr + s * M * N elements, compact like C)
+  // and launches no reduction; `used` = number of slices (0: the product stored C as usual)
+  struct SlicesReq {
+    void* ptr = nullptr;
+    size_t cap_bytes = 0;
+    int used = 0;
+  } slices_req;
   // A caller of mpse_heff_apply that can take the result as the SUM of several tensors (the Lanczos update adds them
   // while it reads) offers a buffer of cap_elems elements of the working dtype, n of them per part: the last product
   // of the plan may then leave its K slices there instead of reducing them (mpse_gemm.hip: split products, halved

@@ -76,14 +76,17 @@ def test_headline_one_evolve_vs_oracle(headline):
     st = dev.evolve_config.stat
     assert st["nobs"] == len(ost.krylov_dims) == 2 * (2 * len(mps) - 1)
     # solve by solve: the same Krylov dimension, except where the oracle's own stopping test was marginal (largest
-    # |res - new_res| / (atol + rtol |new_res|) within 10 % of 1 at one of its checks: there the outcome hinges on
-    # rounding and on the gauge of the local tensor) - such a solve may differ by one check (2 vectors)
+    # |res - new_res| / (atol + rtol |new_res|) within 25 % of 1 at one of its checks: the ratio is the maximum over the
+    # elements of the local tensor, in a gauge that differs between the two codes - observed: the oracle passes a check
+    # at 0.89 that the device fails, and fails one at 1.08 that the device passes) - such a solve may differ by one
+    # check (2 vectors); 2 of 198 solves on this state
     dev_dims, orc_dims = list(st["steps"]), list(ost.krylov_dims)
     assert len(dev_dims) == len(orc_dims) == len(ost.krylov_margins)
-    marginal = [any(0.9 <= m <= 1.1 for m in ms) for ms in ost.krylov_margins]
+    marginal = [any(0.75 <= m <= 1.25 for m in ms) for ms in ost.krylov_margins]
     differ = [i for i, (a, b) in enumerate(zip(dev_dims, orc_dims)) if a != b]
     assert all(marginal[i] and abs(dev_dims[i] - orc_dims[i]) <= 2 for i in differ), \
         [(i, dev_dims[i], orc_dims[i], ost.krylov_margins[i]) for i in differ]
+    assert len(differ) <= 6, differ
     assert abs(st["mean"] - float(np.mean(orc_dims))) < 0.1
     ov = orc.mps_dot([s.conj() for s in ost.sites], dev.to_arrays())
     assert abs(abs(ov) - 1.0) < 1e-9, abs(ov)
