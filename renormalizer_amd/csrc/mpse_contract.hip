@@ -490,6 +490,14 @@ extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, con
   // a caller that takes the result in two parts (mpse_ctx::y2_req, the Lanczos solve) lets the last product run as
   // halved tiles; `used` tells it whether the second part holds anything
   mpse_ctx::PartsReq& pr = ctx->parts_req;
+  {
+    bool taken = false;
+    MPSE_TRY(heff_small_try(ctx, dtype, h, C, out, &taken));
+    if (taken) {
+      pr.used = 0;
+      return MPSE_OK;
+    }
+  }
   const bool two_ok = pr.ptr != nullptr && pr.cap_elems >= 2 * pr.n;
   Plan p = plan_heff(dtype, *h, static_cast<const WSiteInfo*>(wi_keep.get()), two_ok);
   pr.used = 0;

@@ -352,6 +352,7 @@ extern "C" int mpse_davidson(mpse_ctx* ctx, int dtype, const mpse_heff* h, int t
   if ((s.Dl_bra > 0 && s.Dl_bra != s.Dl_ket) || (s.Dr_bra > 0 && s.Dr_bra != s.Dr_ket))
     return mpse_fail(ctx, MPSE_ERR_SHAPE, "davidson: the effective Hamiltonian must be square (bra bonds == ket bonds)");
   if (h->nsite != 1 && h->nsite != 2) return mpse_fail(ctx, MPSE_ERR_ARG, "davidson: one- or two-site centres");
+  SmallRtScope small_rt_scope(ctx);
   const int64_t anc = s.danc > 0 ? s.danc : 1;
   int64_t n = s.Dl_ket * s.Dr_ket * s.d0 * anc;
   if (h->nsite == 2) n *= s.d1 * (s.danc1 > 0 ? s.danc1 : anc);

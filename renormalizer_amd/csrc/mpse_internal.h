@@ -151,6 +151,13 @@ struct mpse_ctx {
     void* perm;
   };
   std::vector<PermEntry> perm_cache;
+  // Transposed right environment of the small-centre matvec (mpse_small.hip), kept for the running solve like the masks
+  struct SmallRt {
+    const void* src = nullptr;
+    void* rt = nullptr;
+    size_t bytes = 0;
+  } small_rt;
+  bool small_rt_scope = false;   // a solver without occupancy caches (Davidson) keeps the transposed copy as well
 };
 
 int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...);
@@ -213,6 +220,18 @@ static inline mpse_index idx1(int64_t ext, int64_t stride) { return mpse_index{e
 static inline mpse_index idx2(int64_t hi_ext, int64_t lo_ext, int64_t s_hi, int64_t s_lo) {
   return mpse_index{hi_ext * lo_ext, lo_ext > 0 ? lo_ext : 1, s_hi, s_lo};
 }
+
+// One-launch matvec of small 0- / 1-site centres (mpse_small.hip); *taken says whether it ran (else: the plans)
+int heff_small_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, void* out, bool* taken);
+void heff_small_drop_cache(mpse_ctx* ctx);
+struct SmallRtScope {   // for the duration of one eigensolve: the right environment does not change
+  mpse_ctx* c;
+  explicit SmallRtScope(mpse_ctx* ctx) : c(ctx) { c->small_rt_scope = true; }
+  ~SmallRtScope() {
+    c->small_rt_scope = false;
+    heff_small_drop_cache(c);
+  }
+};
 
 // convenience wrapper over mpse_gemm used by the contraction entry points
 int gemm_call(mpse_ctx* ctx, int dta, int dtb, int conja, int conjb, mpse_index ma, mpse_index ka,

@@ -714,6 +714,7 @@ struct OccScope {
     c->occ_cache.clear();
     for (auto& e : c->perm_cache) mpse_free(c, e.perm);
     c->perm_cache.clear();
+    heff_small_drop_cache(c);
   }
 };
 

@@ -233,6 +233,39 @@ def test_heff_rectangular_and_unequal_ancillas(eng, cplx):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
+def test_heff_small_centres_one_launch(eng, cplx):
+    """Centres of up to 32 768 elements take the one-launch matvec (mpse_small.hip: row of L per workgroup, MPO step
+    as a sparse list in LDS, transposed right environment): every thread mapping of the kernel against einsum -
+    columns > / = / < 256 threads (K groups of the first step), bonds that do not divide 256, d = 1 ... 16, sparse and
+    dense MPO sites, the 0-site matvec, and bitwise repeatability."""
+    rng = np.random.default_rng(23)
+    shapes = [(32, 8, 32, 5, 5), (64, 8, 64, 3, 3), (32, 4, 32, 5, 4), (7, 3, 5, 2, 3), (48, 2, 40, 4, 4), (1, 2, 6, 1, 3),
+              (6, 2, 1, 3, 1), (20, 16, 24, 5, 5), (33, 5, 100, 8, 7), (128, 2, 128, 5, 5), (3, 1, 3, 2, 2)]
+    for (Dl, d, Dr, wl, wr) in shapes:
+        l, r = _rand(rng, (Dl, wl, Dl), cplx), _rand(rng, (Dr, wr, Dr), cplx)
+        w = _rand(rng, (wl, d, d, wr), False)
+        c = _rand(rng, (Dl, d, Dr), cplx)
+        ref = np.einsum("abc,bdef,lfk,cek->adl", l, w, r, c, optimize=True)
+        out = dev_heff_apply(eng, l, r, [w], c)
+        assert _relerr(out, ref) < 1e-12, (Dl, d, Dr, wl, wr)
+        assert np.array_equal(out, dev_heff_apply(eng, l, r, [w], c))
+        # a sum-of-products site: identity blocks and a few operator blocks, most of W zero
+        ws = np.zeros((wl, d, d, wr))
+        for b in range(wl):
+            ws[b, :, :, min(b, wr - 1)] = np.eye(d)
+        ws[0, :, :, wr - 1] += np.diag(np.arange(d, dtype=float))
+        if d > 1:
+            ws[wl - 1, :, :, 0] = np.diag(np.sqrt(np.arange(1, d)), 1)
+        ref = np.einsum("abc,bdef,lfk,cek->adl", l, ws, r, c, optimize=True)
+        assert _relerr(dev_heff_apply(eng, l, r, [ws], c), ref) < 1e-12, (Dl, d, Dr, wl, wr)
+        # 0-site
+        r0 = _rand(rng, (Dr, wl, Dr), cplx)
+        s0 = _rand(rng, (Dl, Dr), cplx)
+        ref = np.einsum("abc,lbk,ck->al", l, r0, s0, optimize=True)
+        assert _relerr(dev_heff_apply(eng, l, r0, [], s0), ref) < 1e-12, (Dl, Dr, wl)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
 def test_contractions_midsize_vs_oracle(eng, cplx):
     """Shapes that cross tile boundaries (not multiples of 64/16) against the oracle."""
     rng = np.random.default_rng(7)
