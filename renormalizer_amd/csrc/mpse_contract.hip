@@ -493,10 +493,7 @@ extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, con
   {
     bool taken = false;
     MPSE_TRY(heff_small_try(ctx, dtype, h, C, out, &taken));
-    if (taken) {
-      pr.used = 0;
-      return MPSE_OK;
-    }
+    if (taken) return MPSE_OK;     // (pr.used is set there: the result may be a sum of parts)
   }
   const bool two_ok = pr.ptr != nullptr && pr.cap_elems >= 2 * pr.n;
   Plan p = plan_heff(dtype, *h, static_cast<const WSiteInfo*>(wi_keep.get()), two_ok);

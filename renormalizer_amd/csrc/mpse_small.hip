@@ -37,11 +37,16 @@ struct SmallArgs {
   double* part;        // (re, im) per workgroup
   const int* skip;     // non-zero word: the launch is a no-op (asynchronous Lanczos past its convergence)
   int Dl, Dr, d, wl, wr;
-  int kg;              // K groups of the first step (threads = kg x min(d Dr, 256 / kg ..))
+  int kh;              // ket bond states of R per workgroup: blockIdx.y = slice h of the bond, k in [h kh, (h + 1) kh);
+                       // slice h writes its own partial result at out + h * part_stride (the caller adds the parts)
+  long long part_stride;   // elements of the working type
+  int kg;              // K groups of the first step (threads = kg x min(d kh, 256 / kg ..))
   int off_L, off_T1, off_X, off_red;   // LDS offsets in elements of the working type
   int csr_pitch;       // entries per (x, f) row of the sparse W list
   int cnt_dbl, idx_dbl, csr_dbl;   // LDS doubles taken by the counts, the indices, the whole sparse list (even)
 };
+
+typedef const __attribute__((address_space(4))) double* ConstD;
 
 template <bool CPLX>
 struct Elem;
@@ -49,6 +54,7 @@ template <>
 struct Elem<true> {
   using T = double2;
   static __device__ __forceinline__ T zero() { return make_double2(0.0, 0.0); }
+  static __device__ __forceinline__ T ld_const(ConstD p, int i) { return make_double2(p[2 * i], p[2 * i + 1]); }
   static __device__ __forceinline__ void mad(T& acc, const T a, const T b) {
     acc.x = fma(a.x, b.x, acc.x);
     acc.x = fma(-a.y, b.y, acc.x);
@@ -69,6 +75,7 @@ template <>
 struct Elem<false> {
   using T = double;
   static __device__ __forceinline__ T zero() { return 0.0; }
+  static __device__ __forceinline__ T ld_const(ConstD p, int i) { return p[i]; }
   static __device__ __forceinline__ void mad(T& acc, const T a, const T b) { acc = fma(a, b, acc); }
   static __device__ __forceinline__ void mad_real(T& acc, const double w, const T b) { acc = fma(w, b, acc); }
   static __device__ __forceinline__ void add(T& acc, const T b) { acc += b; }
@@ -91,6 +98,149 @@ __global__ __launch_bounds__(SM_THREADS) void k_env_transpose(double* __restrict
   }
 }
 
+constexpr int SM_U = 8;   // loads in flight per column and lane
+
+// dst[b * bstride + lcols[p]] = sum over c = c0, c0 + cstep, .. < Dl of L[b, c] C[c, cols[p]], b < WL, for the columns
+// p < ncol of this thread; the loads of C run one batch of rows ahead of the arithmetic.  The row of L sits in LDS: every
+// value is a broadcast read that two columns share (with one column per thread the LDS pipe, not the FP64 pipe, bounds
+// the step; scalar loads of L were tried - forty live values per batch spill the scalar registers).
+template <bool CPLX, int NC, int WL>
+__device__ __forceinline__ void small_t1(const typename Elem<CPLX>::T* __restrict__ Cm, const typename Elem<CPLX>::T* sL, int Dl, int N1,
+                                         int c0, int cstep, const int (&cols)[NC], const int (&lcols)[NC], int ncol,
+                                         typename Elem<CPLX>::T* dst, int bstride) {
+  using E = Elem<CPLX>;
+  using T = typename E::T;
+  constexpr int U = SM_U / NC;   // the same number of loads in flight per lane whatever the column count
+  T acc[NC][WL];
+#pragma unroll
+  for (int p = 0; p < NC; ++p)
+#pragma unroll
+    for (int b = 0; b < WL; ++b) acc[p][b] = E::zero();
+  const int nc = Dl > c0 ? (Dl - c0 + cstep - 1) / cstep : 0;
+  const int nbatch = nc / U;
+  T cur[NC][U], nxt[NC][U];
+  int c = c0;
+  if (nbatch > 0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int p = 0; p < NC; ++p) cur[p][u] = Cm[(long long)(c + u * cstep) * N1 + cols[p]];
+  }
+  for (int bi = 0; bi < nbatch; ++bi) {
+    const bool more = bi + 1 < nbatch;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < NC; ++p) nxt[p][u] = Cm[(long long)(c + (U + u) * cstep) * N1 + cols[p]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int b = 0; b < WL; ++b) {
+        const T lv = sL[b * Dl + c + u * cstep];
+#pragma unroll
+        for (int p = 0; p < NC; ++p) E::mad(acc[p][b], lv, cur[p][u]);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int p = 0; p < NC; ++p) cur[p][u] = nxt[p][u];
+    }
+    c += U * cstep;
+  }
+  for (; c < Dl; c += cstep) {
+#pragma unroll
+    for (int b = 0; b < WL; ++b) {
+      const T lv = sL[b * Dl + c];
+#pragma unroll
+      for (int p = 0; p < NC; ++p) E::mad(acc[p][b], lv, Cm[(long long)c * N1 + cols[p]]);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NC; ++p)
+    if (p < ncol) {
+#pragma unroll
+      for (int b = 0; b < WL; ++b) dst[b * bstride + lcols[p]] = acc[p][b];
+    }
+}
+
+template <bool CPLX, int NC>
+__device__ __forceinline__ void small_t1_wl(int wl, const typename Elem<CPLX>::T* __restrict__ Cm, const typename Elem<CPLX>::T* Lrow, int Dl,
+                                            int N1, int c0, int cstep, const int (&cols)[NC], const int (&lcols)[NC], int ncol,
+                                            typename Elem<CPLX>::T* dst, int bstride) {
+  switch (wl) {   // (uniform)
+    case 1: small_t1<CPLX, NC, 1>(Cm, Lrow, Dl, N1, c0, cstep, cols, lcols, ncol, dst, bstride); break;
+    case 2: small_t1<CPLX, NC, 2>(Cm, Lrow, Dl, N1, c0, cstep, cols, lcols, ncol, dst, bstride); break;
+    case 3: small_t1<CPLX, NC, 3>(Cm, Lrow, Dl, N1, c0, cstep, cols, lcols, ncol, dst, bstride); break;
+    case 4: small_t1<CPLX, NC, 4>(Cm, Lrow, Dl, N1, c0, cstep, cols, lcols, ncol, dst, bstride); break;
+    case 5: small_t1<CPLX, NC, 5>(Cm, Lrow, Dl, N1, c0, cstep, cols, lcols, ncol, dst, bstride); break;
+    case 6: small_t1<CPLX, NC, 6>(Cm, Lrow, Dl, N1, c0, cstep, cols, lcols, ncol, dst, bstride); break;
+    case 7: small_t1<CPLX, NC, 7>(Cm, Lrow, Dl, N1, c0, cstep, cols, lcols, ncol, dst, bstride); break;
+    default: small_t1<CPLX, NC, 8>(Cm, Lrow, Dl, N1, c0, cstep, cols, lcols, ncol, dst, bstride); break;
+  }
+}
+
+// acc[x] = sum over q = q0, q0 + G, .. < K3 of P[x, q] Rt[q, l], x < DX (P rows beyond the physical dimension are padding
+// of the LDS area: their sums are never stored); loads of Rt SM_U deep, one batch ahead of the arithmetic
+template <bool CPLX, int DX>
+__device__ __forceinline__ void small_t3(const typename Elem<CPLX>::T* __restrict__ Rt, const typename Elem<CPLX>::T* sP,
+                                         int K3, int Dr, int kh, int k0, int G, int grp, int l,
+                                         typename Elem<CPLX>::T* sRed, int d) {
+  using E = Elem<CPLX>;
+  using T = typename E::T;
+  constexpr int U = DX <= 4 ? SM_U : (DX == 8 ? 4 : 2);   // DX x U broadcast reads of P per batch stay in registers
+  T acc[DX];
+#pragma unroll
+  for (int x = 0; x < DX; ++x) acc[x] = E::zero();
+  const bool on = grp < G;
+  if (on) {
+    // q = (f, kk) of this slice -> row f * Dr + k0 + kk of Rt
+    auto rt_at = [&](int q) -> T {
+      const int f = q / kh, kk = q - f * kh;
+      return Rt[(long long)(f * Dr + k0 + kk) * Dr + l];
+    };
+    const int ni = (K3 - grp + G - 1) / G;      // my q values
+    const int nbatch = ni / U;
+    T cur[U], nxt[U];
+    int q = grp;
+    if (nbatch > 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = rt_at(q + u * G);
+    }
+    for (int bi = 0; bi < nbatch; ++bi) {
+      const bool more = bi + 1 < nbatch;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) nxt[u] = rt_at(q + (U + u) * G);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int x = 0; x < DX; ++x) E::mad(acc[x], sP[x * K3 + q + u * G], cur[u]);
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+      }
+      q += U * G;
+    }
+    for (; q < K3; q += G) {
+      const T r0 = rt_at(q);
+#pragma unroll
+      for (int x = 0; x < DX; ++x) E::mad(acc[x], sP[x * K3 + q], r0);
+    }
+  }
+  __syncthreads();   // every read of P is done: the reduction area may overlay it
+  if (on) {
+#pragma unroll
+    for (int x = 0; x < DX; ++x)
+      if (x < d) sRed[(grp * d + x) * Dr + l] = acc[x];
+  }
+}
+
 template <bool CPLX>
 __global__ __launch_bounds__(SM_THREADS) void k_heff_small(const SmallArgs g) {
   using E = Elem<CPLX>;
@@ -100,7 +250,9 @@ __global__ __launch_bounds__(SM_THREADS) void k_heff_small(const SmallArgs g) {
   const int tid = threadIdx.x;
   const int a = blockIdx.x;
   const int Dl = g.Dl, Dr = g.Dr, d = g.d, wl = g.wl, wr = g.wr;
-  const int N1 = d * Dr;
+  const int kh = g.kh, k0 = blockIdx.y * kh;     // this workgroup's slice of the ket bond of R
+  const int N1 = d * Dr;                          // a row of C / of the result
+  const int N1h = d * kh;                         // columns (e, kk) of this slice
   const bool has_w = g.W != nullptr;
   // LDS: [sparse W: counts (int), indices (int), values (double)] [L row] [T1] [X = K-group partials, then P]
   const int nrow_w = has_w ? d * wr : 0;
@@ -136,117 +288,76 @@ __global__ __launch_bounds__(SM_THREADS) void k_heff_small(const SmallArgs g) {
   }
   __syncthreads();
 
-  // ---- T1[b, col] = sum_c L[a, b, c] C[c, col],  col = (e, k)
+  // ---- T1[b, (e, kk)] = sum_c L[a, b, c] C[c, e, k0 + kk]
   {
-    const T* Cm = reinterpret_cast<const T*>(g.C);
+    const T* __restrict__ Cm = reinterpret_cast<const T*>(g.C);
     const int kg = g.kg;
+    auto gcol = [&](int lc) {   // column of C behind column lc = e * kh + kk of the slice
+      const int e = lc / kh;
+      return e * Dr + k0 + (lc - e * kh);
+    };
     if (kg == 1) {
-      for (int col = tid; col < N1; col += SM_THREADS) {
-        T acc[SM_WMAX];
-#pragma unroll
-        for (int b = 0; b < SM_WMAX; ++b) acc[b] = E::zero();
-        int c = 0;
-        for (; c + 4 <= Dl; c += 4) {
-          const T c0 = Cm[(long long)c * N1 + col], c1 = Cm[(long long)(c + 1) * N1 + col];
-          const T c2 = Cm[(long long)(c + 2) * N1 + col], c3 = Cm[(long long)(c + 3) * N1 + col];
-#pragma unroll
-          for (int b = 0; b < SM_WMAX; ++b)
-            if (b < wl) {
-              E::mad(acc[b], sL[b * Dl + c], c0);
-              E::mad(acc[b], sL[b * Dl + c + 1], c1);
-              E::mad(acc[b], sL[b * Dl + c + 2], c2);
-              E::mad(acc[b], sL[b * Dl + c + 3], c3);
-            }
-        }
-        for (; c < Dl; ++c) {
-          const T c0 = Cm[(long long)c * N1 + col];
-#pragma unroll
-          for (int b = 0; b < SM_WMAX; ++b)
-            if (b < wl) E::mad(acc[b], sL[b * Dl + c], c0);
-        }
-#pragma unroll
-        for (int b = 0; b < SM_WMAX; ++b)
-          if (b < wl) sT1[b * N1 + col] = acc[b];
+      // two columns per thread and pass
+      for (int col = tid; col < N1h; col += 2 * SM_THREADS) {
+        const bool two = col + SM_THREADS < N1h;
+        const int lcols[2] = {col, two ? col + SM_THREADS : col};
+        const int cols[2] = {gcol(lcols[0]), gcol(lcols[1])};
+        small_t1_wl<CPLX, 2>(wl, Cm, sL, Dl, N1, 0, 1, cols, lcols, two ? 2 : 1, sT1, N1h);
       }
     } else {
       // fewer columns than threads: kg groups of threads share the K range (c = grp, grp + kg, ..), partials through LDS
-      const int grp = tid / N1, col = tid - grp * N1;
+      const int grp = tid / N1h;
+      const int col = tid - grp * N1h;
       if (grp < kg) {
-        T acc[SM_WMAX];
-#pragma unroll
-        for (int b = 0; b < SM_WMAX; ++b) acc[b] = E::zero();
-        for (int c = grp; c < Dl; c += kg) {
-          const T c0 = Cm[(long long)c * N1 + col];
-#pragma unroll
-          for (int b = 0; b < SM_WMAX; ++b)
-            if (b < wl) E::mad(acc[b], sL[b * Dl + c], c0);
-        }
-#pragma unroll
-        for (int b = 0; b < SM_WMAX; ++b)
-          if (b < wl) sX[(grp * wl + b) * N1 + col] = acc[b];
+        const int lcols[1] = {col};
+        const int cols[1] = {gcol(col)};
+        small_t1_wl<CPLX, 1>(wl, Cm, sL, Dl, N1, grp, kg, cols, lcols, 1, sX + grp * wl * N1h, N1h);
       }
       __syncthreads();
-      for (int i = tid; i < wl * N1; i += SM_THREADS) {
+      for (int i = tid; i < wl * N1h; i += SM_THREADS) {
         T s = sX[i];
-        for (int q = 1; q < kg; ++q) E::add(s, sX[q * wl * N1 + i]);
+        for (int q = 1; q < kg; ++q) E::add(s, sX[q * wl * N1h + i]);
         sT1[i] = s;
       }
     }
   }
   __syncthreads();
 
-  // ---- P[x, (f, k)] = sum_{b, e} W[b, x, e, f] T1[b, e, k]   (0-site: P = T1)
-  const int K3 = wr * Dr;
+  // ---- P[x, (f, kk)] = sum_{b, e} W[b, x, e, f] T1[b, e, kk]   (0-site: P = T1)
+  const int K3 = wr * kh;
   const T* sP = sT1;
   if (has_w) {
     for (int i = tid; i < d * K3; i += SM_THREADS) {
-      const int k = i % Dr;
-      const int r = i / Dr;            // x * wr + f
+      const int k = i % kh;
+      const int r = i / kh;            // x * wr + f
       const int cnt = s_cnt[r];
       T acc = E::zero();
-      for (int q = 0; q < cnt; ++q) E::mad_real(acc, s_val[r * g.csr_pitch + q], sT1[s_idx[r * g.csr_pitch + q] * Dr + k]);
+      for (int q = 0; q < cnt; ++q) E::mad_real(acc, s_val[r * g.csr_pitch + q], sT1[s_idx[r * g.csr_pitch + q] * kh + k]);
       sX[i] = acc;
     }
     sP = sX;
     __syncthreads();
   }
 
-  // ---- out[a, x, l] = sum_q P[x, q] Rt[q, l], q = (f, k); thread = (K group, l)
+  // ---- part[a, x, l] = sum_q P[x, q] Rt[row(q), l], q = (f, kk); thread = (K group, l): group grp takes q = grp, grp + G, ..
   {
-    const T* Rt = reinterpret_cast<const T*>(g.Rt);
+    const T* __restrict__ Rt = reinterpret_cast<const T*>(g.Rt);
     int G = SM_THREADS / Dr;
     if (G > K3) G = K3;
     const int grp = tid / Dr, l = tid - grp * Dr;
-    T acc[SM_DMAX];
-#pragma unroll
-    for (int x = 0; x < SM_DMAX; ++x) acc[x] = E::zero();
-    if (grp < G) {
-      int q = grp;
-      for (; q + G < K3; q += 2 * G) {
-        const T r0 = Rt[(long long)q * Dr + l], r1 = Rt[(long long)(q + G) * Dr + l];
-#pragma unroll
-        for (int x = 0; x < SM_DMAX; ++x)
-          if (x < d) {
-            E::mad(acc[x], sP[x * K3 + q], r0);
-            E::mad(acc[x], sP[x * K3 + q + G], r1);
-          }
-      }
-      for (; q < K3; q += G) {
-        const T r0 = Rt[(long long)q * Dr + l];
-#pragma unroll
-        for (int x = 0; x < SM_DMAX; ++x)
-          if (x < d) E::mad(acc[x], sP[x * K3 + q], r0);
-      }
-    }
-    __syncthreads();   // every read of P is done: the reduction area may overlay it
-    if (grp < G) {
-#pragma unroll
-      for (int x = 0; x < SM_DMAX; ++x)
-        if (x < d) sRed[(grp * d + x) * Dr + l] = acc[x];
-    }
+    if (d == 1)
+      small_t3<CPLX, 1>(Rt, sP, K3, Dr, kh, k0, G, grp, l, sRed, d);
+    else if (d == 2)
+      small_t3<CPLX, 2>(Rt, sP, K3, Dr, kh, k0, G, grp, l, sRed, d);
+    else if (d <= 4)
+      small_t3<CPLX, 4>(Rt, sP, K3, Dr, kh, k0, G, grp, l, sRed, d);
+    else if (d <= 8)
+      small_t3<CPLX, 8>(Rt, sP, K3, Dr, kh, k0, G, grp, l, sRed, d);
+    else
+      small_t3<CPLX, 16>(Rt, sP, K3, Dr, kh, k0, G, grp, l, sRed, d);
     __syncthreads();
     double dre = 0.0, dim = 0.0;
-    T* orow = reinterpret_cast<T*>(g.out) + (long long)a * N1;
+    T* orow = reinterpret_cast<T*>(g.out) + (long long)blockIdx.y * g.part_stride + (long long)a * N1;
     const T* yrow = g.y ? reinterpret_cast<const T*>(g.y) + (long long)a * N1 : nullptr;
     for (int i = tid; i < N1; i += SM_THREADS) {
       T s = sRed[i];
@@ -254,11 +365,12 @@ __global__ __launch_bounds__(SM_THREADS) void k_heff_small(const SmallArgs g) {
       orow[i] = s;
       if (yrow) E::dot(dre, dim, s, yrow[i]);
     }
-    if (g.y) {   // grid-uniform
+    if (g.y) {   // grid-uniform; the dot product is linear in the parts: one partial per workgroup
       block_allsum2(dre, dim);
       if (tid == 0) {
-        g.part[2 * a] = dre;
-        g.part[2 * a + 1] = dim;
+        const int slot = a * gridDim.y + blockIdx.y;
+        g.part[2 * slot] = dre;
+        g.part[2 * slot + 1] = dim;
       }
     }
   }
@@ -309,8 +421,23 @@ int heff_small_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, 
   if (Dl * d * Dr > lim) return MPSE_OK;
   const bool cplx = dtype == MPSE_C128;
   const size_t es = dtype_size(dtype);
+  // Slices of the ket bond of R: when the caller takes the result as a sum of parts (the Lanczos update adds them while
+  // it reads), a row of L is worked on by KH workgroups, each with 1 / KH of the centre's columns and of R - the launch
+  // covers KH times as many compute units and every workgroup streams 1 / KH of the bytes
+  mpse_ctx::PartsReq& pr = ctx->parts_req;
+  int64_t KH = 1;
+  if (pr.ptr && pr.n == Dl * d * Dr) {
+    for (int64_t c : {4, 2}) {
+      if (Dr % c == 0 && Dr / c >= 16 && Dl * c <= 512 && pr.cap_elems >= c * pr.n &&
+          (!ctx->dot_req.y || Dl * c <= ctx->dot_req.cap)) {
+        KH = c;
+        break;
+      }
+    }
+  }
+  const int64_t kh = Dr / KH;
   // LDS layout (mirrors the kernel)
-  const int64_t N1 = d * Dr, K3 = wr * Dr;
+  const int64_t N1 = d * kh, K3 = wr * kh;
   int kg = 1;
   if (N1 < SM_THREADS) {
     kg = int(SM_THREADS / N1);
@@ -323,9 +450,10 @@ int heff_small_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, 
   const int64_t csr_doubles = (cnt_dbl + idx_dbl + nrow_w * pitch + 1) & ~int64_t(1);
   int64_t G = SM_THREADS / Dr;
   if (G > K3) G = K3;
-  const int64_t off_L = 0, off_T1 = wl * Dl, off_X = off_T1 + wl * N1;
-  const int64_t x_len = std::max<int64_t>(kg > 1 ? kg * wl * N1 : 0, has_w ? d * K3 : 0);
-  const int64_t red_len = G * N1;
+  const int64_t d_pad = d <= 2 ? d : (d <= 4 ? 4 : (d <= 8 ? 8 : 16));   // rows of P the last step reads (small_t3)
+  const int64_t off_L = 0, off_T1 = wl * Dl, off_X = off_T1 + std::max<int64_t>(wl * N1, has_w ? 0 : d_pad * K3);
+  const int64_t x_len = std::max<int64_t>(kg > 1 ? kg * wl * N1 : 0, has_w ? d_pad * K3 : 0);
+  const int64_t red_len = G * d * Dr;
   const int64_t el = std::max<int64_t>(off_X + x_len, red_len);
   const int64_t lds = csr_doubles * 8 + el * int64_t(es);
   if (lds > lds_limit_bytes()) return MPSE_OK;
@@ -366,23 +494,26 @@ int heff_small_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, 
   g.Rt = rt;
   g.W = has_w ? static_cast<const double*>(h->W0) : nullptr;
   g.C = static_cast<const double*>(C);
-  g.out = static_cast<double*>(out);
+  g.out = KH > 1 ? static_cast<double*>(pr.ptr) : static_cast<double*>(out);
+  g.kh = (int)kh;
+  g.part_stride = pr.n;
   g.skip = ctx->skip_flag;
   g.Dl = (int)Dl, g.Dr = (int)Dr, g.d = (int)d, g.wl = (int)wl, g.wr = (int)wr;
   g.kg = kg;
   g.off_L = (int)off_L, g.off_T1 = (int)off_T1, g.off_X = (int)off_X, g.off_red = 0;
   g.csr_pitch = (int)pitch;
   g.cnt_dbl = (int)cnt_dbl, g.idx_dbl = (int)idx_dbl, g.csr_dbl = (int)csr_doubles;
-  if (ctx->dot_req.y && Dl <= ctx->dot_req.cap) {
+  if (ctx->dot_req.y && Dl * KH <= ctx->dot_req.cap) {
     g.y = static_cast<const double*>(ctx->dot_req.y);
     g.part = ctx->dot_req.part;
-    ctx->dot_req.nb_out = (int)Dl;
+    ctx->dot_req.nb_out = (int)(Dl * KH);
   }
   if (cplx)
-    hipLaunchKernelGGL((k_heff_small<true>), dim3((unsigned)Dl), dim3(SM_THREADS), (size_t)lds, ctx->stream, g);
+    hipLaunchKernelGGL((k_heff_small<true>), dim3((unsigned)Dl, (unsigned)KH), dim3(SM_THREADS), (size_t)lds, ctx->stream, g);
   else
-    hipLaunchKernelGGL((k_heff_small<false>), dim3((unsigned)Dl), dim3(SM_THREADS), (size_t)lds, ctx->stream, g);
+    hipLaunchKernelGGL((k_heff_small<false>), dim3((unsigned)Dl, (unsigned)KH), dim3(SM_THREADS), (size_t)lds, ctx->stream, g);
   MPSE_HIP(ctx, hipGetLastError());
+  pr.used = KH > 1 ? (int)KH : 0;
   *taken = true;
   return MPSE_OK;
 }

@@ -742,7 +742,7 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
   TmpBuf V(ctx), W(ctx), RES(ctx), SCAL(ctx);
   MPSE_TRY(V.alloc(size_t(cap) * n * es));
   // the matvec result, with room for a second part (mpse_ctx::parts_req: halved tiles)
-  const long long wcap = 2 * n;
+  const long long wcap = (n <= 65536 ? 4 : 2) * n;   // (small centres: up to four slices, mpse_small.hip)
   MPSE_TRY(W.alloc(size_t(wcap) * es));
   MPSE_TRY(RES.alloc(size_t(n) * es));
   // scalars as in the synchronous solve: [0..1] |v|^2 ; per j: alpha at 4+4j, beta^2 at 6+4j ; then control + coefficients

@@ -235,9 +235,10 @@ def test_heff_rectangular_and_unequal_ancillas(eng, cplx):
 @pytest.mark.parametrize("cplx", [False, True])
 def test_heff_small_centres_one_launch(eng, cplx):
     """Centres of up to 32 768 elements take the one-launch matvec (mpse_small.hip: row of L per workgroup, MPO step
-    as a sparse list in LDS, transposed right environment): every thread mapping of the kernel against einsum -
+    as a sparse list in LDS, transposed right environment): every thread mapping of the kernel against the oracle -
     columns > / = / < 256 threads (K groups of the first step), bonds that do not divide 256, d = 1 ... 16, sparse and
-    dense MPO sites, the 0-site matvec, and bitwise repeatability."""
+    dense MPO sites, the 0-site matvec, bitwise repeatability; and through the Krylov solve, where the result arrives
+    as slices of the ket bond that the Lanczos update adds (same Krylov dimension and vector as the oracle's)."""
     rng = np.random.default_rng(23)
     shapes = [(32, 8, 32, 5, 5), (64, 8, 64, 3, 3), (32, 4, 32, 5, 4), (7, 3, 5, 2, 3), (48, 2, 40, 4, 4), (1, 2, 6, 1, 3),
               (6, 2, 1, 3, 1), (20, 16, 24, 5, 5), (33, 5, 100, 8, 7), (128, 2, 128, 5, 5), (3, 1, 3, 2, 2)]
@@ -245,9 +246,8 @@ def test_heff_small_centres_one_launch(eng, cplx):
         l, r = _rand(rng, (Dl, wl, Dl), cplx), _rand(rng, (Dr, wr, Dr), cplx)
         w = _rand(rng, (wl, d, d, wr), False)
         c = _rand(rng, (Dl, d, Dr), cplx)
-        ref = np.einsum("abc,bdef,lfk,cek->adl", l, w, r, c, optimize=True)
         out = dev_heff_apply(eng, l, r, [w], c)
-        assert _relerr(out, ref) < 1e-12, (Dl, d, Dr, wl, wr)
+        assert _relerr(out, orc.hop_apply(l, r, [w], c)) < 1e-12, (Dl, d, Dr, wl, wr)
         assert np.array_equal(out, dev_heff_apply(eng, l, r, [w], c))
         # a sum-of-products site: identity blocks and a few operator blocks, most of W zero
         ws = np.zeros((wl, d, d, wr))
@@ -256,13 +256,29 @@ def test_heff_small_centres_one_launch(eng, cplx):
         ws[0, :, :, wr - 1] += np.diag(np.arange(d, dtype=float))
         if d > 1:
             ws[wl - 1, :, :, 0] = np.diag(np.sqrt(np.arange(1, d)), 1)
-        ref = np.einsum("abc,bdef,lfk,cek->adl", l, ws, r, c, optimize=True)
-        assert _relerr(dev_heff_apply(eng, l, r, [ws], c), ref) < 1e-12, (Dl, d, Dr, wl, wr)
+        assert _relerr(dev_heff_apply(eng, l, r, [ws], c), orc.hop_apply(l, r, [ws], c)) < 1e-12, (Dl, d, Dr, wl, wr)
         # 0-site
         r0 = _rand(rng, (Dr, wl, Dr), cplx)
         s0 = _rand(rng, (Dl, Dr), cplx)
-        ref = np.einsum("abc,lbk,ck->al", l, r0, s0, optimize=True)
-        assert _relerr(dev_heff_apply(eng, l, r0, [], s0), ref) < 1e-12, (Dl, Dr, wl)
+        assert _relerr(dev_heff_apply(eng, l, r0, [], s0), orc.hop_apply(l, r0, [], s0)) < 1e-12, (Dl, Dr, wl)
+    # Krylov solves on Hermitian parts (complex: real-time step; real: imaginary-time step)
+    for (Dl, d, Dr, wl) in [(32, 8, 32, 5), (64, 8, 64, 3), (32, 4, 32, 4), (64, 2, 64, 5), (24, 3, 40, 3)]:
+        l, r = _rand(rng, (Dl, wl, Dl), cplx), _rand(rng, (Dr, wl, Dr), cplx)
+        l = (l + l.transpose(2, 1, 0).conj()) / (4 * Dl)
+        r = (r + r.transpose(2, 1, 0).conj()) / (4 * Dr)
+        w = _rand(rng, (wl, d, d, wl), False)
+        w = (w + w.transpose(0, 2, 1, 3)) / 2
+        c = _rand(rng, (Dl, d, Dr), cplx)
+        c /= np.linalg.norm(c)
+        dt = -0.4j if cplx else -0.4
+        ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(l, r, [w], y.reshape(c.shape)).ravel(), dt, c.ravel())
+        out, nv = dev_expm(eng, l, r, [w], c, dt)
+        assert nv == nref and _relerr(out.ravel(), ref) < 1e-10, (Dl, d, Dr, wl)
+        s0 = _rand(rng, (Dl, Dr), cplx)
+        s0 /= np.linalg.norm(s0)
+        ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(l, r, [], y.reshape(s0.shape)).ravel(), dt, s0.ravel())
+        out, nv = dev_expm(eng, l, r, [], s0, dt)
+        assert nv == nref and _relerr(out.ravel(), ref) < 1e-10, (Dl, Dr, wl)
 
 
 @pytest.mark.parametrize("cplx", [False, True])
