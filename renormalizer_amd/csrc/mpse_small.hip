@@ -456,7 +456,7 @@ int heff_small_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, 
   const int64_t red_len = G * d * Dr;
   const int64_t el = std::max<int64_t>(off_X + x_len, red_len);
   const int64_t lds = csr_doubles * 8 + el * int64_t(es);
-  if (lds > lds_limit_bytes()) return MPSE_OK;
+  if (lds + 256 > lds_limit_bytes()) return MPSE_OK;     // (+ the static words of the block reduction)
 
   // transposed right environment: once per solve (the cache lives as long as the solve's occupancy caches)
   const size_t rbytes = size_t(Dr) * wr * Dr * es;

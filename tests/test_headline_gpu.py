@@ -143,6 +143,7 @@ _SWITCHES = {
     "MPSE_DEFER=0": True,             # QR / environment update / absorption issued from Python after each solve returns
     "MPSE_SPLIT2=0": False,           # products with R as one workgroup per tile (other summation order)
     "MPSE_WFOLD=0": False,            # one-site matvec as the three-step chain (L.C, MPO step, .R) instead of the folded plan
+    "MPSE_SMALL=0": False,            # the small centres at the chain ends through the plans instead of the one-launch matvec
 }
 
 
