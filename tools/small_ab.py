@@ -46,8 +46,10 @@ if "sbm" in which:
     mps = mps.expand_bond_dimension(mpo, coef=1e-16, include_ex=False)
     timed(mps, mpo, 0.1, 10, "#2 spin-boson 21 sites d=2/8 D=64", 2 * 21)
 
-if "holstein" in which:
-    nmol, D = 10, 64
+for key, D in (("holstein", 64), ("holstein128", 128)):
+    if key not in which:
+        continue
+    nmol = 10
     ph = Phonon.simple_phonon(Quantity(6.128e-3), Quantity(16.274571056529368), 16)
     model = HolsteinModel([Mol(Quantity(0), [ph])] * nmol, Quantity(3.0e-2), 3)
     psi = Mpo.onsite(model, r"a^\dagger", dof_set={nmol // 2}).apply(Mps.ground_state(model, False))
@@ -55,7 +57,7 @@ if "holstein" in which:
     psi.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=D)
     psi.evolve_config = EvolveConfig(EvolveMethod.tdvp_ps)
     psi = psi.expand_bond_dimension(mpo).canonicalise()
-    timed(psi, mpo, 10.0, 5, "#3 Holstein 20 sites d=2/16 D=64", 4 * nmol)
+    timed(psi, mpo, 10.0, 5, f"#3 Holstein 20 sites d=2/16 D={D}", 4 * nmol)
 
 for key, temp in (("fmo", 0.0), ("fmo77", 77.0)):
     if key not in which:
