@@ -527,17 +527,7 @@ __global__ void k_publish(const double* __restrict__ src, double* dst, int count
 }
 }  // namespace
 
-int publish_and_wait(mpse_ctx* ctx, const double* dsrc, int count, int slot) {
-  if (count < 0 || count > 1024 || slot < 0 || slot + count > 4000) return mpse_fail(ctx, MPSE_ERR_ARG, "publish: range");
-  if (!ctx->pinned_dev) {  // no mapped view of the pinned buffer: plain copy + synchronise
-    MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + slot, dsrc, size_t(count) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return MPSE_OK;
-  }
-  const double seq = double(++ctx->publish_seq);
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, dsrc, ctx->pinned_dev + slot, count,
-                     (volatile double*)(ctx->pinned_dev + 4095), seq);
-  MPSE_HIP(ctx, hipGetLastError());
+int publish_wait_seq(mpse_ctx* ctx, double seq, const double* dsrc, int count, int slot) {
   volatile double* flag = ctx->pinned + 4095;
   for (long long spins = 0; *flag != seq; ++spins) {
     if (spins > 2000000000LL || ((spins & 0xfffff) == 0xfffff && hipStreamQuery(ctx->stream) == hipSuccess && *flag != seq)) {
@@ -549,4 +539,18 @@ int publish_and_wait(mpse_ctx* ctx, const double* dsrc, int count, int slot) {
   }
   __sync_synchronize();
   return MPSE_OK;
+}
+
+int publish_and_wait(mpse_ctx* ctx, const double* dsrc, int count, int slot) {
+  if (count < 0 || count > 1024 || slot < 0 || slot + count > 4000) return mpse_fail(ctx, MPSE_ERR_ARG, "publish: range");
+  if (!ctx->pinned_dev) {  // no mapped view of the pinned buffer: plain copy + synchronise
+    MPSE_HIP(ctx, hipMemcpyAsync(ctx->pinned + slot, dsrc, size_t(count) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MPSE_OK;
+  }
+  const double seq = double(++ctx->publish_seq);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, dsrc, ctx->pinned_dev + slot, count,
+                     (volatile double*)(ctx->pinned_dev + 4095), seq);
+  MPSE_HIP(ctx, hipGetLastError());
+  return publish_wait_seq(ctx, seq, dsrc, count, slot);
 }

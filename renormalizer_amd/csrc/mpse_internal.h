@@ -275,6 +275,9 @@ int occ_mask_get(mpse_ctx* ctx, const void* ptr, int dtype, mpse_index r, mpse_i
 // transfer plus hipStreamSynchronize (the gap the GPU idles after every convergence check shrinks from ~25 us to
 // the launch latency).  count <= 1024; the values land at ctx->pinned + slot.
 int publish_and_wait(mpse_ctx* ctx, const double* dsrc, int count, int slot);
+// The waiting half alone, for a kernel that publishes by itself (writes `count` doubles at pinned_dev + slot, then the
+// sequence number `seq` = double(++ctx->publish_seq) at pinned_dev + 4095, each followed by __threadfence_system()).
+int publish_wait_seq(mpse_ctx* ctx, double seq, const double* dsrc, int count, int slot);
 
 // reductions (mpse_vec.hip): results land in ctx->pinned after a stream sync
 int dotc_sync(mpse_ctx* ctx, int dtype, const void* x, const void* y, int64_t n, double* re, double* im);

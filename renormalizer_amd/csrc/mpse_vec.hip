@@ -646,18 +646,29 @@ __global__ void k_lincomb_dev(double* __restrict__ res, const double* __restrict
   if ((prev || m_early > 0) && bad) atomicMax(flag, gen);
 }
 
-// the decision of the check at iteration j (its estimate went to buffer `which`)
+// the decision of the check at iteration j (its estimate went to buffer `which`).  ``pub`` != null: the host waits at this
+// check - the control block goes to the mapped pinned buffer and the sequence number after it (what a k_publish launch
+// behind k_lz_final did before: one launch and its latency less per wait; the copy of the answer into `out`, k_lz_final,
+// only has to precede the launches that read `out`, and those come later on the same stream).
 __global__ void k_lz_decide(LzCtl* ctl, const unsigned int* __restrict__ flag, unsigned int gen, int has_prev, int j,
-                            int which) {
-  if (ctl->done || ctl->need_host) return;
-  if (ctl->forced_m > 0) {
-    ctl->done = 1;
-    ctl->nvec = ctl->forced_m;
-    ctl->which = which;
-  } else if (has_prev && *flag != gen) {
-    ctl->done = 1;
-    ctl->nvec = j + 1;
-    ctl->which = which;
+                            int which, double* pub, volatile double* seq_slot, double seq) {
+  if (!(ctl->done || ctl->need_host)) {
+    if (ctl->forced_m > 0) {
+      ctl->done = 1;
+      ctl->nvec = ctl->forced_m;
+      ctl->which = which;
+    } else if (has_prev && *flag != gen) {
+      ctl->done = 1;
+      ctl->nvec = j + 1;
+      ctl->which = which;
+    }
+  }
+  if (pub) {
+    const double* src = reinterpret_cast<const double*>(ctl);
+    for (int i = 0; i < int(sizeof(LzCtl) / sizeof(double)); ++i) pub[i] = src[i];
+    __threadfence_system();
+    *seq_slot = seq;
+    __threadfence_system();
   }
 }
 
@@ -897,14 +908,21 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
         hipLaunchKernelGGL((k_lincomb_dev<false>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst,
                            V.as<double>(), (long long)n, j + 1, (const double*)coef, (const double*)prev, rtol, atol,
                            dflag, gen, (const LzCtl*)ctl, merged ? j - 1 : 0);
+      const bool wait_here = j >= wait_from || waited || last;
+      const bool self_pub = wait_here && ctx->pinned_dev != nullptr;
+      const double seq = self_pub ? double(++ctx->publish_seq) : 0.0;
       hipLaunchKernelGGL(k_lz_decide, dim3(1), dim3(1), 0, ctx->stream, ctl, (const unsigned int*)dflag, gen,
-                         (prev || merged) ? 1 : 0, j, dst == out ? 0 : 1);
+                         (prev || merged) ? 1 : 0, j, dst == out ? 0 : 1, self_pub ? ctx->pinned_dev + 24 : (double*)nullptr,
+                         (volatile double*)(self_pub ? ctx->pinned_dev + 4095 : nullptr), seq);
       prev = dst;
       MPSE_HIP(ctx, hipGetLastError());
-      if (j >= wait_from || waited || last) {
+      if (wait_here) {
         hipLaunchKernelGGL(k_lz_final, dim3(ew_blocks(nd)), dim3(256), 0, ctx->stream, (double*)out,
                            (const double*)RES.p, (long long)nd, (const LzCtl*)ctl);
-        MPSE_TRY(publish_and_wait(ctx, reinterpret_cast<const double*>(ctl), int(sizeof(LzCtl) / sizeof(double)), 24));
+        if (self_pub)
+          MPSE_TRY(publish_wait_seq(ctx, seq, reinterpret_cast<const double*>(ctl), int(sizeof(LzCtl) / sizeof(double)), 24));
+        else
+          MPSE_TRY(publish_and_wait(ctx, reinterpret_cast<const double*>(ctl), int(sizeof(LzCtl) / sizeof(double)), 24));
         if (ctx->prof_pending.size() > 2048) prof_drain(ctx);
         memcpy(&hc, ctx->pinned + 24, sizeof(LzCtl));
         waited = true;
