@@ -647,9 +647,8 @@ __global__ void k_lincomb_dev(double* __restrict__ res, const double* __restrict
 }
 
 // the decision of the check at iteration j (its estimate went to buffer `which`).  ``pub`` != null: the host waits at this
-// check - the control block goes to the mapped pinned buffer and the sequence number after it (what a k_publish launch
-// behind k_lz_final did before: one launch and its latency less per wait; the copy of the answer into `out`, k_lz_final,
-// only has to precede the launches that read `out`, and those come later on the same stream).
+// check - the control block goes to the mapped pinned buffer and the sequence number after it (a k_publish launch did
+// that before: one launch and its latency less per wait).
 __global__ void k_lz_decide(LzCtl* ctl, const unsigned int* __restrict__ flag, unsigned int gen, int has_prev, int j,
                             int which, double* pub, volatile double* seq_slot, double seq) {
   if (!(ctl->done || ctl->need_host)) {
@@ -672,12 +671,41 @@ __global__ void k_lz_decide(LzCtl* ctl, const unsigned int* __restrict__ flag, u
   }
 }
 
-// answer -> out when it sits in the spare buffer
-__global__ void k_lz_final(double* __restrict__ out, const double* __restrict__ spare, long long n_doubles,
-                           const LzCtl* __restrict__ ctl) {
-  if (!(ctl->done && ctl->which == 1 && !ctl->bad)) return;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_doubles; i += stride) out[i] = spare[i];
+// Start of an asynchronous solve in one launch (three before: zero fill of the control block, copy of the start vector,
+// its norm partials): U_0 = C, partial[b] = sum over block b of |C_i|^2 in the order of k_dot_partial(C, C), *ctl = 0.
+template <bool CPLX>
+__global__ __launch_bounds__(RED_THREADS) void k_lz_start(double* __restrict__ u0, const double* __restrict__ c, long long n,
+                                                          double* __restrict__ partial, LzCtl* ctl) {
+  if (blockIdx.x == 0 && threadIdx.x < int(sizeof(LzCtl) / sizeof(int))) reinterpret_cast<int*>(ctl)[threadIdx.x] = 0;
+  double re = 0, im = 0;
+  const long long stride = (long long)gridDim.x * RED_THREADS;
+  if (CPLX) {
+    const double2* x2 = reinterpret_cast<const double2*>(c);
+    double2* o2 = reinterpret_cast<double2*>(u0);
+    for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += 2 * stride) {
+      const long long i1 = i + stride;
+      const bool h1 = i1 < n;
+      const double2 a0 = x2[i];
+      const double2 a1 = h1 ? x2[i1] : make_double2(0.0, 0.0);
+      o2[i] = a0;
+      if (h1) o2[i1] = a1;
+      re += a0.x * a0.x + a0.y * a0.y;
+      im += a0.x * a0.y - a0.y * a0.x;
+      re += a1.x * a1.x + a1.y * a1.y;
+      im += a1.x * a1.y - a1.y * a1.x;
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += stride) {
+      const double v = c[i];
+      u0[i] = v;
+      re += v * v;
+    }
+  }
+  block_allsum2(re, im);
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = re;
+    partial[2 * blockIdx.x + 1] = im;
+  }
 }
 
 inline bool lanczos_async_enabled() {
@@ -762,7 +790,6 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
   double* scal = SCAL.as<double>();
   LzCtl* ctl = reinterpret_cast<LzCtl*>(scal + SC_CTL);
   double* coef = scal + SC_COEF;
-  MPSE_TRY(device_zero(ctx, ctl, sizeof(LzCtl)));
   const int* done = &ctl->done;
   const int nb = red_blocks(nd);
   double* part_a = ctx->dscratch;
@@ -814,8 +841,14 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
   };
   // U_0 = C itself (the Krylov basis is kept unnormalised, k_lanczos_update_u); |C|^2 partials feed the first step
   double* part_b2[2] = {ctx->dscratch + 4 * RED_MAX_BLOCKS, ctx->dscratch + 8 * RED_MAX_BLOCKS};
-  MPSE_TRY(mpse_memcpy_d2d(ctx, vec(0), Cin, size_t(n) * es));
-  dot_partials(Cin, Cin, part_b2[0]);
+  bracket(3.0 * vbytes, [&] {
+    if (cplx)
+      hipLaunchKernelGGL((k_lz_start<true>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(0), (const double*)Cin,
+                         (long long)n, part_b2[0], ctl);
+    else
+      hipLaunchKernelGGL((k_lz_start<false>), dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(0),
+                         (const double*)Cin, (long long)n, part_b2[0], ctl);
+  });
   MPSE_HIP(ctx, hipGetLastError());
 
   unsigned int* dflag = reinterpret_cast<unsigned int*>(ctx->dscratch + (size_t(1) << 16) - 8);
@@ -917,8 +950,6 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
       prev = dst;
       MPSE_HIP(ctx, hipGetLastError());
       if (wait_here) {
-        hipLaunchKernelGGL(k_lz_final, dim3(ew_blocks(nd)), dim3(256), 0, ctx->stream, (double*)out,
-                           (const double*)RES.p, (long long)nd, (const LzCtl*)ctl);
         if (self_pub)
           MPSE_TRY(publish_wait_seq(ctx, seq, reinterpret_cast<const double*>(ctl), int(sizeof(LzCtl) / sizeof(double)), 24));
         else
@@ -928,7 +959,12 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
         waited = true;
         if (hc.bad) return mpse_fail(ctx, MPSE_ERR_ARG, "expm_lanczos: zero start vector");
         if (hc.need_host) return LZ_FALLBACK;
-        if (hc.done) break;
+        if (hc.done) {
+          // the answer sits in the spare buffer (an even number of estimates): copied now - the host knows; before, a
+          // conditional copy kernel was enqueued at every waited check
+          if (hc.which == 1) MPSE_TRY(mpse_memcpy_d2d(ctx, out, RES.p, size_t(n) * es));
+          break;
+        }
       }
     }
     if (last) return LZ_FALLBACK;     // beyond one wavefront of coefficients (or no convergence): the synchronous solve decides
