@@ -1,8 +1,8 @@
 // Effective-Hamiltonian matvec of SMALL centres (0- and 1-site, mps/hop_expr.py:63-79) as ONE launch.
 //
 // At bond dimensions of a few tens the three-step chain of mpse_plans.h (two strided GEMMs around the MPO step, plus
-// split-K reductions) is 3-6 launches of a few microseconds each: the Krylov solve of such a site is bound by the
-// launch path of the host, not by arithmetic (profiles/r04_traj_scaling.jsonl).  The chain
+// split-K reductions) is 3-6 launches of a few microseconds each: the Krylov solve of such a site is bound by launches
+// and kernel boundaries, not by arithmetic (profiles/r04_traj_scaling.jsonl).  The chain
 //   out[a,x,l] = sum_{b,c,e,f,k} L[a,b,c] W[b,x,e,f] C[c,e,k] R[l,f,k]
 // needs no exchange between workgroups when it is cut along the bra bond a of L: the workgroup of row a forms
 //   T1[b,(e,k)] = sum_c L[a,b,c] C[c,(e,k)]          (wl x d Dr, in LDS)
@@ -13,6 +13,11 @@
 // once per Krylov solve (the environments are constant over a solve), so that the last step reads coalesced rows.
 // The partial sums of <result, y> that the Lanczos update needs ride on the same launch (mpse_ctx::dot_req), one
 // (re, im) pair per workgroup in a fixed order: results are bitwise reproducible run to run.
+//
+// When the caller takes the result as a sum of parts (mpse_ctx::parts_req: the Lanczos update adds them while it reads),
+// the ket bond k of R is cut into up to four slices over blockIdx.y: a workgroup then works on the columns (e, k) of C and
+// the rows (f, k) of Rt of its slice only and writes its own partial result - four times the compute units, a quarter of
+// the bytes per workgroup (27 -> 11.5 us per matvec at D = 64 together with the prefetch pipeline).
 //
 // The 0-site matvec (abc,lbk,ck->al) is the same kernel with d = 1 and no MPO step (P = T1, wl == wr).
 #include <algorithm>
