@@ -260,6 +260,7 @@ class Mpo:
     def __init__(self, model=None, terms=None, offset: Quantity = Quantity(0)):
         self._mp = []
         self._dev = {}
+        self._snap = {}
         self.model = model
         self.qn = None
         self.qntot = None
@@ -386,8 +387,30 @@ class Mpo:
     def is_complex(self):
         return any(np.iscomplexobj(w) for w in self._mp)
 
+    def site_version(self, i):
+        """Content version of site ``i``: 0 at first sight, +1 every time the host array is found to be another object
+        or to hold other values than at the last look (an MPO site edited in place - a time-dependent Hamiltonian - or
+        replaced, as ``try_swap_site`` does).  A new version drops the cached device copies of the site (freeing the
+        device buffer drops the engine's block-structure hint with it), so the next ``device(i, eng)`` uploads and
+        describes the current values.  Costs one comparison with a host snapshot (~3 us for a 5 x 16 x 16 x 4 site)."""
+        w = self._mp[i]
+        rec = self._snap.get(i)
+        is_arr = isinstance(w, np.ndarray)
+        if rec is None or rec[0] is not w or (is_arr and not np.array_equal(w, rec[1])):
+            rec = self._snap[i] = (w, w.copy() if is_arr else None, rec[2] + 1 if rec else 0)
+            for key in [k for k in self._dev if k[0] == i]:
+                del self._dev[key]
+        return rec[2]
+
+    def versions(self):
+        """Content versions of all sites (see ``site_version``): what the carried environments of a TDVP-PS step are
+        checked against."""
+        return tuple(self.site_version(i) for i in range(len(self._mp)))
+
     def device(self, i, eng):
-        """HBM copy of site tensor i (cached)."""
+        """HBM copy of site tensor i (cached; re-uploaded and re-described to the engine when the host array has
+        changed since the copy was made)."""
+        self.site_version(i)
         key = (i, id(eng))
         if key not in self._dev:
             self._dev[key] = eng.asdevice(self._mp[i])

@@ -1439,18 +1439,17 @@ _CARRY = threading.local()
 def _carry_environ(mps, mpo, environ):
     ahead = "R" if mps.to_right else "L"
     environ.drop("L" if ahead == "R" else "R")
-    # the take-over test compares the MPO sites as OBJECTS and by a fingerprint of their contents: a site replaced (as
-    # try_swap_site does) or edited in place (a time-dependent Hamiltonian) drops the carried environments - the
-    # caller's arrays are left as they are
+    # the take-over test compares the MPO sites as OBJECTS and by their content versions (Mpo.site_version: a host
+    # snapshot per site): a site replaced (as try_swap_site does) or edited in place (a time-dependent Hamiltonian) drops
+    # the carried environments AND the cached device copy of that site - the caller's arrays are left as they are
     sites = list(mpo._mp) if hasattr(mpo, "_mp") else None
-    _CARRY.slot = (mpo, sites, ahead, environ, list(mps._mp), _mpo_fingerprint(sites))
+    _CARRY.slot = (mpo, sites, ahead, environ, list(mps._mp), _mpo_fingerprint(mpo, sites))
 
 
-def _mpo_fingerprint(sites):
+def _mpo_fingerprint(mpo, sites):
     if sites is None:
         return None
-    import zlib
-    return tuple(zlib.crc32(np.ascontiguousarray(w).view(np.uint8)) if isinstance(w, np.ndarray) else id(w) for w in sites)
+    return mpo.versions() if hasattr(mpo, "versions") else tuple(id(w) for w in sites)
 
 
 def clear_evolve_cache():
@@ -1472,7 +1471,7 @@ def _carried_environ(mps, mpo, ahead):
     n = len(mps)
     if cmpo is not mpo or cmpo_sites is None or cahead != ahead or len(csites) != n or len(cmpo_sites) != n:
         return None
-    if any(a is not b for a, b in zip(mpo._mp, cmpo_sites)) or _mpo_fingerprint(list(mpo._mp)) != cprint:
+    if any(a is not b for a, b in zip(mpo._mp, cmpo_sites)) or _mpo_fingerprint(mpo, list(mpo._mp)) != cprint:
         return None
     # R(i) depends on the sites i .. n-1 (needed for i >= 1), L(i) on 0 .. i (needed for i <= n-2); the centre site
     # (rescaled by normalize) is in neither

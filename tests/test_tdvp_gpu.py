@@ -839,8 +839,16 @@ def test_environments_carried_between_tdvp_ps_steps(golden_dir, monkeypatch):
                 saved = w0.copy()
                 w0[...] = 2.0 * saved
                 nb = len(built)
-                after.evolve(mpo, 10.0)
+                edited = after.evolve(mpo, 10.0)
                 assert len(built) == nb + 1
+                # ... and the matvec runs on the EDITED values: the cached device copy of the site and its block-structure
+                # hint are refreshed (Mpo.site_version) - same tensors as with an operator built from the edited arrays
+                fresh = Mpo.from_arrays(mpo.model, [np.array(w, copy=True) for w in mpo])
+                ref = after.evolve(fresh, 10.0)
+                for a, b in zip(edited, ref):
+                    assert np.array_equal(a.to_host(), b.to_host())
+                unedited = Mpo.from_arrays(mpo.model, [saved] + [np.array(w, copy=True) for w in list(mpo)[1:]])
+                assert not np.allclose(after.evolve(unedited, 10.0).e_occupations, edited.e_occupations, atol=1e-9)
                 w0[...] = saved
                 after = other.evolve(mpo, 10.0)
             # ... and the slot can be dropped by hand: the next step rebuilds
