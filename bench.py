@@ -162,6 +162,47 @@ def cpu_baseline(model, mpo, mps, dt, n_updates):
                 host_cpus=os.cpu_count(), est_step_s=step_time)
 
 
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks here (one process per GPU, LOCAL_RANK = i, a
+    free MASTER_PORT, a launch id that keys their rendezvous), relay rank 0's JSON line, and return non-zero if any
+    rank does - the others are stopped then (they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    launch_id = os.urandom(8).hex()
+    procs = []
+    for i in range(n):
+        env = dict(os.environ, RANK=str(i), LOCAL_RANK=str(i), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MPSE_LAUNCH_ID=launch_id)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if i == 0 else subprocess.DEVNULL))
+    print(f"bench.py: started {n} ranks (pids {[p.pid for p in procs]}, MASTER_PORT {port})", file=sys.stderr, flush=True)
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    code = 0
+    live = set(range(n))
+    while live:
+        for i in list(live):
+            rc = procs[i].poll()
+            if rc is not None:
+                live.discard(i)
+                if rc != 0 and code == 0:
+                    code = rc
+                    print(f"bench.py: rank {i} exited with status {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for j in live:
+                        procs[j].terminate()
+        time.sleep(0.05)
+    reader.join(5.0)
+    if code == 0 and out0 and out0[0]:
+        sys.stdout.write(out0[0].decode())
+        sys.stdout.flush()
+    return code if code >= 0 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +227,16 @@ def main():
                     help="gloo + --share-gpu exercises the multi-rank flow on a single GPU (testing only)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use GPU 0 (testing only)")
     args = ap.parse_args()
+
+    # --gpus N is the number of ranks.  Under a launcher (RANK / WORLD_SIZE set) the two must agree; without one this
+    # process starts the N ranks itself
+    if os.environ.get("WORLD_SIZE") is None and os.environ.get("RANK") is None:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus))
+    elif int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {os.environ.get('WORLD_SIZE', '1')}: "
+              "refusing to report a figure for another number of ranks than asked for", file=sys.stderr, flush=True)
+        sys.exit(2)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

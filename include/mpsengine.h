@@ -309,6 +309,13 @@ int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int6
                   const int64_t* col_idx_host, const int64_t* col_off_host,
                   int system_is_R, void* U, void* Vt, int64_t K);
 
+/* How many mpse_block_qr decompositions this context has run, how many of them went through the Cholesky-QR kernels
+ * (tall blocks of up to 256 columns: three Gram / Cholesky / triangular-solve passes on MFMA, all compute units) and how
+ * many of those were redone by the Householder kernels because a block was rank deficient or too ill conditioned for
+ * the scheme (device-side flag).  No reference counterpart (diagnostics; bench.py reports the rates).  Any pointer may
+ * be NULL. */
+int mpse_block_qr_stats(mpse_ctx* ctx, int64_t* calls, int64_t* chol_calls, int64_t* chol_fallbacks);
+
 /* Quantum-number blocked economic SVD by one-sided Jacobi, replaces mps/svd_qn.py:99-240
  * with QR=False, full_matrices=False (scipy.linalg.svd gesdd per block).  Same block
  * description; outputs U (nrow x K), Vt (K x ncol) (block order, NOT globally sorted) and

@@ -158,6 +158,8 @@ struct mpse_ctx {
     size_t bytes = 0;
   } small_rt;
   bool small_rt_scope = false;   // a solver without occupancy caches (Davidson) keeps the transposed copy as well
+  // mpse_block_qr: decompositions that took the Cholesky-QR path / that fell back from it to Householder
+  long long qr_chol_calls = 0, qr_chol_fallbacks = 0, qr_calls = 0;
 };
 
 int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...);
@@ -311,5 +313,11 @@ constexpr int GEMM_TRACE_WORDS = 10;                         // 64-bit words per
 // ``blks_dev``: the same descriptors already on the device (else they are uploaded here)
 int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm, const QrBlk* blks_host, int nblk,
                   bool form_q, const QrBlk* blks_dev = nullptr);
+// Shifted Cholesky-QR of tall blocks on MFMA (mpse_cholqr.hip).  The blocks are factorised in place in their column-major
+// workspaces and scattered to U / Vt like mpse_block_qr does; *ok = false when a block was rank deficient or too ill
+// conditioned for the scheme (device flag, one read-back): the caller then runs the Householder path on fresh copies.
+bool cholqr_eligible(const QrBlk* blks, int nblk);
+int cholqr_blocks(mpse_ctx* ctx, bool cplx, double* ws, const QrBlk* blks, int nblk, const long long* drows,
+                  const long long* dcols, int herm, void* U, void* Vt, long long K, long long ncol, bool* ok);
 // zero fill of two ranges in one launch (8-byte aligned)
 int device_zero2(mpse_ctx* ctx, void* a, size_t abytes, void* b, size_t bbytes);

@@ -328,23 +328,37 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   // ~4 us between the dependent panel / update kernels are spent on the device, not by the host - and was removed)
   const bool batched = max_mm <= HH_BATCH_MAX_ROWS;
   TmpBuf IDX(ctx), WS(ctx), Q(ctx), PRM(ctx);
-  void* bufs[4] = {nullptr, nullptr, nullptr, nullptr};
-  const size_t need[4] = {ib + db, size_t(ws_tot) * es, size_t(q_tot) * es, size_t(ktot + 1) * sizeof(HhParam)};
-  MPSE_TRY(IDX.alloc(need[0]));
-  MPSE_TRY(WS.alloc(need[1]));
-  MPSE_TRY(Q.alloc(need[2]));
-  MPSE_TRY(PRM.alloc(need[3]));
-  bufs[0] = IDX.p, bufs[1] = WS.p, bufs[2] = Q.p, bufs[3] = PRM.p;
-  MPSE_TRY(stage_h2d(ctx, bufs[0], host.data(), ib + db));
-  const long long* drows = static_cast<const long long*>(bufs[0]);
+  MPSE_TRY(IDX.alloc(ib + db));
+  MPSE_TRY(WS.alloc(size_t(ws_tot) * es));
+  MPSE_TRY(stage_h2d(ctx, IDX.p, host.data(), ib + db));
+  const long long* drows = static_cast<const long long*>(IDX.p);
   const long long* dcols = drows + nri;
-  const QrBlk* dblk = reinterpret_cast<const QrBlk*>(static_cast<const char*>(bufs[0]) + ib);
-  double* ws = static_cast<double*>(bufs[1]);
-  double* q = static_cast<double*>(bufs[2]);
-  HhParam* prm = static_cast<HhParam*>(bufs[3]);
+  const QrBlk* dblk = reinterpret_cast<const QrBlk*>(static_cast<const char*>(IDX.p) + ib);
+  double* ws = static_cast<double*>(WS.p);
   constexpr int E = CPLX ? 2 : 1;
+  ++ctx->qr_calls;
   hipLaunchKernelGGL((k_gather_blocks<CPLX>), dim3(ew_blocks(max_el), (unsigned)blks.size()), dim3(256), 0, ctx->stream, ws,
                      (const double*)coef, (long long)ncol, drows, dcols, dblk, herm);
+  // tall blocks of up to 256 columns: shifted Cholesky-QR on MFMA (mpse_cholqr.hip), all compute units instead of one
+  // per block; a block it cannot decide (rank deficient, condition beyond ~1e15) raises a device flag and the whole
+  // call is redone by the Householder kernels below on fresh copies of the blocks
+  if (cholqr_eligible(blks.data(), (int)blks.size())) {
+    bool ok = false;
+    MPSE_TRY(cholqr_blocks(ctx, CPLX, ws, blks.data(), (int)blks.size(), drows, dcols, herm, U, Vt, (long long)K,
+                           (long long)ncol, &ok));
+    ++ctx->qr_chol_calls;
+    if (ok) {
+      if (qpt) prof_end(ctx, qrec);
+      return MPSE_OK;
+    }
+    ++ctx->qr_chol_fallbacks;
+    hipLaunchKernelGGL((k_gather_blocks<CPLX>), dim3(ew_blocks(max_el), (unsigned)blks.size()), dim3(256), 0, ctx->stream,
+                       ws, (const double*)coef, (long long)ncol, drows, dcols, dblk, herm);
+  }
+  MPSE_TRY(Q.alloc(size_t(q_tot) * es));
+  MPSE_TRY(PRM.alloc(size_t(ktot + 1) * sizeof(HhParam)));
+  double* q = static_cast<double*>(Q.p);
+  HhParam* prm = static_cast<HhParam*>(PRM.p);
   if (batched) {
     MPSE_TRY(hh_qr_batched(ctx, CPLX, ws, q, prm, blks.data(), (int)blks.size(), true, dblk));
   } else {
@@ -422,6 +436,14 @@ int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int6
     return block_qr_impl<false>(ctx, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host,
                                 col_off_host, system_is_R ? 1 : 0, U, Vt, K);
   return mpse_fail(ctx, MPSE_ERR_ARG, "block_qr: unknown dtype");
+}
+
+int mpse_block_qr_stats(mpse_ctx* ctx, int64_t* calls, int64_t* chol_calls, int64_t* chol_fallbacks) {
+  if (!ctx) return MPSE_ERR_ARG;
+  if (calls) *calls = ctx->qr_calls;
+  if (chol_calls) *chol_calls = ctx->qr_chol_calls;
+  if (chol_fallbacks) *chol_fallbacks = ctx->qr_chol_fallbacks;
+  return MPSE_OK;
 }
 
 int mpse_gather_cols(mpse_ctx* ctx, int dtype, void* out, const void* in, int64_t nrow, int64_t ncol_in,

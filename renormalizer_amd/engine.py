@@ -91,6 +91,7 @@ _SIGNATURES = {
     "mpse_prof_get_ktiles": [C.c_void_p, C.c_int, C.POINTER(C.c_int64)],
     "mpse_prof_get_svd_sweeps": [C.c_void_p, C.POINTER(C.c_int64)],
     "mpse_mpo_site_hint": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64],
+    "mpse_block_qr_stats": [C.c_void_p] + [C.POINTER(C.c_int64)] * 3,
     "mpse_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
     "mpse_free": [C.c_void_p, C.c_void_p],
     "mpse_pool_trim": [C.c_void_p],
@@ -437,6 +438,12 @@ class Engine:
 
     def prof_reset(self):
         self._check(self.lib.mpse_prof_reset(self.ctx))
+
+    def block_qr_stats(self):
+        """(block QR calls, of which through the Cholesky-QR kernels, of which redone by Householder) of this context."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.mpse_block_qr_stats(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def prof_get(self):
         """{variant: dict(ms, flops, bytes, launches)} for the contraction kernel variants."""

@@ -6,8 +6,11 @@ data path.  At the end every rank contributes its observable rows to one all-gat
 xGMI.
 
 The product path binds ``librccl.so`` directly through ctypes (``RcclCollective``: ncclGetUniqueId / ncclCommInitRank /
-ncclAllGather / ncclAllReduce on the engine's HIP stream, buffers from the engine's allocator; the 128-byte unique id
-travels through a private file keyed by the launcher's process instance, single node only).  No PyTorch: the CPU
+ncclAllGather / ncclAllReduce on the engine's HIP stream, buffers from the engine's allocator).  The 128-byte unique id
+and a per-launch nonce travel over a plain TCP exchange with rank 0 at MASTER_ADDR (``SocketRendezvous``: rank 0 listens
+on the first free port of MASTER_PORT .. MASTER_PORT + 16 - under torch.distributed.run the agent's own store holds
+MASTER_PORT itself - and the other ranks find it by its handshake), so ranks need not share a parent process or a
+start time; ``MPSE_RENDEZVOUS_TAG`` selects the older exchange through a private file instead.  No PyTorch: the CPU
 stand-in of the same three operations that the world_size-2 tests use lives in ``tests/gloo_collective.py``."""
 import ctypes as C
 import os
@@ -64,6 +67,168 @@ def _parent_instance():
     return ppid, start
 
 
+_RDZV_MAGIC = b"MPSE-RDZV-1\0"      # 12 bytes
+_RDZV_PORTS = 17                      # MASTER_PORT .. MASTER_PORT + 16
+
+
+def _launch_key() -> bytes:
+    """What all ranks of one launch know without talking to each other: the number of ranks, the advertised port, the
+    launcher's run id when it has a real one and - when bench.py started the ranks itself - its launch id.  It keeps a
+    rank from joining the rendezvous of ANOTHER launch that happens to listen in the same port range."""
+    import hashlib
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
+    txt = "|".join([os.environ.get("WORLD_SIZE", "1"), os.environ.get("MASTER_PORT", "0"),
+                    run_id if run_id not in ("", "none") else "", os.environ.get("MPSE_LAUNCH_ID", "")])
+    return hashlib.sha256(txt.encode()).digest()[:16]
+
+
+def _recv_exact(conn, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the connection")
+        buf += chunk
+    return buf
+
+
+class SocketRendezvous:
+    """Small key -> bytes exchange of one launch over MASTER_ADDR (single node or not: plain TCP).  Rank 0 listens on
+    the first free port of MASTER_PORT .. MASTER_PORT + 16 (a launcher's own store may hold MASTER_PORT:
+    torch.distributed.run's agent does) and draws the launch nonce; rank r > 0 walks the same ports and takes the
+    first listener that answers with the right magic AND the right launch key - it never sends anything to MASTER_PORT
+    itself when a launcher's store is known to sit there.  Request: magic | launch key (16) | rank (int32) | key (16).
+    Reply: magic | nonce (8) | status (int32: 0 data follows, 1 not published yet, 2 another launch) | length | data.
+    Independent of process ancestry and of the file system; a crashed earlier launch leaves nothing behind."""
+
+    def __init__(self, rank: int, world: int, timeout_s: float = 120.0):
+        import socket
+        import threading
+        self.rank, self.world, self.timeout_s = int(rank), int(world), float(timeout_s)
+        self.addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        self.base_port = int(os.environ.get("MASTER_PORT", "29500"))
+        self.key = _launch_key()
+        self.port = None
+        self._store, self._lock, self._stop, self._thread, self._srv = {}, threading.Lock(), False, None, None
+        if self.rank == 0:
+            self.nonce = os.urandom(8)
+            last = None
+            for off in range(_RDZV_PORTS):
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    srv.bind((self.addr, self.base_port + off))
+                    srv.listen(64)
+                    self._srv, self.port = srv, self.base_port + off
+                    break
+                except OSError as exc:
+                    last = exc
+                    srv.close()
+            if self._srv is None:
+                raise OSError(f"rank 0: no free port in {self.base_port} .. {self.base_port + _RDZV_PORTS - 1} "
+                              f"on {self.addr} for the rendezvous ({last})")
+            self._srv.settimeout(0.2)
+            self._thread = threading.Thread(target=self._serve, daemon=True)
+            self._thread.start()
+        else:
+            self.nonce = None
+            self.nonce = self.fetch("nonce")[:8]
+
+    # ---- rank 0
+    def _serve(self):
+        import socket
+        import struct
+        while not self._stop:
+            try:
+                conn, _ = self._srv.accept()
+            except socket.timeout:
+                continue
+            except OSError:
+                return
+            try:
+                conn.settimeout(5.0)
+                req = _recv_exact(conn, 12 + 16 + 4 + 16)
+                if req[:12] != _RDZV_MAGIC:
+                    continue
+                key = req[32:48].rstrip(b"\0").decode(errors="replace")
+                if req[12:28] != self.key:
+                    status, data = 2, b""
+                else:
+                    with self._lock:
+                        data = self.nonce if key == "nonce" else self._store.get(key)
+                    status, data = (0, data) if data is not None else (1, b"")
+                conn.sendall(_RDZV_MAGIC + self.nonce + struct.pack("<ii", status, len(data)) + data)
+            except (OSError, ConnectionError):
+                pass
+            finally:
+                conn.close()
+
+    def publish(self, key: str, data: bytes):
+        assert self.rank == 0 and len(key.encode()) <= 16
+        with self._lock:
+            self._store[key] = bytes(data)
+
+    # ---- ranks > 0
+    def _ask(self, port, key):
+        import socket
+        import struct
+        with socket.create_connection((self.addr, port), timeout=1.0) as conn:
+            conn.settimeout(5.0)
+            conn.sendall(_RDZV_MAGIC + self.key + struct.pack("<i", self.rank) + key.encode().ljust(16, b"\0"))
+            head = _recv_exact(conn, 12 + 8 + 8)
+            if head[:12] != _RDZV_MAGIC:
+                return 2, b"", b""
+            status, n = struct.unpack("<ii", head[20:28])
+            return status, head[12:20], (_recv_exact(conn, n) if n > 0 else b"")
+
+    def fetch(self, key: str, timeout_s: float = None) -> bytes:
+        """The bytes rank 0 published under ``key`` (waits until they are there)."""
+        timeout_s = self.timeout_s if timeout_s is None else timeout_s
+        t0 = time.time()
+        agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() in ("1", "true")
+        while True:
+            ports = [self.port] if self.port else [self.base_port + off for off in range(_RDZV_PORTS)
+                                                   if not (off == 0 and agent_store)]
+            for port in ports:
+                try:
+                    status, nonce, data = self._ask(port, key)
+                except (OSError, ConnectionError):
+                    continue
+                if status == 2:
+                    continue
+                if self.nonce is not None and nonce != self.nonce:
+                    raise RuntimeError(f"rank {self.rank}: the rendezvous at {self.addr}:{port} changed its launch nonce")
+                self.port = port
+                if status == 0:
+                    return nonce + data if key == "nonce" else data
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"rank {self.rank}: no answer for '{key}' from rank 0's rendezvous at {self.addr}:"
+                                   f"{self.base_port}..{self.base_port + _RDZV_PORTS - 1} within {timeout_s} s "
+                                   "(is rank 0 of this launch running?)")
+            time.sleep(0.02)
+
+    def close(self):
+        self._stop = True
+        if self._srv is not None:
+            try:
+                self._srv.close()
+            except OSError:
+                pass
+
+
+_RDZV = {}
+
+
+def launch_rendezvous(rank: int, world: int, timeout_s: float = 120.0):
+    """The socket rendezvous of this process's launch (created once), or None when there is only one rank or when
+    ``MPSE_RENDEZVOUS_TAG`` asks for the exchange through a private file."""
+    if world <= 1 or os.environ.get("MPSE_RENDEZVOUS_TAG"):
+        return None
+    if "r" not in _RDZV:
+        _RDZV["r"] = SocketRendezvous(rank, world, timeout_s)
+    return _RDZV["r"]
+
+
 def _rendezvous_dir():
     """Private directory (mode 0700, owned by this user) for the id files: nobody else can plant or link one."""
     d = os.environ.get("MPSE_RENDEZVOUS_DIR") or os.path.join(
@@ -80,6 +245,8 @@ def _rendezvous_path():
     """One file per launch: MPSE_RENDEZVOUS_TAG / TORCHELASTIC_RUN_ID when the launcher gives a real one, else the
     parent's pid and start time, plus the advertised port.  Single node only (shared file system path)."""
     tag = os.environ.get("MPSE_RENDEZVOUS_TAG")
+    if not tag and "r" in _RDZV:
+        tag = "n" + _RDZV["r"].nonce.hex()          # socket rendezvous: a name no other launch can have
     if not tag:
         run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
         ppid, start = _parent_instance()
@@ -169,14 +336,32 @@ def _exit_hard_at_end():
         return
     _HARD_EXIT.append(True)
     import atexit
+    code = {"v": 0}
+    real_exit, real_hook = sys.exit, sys.excepthook
+
+    def exit_recording(status=0):          # sys.exit(n) -> SystemExit(n): remember n for the hard exit below
+        code["v"] = status if isinstance(status, int) else (0 if status is None else 1)
+        real_exit(status)
+
+    def hook_recording(*exc):
+        code["v"] = 1
+        real_hook(*exc)
+
+    sys.exit, sys.excepthook = exit_recording, hook_recording
 
     def bye():
+        # atexit runs handlers last-registered-first: this one would run BEFORE everything registered earlier (logging
+        # shutdown, result writers) and os._exit would skip them - so it runs them itself, then leaves
+        try:
+            atexit._run_exitfuncs()
+        except Exception:                      # noqa: BLE001 - a failing handler must not keep the process alive
+            code["v"] = code["v"] or 1
         for fh in (sys.stdout, sys.stderr):
             try:
                 fh.flush()
             except (OSError, ValueError):
                 pass
-        os._exit(1 if getattr(sys, "last_value", None) is not None else 0)
+        os._exit(code["v"] if code["v"] else (1 if getattr(sys, "last_value", None) is not None else 0))
 
     atexit.register(bye)
 
@@ -198,14 +383,22 @@ class RcclCollective:
         for name in ("ncclCommCount", "ncclCommUserRank", "ncclCommCuDevice"):
             getattr(L, name).argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         uid = _ncclUniqueId()
+        rdz = launch_rendezvous(self.rank, self.world, timeout_s)
         path = _rendezvous_path()
-        self._path = path if self.rank == 0 else None
+        self._path = path if (self.rank == 0 and rdz is None) else None
         with _StdoutToStderr():
             if self.rank == 0:
                 self._ok(L.ncclGetUniqueId(C.byref(uid)))
-                publish_id(path, C.string_at(C.addressof(uid), 128))        # all 128 bytes, zeros included
+                raw = C.string_at(C.addressof(uid), 128)                    # all 128 bytes, zeros included
+                if rdz is not None:
+                    rdz.publish("rccl_id", raw)
+                else:
+                    publish_id(path, raw)
             else:
-                C.memmove(C.byref(uid), await_id(path, timeout_s, self.rank), 128)
+                raw = rdz.fetch("rccl_id", timeout_s) if rdz is not None else await_id(path, timeout_s, self.rank)
+                if len(raw) != 128:
+                    raise RuntimeError(f"rank {self.rank}: the rendezvous returned {len(raw)} bytes for the RCCL id")
+                C.memmove(C.byref(uid), raw, 128)
             eng.sync()                                 # binds this thread to the engine's device (the comm's device)
             self.comm = C.c_void_p()
             # ncclCommInitRank blocks until every rank has called it with the same id: a mismatched id (or a rank
@@ -227,7 +420,8 @@ class RcclCollective:
                 if th.is_alive():
                     _exit_hard_at_end()
                     raise TimeoutError(f"rank {self.rank}: ncclCommInitRank did not return within {timeout_s} s "
-                                       f"({self.world} ranks expected; id file {path})")
+                                       f"({self.world} ranks expected; id through "
+                                       f"{'the socket rendezvous' if rdz is not None else 'the file ' + path})")
             else:
                 init()
         if "exc" in res:
@@ -293,12 +487,18 @@ class FileCollective:
         # Every message carries the launch's nonce: a file an earlier launch with the same tag left behind (same name,
         # same sequence number, possibly only seconds old) can never be taken for one of this launch.  Rank 0 draws it
         # and publishes it like the RCCL id (exclusive create + rename; readers insist on a file no older than they are).
-        npath = self._base + ".nonce"
-        if self.rank == 0:
-            raw = os.urandom(8) + b"\0" * 120
-            publish_id(npath, raw)
+        # With the socket rendezvous the nonce is the launch's own (and the file names carry it).
+        rdz = launch_rendezvous(self.rank, self.world, self.timeout_s)
+        if rdz is not None:
+            self._base = _rendezvous_path() + "." + tag
+            raw = rdz.nonce
         else:
-            raw = await_id(npath, self.timeout_s, self.rank)
+            npath = self._base + ".nonce"
+            if self.rank == 0:
+                raw = os.urandom(8) + b"\0" * 120
+                publish_id(npath, raw)
+            else:
+                raw = await_id(npath, self.timeout_s, self.rank)
         self._nonce = raw[:8]
         self._mine = []
 
@@ -392,11 +592,13 @@ def make_collective(eng=None, backend=None, strict=False):
     if world == 1 and want != "rccl":
         return SerialCollective()
     if want == "file":
+        launch_rendezvous(rank, world, 600.0)
         return FileCollective(rank, world)
     if eng is None:
         from .engine import get_engine
         eng = get_engine()
     timeout = float(os.environ.get("MPSE_RCCL_TIMEOUT", "120"))
+    launch_rendezvous(rank, world, timeout + 300.0)        # rank 0 listens before anything else can wait for it
     if want == "rccl" or world == 1:
         return RcclCollective(eng, rank, world, timeout_s=timeout)
     vote = FileCollective(rank, world, timeout_s=timeout + 300.0, tag="vote")

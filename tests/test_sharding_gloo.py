@@ -135,3 +135,78 @@ def test_file_collective_two_processes(tmp_path):
         out, err = p.communicate(timeout=120)
         assert p.returncode == 0, err[-2000:]
         assert f"OK {{rank}}".format(rank=rank) in out
+
+
+def test_socket_rendezvous_two_processes_without_common_ancestry(tmp_path):
+    """The launch nonce and a 128-byte payload reach rank 1 over MASTER_ADDR although the two ranks are started through
+    separate shells (different parents - the file keyed by the parent's pid could never have paired them), with the
+    advertised MASTER_PORT itself occupied (as torch.distributed.run's agent store occupies it) and with a listener of
+    ANOTHER launch in the same port range; the file collective then runs on names derived from the nonce."""
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {REPO!r})
+        import numpy as np
+        from renormalizer_amd import parallel
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        rdz = parallel.launch_rendezvous(rank, world, 60.0)
+        assert rdz is not None and len(rdz.nonce) == 8
+        payload = bytes(range(128))
+        if rank == 0:
+            assert rdz.port != int(os.environ["MASTER_PORT"])       # that one is taken
+            rdz.publish("rccl_id", payload)
+        else:
+            assert rdz.fetch("rccl_id", 60.0) == payload
+        coll = parallel.make_collective()                            # MPSE_COLLECTIVE=file: same rendezvous object
+        assert coll.kind == "file" and parallel._rendezvous_path().endswith("n" + rdz.nonce.hex() + ".id")
+        tab = parallel.gather_observables(coll, np.array([[float(rank), 2.0 * rank]]), [rank], 2)
+        assert tab.tolist() == [[0.0, 0.0], [1.0, 2.0]]
+        coll.close()
+        print("OK", rank, rdz.nonce.hex())
+    """))
+    # MASTER_PORT itself is occupied by a foreign listener that speaks another protocol ...
+    blocker = socket.socket()
+    blocker.bind(("127.0.0.1", 0))
+    blocker.listen(4)
+    port = blocker.getsockname()[1]
+    # ... and the next port by the rendezvous of another launch (other launch key): must be skipped
+    from renormalizer_amd import parallel
+    other_env = dict(WORLD_SIZE="2", MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1", MPSE_LAUNCH_ID="another-launch")
+    saved = {k: os.environ.get(k) for k in other_env}
+    os.environ.update(other_env)
+    try:
+        other = parallel.SocketRendezvous(0, 2, 5.0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert other.port == port + 1
+    procs = []
+    try:
+        for rank in (1, 0):                                             # rank 1 first: it has to wait for rank 0
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       MPSE_COLLECTIVE="file", MPSE_RENDEZVOUS_DIR=str(tmp_path), MPSE_LAUNCH_ID="this-launch")
+            env.pop("MPSE_RENDEZVOUS_TAG", None)
+            # each rank through its own shell: no common parent process
+            procs.append(subprocess.Popen(["bash", "-c", f"sleep 0.{3 * (1 - rank)}; exec {sys.executable} {script}"], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = []
+        for p in procs:
+            out, err = p.communicate(timeout=120)
+            assert p.returncode == 0, err[-2000:]
+            outs.append(out.split())
+        assert outs[0][0] == outs[1][0] == "OK" and outs[0][2] == outs[1][2] and outs[0][2] != other.nonce.hex()
+    finally:
+        other.close()
+        blocker.close()
+
+
+def test_bench_refuses_world_size_other_than_gpus():
+    """`--gpus N` under a launcher whose WORLD_SIZE differs ends with a non-zero status before any GPU work - a line for
+    another number of ranks than asked for must not exist (verdict round 4, item 3c)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()
