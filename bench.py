@@ -13,7 +13,8 @@ environments are resident in HBM before the timed region starts.  Rank 0 prints 
     roofline   = FP64-MFMA roofline of the dominant kernel (complex x complex contraction), measured
                  with HIP events on the engine's stream over the timed region: `achieved` counts the MFMA
                  work actually issued (visited K tiles x 6 real flops per complex multiply-add of the 3M
-                 scheme), `achieved_dense_equiv` the algorithmic 8 M N K of SURVEY.md 8(d); `classes` adds the
+                 scheme), `dense_equiv_tflops` the algorithmic 8 M N K of SURVEY.md 8(d) (no fraction: it exceeds the
+                 peak by kernel time - empty K tiles are skipped); `classes` adds the
                  HBM-bound Lanczos vector kernels and the block QR
 No PyTorch: ranks talk through librccl.so bound with ctypes (renormalizer_amd/parallel.py), only for the barrier,
 the max of the elapsed time and ONE all-gather of the observables.
@@ -162,6 +163,50 @@ def cpu_baseline(model, mpo, mps, dt, n_updates):
                 host_cpus=os.cpu_count(), est_step_s=step_time)
 
 
+def step_work(steps, to_right_first, bond_dims, pdims, wdims):
+    """Algorithmic work of one TDVP-PS evolve from what it actually did (complex128: a complex
+    multiply-add = 8 real flops, complex x real = 4): ``steps`` = Krylov dimensions of its 2 (2N - 1) local solves in the
+    order the sweep performed them (site, bond, site, ..), bond / physical / MPO-bond dimensions of the chain.
+    Returns (effective-Hamiltonian applications, flops): k F_hop1 per site solve + F_qr + F_env (+ F_absorb) per split
+    site, k F_hop0 per bond solve."""
+    n = len(pdims)
+
+    def hop1(i):
+        dl, dr, d, wl, wr = bond_dims[i], bond_dims[i + 1], pdims[i], wdims[i], wdims[i + 1]
+        return 8.0 * dl * dl * wl * d * dr + 4.0 * dl * dr * wl * wr * d * d + 8.0 * dl * dr * dr * wr * d
+
+    def hop0(b):            # bond b sits between sites b - 1 and b
+        dl = dr = bond_dims[b]
+        return 8.0 * wdims[b] * dl * dr * (dl + dr)
+
+    def qr(i, right):
+        m, k = (bond_dims[i] * pdims[i], bond_dims[i + 1]) if right else (bond_dims[i + 1] * pdims[i], bond_dims[i])
+        k = min(m, k)
+        return 4.0 * (4.0 * m * k * k - 4.0 * k ** 3 / 3.0)
+
+    matvecs, flops, pos = 0, 0.0, 0
+    for half in range(2):
+        right = to_right_first if half == 0 else not to_right_first
+        order = list(range(n)) if right else list(range(n - 1, -1, -1))
+        for idx, i in enumerate(order):
+            k = steps[pos]
+            pos += 1
+            matvecs += k
+            flops += k * hop1(i)
+            if idx == n - 1:
+                continue                     # the last site of a half sweep is not split
+            flops += qr(i, right) + hop1(i)  # block QR + one environment update
+            b = i + 1 if right else i
+            kb = steps[pos]
+            pos += 1
+            matvecs += kb
+            flops += kb * hop0(b)
+            nb = i + 1 if right else i - 1   # absorption of the bond factor into the neighbour
+            flops += 8.0 * bond_dims[b] ** 2 * pdims[nb] * (bond_dims[nb + 1] if right else bond_dims[nb])
+    assert pos == len(steps)
+    return matvecs, flops
+
+
 def spawn_ranks(n):
     """``python bench.py --gpus N`` without a launcher: start the N ranks here (one process per GPU, LOCAL_RANK = i, a
     free MASTER_PORT, a launch id that keys their rendezvous), relay rank 0's JSON line, and return non-zero if any
@@ -294,21 +339,26 @@ def main():
                 mps = mps.evolve(mpo, args.dt)
             engines[t].prof_reset()
             engines[t].prof_enable(PROF_STRIDE)
+            qr0 = engines[t].block_qr_stats()
             engines[t].sync()
             sync.wait()                    # all trajectories ready -> main thread takes t0
             rtx = _roctx()
             if rtx is not None:
                 rtx.roctxProfilerResume(0)
-            kry = []
+            kry, work = [], []
             for _ in range(args.steps):
+                first_right = bool(mps.to_right)
                 mps = mps.evolve(mpo, args.dt)
                 kry.append(mps.evolve_config.stat["mean"])
+                if args.scheme == "tdvp_ps":
+                    work.append((list(mps.evolve_config.stat["steps"]), first_right))
             engines[t].sync()
             if rtx is not None:
                 rtx.roctxProfilerPause(0)
             sync.wait()                    # all done -> main thread takes t1
             engines[t].prof_enable(False)
-            results[t] = dict(model=model, mpo=mpo, mps=mps, kry=kry, prof=engines[t].prof_get())
+            results[t] = dict(model=model, mpo=mpo, mps=mps, kry=kry, work=work, prof=engines[t].prof_get(),
+                              qr=tuple(b - a for a, b in zip(qr0, engines[t].block_qr_stats())))
         except BaseException as exc:       # noqa: BLE001 - report and unblock the barrier
             errors.append(exc)
             sync.abort()
@@ -333,6 +383,11 @@ def main():
         raise errors[0]
     model, mpo, mps = results[0]["model"], results[0]["mpo"], results[0]["mps"]
     kry = [k for r in results for k in r["kry"]]
+    work_tot = []
+    for r in results:
+        dims = [int(d) for d in r["mps"].bond_dims]
+        pd, wd = list(r["model"].pbond_list), [int(w) for w in r["mpo"].bond_dims]
+        work_tot += [step_work(st, fr, dims, pd, wd) for st, fr in r["work"]]
     prof = {}
     for r in results:
         for k, v in r["prof"].items():
@@ -386,6 +441,22 @@ def main():
                               f"CHANGED since that pass: traffic withheld, the stale figure was {traffic_ref:.4g} bytes/launch"))
         except (OSError, KeyError, ValueError, StopIteration, IndexError, ZeroDivisionError):
             pass
+        # the same for the kernel's duration by the profiler's clock: profiles/rNN_kernel_time.json (tools/rocpd_kernel_time.py
+        # on a rocprofv3 kernel trace of this command's timed region)
+        ktime, ktime_src = None, None
+        try:
+            kt_file = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_kernel_time.json")))[-1]
+            with open(kt_file, "rb") as fh:
+                raw = fh.read()
+            kt = json.loads(raw)
+            fresh_kt = kt.get("kernel_source_sha") is not None and kt.get("kernel_source_sha") == _kernel_source_sha()
+            ktime = kt if fresh_kt else None
+            ktime_src = (f"profiles/{os.path.basename(kt_file)} sha256:{hashlib.sha256(raw).hexdigest()[:16]} (rocprofv3 "
+                         "--kernel-trace of this command's timed region, a committed measurement); kernel sources "
+                         + ("unchanged since that trace" if fresh_kt else
+                            f"CHANGED since that trace: figure withheld, the stale average was {kt.get('avg_us', 0):.1f} us"))
+        except (OSError, KeyError, ValueError, IndexError, NameError):
+            pass
         zz = prof["c128xc128"]
         sec = zz["ms"] * 1e-3
         dense = zz["flops"] / sec / 1e12 if sec > 0 else 0.0
@@ -433,6 +504,11 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,   # wall time per evolve of each trajectory
+            # state-independent rates: the effective-Hamiltonian applications the solves of the timed steps needed
+            # (their Krylov dimensions) and the algorithmic flops of SURVEY.md 8(d) at the printed bond dimensions
+            "heff_matvecs_per_s": (world * sum(w[0] for w in work_tot) / elapsed) if work_tot else None,
+            "alg_tflops_per_step": (sum(w[1] for w in work_tot) / len(work_tot) / 1e12) if work_tot else None,
+            "alg_tflops_per_s": (world * sum(w[1] for w in work_tot) / elapsed / 1e12) if work_tot else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -450,6 +526,10 @@ def main():
                        "rank_devices": rank_devices, "rank_pci_bus_ids": rank_pci,
                        "rccl_comm_count": comm_count, "rccl_comm_user_rank": comm_rank, "rccl_comm_device": comm_dev,
                        "distinct_trajectories": distinct,
+                       # block QR / RQ decompositions of the timed steps: how many went through the Cholesky-QR kernels
+                       # (tall blocks) and how many of those a device flag sent back to the Householder kernels
+                       "block_qr": dict(zip(("calls", "cholesky_qr", "redone_by_householder"),
+                                            [int(sum(r["qr"][k] for r in results)) for k in range(3)])),
                        "bond_dims": [int(d) for d in mps.bond_dims],
                        "environments": ("rebuilt at every step (MPSE_ENV_CARRY=0)" if os.environ.get("MPSE_ENV_CARRY") == "0"
                                         else "those ahead of the first half sweep are taken over from the previous step "
@@ -458,7 +538,15 @@ def main():
                          "achieved": issued, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": issued / FP64_MFMA_PEAK_TFLOPS,
                          "achieved_note": "issued MFMA work: K tiles visited (device counters) x 65536 MACs x 6 real flops",
-                         "achieved_dense_equiv": dense, "frac_dense_equiv": dense / FP64_MFMA_PEAK_TFLOPS,
+                         # the same issued work over the kernel's own duration in a committed rocprofv3 trace (the HIP-event
+                         # bracket above also spans the split-K reduction launches and the events' own gaps)
+                         "frac_kernel_time": (zz["issued_flops"] / max(1, zz["launches"]) / (ktime["avg_us"] * 1e-6) / 1e12
+                                              / FP64_MFMA_PEAK_TFLOPS) if ktime else None,
+                         "kernel_time_avg_us": ktime["avg_us"] if ktime else None,
+                         "kernel_time_source": ktime_src,
+                         # algorithmic 8 M N K of SURVEY.md 8(d) over the same time: NOT a roofline fraction (the kernel
+                         # skips structurally empty K tiles and uses three real products per complex one)
+                         "dense_equiv_tflops": dense,
                          "visited_ktile_share": (zz["ktiles"] * 65536.0 * 8.0 / zz["flops"]) if zz["flops"] else None,
                          "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,

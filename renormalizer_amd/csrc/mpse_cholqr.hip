@@ -445,13 +445,13 @@ __global__ __launch_bounds__(512) void k_cq_chol(const double* __restrict__ G, c
 // panel of a step goes through LDS (two buffers by parity) and is the operand of all updates of that step - no global
 // load sits inside the loop (the left-looking form above read its operands back from L2 in a loop of dependent round
 // trips: 100 us per factorisation at n = 145 against the ~35 us the chain diagonal factor -> row solve -> update needs).
-// NS: accumulator slots per wave (7: P <= 10, 10: P <= 12).  XLDS: the row solve re-reads its finished rows from LDS
+// NW waves, NS accumulator slots per wave (8 x 7: P <= 10; 16 x 5: P <= 12 - ten slots on eight waves spilled).  XLDS: the row solve re-reads its finished rows from LDS
 // instead of keeping them in 64 registers next to the 160 of ten slots (which spilled).
-template <bool CPLX, int NS, bool XLDS>
-__global__ __launch_bounds__(512) void k_cq_chol_rl(const double* __restrict__ G, const double* __restrict__ tinfo,
+template <bool CPLX, int NW, int NS, bool XLDS>
+__global__ __launch_bounds__(64 * NW) void k_cq_chol_rl(const double* __restrict__ G, const double* __restrict__ tinfo,
                                                      double* __restrict__ R, const CqBlk* __restrict__ blks,
                                                      int* __restrict__ status, int pass) {
-  constexpr int E = CPLX ? 2 : 1, PMAX = 12;
+  constexpr int E = CPLX ? 2 : 1, PMAX = 12, NT = 64 * NW;
   const CqBlk B = blks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15, kq = lane >> 4;
   const int P = B.P, T = B.T, nn = B.nn;
@@ -463,22 +463,22 @@ __global__ __launch_bounds__(512) void k_cq_chol_rl(const double* __restrict__ G
   double* s_red = reinterpret_cast<double*>(&sRow[0][0][0]);   // scratch of the reductions before the loop
   {
     double m = 0.0, tr = 0.0;
-    for (int t = tid; t < T; t += 512) {
+    for (int t = tid; t < T; t += NT) {
       m = fmax(m, tinfo[2 * (B.t_off + t)]);
       tr += tinfo[2 * (B.t_off + t) + 1];
     }
     s_red[tid] = m;
-    s_red[512 + tid] = tr;
+    s_red[NT + tid] = tr;
     __syncthreads();
-    for (int h = 256; h > 0; h >>= 1) {
+    for (int h = NT / 2; h > 0; h >>= 1) {
       if (tid < h) {
         s_red[tid] = fmax(s_red[tid], s_red[tid + h]);
-        s_red[512 + tid] += s_red[512 + tid + h];
+        s_red[NT + tid] += s_red[NT + tid + h];
       }
       __syncthreads();
     }
   }
-  const double maxdev = s_red[0], trace = s_red[512];
+  const double maxdev = s_red[0], trace = s_red[NT];
   __syncthreads();
   const double shift = pass == 1 ? 11.0 * ((double)B.mm * nn + (double)nn * (nn + 1)) * 1.1102230246251565e-16 * trace : 0.0;
   if (pass == 3 && (double)nn * maxdev <= 1e-9) {
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(512) void k_cq_chol_rl(const double* __restrict__ G
   v4d ar[NS], ai[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int t = wave + 8 * s;
+    const int t = wave + NW * s;
     tq[s] = tc[s] = -1;
     ar[s] = v4d{0, 0, 0, 0};
     ai[s] = v4d{0, 0, 0, 0};
@@ -540,69 +540,78 @@ __global__ __launch_bounds__(512) void k_cq_chol_rl(const double* __restrict__ G
         for (int r = 0; r < 4; ++r) sRow[buf][tc[s] - p][(kq + 4 * r) * 16 + x] = make_double2(ar[s][r], ai[s][r]);
       }
     __syncthreads();
-    // ---- diagonal tile: one wave, lane (g, j) holds rows g, g + 4, g + 8, g + 12 of column j; row k of the factor is
-    // handed to the other row groups through LDS (one wave: program order, no barrier)
+    // ---- diagonal tile: one wave, lane (g, j) holds rows 4g .. 4g + 3 of column j.  Block step b: the four pivot rows
+    // live in lane group b, their mutual updates go through DPP row broadcasts (no memory); the finished rows reach the
+    // groups below through LDS (one wave: program order, no barrier) - three exchanges per tile instead of fifteen
     if (wave == 0) {
       double cr[4], ci[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double2 v = sRow[buf][0][(kq + 4 * r) * 16 + x];
-        cr[r] = v.x;
-        ci[r] = v.y;
+      for (int m = 0; m < 4; ++m) {
+        const double2 v = sRow[buf][0][(4 * kq + m) * 16 + x];
+        cr[m] = v.x;
+        ci[m] = v.y;
       }
-      auto step = [&](auto kc) {
-        constexpr int k = decltype(kc)::value, gk = k & 3, rk = k >> 2;
-        double dkk = readlane_d(cr[rk], 16 * gk + k);
-        bool ok = dkk > 0.0 && dkk < 1e300;
-        if (pass == 3 && !(dkk >= 0.25 && dkk <= 4.0)) ok = false;
-        if (!(dkk > 0.0 && dkk < 1e300)) dkk = 1.0;
-        if (!ok) bad = 1;
-        const double rs = fast_rsqrt(dkk);
-        if (kq == gk) {
-          const double rkr = x >= k ? cr[rk] * rs : 0.0;
-          const double rki = x > k ? ci[rk] * rs : 0.0;
-          cr[rk] = rkr;
-          ci[rk] = rki;
-          sRpp[k * 16 + x] = make_double2(rkr, rki);
-          if (x == k) sDinv[k] = rs;
+      auto blockstep = [&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        // pivots of the block as scalars, for the checks (the values the group-b lanes hold when their turn comes are
+        // read inside the divergent region below)
+        if (kq == b) {
+          auto mini = [&](auto mc) {
+            constexpr int m = decltype(mc)::value, k = 4 * b + m;
+            double dkk = row_share<k>(cr[m]);
+            const bool ok = dkk > 0.0 && dkk < 1e300 && !(pass == 3 && !(dkk >= 0.25 && dkk <= 4.0));
+            if (!(dkk > 0.0 && dkk < 1e300)) dkk = 1.0;
+            if (!ok) bad = 1;
+            const double rs = fast_rsqrt(dkk);
+            const double rkr = x >= k ? cr[m] * rs : 0.0;
+            const double rki = x > k ? ci[m] * rs : 0.0;
+            cr[m] = rkr;
+            ci[m] = rki;
+            if (x == k) sDinv[k] = rs;
+#pragma unroll
+            for (int m2 = m + 1; m2 < 4; ++m2) {
+              double er, ei;
+              // r(k, 4b + m2): the value lane 4b + m2 of this row holds
+              if (m2 == 1) { er = row_share<4 * b + 1>(rkr); ei = CPLX ? row_share<4 * b + 1>(rki) : 0.0; }
+              else if (m2 == 2) { er = row_share<4 * b + 2>(rkr); ei = CPLX ? row_share<4 * b + 2>(rki) : 0.0; }
+              else { er = row_share<4 * b + 3>(rkr); ei = CPLX ? row_share<4 * b + 3>(rki) : 0.0; }
+              cr[m2] -= er * rkr + ei * rki;
+              if constexpr (CPLX) ci[m2] -= er * rki - ei * rkr;
+            }
+            sRpp[k * 16 + x] = make_double2(rkr, rki);
+          };
+          mini(std::integral_constant<int, 0>{});
+          mini(std::integral_constant<int, 1>{});
+          mini(std::integral_constant<int, 2>{});
+          mini(std::integral_constant<int, 3>{});
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (k < 15) {
-          const double2 rj = sRpp[k * 16 + x];
+        if constexpr (b < 3) {
+          if (kq > b) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (4 * r + 3 > k) {   // (static: this register still holds rows below k)
-              const int i = kq + 4 * r;
-              const double2 e = sRpp[k * 16 + i];   // r(k, i)
-              if (i > k) {
-                cr[r] -= e.x * rj.x + e.y * rj.y;
-                if constexpr (CPLX) ci[r] -= e.x * rj.y - e.y * rj.x;
+            for (int m = 0; m < 4; ++m) {
+              const int k = 4 * b + m;
+              const double2 rj = sRpp[k * 16 + x];
+#pragma unroll
+              for (int m2 = 0; m2 < 4; ++m2) {
+                const double2 e = sRpp[k * 16 + 4 * kq + m2];   // r(k, i), i = this lane's row
+                cr[m2] -= e.x * rj.x + e.y * rj.y;
+                if constexpr (CPLX) ci[m2] -= e.x * rj.y - e.y * rj.x;
               }
             }
           }
         }
       };
-      step(std::integral_constant<int, 0>{});
-      step(std::integral_constant<int, 1>{});
-      step(std::integral_constant<int, 2>{});
-      step(std::integral_constant<int, 3>{});
-      step(std::integral_constant<int, 4>{});
-      step(std::integral_constant<int, 5>{});
-      step(std::integral_constant<int, 6>{});
-      step(std::integral_constant<int, 7>{});
-      step(std::integral_constant<int, 8>{});
-      step(std::integral_constant<int, 9>{});
-      step(std::integral_constant<int, 10>{});
-      step(std::integral_constant<int, 11>{});
-      step(std::integral_constant<int, 12>{});
-      step(std::integral_constant<int, 13>{});
-      step(std::integral_constant<int, 14>{});
-      step(std::integral_constant<int, 15>{});
+      blockstep(std::integral_constant<int, 0>{});
+      blockstep(std::integral_constant<int, 1>{});
+      blockstep(std::integral_constant<int, 2>{});
+      blockstep(std::integral_constant<int, 3>{});
+      bad = __any(bad) ? 1 : bad;
       double* td = Rt + (long long)tile_index(p, p, P) * 256 * E;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = kq + 4 * r;
-        st2<CPLX>(td, i * 16 + x, i <= x ? cr[r] : 0.0, i <= x ? ci[r] : 0.0);
+      for (int m = 0; m < 4; ++m) {
+        const int i = 4 * kq + m;
+        st2<CPLX>(td, i * 16 + x, i <= x ? cr[m] : 0.0, i <= x ? ci[m] : 0.0);
       }
     }
     __syncthreads();
@@ -612,11 +621,11 @@ __global__ __launch_bounds__(512) void k_cq_chol_rl(const double* __restrict__ G
       const int ct = 1 + (tid >> 4), col = tid & 15;
       double* td = Rt + (long long)tile_index(p, p + ct, P) * 256 * E;
       if constexpr (XLDS) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const double2 s0 = sRow[buf][ct][i * 16 + col];
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {     // (rolled: nothing here needs static register indices, and unrolled the
+          const double2 s0 = sRow[buf][ct][i * 16 + col];   // hoisted LDS reads pushed the accumulators out of registers)
           double sr = s0.x, si = s0.y;
-#pragma unroll
+#pragma unroll 2
           for (int t = 0; t < i; ++t) {
             const double2 rt = sRpp[t * 16 + i], xt = sRow[buf][ct][t * 16 + col];
             sr -= rt.x * xt.x + rt.y * xt.y;
@@ -825,23 +834,25 @@ __global__ __launch_bounds__(256) void k_cq_trsm(double* __restrict__ ws, const 
 #pragma unroll
       for (int t = 1; t < 16; ++t) dj = x == t ? rr[t] : dj;
       const double dinv = fast_rcp(dj);
+      // (only rows t < x of column x take part: zeros elsewhere make the updates unconditional)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if (t >= x) rr[t] = ri[t] = 0.0;
+      }
       v4d vr, vi;
       vr = slot == 0 ? ar[0] : slot == 1 ? ar[1] : slot == 2 ? ar[2] : ar[3];
       vi = slot == 0 ? ai[0] : slot == 1 ? ai[1] : slot == 2 ? ai[2] : ai[3];
+      // column t of X is final once the columns before it have been subtracted: x_t = v_t / r_tt, read from lane t of
+      // the 16-lane row together with 1 / r_tt; every lane scales its own column at the end
       auto step = [&](auto tc) {
         constexpr int t = decltype(tc)::value;
+        const double dt = row_share<t>(dinv);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (x == t) {
-            vr[r] *= dinv;
-            vi[r] *= dinv;
-          }
-          const double br = row_share<t>(vr[r]);
-          const double bi = CPLX ? row_share<t>(vi[r]) : 0.0;
-          if (x > t) {   // a -= x_t r(t, j):  (br + i bi)(rr + i ri)
-            vr[r] -= br * rr[t] - bi * ri[t];
-            if constexpr (CPLX) vi[r] -= br * ri[t] + bi * rr[t];
-          }
+          const double br = row_share<t>(vr[r]) * dt;
+          const double bi = CPLX ? row_share<t>(vi[r]) * dt : 0.0;
+          vr[r] -= br * rr[t] - bi * ri[t];       // (br + i bi)(rr + i ri)
+          if constexpr (CPLX) vi[r] -= br * ri[t] + bi * rr[t];
         }
       };
       step(std::integral_constant<int, 0>{});
@@ -859,7 +870,11 @@ __global__ __launch_bounds__(256) void k_cq_trsm(double* __restrict__ ws, const 
       step(std::integral_constant<int, 12>{});
       step(std::integral_constant<int, 13>{});
       step(std::integral_constant<int, 14>{});
-      step(std::integral_constant<int, 15>{});
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        vr[r] *= dinv;
+        vi[r] *= dinv;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         sXr[buf][(kq + 4 * r) * 17 + x] = vr[r];
@@ -1006,16 +1021,23 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
   int* status = reinterpret_cast<int*>(base + db + pb + 6 * tb + ib);
   double* dstat = reinterpret_cast<double*>(base + db + pb + 6 * tb + ib + sb);
   const double* racc = nullptr;
+  static const int chol12_var = [] {     // development switch: which Cholesky kernel takes 161 - 192 columns
+    const char* e = getenv("MPSE_CQ_CHOL12");
+    return e ? atoi(e) : 0;
+  }();
   for (int pass = 1; pass <= 3; ++pass) {
     double* Rcur = Rb[pass - 1];
     hipLaunchKernelGGL((k_cq_gram<CPLX>), dim3(max_gram, nblk), dim3(256), 0, ctx->stream, (const double*)ws, part, dblk,
                        status, pass == 1 ? nblk + 1 : 0);
     hipLaunchKernelGGL((k_cq_reduce<CPLX>), dim3(max_T, nblk), dim3(256), 0, ctx->stream, (const double*)part, G, tinfo, dblk);
     if (max_P <= 10)
-      hipLaunchKernelGGL((k_cq_chol_rl<CPLX, 7, false>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G,
+      hipLaunchKernelGGL((k_cq_chol_rl<CPLX, 8, 7, false>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G,
                          (const double*)tinfo, Rcur, dblk, status, pass);
-    else if (max_P <= 12)
-      hipLaunchKernelGGL((k_cq_chol_rl<CPLX, 10, true>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G,
+    else if (max_P <= 12 && chol12_var == 0)
+      hipLaunchKernelGGL((k_cq_chol_rl<CPLX, 8, 10, true>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G,
+                         (const double*)tinfo, Rcur, dblk, status, pass);
+    else if (max_P <= 12 && chol12_var == 1)
+      hipLaunchKernelGGL((k_cq_chol_rl<CPLX, 16, 5, true>), dim3(nblk), dim3(1024), 0, ctx->stream, (const double*)G,
                          (const double*)tinfo, Rcur, dblk, status, pass);
     else
       hipLaunchKernelGGL((k_cq_chol<CPLX>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G, (const double*)tinfo,
@@ -1050,21 +1072,29 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
 
 }  // namespace
 
-// Eligible: every block at least as tall as wide (k = nn), at most 256 columns, and the call large enough for the
-// twelve launches to pay (the Householder chain of a small block is shorter).  MPSE_CHOLQR=0 switches the path off.
+// Eligible: every block at least as tall as wide (k = nn), at most 256 columns, and the tallest block tall enough for the
+// scheme to win: its cost is ~14 launches whose Cholesky / triangular-solve chains depend on the COLUMN count only
+// (0.30 - 0.50 ms at 100 - 180 columns), the Householder chain grows with the rows (0.32 ms at 256 rows, 0.78 ms at
+// 2 800: tools/qr_bench.py, profiles/r05_qr_cholqr.md).  MPSE_CHOLQR=0 switches the path off, MPSE_CHOLQR=2 takes every
+// eligible shape (tests); MPSE_CHOLQR_MINROWS moves the row threshold.
 bool cholqr_eligible(const QrBlk* blks, int nblk) {
   static const int mode = [] {
     const char* e = getenv("MPSE_CHOLQR");
     return e ? atoi(e) : 1;
   }();
+  static const int min_rows = [] {
+    const char* e = getenv("MPSE_CHOLQR_MINROWS");
+    return e ? atoi(e) : 1024;
+  }();
   if (mode == 0 || nblk <= 0) return false;
-  long long work = 0;
+  int max_mm = 0, max_nn = 0;
   for (int b = 0; b < nblk; ++b) {
     if (blks[b].mm < blks[b].nn || blks[b].k != blks[b].nn || blks[b].nn > 256) return false;
-    work += (long long)blks[b].mm * blks[b].nn * blks[b].nn;
+    max_mm = std::max(max_mm, blks[b].mm);
+    max_nn = std::max(max_nn, blks[b].nn);
   }
-  const long long floor_work = mode >= 2 ? 0 : 64LL * 64 * 64 * 8;   // MPSE_CHOLQR=2: every eligible shape (tests)
-  return work >= floor_work;
+  if (mode >= 2) return true;
+  return max_mm >= min_rows && max_nn >= 32;
 }
 
 int cholqr_blocks(mpse_ctx* ctx, bool cplx, double* ws, const QrBlk* blks, int nblk, const long long* drows,

@@ -99,10 +99,18 @@ def test_headline_five_evolves_conserve(headline):
     model, mpo, mps, _ = headline
     e0 = mps.expectation(mpo)
     dims0 = list(mps.bond_dims)
+    # the prepared benchmark state is pinned (tests/golden/headline_state_pin.npz, written by
+    # tools/make_headline_state_pin.py from this engine): a change in expand_bond_dimension / the block SVD that makes
+    # the local problems easier or harder moves bench.py's figure - it has to fail here first
+    pin = np.load(os.path.join(REPO, "tests", "golden", "headline_state_pin.npz"))
+    assert abs(mps.evolve_config.stat["mean"] - float(pin["mean_krylov"][0])) < 0.15, mps.evolve_config.stat["mean"]
+    assert np.abs(np.asarray(mps.e_occupations) - pin["occ"][0]).max() < 1e-6
     cur = mps
     for step in range(5):
         cur = cur.evolve(mpo, 10.0)
         occ = np.asarray(cur.e_occupations)
+        assert np.abs(occ - pin["occ"][step + 1]).max() < 1e-6, (step, np.abs(occ - pin["occ"][step + 1]).max())
+        assert abs(cur.evolve_config.stat["mean"] - float(pin["mean_krylov"][step + 1])) < 0.15
         assert abs(occ.sum() - 1.0) < 1e-9, (step, occ.sum())
         assert occ.min() > -1e-12
         assert abs(cur.mp_norm - 1.0) < 1e-11, (step, cur.mp_norm)

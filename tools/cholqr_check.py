@@ -90,6 +90,8 @@ def main():
             ("real d2", 256, 256, 160, 96, 1e3, False, "R"),
             ("one block 4096x256", 4096, 0, 256, 0, 1e4, True, "L"),
             ("odd sizes", 1001, 333, 77, 19, 1e8, True, "L"),
+            ("d16 site, 182 + 74 columns", 2608, 1488, 182, 74, 1e7, True, "L"),
+            ("d2 site, 182 + 74 columns", 256, 256, 182, 74, 1e7, True, "L"),
             ("tiny n", 300, 200, 5, 1, 10, True, "L"),
             ("well conditioned (first-order pass 3)", 2816, 1280, 145, 111, 3, True, "L"),
             ("rank deficient", 2816, 1280, 145, 111, 1e3, True, "L"),
