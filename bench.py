@@ -207,6 +207,13 @@ def step_work(steps, to_right_first, bond_dims, pdims, wdims):
     return matvecs, flops
 
 
+def _redone():
+    """evolve steps (whole run, warm-up included) the optimistic block QR discarded and repeated on verified
+    decompositions (mps/mps.py::_evolve_tdvp_ps)"""
+    from renormalizer_amd.mps import mps as _m
+    return _m._OPTIMISTIC_REDONE[0]
+
+
 def spawn_ranks(n):
     """``python bench.py --gpus N`` without a launcher: start the N ranks here (one process per GPU, LOCAL_RANK = i, a
     free MASTER_PORT, a launch id that keys their rendezvous), relay rank 0's JSON line, and return non-zero if any
@@ -529,7 +536,8 @@ def main():
                        # block QR / RQ decompositions of the timed steps: how many went through the Cholesky-QR kernels
                        # (tall blocks) and how many of those a device flag sent back to the Householder kernels
                        "block_qr": dict(zip(("calls", "cholesky_qr", "redone_by_householder"),
-                                            [int(sum(r["qr"][k] for r in results)) for k in range(3)])),
+                                            [int(sum(r["qr"][k] for r in results)) for k in range(3)]),
+                                        steps_repeated_after_breakdown=int(_redone())),
                        "bond_dims": [int(d) for d in mps.bond_dims],
                        "environments": ("rebuilt at every step (MPSE_ENV_CARRY=0)" if os.environ.get("MPSE_ENV_CARRY") == "0"
                                         else "those ahead of the first half sweep are taken over from the previous step "

@@ -316,6 +316,16 @@ int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int6
  * be NULL. */
 int mpse_block_qr_stats(mpse_ctx* ctx, int64_t* calls, int64_t* chol_calls, int64_t* chol_fallbacks);
 
+/* Optimistic mode of the Cholesky-QR path, for callers that can repeat a whole step (the TDVP-PS sweep, whose input
+ * state stays untouched until the step returns): while it is on, mpse_block_qr does not read the breakdown flag back
+ * after each decomposition - the read-back stalls the host exactly where it should be enqueueing the next local solve -
+ * a breakdown raises a sticky device word instead and the results of that decomposition are NOT an isometry.
+ * mpse_block_qr_check (synchronous) says whether any decomposition since the mode was switched on broke down: the caller
+ * then discards the step and repeats it with the mode off (every decomposition verified, Householder where needed).
+ * Switching the mode on clears the word.  No reference counterpart. */
+int mpse_block_qr_optimistic(mpse_ctx* ctx, int on);
+int mpse_block_qr_check(mpse_ctx* ctx, int* tripped);
+
 /* Quantum-number blocked economic SVD by one-sided Jacobi, replaces mps/svd_qn.py:99-240
  * with QR=False, full_matrices=False (scipy.linalg.svd gesdd per block).  Same block
  * description; outputs U (nrow x K), Vt (K x ncol) (block order, NOT globally sorted) and

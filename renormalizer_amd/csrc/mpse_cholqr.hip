@@ -259,6 +259,87 @@ __global__ __launch_bounds__(256) void k_cq_reduce(const double* __restrict__ pa
   }
 }
 
+// Row panel p of the factor from the Schur-complement tiles S(p, p .. P-1) (16 rows x W = 16 (P - p) columns in LDS,
+// tile 0 = the diagonal tile): the Cholesky elimination of the diagonal tile applied to the WHOLE panel, one thread per
+// column with its 16 rows in registers.  Step k: every column subtracts conj(s_ki) s_kj / s_kk from its rows i > k;
+// what the step needs from other columns is row k of the diagonal tile alone, which the 16 threads of that tile
+// publish in place one step ahead.  After 15 steps row i holds S_i(final); R(p, :) = rows scaled by 1 / sqrt(s_ii).
+// This replaces "factor the diagonal tile on one wave, then forward-substitute the other tiles" (4.4 + 2.5 us per panel,
+// measured by switching the phases off: a dependent chain of FP64 operations on a single wave) by 15 short steps on
+// all columns at once.  Called by every thread of the workgroup (the barriers are workgroup barriers); threads past
+// the panel width only keep the barriers.  Pivots are checked at the end: status |= 1 (through *bad).
+template <bool CPLX>
+__device__ __forceinline__ void panel_eliminate(double2 (*tiles)[256], int W, int p, int P, int nn_unused, double* Rt,
+                                                double* sDinv, int pass, int tid, int* bad) {
+  (void)nn_unused;
+  constexpr int E = CPLX ? 2 : 1;
+  const bool act = tid < W;
+  const int ct = tid >> 4, col = tid & 15;
+  double cr[16], ci[16];
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const double2 v = tiles[ct][i * 16 + col];
+      cr[i] = v.x;
+      ci[i] = v.y;
+    }
+  }
+  auto step = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    if (act) {
+      const double inv = fast_rcp(tiles[0][k * 16 + k].x);     // (a bad pivot makes garbage here; flagged below)
+      const double tr = cr[k] * inv, ti = ci[k] * inv;
+#pragma unroll
+      for (int i = k + 1; i < 16; ++i) {
+        const double2 e = tiles[0][k * 16 + i];   // s(k, i); rows i > k lose conj(s_ki) s_kj / s_kk
+        cr[i] -= e.x * tr + e.y * ti;
+        if constexpr (CPLX) ci[i] -= e.x * ti - e.y * tr;
+      }
+      if (ct == 0) tiles[0][(k + 1) * 16 + col] = make_double2(cr[k + 1], ci[k + 1]);
+    }
+    lds_barrier();
+  };
+  step(std::integral_constant<int, 0>{});
+  step(std::integral_constant<int, 1>{});
+  step(std::integral_constant<int, 2>{});
+  step(std::integral_constant<int, 3>{});
+  step(std::integral_constant<int, 4>{});
+  step(std::integral_constant<int, 5>{});
+  step(std::integral_constant<int, 6>{});
+  step(std::integral_constant<int, 7>{});
+  step(std::integral_constant<int, 8>{});
+  step(std::integral_constant<int, 9>{});
+  step(std::integral_constant<int, 10>{});
+  step(std::integral_constant<int, 11>{});
+  step(std::integral_constant<int, 12>{});
+  step(std::integral_constant<int, 13>{});
+  step(std::integral_constant<int, 14>{});
+  // pivots s_ii (row i as published): checks and 1 / sqrt
+  if (tid < 16) {
+    double d = tiles[0][tid * 16 + tid].x;
+    bool ok = d > 0.0 && d < 1e300;
+    if (pass == 3 && !(d >= 0.25 && d <= 4.0)) ok = false;
+    if (!(d > 0.0 && d < 1e300)) d = 1.0;
+    if (!ok) *bad = 1;
+    sDinv[tid] = fast_rsqrt(d);
+  }
+  lds_barrier();
+  if (act) {
+    double* td = Rt + (long long)tile_index(p, p + ct, P) * 256 * E;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const double rs = sDinv[i];
+      double vr = cr[i] * rs, vi = ci[i] * rs;
+      if (ct == 0) {
+        if (i > col) vr = vi = 0.0;
+        if (i == col) vi = 0.0;
+      }
+      tiles[ct][i * 16 + col] = make_double2(vr, vi);
+      st2<CPLX>(td, i * 16 + col, vr, vi);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------ Cholesky
 // One workgroup (8 waves) per block: R^H R = G (+ shift), R upper triangular, stored as 16 x 16 tiles (q <= c), row
 // major inside a tile.  Left-looking by row panels: S(p, c) = G(p, c) - sum_{q<p} R(q, p)^H R(q, c) on MFMA with the
@@ -269,7 +350,7 @@ __global__ __launch_bounds__(256) void k_cq_reduce(const double* __restrict__ pa
 template <bool CPLX>
 __global__ __launch_bounds__(512) void k_cq_chol(const double* __restrict__ G, const double* __restrict__ tinfo,
                                                   double* __restrict__ R, const CqBlk* __restrict__ blks,
-                                                  int* __restrict__ status, int pass) {
+                                                  int* __restrict__ status, int pass, int* __restrict__ gflag) {
   constexpr int E = CPLX ? 2 : 1;
   const CqBlk B = blks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15, kq = lane >> 4;
@@ -277,7 +358,6 @@ __global__ __launch_bounds__(512) void k_cq_chol(const double* __restrict__ G, c
   const double* Gt = G + B.t_off * 256 * E;
   double* Rt = R + B.t_off * 256 * E;
   __shared__ double2 sS[16][256];
-  __shared__ double2 sRpp[256];
   __shared__ double sDinv[16];
   __shared__ double s_red[2][512];
   // trace and max |G - I| of the block (fixed order)
@@ -370,74 +450,18 @@ __global__ __launch_bounds__(512) void k_cq_chol(const double* __restrict__ G, c
       for (int r = 0; r < 4; ++r) sS[c - p][(kq + 4 * r) * 16 + x] = make_double2(ar[r], ai[r]);
     }
     __syncthreads();
-    // ---- diagonal tile: Cholesky in registers, lane j (of every 16-lane row of wave 0) holds column j
-    if (wave == 0) {
-      double cr[16], ci[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const double2 v = sS[0][i * 16 + x];
-        cr[i] = v.x;
-        ci[i] = v.y;
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        double dkk = readlane_d(cr[k], k);
-        bool ok = dkk > 0.0 && dkk < 1e300;
-        if (pass == 3 && !(dkk >= 0.25 && dkk <= 4.0)) ok = false;
-        if (!(dkk > 0.0 && dkk < 1e300)) dkk = 1.0;
-        if (!ok) bad = 1;
-        const double rs = fast_rsqrt(dkk);
-        const double rkr = x >= k ? cr[k] * rs : 0.0;
-        const double rki = x > k ? ci[k] * rs : 0.0;
-        cr[k] = rkr;
-        ci[k] = rki;
-#pragma unroll
-        for (int i = k + 1; i < 16; ++i) {
-          const double er = readlane_d(rkr, i), ei = CPLX ? readlane_d(rki, i) : 0.0;   // r(k, i)
-          cr[i] -= er * rkr + ei * rki;
-          if constexpr (CPLX) ci[i] -= er * rki - ei * rkr;
-        }
-      }
-      if (lane < 16) {
-        double* td = Rt + (long long)tile_index(p, p, P) * 256 * E;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const double vr = i <= x ? cr[i] : 0.0, vi = i <= x ? ci[i] : 0.0;
-          sRpp[i * 16 + x] = make_double2(vr, vi);
-          st2<CPLX>(td, i * 16 + x, vr, vi);
-        }
-        double dj = cr[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) dj = x == i ? cr[i] : dj;
-        sDinv[x] = fast_rcp(dj);
-      }
-    }
-    __syncthreads();
-    // ---- rest of the row panel: R(p, c) = Rpp^-H S(p, c), one thread per column
-    const int nrest = 16 * (P - p - 1);
-    if (tid < nrest) {
-      const int ct = 1 + (tid >> 4), col = tid & 15;
-      double xr[16], xi[16];
-      double* td = Rt + (long long)tile_index(p, p + ct, P) * 256 * E;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const double2 s0 = sS[ct][i * 16 + col];
-        double sr = s0.x, si = s0.y;
-#pragma unroll
-        for (int t = 0; t < i; ++t) {
-          const double2 rt = sRpp[t * 16 + i];   // conj(r) x = (rr xr + ri xi) + i (rr xi - ri xr)
-          sr -= rt.x * xr[t] + rt.y * xi[t];
-          if constexpr (CPLX) si -= rt.x * xi[t] - rt.y * xr[t];
-        }
-        const double d = sDinv[i];
-        xr[i] = sr * d;
-        xi[i] = si * d;
-        st2<CPLX>(td, i * 16 + col, xr[i], xi[i]);
-      }
+    // ---- the row panel of the factor (diagonal factor + forward substitution in one elimination, see panel_eliminate)
+    {
+      int badp = 0;
+      panel_eliminate<CPLX>(sS, 16 * (P - p), p, P, nn, Rt, sDinv, pass, tid, &badp);
+      if (badp) bad = 1;
     }
     __syncthreads();   // the tiles of row panel p are visible to the MFMA loads of the next panels
   }
-  if (bad && lane == 0 && wave == 0) atomicOr(status, 1);
+  if (bad) {
+    atomicOr(status, 1);
+    if (gflag) atomicOr(gflag, 1);   // optimistic mode: the context's sticky flag, read at the end of the sweep
+  }
 }
 
 // Right-looking form for blocks of up to 192 columns (P <= 12, T <= 78): every tile of the trailing matrix lives in
@@ -450,7 +474,7 @@ __global__ __launch_bounds__(512) void k_cq_chol(const double* __restrict__ G, c
 template <bool CPLX, int NW, int NS, bool XLDS>
 __global__ __launch_bounds__(64 * NW) void k_cq_chol_rl(const double* __restrict__ G, const double* __restrict__ tinfo,
                                                      double* __restrict__ R, const CqBlk* __restrict__ blks,
-                                                     int* __restrict__ status, int pass) {
+                                                     int* __restrict__ status, int pass, int dbg, int* __restrict__ gflag) {
   constexpr int E = CPLX ? 2 : 1, PMAX = 12, NT = 64 * NW;
   const CqBlk B = blks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15, kq = lane >> 4;
@@ -458,7 +482,6 @@ __global__ __launch_bounds__(64 * NW) void k_cq_chol_rl(const double* __restrict
   const double* Gt = G + B.t_off * 256 * E;
   double* Rt = R + B.t_off * 256 * E;
   __shared__ double2 sRow[2][PMAX][256];
-  __shared__ double2 sRpp[256];
   __shared__ double sDinv[16];
   double* s_red = reinterpret_cast<double*>(&sRow[0][0][0]);   // scratch of the reductions before the loop
   {
@@ -540,129 +563,17 @@ __global__ __launch_bounds__(64 * NW) void k_cq_chol_rl(const double* __restrict
         for (int r = 0; r < 4; ++r) sRow[buf][tc[s] - p][(kq + 4 * r) * 16 + x] = make_double2(ar[s][r], ai[s][r]);
       }
     __syncthreads();
-    // ---- diagonal tile: one wave, lane (g, j) holds rows 4g .. 4g + 3 of column j.  Block step b: the four pivot rows
-    // live in lane group b, their mutual updates go through DPP row broadcasts (no memory); the finished rows reach the
-    // groups below through LDS (one wave: program order, no barrier) - three exchanges per tile instead of fifteen
-    if (wave == 0) {
-      double cr[4], ci[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const double2 v = sRow[buf][0][(4 * kq + m) * 16 + x];
-        cr[m] = v.x;
-        ci[m] = v.y;
-      }
-      auto blockstep = [&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        // pivots of the block as scalars, for the checks (the values the group-b lanes hold when their turn comes are
-        // read inside the divergent region below)
-        if (kq == b) {
-          auto mini = [&](auto mc) {
-            constexpr int m = decltype(mc)::value, k = 4 * b + m;
-            double dkk = row_share<k>(cr[m]);
-            const bool ok = dkk > 0.0 && dkk < 1e300 && !(pass == 3 && !(dkk >= 0.25 && dkk <= 4.0));
-            if (!(dkk > 0.0 && dkk < 1e300)) dkk = 1.0;
-            if (!ok) bad = 1;
-            const double rs = fast_rsqrt(dkk);
-            const double rkr = x >= k ? cr[m] * rs : 0.0;
-            const double rki = x > k ? ci[m] * rs : 0.0;
-            cr[m] = rkr;
-            ci[m] = rki;
-            if (x == k) sDinv[k] = rs;
-#pragma unroll
-            for (int m2 = m + 1; m2 < 4; ++m2) {
-              double er, ei;
-              // r(k, 4b + m2): the value lane 4b + m2 of this row holds
-              if (m2 == 1) { er = row_share<4 * b + 1>(rkr); ei = CPLX ? row_share<4 * b + 1>(rki) : 0.0; }
-              else if (m2 == 2) { er = row_share<4 * b + 2>(rkr); ei = CPLX ? row_share<4 * b + 2>(rki) : 0.0; }
-              else { er = row_share<4 * b + 3>(rkr); ei = CPLX ? row_share<4 * b + 3>(rki) : 0.0; }
-              cr[m2] -= er * rkr + ei * rki;
-              if constexpr (CPLX) ci[m2] -= er * rki - ei * rkr;
-            }
-            sRpp[k * 16 + x] = make_double2(rkr, rki);
-          };
-          mini(std::integral_constant<int, 0>{});
-          mini(std::integral_constant<int, 1>{});
-          mini(std::integral_constant<int, 2>{});
-          mini(std::integral_constant<int, 3>{});
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (b < 3) {
-          if (kq > b) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-              const int k = 4 * b + m;
-              const double2 rj = sRpp[k * 16 + x];
-#pragma unroll
-              for (int m2 = 0; m2 < 4; ++m2) {
-                const double2 e = sRpp[k * 16 + 4 * kq + m2];   // r(k, i), i = this lane's row
-                cr[m2] -= e.x * rj.x + e.y * rj.y;
-                if constexpr (CPLX) ci[m2] -= e.x * rj.y - e.y * rj.x;
-              }
-            }
-          }
-        }
-      };
-      blockstep(std::integral_constant<int, 0>{});
-      blockstep(std::integral_constant<int, 1>{});
-      blockstep(std::integral_constant<int, 2>{});
-      blockstep(std::integral_constant<int, 3>{});
-      bad = __any(bad) ? 1 : bad;
-      double* td = Rt + (long long)tile_index(p, p, P) * 256 * E;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int i = 4 * kq + m;
-        st2<CPLX>(td, i * 16 + x, i <= x ? cr[m] : 0.0, i <= x ? ci[m] : 0.0);
-      }
-    }
-    __syncthreads();
-    // ---- rest of the row panel: R(p, c) = Rpp^-H S(p, c), one thread per column, in place in LDS
-    const int nrest = 16 * (P - p - 1);
-    if (tid < nrest) {
-      const int ct = 1 + (tid >> 4), col = tid & 15;
-      double* td = Rt + (long long)tile_index(p, p + ct, P) * 256 * E;
-      if constexpr (XLDS) {
-#pragma unroll 1
-        for (int i = 0; i < 16; ++i) {     // (rolled: nothing here needs static register indices, and unrolled the
-          const double2 s0 = sRow[buf][ct][i * 16 + col];   // hoisted LDS reads pushed the accumulators out of registers)
-          double sr = s0.x, si = s0.y;
-#pragma unroll 2
-          for (int t = 0; t < i; ++t) {
-            const double2 rt = sRpp[t * 16 + i], xt = sRow[buf][ct][t * 16 + col];
-            sr -= rt.x * xt.x + rt.y * xt.y;
-            if constexpr (CPLX) si -= rt.x * xt.y - rt.y * xt.x;
-          }
-          const double d = sDinv[i];
-          sRow[buf][ct][i * 16 + col] = make_double2(sr * d, si * d);
-          st2<CPLX>(td, i * 16 + col, sr * d, si * d);
-        }
-      } else {
-        double xr[16], xi[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const double2 s0 = sRow[buf][ct][i * 16 + col];
-          double sr = s0.x, si = s0.y;
-#pragma unroll
-          for (int t = 0; t < i; ++t) {
-            const double2 rt = sRpp[t * 16 + i];
-            sr -= rt.x * xr[t] + rt.y * xi[t];
-            if constexpr (CPLX) si -= rt.x * xi[t] - rt.y * xr[t];
-          }
-          const double d = sDinv[i];
-          xr[i] = sr * d;
-          xi[i] = si * d;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          sRow[buf][ct][i * 16 + col] = make_double2(xr[i], xi[i]);
-          st2<CPLX>(td, i * 16 + col, xr[i], xi[i]);
-        }
-      }
+    // ---- the row panel of the factor (diagonal factor + forward substitution in one elimination, see panel_eliminate)
+    if (!(dbg & 1)) {
+      int badp = 0;
+      panel_eliminate<CPLX>(sRow[buf], 16 * (P - p), p, P, nn, Rt, sDinv, pass, tid, &badp);
+      if (badp) bad = 1;
     }
     __syncthreads();
     // ---- updates: S(q, c) -= R(p, q)^H R(p, c) for this wave's tiles below the panel
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-      if (tq[s] > p) {
+      if (tq[s] > p && !(dbg & 4)) {
         const double2* ta = sRow[buf][tq[s] - p];
         const double2* tb = sRow[buf][tc[s] - p];
 #pragma unroll
@@ -677,7 +588,10 @@ __global__ __launch_bounds__(64 * NW) void k_cq_chol_rl(const double* __restrict
         }
       }
   }
-  if (bad && lane == 0 && wave == 0) atomicOr(status, 1);
+  if (bad) {
+    atomicOr(status, 1);
+    if (gflag) atomicOr(gflag, 1);   // optimistic mode: the context's sticky flag, read at the end of the sweep
+  }
 }
 
 // --------------------------------------------------------------------------------------- triangular solve + R product
@@ -961,6 +875,9 @@ __global__ void k_cq_scatter(double* U, double* Vt, const double* __restrict__ w
 template <bool CPLX>
 int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const long long* drows, const long long* dcols,
                int herm, void* U, void* Vt, long long K, long long ncol, bool* ok) {
+  // optimistic mode (mpse_block_qr_optimistic): no read-back here - a breakdown sets the context's sticky device flag,
+  // which the caller of the sweep reads once at its end (and then repeats the step on the Householder kernels)
+  int* gflag = ctx->qr_optimistic ? ctx->qr_flag_dev : nullptr;
   constexpr size_t es = CPLX ? 16 : 8;
   std::vector<CqBlk> cb(nblk);
   long long part_tot = 0, t_tot = 0;
@@ -1021,9 +938,13 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
   int* status = reinterpret_cast<int*>(base + db + pb + 6 * tb + ib);
   double* dstat = reinterpret_cast<double*>(base + db + pb + 6 * tb + ib + sb);
   const double* racc = nullptr;
+  static const int cq_dbg = [] {         // development: skip phases of the Cholesky kernel (wrong results, timings only)
+    const char* e = getenv("MPSE_CQ_DBG");
+    return e ? atoi(e) : 0;
+  }();
   static const int chol12_var = [] {     // development switch: which Cholesky kernel takes 161 - 192 columns
     const char* e = getenv("MPSE_CQ_CHOL12");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 2;      // (2: the left-looking kernel - the ten-slot right-looking one spills)
   }();
   for (int pass = 1; pass <= 3; ++pass) {
     double* Rcur = Rb[pass - 1];
@@ -1032,16 +953,16 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
     hipLaunchKernelGGL((k_cq_reduce<CPLX>), dim3(max_T, nblk), dim3(256), 0, ctx->stream, (const double*)part, G, tinfo, dblk);
     if (max_P <= 10)
       hipLaunchKernelGGL((k_cq_chol_rl<CPLX, 8, 7, false>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G,
-                         (const double*)tinfo, Rcur, dblk, status, pass);
+                         (const double*)tinfo, Rcur, dblk, status, pass, cq_dbg, gflag);
     else if (max_P <= 12 && chol12_var == 0)
       hipLaunchKernelGGL((k_cq_chol_rl<CPLX, 8, 10, true>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G,
-                         (const double*)tinfo, Rcur, dblk, status, pass);
+                         (const double*)tinfo, Rcur, dblk, status, pass, cq_dbg, gflag);
     else if (max_P <= 12 && chol12_var == 1)
       hipLaunchKernelGGL((k_cq_chol_rl<CPLX, 16, 5, true>), dim3(nblk), dim3(1024), 0, ctx->stream, (const double*)G,
-                         (const double*)tinfo, Rcur, dblk, status, pass);
+                         (const double*)tinfo, Rcur, dblk, status, pass, cq_dbg, gflag);
     else
       hipLaunchKernelGGL((k_cq_chol<CPLX>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G, (const double*)tinfo,
-                         Rcur, dblk, status, pass);
+                         Rcur, dblk, status, pass, gflag);
     double* Rout = pass == 2 ? Rb[3] : Rb[4];
     const int rmul = pass >= 2 ? 1 : 0;
     static const int trsm_var = [] {
@@ -1065,6 +986,10 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
   hipLaunchKernelGGL((k_cq_scatter<CPLX>), dim3(nb, nblk), dim3(256), 0, ctx->stream, (double*)U, (double*)Vt, (const double*)ws,
                      racc, K, ncol, drows, dcols, dblk, herm, (const int*)status, dstat);
   MPSE_HIP(ctx, hipGetLastError());
+  if (gflag) {
+    *ok = true;
+    return MPSE_OK;
+  }
   MPSE_TRY(publish_and_wait(ctx, dstat, 1, 3990));
   *ok = ctx->pinned[3990] == 0.0;
   return MPSE_OK;

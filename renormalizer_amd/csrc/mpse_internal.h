@@ -160,6 +160,10 @@ struct mpse_ctx {
   bool small_rt_scope = false;   // a solver without occupancy caches (Davidson) keeps the transposed copy as well
   // mpse_block_qr: decompositions that took the Cholesky-QR path / that fell back from it to Householder
   long long qr_chol_calls = 0, qr_chol_fallbacks = 0, qr_calls = 0;
+  // optimistic mode of the Cholesky-QR path (mpse_block_qr_optimistic): breakdowns raise this sticky device word
+  // instead of being read back per decomposition
+  bool qr_optimistic = false;
+  int* qr_flag_dev = nullptr;
 };
 
 int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...);

@@ -438,6 +438,32 @@ int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int6
   return mpse_fail(ctx, MPSE_ERR_ARG, "block_qr: unknown dtype");
 }
 
+int mpse_block_qr_optimistic(mpse_ctx* ctx, int on) {
+  if (!ctx) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
+  if (on) {
+    if (!ctx->qr_flag_dev) {
+      void* p = nullptr;
+      MPSE_TRY(mpse_malloc(ctx, 16, &p));
+      ctx->qr_flag_dev = static_cast<int*>(p);
+    }
+    MPSE_TRY(device_zero(ctx, ctx->qr_flag_dev, 16));
+  }
+  ctx->qr_optimistic = on != 0;
+  return MPSE_OK;
+}
+
+int mpse_block_qr_check(mpse_ctx* ctx, int* tripped) {
+  if (!ctx || !tripped) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
+  *tripped = 0;
+  if (!ctx->qr_flag_dev) return MPSE_OK;
+  int v[4] = {0, 0, 0, 0};
+  MPSE_TRY(mpse_memcpy_d2h(ctx, v, ctx->qr_flag_dev, 16));
+  *tripped = v[0] != 0;
+  return MPSE_OK;
+}
+
 int mpse_block_qr_stats(mpse_ctx* ctx, int64_t* calls, int64_t* chol_calls, int64_t* chol_fallbacks) {
   if (!ctx) return MPSE_ERR_ARG;
   if (calls) *calls = ctx->qr_calls;

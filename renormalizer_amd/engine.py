@@ -92,6 +92,8 @@ _SIGNATURES = {
     "mpse_prof_get_svd_sweeps": [C.c_void_p, C.POINTER(C.c_int64)],
     "mpse_mpo_site_hint": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64],
     "mpse_block_qr_stats": [C.c_void_p] + [C.POINTER(C.c_int64)] * 3,
+    "mpse_block_qr_optimistic": [C.c_void_p, C.c_int],
+    "mpse_block_qr_check": [C.c_void_p, C.POINTER(C.c_int)],
     "mpse_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
     "mpse_free": [C.c_void_p, C.c_void_p],
     "mpse_pool_trim": [C.c_void_p],
@@ -444,6 +446,16 @@ class Engine:
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self.lib.mpse_block_qr_stats(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def block_qr_optimistic(self, on):
+        """Optimistic mode of the Cholesky-QR path (``mpse_block_qr_optimistic``): breakdowns are not read back per
+        decomposition but raise a sticky flag - ``block_qr_check()`` at the end of a step that can be repeated."""
+        self._check(self.lib.mpse_block_qr_optimistic(self.ctx, int(bool(on))))
+
+    def block_qr_check(self):
+        v = C.c_int(0)
+        self._check(self.lib.mpse_block_qr_check(self.ctx, C.byref(v)))
+        return bool(v.value)
 
     def prof_get(self):
         """{variant: dict(ms, flops, bytes, launches)} for the contraction kernel variants."""

@@ -13,7 +13,7 @@ from typing import Dict, List
 
 import numpy as np
 
-from ..engine import DeviceTensor, get_engine
+from ..engine import DeviceTensor, EngineError, get_engine
 from ..lib.krylov import expm_krylov
 from ..model import Model, Op, OpSum
 from ..utils import CompressConfig, CompressCriteria, EvolveConfig, EvolveMethod, OptimizeConfig
@@ -1291,6 +1291,36 @@ class Mps:
         return new_mps
 
     def _evolve_tdvp_ps(self, mpo, evolve_dt) -> "Mps":
+        """One-site TDVP with projector splitting (see ``_evolve_tdvp_ps_sweeps``).  The block QR of tall centres runs
+        through the engine's Cholesky-QR kernels, which cannot decide rank-deficient / extremely ill-conditioned blocks
+        (the 1e-10 padding of ``expand_bond_dimension`` in the first steps of a run); reading their breakdown flag
+        back after every decomposition would stall the host exactly where it should be enqueueing the next local solve
+        (measured: ~80 us of idle GPU per decomposition).  The step is therefore run OPTIMISTICALLY: the flag is a sticky
+        device word read once at the end, and a step in which any decomposition broke down is discarded and repeated
+        with every decomposition verified (Householder where needed) - ``self`` is untouched until the step returns.
+        ``MPSE_QR_OPTIMISTIC=0``: verify every decomposition as it happens."""
+        eng = get_engine()
+        if os.environ.get("MPSE_QR_OPTIMISTIC", "1") == "0" or os.environ.get("MPSE_DEFER", "1") == "0":
+            return self._evolve_tdvp_ps_sweeps(mpo, evolve_dt)
+        eng.block_qr_optimistic(True)
+        try:
+            new = self._evolve_tdvp_ps_sweeps(mpo, evolve_dt)
+            failed = eng.block_qr_check()
+        except (EngineError, ArithmeticError, ValueError, np.linalg.LinAlgError):
+            # a decomposition that broke down leaves something that is not an isometry: what follows may fail in many
+            # ways - only if the flag is up is the failure the optimistic mode's own
+            if not eng.block_qr_check():
+                raise
+            failed = True
+        finally:
+            eng.block_qr_optimistic(False)
+        if failed:
+            clear_evolve_cache()
+            _OPTIMISTIC_REDONE[0] += 1
+            new = self._evolve_tdvp_ps_sweeps(mpo, evolve_dt)
+        return new
+
+    def _evolve_tdvp_ps_sweeps(self, mpo, evolve_dt) -> "Mps":
         """One-site TDVP with projector splitting, PhysRevB 94, 165116; order of operations of
         mps/mps.py:1267-1404: two half sweeps; per site a forward step -i dt/2 of the centre
         tensor (Lanczos), QR/RQ by quantum-number block, one environment update, a backward
@@ -1430,6 +1460,9 @@ class Mps:
         _carry_environ(mps, mpo, environ)
         return mps
 
+
+# steps the optimistic block QR had to repeat (diagnostics; bench.py reports it)
+_OPTIMISTIC_REDONE = [0]
 
 # One slot per host thread (= per trajectory): the environments ahead of the next half sweep, as the last TDVP-PS step
 # left them, with the objects they were computed from.  Bounded: a new step replaces the slot.
