@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRCS="mpse_core.hip mpse_gemm.hip mpse_contract.hip mpse_small.hip mpse_vec.hip mpse_qr.hip mpse_qr2.hip mpse_cholqr.hip mpse_svd.hip mpse_davidson.hip"
+SRCS="mpse_core.hip mpse_gemm.hip mpse_contract.hip mpse_small.hip mpse_heff0.hip mpse_vec.hip mpse_qr.hip mpse_qr2.hip mpse_cholqr.hip mpse_svd.hip mpse_davidson.hip"
 OBJS=""
 PIDS=""
 for s in $SRCS; do

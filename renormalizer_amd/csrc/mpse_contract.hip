@@ -494,6 +494,8 @@ extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, con
     bool taken = false;
     MPSE_TRY(heff_small_try(ctx, dtype, h, C, out, &taken));
     if (taken) return MPSE_OK;     // (pr.used is set there: the result may be a sum of parts)
+    MPSE_TRY(heff0_fused_try(ctx, dtype, h, C, &taken));
+    if (taken) return MPSE_OK;     // (tile-masked parts: pr.used, pr.mask)
   }
   const bool two_ok = pr.ptr != nullptr && pr.cap_elems >= 2 * pr.n;
   Plan p = plan_heff(dtype, *h, static_cast<const WSiteInfo*>(wi_keep.get()), two_ok);

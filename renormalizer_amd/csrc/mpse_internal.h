@@ -121,6 +121,12 @@ struct mpse_ctx {
     void* ptr = nullptr;
     long long cap_elems = 0, n = 0;
     int used = 0;
+    // The caller can also take parts that hold only SOME 16 x 16 tiles of the result (mpse_heff0.hip): the callee then
+    // sets `mask` (device; one 64-bit word per tile of the result viewed as a matrix with rows of mask_row elements,
+    // mask_tiles tiles per tile row: bit s = part s holds the tile) and the consumer adds exactly the parts named there
+    bool masked_ok = false;
+    const unsigned long long* mask = nullptr;
+    int mask_row = 0, mask_tiles = 0;
   } parts_req;
   // Tile-occupancy mask of the centre tensor as operand B of the first products of a matvec, supplied by the caller
   // (mpse_expm_centre_mask: the structural pattern of the quantum numbers, the same for every Krylov vector).
@@ -158,6 +164,12 @@ struct mpse_ctx {
     size_t bytes = 0;
   } small_rt;
   bool small_rt_scope = false;   // a solver without occupancy caches (Davidson) keeps the transposed copy as well
+  // Per-solve data of the fused 0-site matvec (mpse_heff0.hip): transposed right environment, tile flags, part mask
+  struct F0Cache {
+    void* buf = nullptr;
+    const void *L = nullptr, *R = nullptr, *cmask = nullptr;
+    int Dl = 0, Dr = 0, w = 0;
+  } f0;
   // mpse_block_qr: decompositions that took the Cholesky-QR path / that fell back from it to Householder
   long long qr_chol_calls = 0, qr_chol_fallbacks = 0, qr_calls = 0;
   // optimistic mode of the Cholesky-QR path (mpse_block_qr_optimistic): breakdowns raise this sticky device word
@@ -230,6 +242,11 @@ static inline mpse_index idx2(int64_t hi_ext, int64_t lo_ext, int64_t s_hi, int6
 // One-launch matvec of small 0- / 1-site centres (mpse_small.hip); *taken says whether it ran (else: the plans)
 int heff_small_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, void* out, bool* taken);
 void heff_small_drop_cache(mpse_ctx* ctx);
+// Fused 0-site matvec for large complex bond matrices (mpse_heff0.hip): number of parts it would deliver (0 = not
+// eligible), the attempt itself (needs mpse_ctx::parts_req.masked_ok), and the release of its per-solve data
+int heff0_fused_parts(const mpse_heff* h, int dtype);
+int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, bool* taken);
+void heff0_drop_cache(mpse_ctx* ctx);
 struct SmallRtScope {   // for the duration of one eigensolve: the right environment does not change
   mpse_ctx* c;
   explicit SmallRtScope(mpse_ctx* ctx) : c(ctx) { c->small_rt_scope = true; }

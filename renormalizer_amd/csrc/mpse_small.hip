@@ -404,6 +404,7 @@ int lds_limit_bytes() {
 }  // namespace
 
 void heff_small_drop_cache(mpse_ctx* ctx) {
+  heff0_drop_cache(ctx);       // (the fused 0-site matvec keeps its per-solve data for the same span)
   if (ctx->small_rt.rt) mpse_free(ctx, ctx->small_rt.rt);
   ctx->small_rt = mpse_ctx::SmallRt();
 }

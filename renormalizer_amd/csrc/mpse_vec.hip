@@ -241,7 +241,12 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
                                                                   double* __restrict__ cur_out,
                                                                   const double* __restrict__ prev2,
                                                                   double* __restrict__ partial,
-                                                                  const int* __restrict__ done) {
+                                                                  const int* __restrict__ done,
+                                                                  const unsigned long long* __restrict__ pmask,
+                                                                  int prow, int ptiles) {
+  // pmask (complex vectors, VEC): the parts hold only some 16 x 16 tiles of the result viewed as rows of prow elements
+  // (fused 0-site matvec, mpse_heff0.hip): word [tile row * ptiles + tile column], bit s = part s holds the tile; the
+  // parts named there are added in part order, the others were never written
   if (done && *done) return;
   double araw, a_im, cur2, z;
   sum_partials(a_partial, a_nb, araw, a_im);
@@ -268,11 +273,35 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
     for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n2; i += 2 * stride) {
       const long long i1 = i + stride;
       const bool h1 = i1 < n2;
-      double2 ya = py[i], yb = h1 ? py[i1] : zz;
-      for (int s = 1; s < nparts; ++s) {
-        const double2* ps = py + s * (part_stride >> 1);
-        const double2 ta = ps[i], tb = h1 ? ps[i1] : zz;
-        ya.x += ta.x, ya.y += ta.y, yb.x += tb.x, yb.y += tb.y;
+      double2 ya, yb;
+      if (pmask) {
+        auto gather = [&](long long e) {
+          const unsigned ee = (unsigned)e, row = ee / (unsigned)prow, col = ee - row * (unsigned)prow;
+          unsigned long long m = pmask[(row >> 4) * ptiles + (col >> 4)];
+          double2 acc = zz;
+          while (m) {          // four parts per round: their loads are in flight together, added in part order
+            int sp[4];
+            double2 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              sp[u] = m ? __builtin_ctzll(m) : -1;
+              m &= m - (m ? 1 : 0);
+              t[u] = sp[u] >= 0 ? py[(long long)sp[u] * (part_stride >> 1) + e] : zz;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc.x += t[u].x, acc.y += t[u].y;
+          }
+          return acc;
+        };
+        ya = gather(i);
+        yb = h1 ? gather(i1) : zz;
+      } else {
+        ya = py[i], yb = h1 ? py[i1] : zz;
+        for (int s = 1; s < nparts; ++s) {
+          const double2* ps = py + s * (part_stride >> 1);
+          const double2 ta = ps[i], tb = h1 ? ps[i1] : zz;
+          ya.x += ta.x, ya.y += ta.y, yb.x += tb.x, yb.y += tb.y;
+        }
       }
       const double2 va = p1[i], ua = u0 ? p0[i] : zz;
       const double2 vb = h1 ? p1[i1] : zz, ub = (h1 && u0) ? p0[i1] : zz;
@@ -781,7 +810,9 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
   TmpBuf V(ctx), W(ctx), RES(ctx), SCAL(ctx);
   MPSE_TRY(V.alloc(size_t(cap) * n * es));
   // the matvec result, with room for a second part (mpse_ctx::parts_req: halved tiles)
-  const long long wcap = (n <= 65536 ? 4 : 2) * n;   // (small centres: up to four slices, mpse_small.hip)
+  long long wcap = (n <= 65536 ? 4 : 2) * n;   // (small centres: up to four slices, mpse_small.hip)
+  const int f0_parts = (cplx && (reinterpret_cast<uintptr_t>(Cin) & 15) == 0) ? heff0_fused_parts(h, dtype) : 0;
+  if ((long long)f0_parts * n > wcap) wcap = (long long)f0_parts * n;   // tile-masked parts of the fused 0-site matvec
   MPSE_TRY(W.alloc(size_t(wcap) * es));
   MPSE_TRY(RES.alloc(size_t(n) * es));
   // scalars as in the synchronous solve: [0..1] |v|^2 ; per j: alpha at 4+4j, beta^2 at 6+4j ; then control + coefficients
@@ -871,7 +902,10 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
     ctx->parts_req.cap_elems = wcap;
     ctx->parts_req.n = n;
     ctx->parts_req.used = 0;
+    ctx->parts_req.masked_ok = f0_parts > 0 && vec16;
     const int st_mv = mpse_heff_apply(ctx, dtype, h, vec(j), W.p);
+    const unsigned long long* pmask = ctx->parts_req.mask;
+    const int prow = ctx->parts_req.mask_row, ptiles = ctx->parts_req.mask_tiles;
     const int used = ctx->parts_req.used;
     const int nparts = used > 0 ? used : (used == -2 ? 2 : 1);
     const bool two = nparts > 1;
@@ -904,13 +938,13 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
                            W.as<const double>(), nparts, (long long)nd, (const double*)vec(j),
                            j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
                            (const double*)part_a, a_nb, scal + 4 + 4 * j, (const double*)cur_part, nb, cur_out, prev2,
-                           new_part, done);
+                           new_part, done, pmask, prow, ptiles);
       else
         hipLaunchKernelGGL(k_lanczos_update_u<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
                            W.as<const double>(), nparts, (long long)nd, (const double*)vec(j),
                            j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
                            (const double*)part_a, a_nb, scal + 4 + 4 * j, (const double*)cur_part, nb, cur_out, prev2,
-                           new_part, done);
+                           new_part, done, pmask, prow, ptiles);
     });
     bool check = (j > 3 && j % 2 == 0);                // krylov.py:76-81
     const bool last = (j + 1 >= limit);

@@ -1382,12 +1382,21 @@ class Mps:
                 mps.qn[imps] = np.array(qnrset, dtype=int).reshape(-1, q)
                 mps.qnidx = imps - 1
                 r_array = environ.GetLR("R", imps, mps, mpo, itensor=r_array, method="System", canonical=True)
-                return hop_expr(l_array, r_array, [], u.shape), u, imps - 1
+                hop_b = hop_expr(l_array, r_array, [], u.shape)
+                if use_cmask and u.shape[0] * u.shape[1] >= (1 << 14):
+                    # structural tile mask of the bond factor (rows: the left bond, columns: the new bond's states)
+                    hop_b.cmask = centre_tile_mask(eng, qnbigl, np.array(qnrset, dtype=int).reshape(-1, q), mps.qntot,
+                                                   u.shape)
+                return hop_b, u, imps - 1
             mps[imps] = u.reshape(shape[:-1] + [-1])
             mps.qn[imps + 1] = np.array(qnlset, dtype=int).reshape(-1, q)
             mps.qnidx = imps + 1
             l_array = environ.GetLR("L", imps, mps, mpo, itensor=l_array, method="System", canonical=True)
-            return hop_expr(l_array, r_array, [], vt.shape), vt, imps + 1
+            hop_b = hop_expr(l_array, r_array, [], vt.shape)
+            if use_cmask and vt.shape[0] * vt.shape[1] >= (1 << 14):
+                hop_b.cmask = centre_tile_mask(eng, np.array(qnlset, dtype=int).reshape(-1, q), qnbigr, mps.qntot,
+                                               vt.shape)
+            return hop_b, vt, imps + 1
 
         def absorb(bond, nbr):
             """the evolved bond factor times the neighbouring site: the next centre"""

@@ -726,3 +726,55 @@ def test_eigh_qn_density_matrix_blocks(eng):
         mine = np.sort(np.array([x for x, qq in zip(s, new_qn) if qq == [sector]]) ** 2)
         assert np.abs(mine - np.clip(w, 0, None)).max() < 1e-11 * np.abs(dm).max()
         assert not np.any(np.abs(uh[np.ix_(np.nonzero(qn[:, 0] != sector)[0], [i for i, qq in enumerate(new_qn) if qq == [sector]])]))
+
+
+@pytest.mark.parametrize("Dl,Dr,w,masked", [(256, 256, 5, True), (256, 256, 5, False), (192, 320, 4, True), (64, 48, 3, True)])
+def test_fused_bond_matvec_in_lanczos(eng, Dl, Dr, w, masked, monkeypatch):
+    """The 0-site effective Hamiltonian as ONE launch with tile-masked parts (mpse_heff0.hip), through the Lanczos solve
+    that consumes it, against the oracle's solve of the same problem (mps/hop_expr.py:63-67, lib/krylov/krylov.py:27-82):
+    block-sparse environments with an identity channel each (as canonical sites leave them), a block-diagonal bond
+    matrix with and without the structural centre mask, bonds that are / are not multiples of 64, the Krylov dimension
+    and the result; then twice more: bitwise the same."""
+    import renormalizer_amd.mps.hop_expr as HE
+    if os.environ.get("MPSE_HEFF0", "1") == "0":
+        pytest.skip("fused bond matvec switched off")
+    rng = np.random.default_rng(Dl + 3 * Dr + w)
+    # two quantum-number sectors per bond: channel b couples sectors (p, (p + shift_b) % 2)
+    sl, sr = (np.arange(Dl) >= Dl // 2 + 16).astype(int), (np.arange(Dr) >= Dr // 2 - 16).astype(int)
+    l = np.zeros((Dl, w, Dl), complex)
+    r = np.zeros((Dr, w, Dr), complex)
+
+    def block(n, sec, shift, herm):
+        x = _rand(rng, (n, n), True) * ((sec[:, None] + shift) % 2 == sec[None, :]) / (4 * np.sqrt(n))
+        return x + x.conj().T if herm else x
+
+    # H = sum_b L_b (x) R_b Hermitian: channel 0 = identity (x) Hermitian, channel w - 1 = Hermitian (x) identity, the
+    # middle channels change the sector and come in adjoint pairs (an unpaired one keeps the sector and is Hermitian)
+    l[:, 0, :], r[:, 0, :] = np.eye(Dl), block(Dr, sr, 0, True)
+    l[:, w - 1, :], r[:, w - 1, :] = block(Dl, sl, 0, True), np.eye(Dr)
+    b = 1
+    while b < w - 1:
+        if b + 1 < w - 1:
+            l[:, b, :], r[:, b, :] = block(Dl, sl, 1, False), block(Dr, sr, 1, False)
+            l[:, b + 1, :], r[:, b + 1, :] = l[:, b, :].conj().T, r[:, b, :].conj().T
+            b += 2
+        else:
+            l[:, b, :], r[:, b, :] = block(Dl, sl, 0, True), block(Dr, sr, 0, True)
+            b += 1
+    c = _rand(rng, (Dl, Dr), True) * (sl[:, None] == sr[None, :])
+    hop = HE.hop_expr(l, r, [], c.shape)
+    if masked:
+        hop.cmask = HE.centre_tile_mask(eng, sl[:, None], (1 - sr)[:, None], np.array([1]), c.shape)
+        assert hop.cmask is not None
+    from renormalizer_amd.lib.krylov import expm_krylov
+    dt = -0.4j
+    ref, nref = orc.expm_krylov(lambda y: orc.hop_apply(l, r, [], y.reshape(c.shape)).ravel(), dt, c.ravel())
+    outs = []
+    for _ in range(3):
+        out, nv = expm_krylov(hop, dt, eng.asdevice(c))
+        outs.append(out.to_host())
+        assert nv == nref
+    assert _relerr(outs[0].ravel(), ref) < 1e-10
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    # structure is kept: nothing leaks outside the quantum-number blocks
+    assert np.abs(outs[0] * (sl[:, None] != sr[None, :])).max() == 0
