@@ -130,29 +130,28 @@ __global__ __launch_bounds__(256) void k_cq_gram(const double* __restrict__ ws, 
   double vr[2][4], vi[2][4];   // [buffer][fragment]
 #pragma unroll
   for (int i = 0; i < 4; ++i) vr[0][i] = vi[0][i] = vr[1][i] = vi[1][i] = 0.0;
+  // (loads are unconditional - rows and columns clamped into the block - and masked where they are consumed: a select
+  // right behind a load waits for it on the spot, and nothing would be in flight ahead of the arithmetic)
   auto load = [&](int buf, int r) {
-    const int row = r + kq;
-    const bool okr = row < re;
-    const long long rc = min(row, B.mm - 1);
+    const long long rc = min(r + kq, B.mm - 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ld2<CPLX>(A, fo[i] + rc, vr[buf][i], vi[buf][i]);
-      if (!(okr && okc[i])) vr[buf][i] = vi[buf][i] = 0.0;
-    }
+    for (int i = 0; i < 4; ++i) ld2<CPLX>(A, fo[i] + rc, vr[buf][i], vi[buf][i]);
   };
   if (rb < re) load(0, rb);
   if (rb + 4 < re) load(1, rb + 4);
   for (int r = rb; r < re; r += 8) {
     double cr[4], ci[4], dr[4], di[4];
+    const bool ok0 = r + kq < re, ok1 = r + 4 + kq < re;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      cr[i] = vr[0][i];
-      ci[i] = vi[0][i];
-      dr[i] = vr[1][i];
-      di[i] = vi[1][i];
+      cr[i] = (ok0 && okc[i]) ? vr[0][i] : 0.0;
+      ci[i] = (ok0 && okc[i]) ? vi[0][i] : 0.0;
+      dr[i] = (ok1 && okc[i]) ? vr[1][i] : 0.0;
+      di[i] = (ok1 && okc[i]) ? vi[1][i] : 0.0;
     }
     if (r + 8 < re) load(0, r + 8);
     if (r + 12 < re) load(1, r + 12);
+    asm volatile("" ::: "memory");
     const bool second = r + 4 < re;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -663,16 +662,26 @@ __global__ __launch_bounds__(256) void k_cq_trsm(double* __restrict__ ws, const 
     const int p = wave + 4 * s;
     ar[s] = v4d{0, 0, 0, 0};
     ai[s] = v4d{0, 0, 0, 0};
-    if (p < P) {
-      const int col = 16 * p + x;
+    if (p < P) {      // (unconditional loads, clamped into the block; masked below, once all are on their way)
+      const int col = min(16 * p + x, nn - 1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = r0 + kq + 4 * r;
-        double vr = 0.0, vi = 0.0;
-        if (row < B.mm && col < nn) ld2<CPLX>(A, (long long)col * mm + row, vr, vi);
+        const int row = min(r0 + kq + 4 * r, B.mm - 1);
+        double vr, vi;
+        ld2<CPLX>(A, (long long)col * mm + row, vr, vi);
         ar[s][r] = vr;
         ai[s][r] = vi;
       }
+    }
+  }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int p = wave + 4 * s;
+    if (p < P) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (!(r0 + kq + 4 * r < B.mm && 16 * p + x < nn)) ar[s][r] = ai[s][r] = 0.0;
     }
   }
   auto store_panel = [&](int p, const v4d& vr, const v4d& vi) {
@@ -744,6 +753,8 @@ __global__ __launch_bounds__(256) void k_cq_trsm(double* __restrict__ ws, const 
     }
     if (wave == owner) {
       if constexpr (VAR < 2) load_rcol(q);
+      asm volatile("" ::: "memory");   // (all sixteen loads are out before the first is consumed: left alone the
+                                         // scheduler pairs each load with its use - sixteen dependent trips to L2)
       double dj = rr[0];
 #pragma unroll
       for (int t = 1; t < 16; ++t) dj = x == t ? rr[t] : dj;
@@ -807,21 +818,25 @@ __global__ __launch_bounds__(256) void k_cq_trsm(double* __restrict__ ws, const 
       if (p > q && p < P) {
         const double* tb = Rt + (long long)tile_index(q, p, P) * 256 * E;
         const bool pre = VAR >= 1 && crit && p == pc;
+        double yr[4], yi[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (pre) {
+            yr[kk] = ycr[kk];
+            yi[kk] = yci[kk];
+          } else {
+            ld2<CPLX>(tb, (4 * kk + kq) * 16 + x, yr[kk], yi[kk]);
+          }
+        }
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const double xr = sXr[buf][x * 17 + 4 * kk + kq], xi = sXi[buf][x * 17 + 4 * kk + kq];
-          double yr, yi;
-          if (pre) {
-            yr = ycr[kk];
-            yi = yci[kk];
-          } else {
-            ld2<CPLX>(tb, (4 * kk + kq) * 16 + x, yr, yi);
-          }
-          ar[s] = mfma(-xr, yr, ar[s]);
+          ar[s] = mfma(-xr, yr[kk], ar[s]);
           if constexpr (CPLX) {
-            ar[s] = mfma(xi, yi, ar[s]);
-            ai[s] = mfma(-xr, yi, ai[s]);
-            ai[s] = mfma(-xi, yr, ai[s]);
+            ar[s] = mfma(xi, yi[kk], ar[s]);
+            ai[s] = mfma(-xr, yi[kk], ai[s]);
+            ai[s] = mfma(-xi, yr[kk], ai[s]);
           }
         }
       }

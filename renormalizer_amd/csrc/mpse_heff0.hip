@@ -45,8 +45,6 @@ struct F0Args {
   const int* skip;
   long long n;
   int Dl, Dr, w, ntl, ntr, nkc, fc_pitch;
-  int dbg;   // development: bit 0 skips step 1, bit 1 step 2 (timings only, wrong results)
-  unsigned long long* trace;   // development (MPSE_F0_TRACE): 8 words per workgroup - clock stamps of its phases
 };
 
 // Rt[(b, k), l] = R[l, b, k]
@@ -113,14 +111,14 @@ __global__ __launch_bounds__(1024) void k_f0_valid(const unsigned char* __restri
   }
 }
 
-template <int NW>   // waves per workgroup: 4, or 8 (two groups of four splitting the c tiles of step 1)
-__global__ __launch_bounds__(64 * NW) void k_heff0_fused(const F0Args g) {
+__global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
+  constexpr int NW = 4;   // waves per workgroup (eight - two groups splitting the c tiles of step 1, added up in LDS -
+                          // spilled registers and lost: 495 against 510 site-updates/s)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15,
             kq = lane >> 4;
   __shared__ double sTr[16 * 65], sTi[16 * 65];
-  __shared__ double s_dot[16];
+  __shared__ double s_dot[8];
   if (g.skip && *g.skip) return;
-  const unsigned long long ts0 = g.trace ? __builtin_readcyclecounter() : 0ull;
   // Launch position -> (bra tile row, part), plain order.  (Measured and dropped: a die - launch position mod 8, one L2
   // each - taking whole parts, so that its L2 holds only the panels of C and Rt its workgroups share.  Dealt channel-major
   // the heavy parts - ket chunks that straddle two quantum-number sectors - piled up on two dies: 39 us against 33; dealt
@@ -139,8 +137,7 @@ __global__ __launch_bounds__(64 * NW) void k_heff0_fused(const F0Args g) {
     return;
   }
   // ---- step 1: T[a, k] for this wave's 16 columns k of the chunk
-  // eight waves: wave w works on column tile w & 3 of the chunk and takes every second occupied c tile (w >> 2)
-  const int wcolt = wave & 3, wgrp = NW == 8 ? wave >> 2 : 0;
+  const int wcolt = wave;
   const int a0 = 16 * at, k0 = 64 * kc + 16 * wcolt;
   const bool wcol = k0 < g.Dr;                       // (last chunk of a Dr that is not a multiple of 64)
   // (every flag this workgroup will consult is requested here, together: a dependent trip to memory costs ~1.5 us, and
@@ -179,72 +176,45 @@ __global__ __launch_bounds__(64 * NW) void k_heff0_fused(const F0Args g) {
       ti = mfma(av[slot][kk].y, bv[slot][kk].x, ti);
     }
   };
-  const unsigned long long ts1 = g.trace ? __builtin_readcyclecounter() : 0ull;
-  // this wave's share of the occupied c tiles: the even-numbered ones (group 0) or the odd-numbered ones (group 1)
-  unsigned long long mine = cts;
-  if constexpr (NW == 8) {
-    mine = 0;
-    unsigned long long m = cts;
-    int i = 0;
-    while (m) {
-      const unsigned long long low = m & (~m + 1);
-      if ((i & 1) == wgrp) mine |= low;
-      m ^= low;
-      ++i;
+  const unsigned long long mine = cts;
+  if (wcol && mine) {
+    // Three c tiles in flight, slots used in a fixed rotation.  The compiler barriers keep the order "request the tile
+    // after next, THEN multiply the oldest": without them the scheduler sinks every batch of loads to just before its
+    // use (fewer live registers) and each tile waits for its own trip to memory - measured: 3 600 cycles per tile against
+    // the 1 024 of its sixteen MFMAs.
+    unsigned long long m = mine;       // tiles still to load
+    auto next_ct = [&]() {
+      const int ct = m ? (int)__builtin_ctzll(m) : -1;
+      m &= m - (m ? 1 : 0);
+      return ct;
+    };
+    int c0 = next_ct(), c1 = next_ct(), c2 = next_ct();
+    if (c0 >= 0) load1(0, c0);
+    if (c1 >= 0) load1(1, c1);
+    if (c2 >= 0) load1(2, c2);
+    while (c0 >= 0) {
+      asm volatile("" ::: "memory");
+      mul1(0);
+      c0 = next_ct();
+      if (c0 >= 0) load1(0, c0);
+      asm volatile("" ::: "memory");
+      if (c1 < 0) break;
+      mul1(1);
+      c1 = next_ct();
+      if (c1 >= 0) load1(1, c1);
+      asm volatile("" ::: "memory");
+      if (c2 < 0) break;
+      mul1(2);
+      c2 = next_ct();
+      if (c2 >= 0) load1(2, c2);
     }
   }
-  if (wcol && mine && !(g.dbg & 1)) {
-    unsigned long long m = mine;       // tiles still to LOAD
-    int pending = 0;                   // loaded, not yet multiplied (slots in ring order)
-    int head = 0;
-    // fill
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      if (m) {
-        const int ct = __builtin_ctzll(m);
-        m &= m - 1;
-        if (i == 0) load1(0, ct);
-        if (i == 1) load1(1, ct);
-        if (i == 2) load1(2, ct);
-        ++pending;
-      }
-    }
-    while (pending) {
-      // multiply the oldest, refill its slot
-      if (head == 0) {
-        mul1(0);
-        if (m) { load1(0, __builtin_ctzll(m)); m &= m - 1; } else --pending;
-        head = 1;
-      } else if (head == 1) {
-        mul1(1);
-        if (m) { load1(1, __builtin_ctzll(m)); m &= m - 1; } else --pending;
-        head = 2;
-      } else {
-        mul1(2);
-        if (m) { load1(2, __builtin_ctzll(m)); m &= m - 1; } else --pending;
-        head = 0;
-      }
-    }
-  }
-  const unsigned long long ts2 = g.trace ? __builtin_readcyclecounter() : 0ull;
-  if (wgrp == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      sTr[(kq + 4 * r) * 65 + 16 * wcolt + x] = tr[r];
-      sTi[(kq + 4 * r) * 65 + 16 * wcolt + x] = ti[r];
-    }
+  for (int r = 0; r < 4; ++r) {
+    sTr[(kq + 4 * r) * 65 + 16 * wcolt + x] = tr[r];
+    sTi[(kq + 4 * r) * 65 + 16 * wcolt + x] = ti[r];
   }
   __syncthreads();
-  if constexpr (NW == 8) {
-    if (wgrp == 1) {                 // (group 0 + group 1, in this order: reproducible)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sTr[(kq + 4 * r) * 65 + 16 * wcolt + x] += tr[r];
-        sTi[(kq + 4 * r) * 65 + 16 * wcolt + x] += ti[r];
-      }
-    }
-    __syncthreads();
-  }
   // ---- step 2: the l tiles this workgroup holds, dealt to the waves in order; the A operand (T) of the whole chunk
   // stays in registers
   double xr[16], xi[16];
@@ -253,7 +223,6 @@ __global__ __launch_bounds__(64 * NW) void k_heff0_fused(const F0Args g) {
     xr[ks] = sTr[x * 65 + 4 * ks + kq];
     xi[ks] = sTi[x * 65 + 4 * ks + kq];
   }
-  const unsigned long long ts3 = g.trace ? __builtin_readcyclecounter() : 0ull;
   double dre = 0.0, dim = 0.0;
   const double2* Rb = reinterpret_cast<const double2*>(g.Rt) + ((long long)b * g.Dr + 64 * kc + kq) * g.Dr + x;
   double2* part = reinterpret_cast<double2*>(g.parts) + (long long)s * g.n;
@@ -266,11 +235,13 @@ __global__ __launch_bounds__(64 * NW) void k_heff0_fused(const F0Args g) {
     return (unsigned)__builtin_amdgcn_readlane((int)frn, lt);
   };
   double2 rv[2][16], yv2[2][4];
-  auto load2 = [&](int slot, int lt, unsigned kts) {
+  auto load2 = [&](int slot, int lt, unsigned) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      rv[slot][ks] = make_double2(0.0, 0.0);
-      if ((kts >> (ks >> 2)) & 1u) rv[slot][ks] = Rb[(long long)(4 * ks) * g.Dr + 16 * lt];
+      // (unconditional: a load guarded by the tile flag becomes load + select, and the select waits for the load on the
+      // spot; k tiles without data are loaded - rows clamped into the tensor - and never multiplied)
+      const long long krow = min((long long)(4 * ks), (long long)(g.Dr - 1 - 64 * kc - kq));
+      rv[slot][ks] = Rb[krow * g.Dr + 16 * lt];
     }
     if (g.y) {
 #pragma unroll
@@ -301,7 +272,7 @@ __global__ __launch_bounds__(64 * NW) void k_heff0_fused(const F0Args g) {
     }
   };
   int idx = wave;
-  int lt0 = (g.dbg & 2) ? -1 : nth_tile(lts, idx), lt1 = -1;
+  int lt0 = nth_tile(lts, idx), lt1 = -1;
   unsigned kt0 = 0, kt1 = 0;
   if (lt0 >= 0) {
     kt0 = k_tiles(lt0);
@@ -314,6 +285,7 @@ __global__ __launch_bounds__(64 * NW) void k_heff0_fused(const F0Args g) {
       kt1 = k_tiles(lt1);
       load2(1, lt1, kt1);
     }
+    asm volatile("" ::: "memory");     // (the next tile's operands are requested before this tile is multiplied)
     mul2(0, lt0, kt0);
     if (lt1 < 0) break;
     idx += NW;
@@ -322,14 +294,8 @@ __global__ __launch_bounds__(64 * NW) void k_heff0_fused(const F0Args g) {
       kt0 = k_tiles(lt0);
       load2(0, lt0, kt0);
     }
+    asm volatile("" ::: "memory");
     mul2(1, lt1, kt1);
-  }
-  if (g.trace && tid == 0) {
-    unsigned long long* r = g.trace + (long long)blockIdx.x * 8;
-    r[0] = ts0, r[1] = ts1, r[2] = ts2, r[3] = ts3, r[4] = __builtin_readcyclecounter();
-    r[5] = ((unsigned long long)__popcll(cts) << 32) | (unsigned long long)__popcll(lts);
-    r[6] = (unsigned long long)s | ((unsigned long long)at << 32);
-    r[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
   }
   if (g.dot_part) {
     dre = wave_sum(dre);
@@ -446,47 +412,12 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
   g.skip = ctx->skip_flag;
   g.n = n;
   g.Dl = Dl, g.Dr = Dr, g.w = w, g.ntl = ntl, g.ntr = ntr, g.nkc = nkc, g.fc_pitch = fc_pitch;
-  static const int f0_dbg = [] {
-    const char* e = getenv("MPSE_F0_DBG");
-    return e ? atoi(e) : 0;
-  }();
-  g.dbg = f0_dbg;
   if (ctx->dot_req.y) {
     g.y = static_cast<const double*>(ctx->dot_req.y);
     g.dot_part = ctx->dot_req.part;
     ctx->dot_req.nb_out = nwg;
   }
-  static unsigned long long* trace_buf = nullptr;
-  static long long trace_launch = 0;
-  static const char* trace_path = getenv("MPSE_F0_TRACE");
-  const int grid = nwg;
-  if (trace_path && !trace_buf) (void)hipMalloc(reinterpret_cast<void**>(&trace_buf), size_t(4096) * 64);
-  ++trace_launch;
-  g.trace = (trace_path && trace_launch == 2000 && grid <= 4096) ? trace_buf : nullptr;
-  if (g.trace) (void)hipMemsetAsync(trace_buf, 0, size_t(4096) * 64, ctx->stream);
-  static const int f0_waves = [] {
-    const char* e = getenv("MPSE_F0_WAVES");
-    return e ? atoi(e) : 4;
-  }();
-  if (f0_waves == 8)
-    hipLaunchKernelGGL(k_heff0_fused<8>, dim3(grid), dim3(512), 0, ctx->stream, g);
-  else
-    hipLaunchKernelGGL(k_heff0_fused<4>, dim3(grid), dim3(256), 0, ctx->stream, g);
-  if (g.trace) {
-    std::vector<unsigned long long> hb(size_t(grid) * 8);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipMemcpy(hb.data(), trace_buf, hb.size() * 8, hipMemcpyDeviceToHost);
-    if (FILE* fh = fopen(trace_path, "w")) {
-      for (int i = 0; i < grid; ++i) {
-        const unsigned long long* r = &hb[size_t(i) * 8];
-        if (r[0] == 0) continue;
-        fprintf(fh, "%d s=%llu at=%llu xcc=%llu ncts=%llu nlts=%llu start=%llu flags=%llu step1=%llu lds=%llu step2=%llu\n", i,
-                r[6] & 0xffffffffull, r[6] >> 32, r[7], r[5] >> 32, r[5] & 0xffffffffull, r[0] - hb[0], r[1] - r[0], r[2] - r[1],
-                r[3] - r[2], r[4] - r[3]);
-      }
-      fclose(fh);
-    }
-  }
+  hipLaunchKernelGGL(k_heff0_fused, dim3(nwg), dim3(256), 0, ctx->stream, g);
   MPSE_HIP(ctx, hipGetLastError());
   pr.used = nparts;
   pr.mask = g.mask;
