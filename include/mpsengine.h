@@ -246,6 +246,12 @@ int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
  * change while the hint stands; mpse_free(W_dev) or a call with W_host == NULL drops it.  No device work. */
 int mpse_mpo_site_hint(mpse_ctx* ctx, const void* W_dev, const double* W_host_f64, int64_t wl, int64_t d, int64_t wr);
 
+/* How many effective-Hamiltonian applications of this context ran as the single fused launch of mpse_heff0.hip (inside
+ * mpse_expm_lanczos: bond matrices, mps/hop_expr.py:63-67, and one-site centres with a two-level physical index,
+ * :75-79) instead of through the contraction plans.  Diagnostics; tests use it to see that the path they mean to check
+ * is the one that ran.  Either pointer may be NULL. */
+int mpse_heff_fused_stats(mpse_ctx* ctx, int64_t* bond_launches, int64_t* site_launches);
+
 /* Two-layer effective Hamiltonian of the (H - omega)^2 functional, replaces the twolayer=True closures of
  * mps/hop_expr.py:24-52 (1-site abcd,befg,cfhi,jgik,aej->dhk ; 2-site abcd,befg,cfhi,gjkl,ikmn,olnp,aejo->dhmp).
  *   L (Dl, wl, wl, Dl), R (Dr, wr, wr, Dr); W0 / W1 serve both layers; no ancilla; nsite in {1, 2}; the unit-channel

@@ -494,7 +494,9 @@ extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, con
     bool taken = false;
     MPSE_TRY(heff_small_try(ctx, dtype, h, C, out, &taken));
     if (taken) return MPSE_OK;     // (pr.used is set there: the result may be a sum of parts)
-    MPSE_TRY(heff0_fused_try(ctx, dtype, h, C, &taken));
+    const WSiteInfo* wi0 = static_cast<const WSiteInfo*>(wi_keep.get());
+    const bool wi_ok = wi0 && h->nsite == 1 && wi0->wl == h->dims.wl && wi0->d == h->dims.d0 && wi0->wr == h->dims.wr;
+    MPSE_TRY(heff0_fused_try(ctx, dtype, h, C, wi_ok ? wi0->w.data() : nullptr, &taken));
     if (taken) return MPSE_OK;     // (tile-masked parts: pr.used, pr.mask)
   }
   const bool two_ok = pr.ptr != nullptr && pr.cap_elems >= 2 * pr.n;

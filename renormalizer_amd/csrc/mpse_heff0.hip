@@ -20,6 +20,13 @@
 // caller's structural centre mask (mpse_expm_centre_mask; without one every tile of C counts as occupied).  A workgroup
 // whose T is structurally zero returns at once; step 1 visits the c tiles where L AND C hold data, step 2 the
 // (l tile, k tile) pairs where R does.
+//
+// The same launch serves one-site centres with a two-level physical index (the electronic sites of the headline chain:
+// abc,bdef,lfk,cek->adl, mps/hop_expr.py:75-79, W real).  The MPO site is a handful of numbers per (left channel, right
+// channel) pair; a workgroup is (16 bra rows, RIGHT channel f, 64 ket columns), and step 1 builds
+//   P_x[a, k] = sum over the non-zero W[b, x, e, f] of  W[b, x, e, f] . L[a, b, :] . C[:, e, k]      (x = 0, 1)
+// as one MFMA chain per term with the scalar folded into the A operand, step 2 multiplies both P_x by the same rows of
+// Rt.  The plans ran this matvec as product + reduction + elementwise MPO step + product + reduction.
 #include "mpse_device.h"
 #include "mpse_internal.h"
 
@@ -31,20 +38,27 @@ __device__ __forceinline__ v4d mfma(double a, double b, v4d c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+constexpr int F0_TMAX = 16;     // terms (non-zero W[b, x, e, f]) per right channel f
+struct F0Term {
+  int b, e, x, pad;
+  double w;
+};
 struct F0Args {
-  const double* L;        // (Dl, w, Dl)
-  const double* Rt;       // (w, Dr, Dr): Rt[b, k, l] = R[l, b, k]
-  const double* C;        // (Dl, Dr)
-  double* parts;          // part s at parts + s * n (complex elements), laid out like out (Dl, Dr)
+  const double* L;        // (Dl, wl, Dl)
+  const double* Rt;       // (wr, Dr, Dr): Rt[f, k, l] = R[l, f, k]
+  const double* C;        // (Dl, d, Dr)
+  double* parts;          // part s at parts + s * n (complex elements), laid out like out (Dl, d, Dr)
   const double* y;        // optional: dot partner laid out like out
   double* dot_part;       // one (re, im) per workgroup
-  const unsigned char* FL;   // [(at * w + b) * ntl + ct]
-  const unsigned char* FC;   // [kc * fc_pitch + ct] (centre mask), or null
-  const unsigned char* FR;   // [(lt * w + b) * ntr + kt]
-  const unsigned long long* mask;   // [at * ntr + lt]: bit s = part s holds this tile
+  const unsigned char* FL;   // [(at * wl + b) * ntl + ct]
+  const unsigned char* FC;   // [(e * nkc + kc) * fc_pitch + ct] (centre mask), or null
+  const unsigned char* FR;   // [(lt * wr + f) * ntr + kt]
+  const unsigned long long* mask;   // [(at * d + x) * ntr + lt]: bit s = part s holds this tile (same word for all x)
+  const F0Term* terms;    // [f * F0_TMAX + t]
+  const int* nterm;       // [f]
   const int* skip;
   long long n;
-  int Dl, Dr, w, ntl, ntr, nkc, fc_pitch;
+  int Dl, Dr, wl, wr, d, ntl, ntr, nkc, fc_pitch;
 };
 
 // Rt[(b, k), l] = R[l, b, k]
@@ -78,57 +92,68 @@ __global__ __launch_bounds__(256) void k_f0_flags(const double2* __restrict__ E,
   if ((int)threadIdx.x < nt) F[((long long)rt * w + b) * nt + threadIdx.x] = s_f[threadIdx.x] ? 1 : 0;
 }
 
-// which parts hold which output tile: bit s = b * nkc + kc of mask[at * ntr + lt] is set when step 1 of workgroup
-// (at, b, kc) has a c tile with data on both sides AND R has data in rows lt, channel b, k chunk kc.  One workgroup.
+// which parts hold which output tile: bit s = f * nkc + kc of the word of (bra tile row at, l tile lt) is set when step 1
+// of workgroup (at, f, kc) has, for one of the terms of f, a c tile with data on both sides AND R has data in rows lt,
+// channel f, k chunk kc.  The word is stored for each of the d tile rows (at * d + x) of the result.  One workgroup.
 __global__ __launch_bounds__(1024) void k_f0_valid(const unsigned char* __restrict__ FL, const unsigned char* __restrict__ FC,
-                                                    const unsigned char* __restrict__ FR, int w, int ntl, int ntr, int nkc,
-                                                    int fc_pitch, unsigned long long* __restrict__ mask,
+                                                    const unsigned char* __restrict__ FR, const F0Term* __restrict__ terms,
+                                                    const int* __restrict__ nterm, int wl, int wr, int d, int ntl, int ntr,
+                                                    int nkc, int fc_pitch, unsigned long long* __restrict__ mask,
                                                     const int* __restrict__ skip) {
   if (skip && *skip) return;
   __shared__ unsigned long long s1[64], s2[64];    // per bra tile row / per l tile: bit s
-  const int nparts = w * nkc, tid = threadIdx.x;
+  const int nparts = wr * nkc, tid = threadIdx.x;
   if (tid < 64) s1[tid] = s2[tid] = 0;
   __syncthreads();
   for (int t = tid; t < ntl * nparts; t += 1024) {
-    const int at = t / nparts, s = t - at * nparts, b = s / nkc, kc = s - b * nkc;
+    const int at = t / nparts, s = t - at * nparts, f = s / nkc, kc = s - f * nkc;
     bool any = false;
-    for (int ct = 0; ct < ntl; ++ct) any = any || (FL[((long long)at * w + b) * ntl + ct] && (!FC || FC[kc * fc_pitch + ct]));
+    for (int q = 0; q < nterm[f]; ++q) {
+      const F0Term tm = terms[f * F0_TMAX + q];
+      for (int ct = 0; ct < ntl; ++ct)
+        any = any || (FL[((long long)at * wl + tm.b) * ntl + ct] && (!FC || FC[(tm.e * nkc + kc) * fc_pitch + ct]));
+    }
     if (any) atomicOr(&s1[at], 1ull << s);
   }
   for (int t = tid; t < ntr * nparts; t += 1024) {
-    const int lt = t / nparts, s = t - lt * nparts, b = s / nkc, kc = s - b * nkc;
+    const int lt = t / nparts, s = t - lt * nparts, f = s / nkc, kc = s - f * nkc;
     bool any = false;
     for (int j = 0; j < 4; ++j) {
       const int kt = 4 * kc + j;
-      if (kt < ntr) any = any || FR[((long long)lt * w + b) * ntr + kt];
+      if (kt < ntr) any = any || FR[((long long)lt * wr + f) * ntr + kt];
     }
     if (any) atomicOr(&s2[lt], 1ull << s);
   }
   __syncthreads();
-  for (int t = tid; t < ntl * ntr; t += 1024) {
-    const int at = t / ntr, lt = t - at * ntr;
-    mask[t] = s1[at] & s2[lt];
+  for (int t = tid; t < ntl * d * ntr; t += 1024) {
+    const int row = t / ntr, lt = t - row * ntr;
+    mask[t] = s1[row / d] & s2[lt];
   }
 }
 
+// blockIdx.y = the value x of the physical index of the result this workgroup forms (0 for a bond matrix): the terms
+// of the other x are another workgroup's - half the chain of the heaviest workgroups, which set the duration of the launch
 __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
+  constexpr int DX = 1;
+  const int xo_wg = blockIdx.y;
   constexpr int NW = 4;   // waves per workgroup (eight - two groups splitting the c tiles of step 1, added up in LDS -
                           // spilled registers and lost: 495 against 510 site-updates/s)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15,
             kq = lane >> 4;
-  __shared__ double sTr[16 * 65], sTi[16 * 65];
+  __shared__ double sTr[DX][16 * 65], sTi[DX][16 * 65];
   __shared__ double s_dot[8];
   if (g.skip && *g.skip) return;
   // Launch position -> (bra tile row, part), plain order.  (Measured and dropped: a die - launch position mod 8, one L2
   // each - taking whole parts, so that its L2 holds only the panels of C and Rt its workgroups share.  Dealt channel-major
   // the heavy parts - ket chunks that straddle two quantum-number sectors - piled up on two dies: 39 us against 33; dealt
   // chunk-major 32 against 29.)
-  const int nparts = g.w * g.nkc;
-  const int wg = blockIdx.x;
-  const int at = wg / nparts, s = wg - at * nparts, b = s / g.nkc, kc = s - b * g.nkc;
+  const int nparts = g.wr * g.nkc;
+  const int wg0 = blockIdx.x;
+  const int wg = wg0 * g.d + xo_wg;                 // slot of the dot partials
+  const int at = wg0 / nparts, s = wg0 - at * nparts, f = s / g.nkc, kc = s - f * g.nkc;
   // which output tiles this workgroup holds (the mask is the single statement of that rule): lane lt looks at tile lt
   const unsigned long long lts =
-      __ballot(lane < g.ntr && ((g.mask[(long long)at * g.ntr + min(lane, g.ntr - 1)] >> s) & 1ull));
+      __ballot(lane < g.ntr && ((g.mask[(long long)at * g.d * g.ntr + min(lane, g.ntr - 1)] >> s) & 1ull));
   if (lts == 0) {
     if (g.dot_part && tid == 0) {
       g.dot_part[2 * wg] = 0.0;
@@ -136,97 +161,120 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
     }
     return;
   }
-  // ---- step 1: T[a, k] for this wave's 16 columns k of the chunk
+  // ---- step 1: P_x[a, k] for this wave's 16 columns k of the chunk
   const int wcolt = wave;
   const int a0 = 16 * at, k0 = 64 * kc + 16 * wcolt;
   const bool wcol = k0 < g.Dr;                       // (last chunk of a Dr that is not a multiple of 64)
   // (every flag this workgroup will consult is requested here, together: a dependent trip to memory costs ~1.5 us, and
   // a workgroup has no neighbour on its compute unit to hide it behind)
-  unsigned frn = 0;          // lane lt: bit j = R has data in rows lt, channel b, k tile 4 kc + j
+  unsigned frn = 0;          // lane lt: bit j = R has data in rows lt, channel f, k tile 4 kc + j
   if (lane < g.ntr) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int kt = 4 * kc + jj;
-      if (kt < g.ntr && g.FR[((long long)lane * g.w + b) * g.ntr + kt]) frn |= 1u << jj;
+      if (kt < g.ntr && g.FR[((long long)lane * g.wr + f) * g.ntr + kt]) frn |= 1u << jj;
     }
   }
   const int lc = min(lane, g.ntl - 1);
-  const unsigned long long cts = __ballot(lane < g.ntl && g.FL[((long long)at * g.w + b) * g.ntl + lc] &&
-                                          (!g.FC || g.FC[kc * g.fc_pitch + lc]));
-  const double2* La = reinterpret_cast<const double2*>(g.L) + ((long long)(a0 + x) * g.w + b) * g.Dl + kq;   // + c
-  const double2* Cb = reinterpret_cast<const double2*>(g.C) + (long long)kq * g.Dr + (wcol ? k0 : 0) + x;     // + c * Dr
-  v4d tr = {0, 0, 0, 0}, ti = {0, 0, 0, 0};
+  const int nt = g.nterm[f];
+  v4d tr[DX], ti[DX];
+#pragma unroll
+  for (int i = 0; i < DX; ++i) {
+    tr[i] = v4d{0, 0, 0, 0};
+    ti[i] = v4d{0, 0, 0, 0};
+  }
   // operands of three c tiles in flight (the tensors come from the memory-side cache: ~1.5 us away, and a workgroup has
   // no neighbour on its compute unit to hide that behind)
   double2 av[3][4], bv[3][4];
-  auto load1 = [&](int slot, int ct) {
+  for (int q = 0; q < nt; ++q) {
+    const F0Term tm = g.terms[f * F0_TMAX + q];
+    const int b = tm.b;
+    const double wv = tm.w;
+    if (tm.x != xo_wg) continue;      // (uniform)
+    const unsigned long long cts =
+        __ballot(lane < g.ntl && g.FL[((long long)at * g.wl + b) * g.ntl + lc] &&
+                 (!g.FC || g.FC[(long long)(tm.e * g.nkc + kc) * g.fc_pitch + lc]));
+    const double2* La = reinterpret_cast<const double2*>(g.L) + ((long long)(a0 + x) * g.wl + b) * g.Dl + kq;   // + c
+    const double2* Cb = reinterpret_cast<const double2*>(g.C) + ((long long)kq * g.d + tm.e) * g.Dr + (wcol ? k0 : 0) + x;
+    const long long cstride = (long long)g.d * g.Dr;                                                    // + c * d * Dr
+    auto load1 = [&](int slot, int ct) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int c = 16 * ct + 4 * kk;
-      av[slot][kk] = La[c];
-      bv[slot][kk] = Cb[(long long)c * g.Dr];
-    }
-  };
-  auto mul1 = [&](int slot) {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      tr = mfma(av[slot][kk].x, bv[slot][kk].x, tr);
-      tr = mfma(-av[slot][kk].y, bv[slot][kk].y, tr);
-      ti = mfma(av[slot][kk].x, bv[slot][kk].y, ti);
-      ti = mfma(av[slot][kk].y, bv[slot][kk].x, ti);
-    }
-  };
-  const unsigned long long mine = cts;
-  if (wcol && mine) {
-    // Three c tiles in flight, slots used in a fixed rotation.  The compiler barriers keep the order "request the tile
-    // after next, THEN multiply the oldest": without them the scheduler sinks every batch of loads to just before its
-    // use (fewer live registers) and each tile waits for its own trip to memory - measured: 3 600 cycles per tile against
-    // the 1 024 of its sixteen MFMAs.
-    unsigned long long m = mine;       // tiles still to load
-    auto next_ct = [&]() {
-      const int ct = m ? (int)__builtin_ctzll(m) : -1;
-      m &= m - (m ? 1 : 0);
-      return ct;
+      for (int kk = 0; kk < 4; ++kk) {
+        const int c = 16 * ct + 4 * kk;
+        av[slot][kk] = La[c];
+        bv[slot][kk] = Cb[(long long)c * cstride];
+      }
     };
-    int c0 = next_ct(), c1 = next_ct(), c2 = next_ct();
-    if (c0 >= 0) load1(0, c0);
-    if (c1 >= 0) load1(1, c1);
-    if (c2 >= 0) load1(2, c2);
-    while (c0 >= 0) {
-      asm volatile("" ::: "memory");
-      mul1(0);
-      c0 = next_ct();
+    auto mul1 = [&](int slot) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double ar = av[slot][kk].x * wv, ai = av[slot][kk].y * wv;
+#pragma unroll
+        for (int i = 0; i < DX; ++i) {
+          {
+            tr[i] = mfma(ar, bv[slot][kk].x, tr[i]);
+            tr[i] = mfma(-ai, bv[slot][kk].y, tr[i]);
+            ti[i] = mfma(ar, bv[slot][kk].y, ti[i]);
+            ti[i] = mfma(ai, bv[slot][kk].x, ti[i]);
+          }
+        }
+      }
+    };
+    if (wcol && cts) {
+      // Three c tiles in flight, slots used in a fixed rotation.  The compiler barriers keep the order "request the tile
+      // after next, THEN multiply the oldest": without them the scheduler sinks every batch of loads to just before its
+      // use (fewer live registers) and each tile waits for its own trip to memory - measured: 3 600 cycles per tile
+      // against the 1 024 of its sixteen MFMAs.
+      unsigned long long m = cts;       // tiles still to load
+      auto next_ct = [&]() {
+        const int ct = m ? (int)__builtin_ctzll(m) : -1;
+        m &= m - (m ? 1 : 0);
+        return ct;
+      };
+      int c0 = next_ct(), c1 = next_ct(), c2 = next_ct();
       if (c0 >= 0) load1(0, c0);
-      asm volatile("" ::: "memory");
-      if (c1 < 0) break;
-      mul1(1);
-      c1 = next_ct();
       if (c1 >= 0) load1(1, c1);
-      asm volatile("" ::: "memory");
-      if (c2 < 0) break;
-      mul1(2);
-      c2 = next_ct();
       if (c2 >= 0) load1(2, c2);
+      while (c0 >= 0) {
+        asm volatile("" ::: "memory");
+        mul1(0);
+        c0 = next_ct();
+        if (c0 >= 0) load1(0, c0);
+        asm volatile("" ::: "memory");
+        if (c1 < 0) break;
+        mul1(1);
+        c1 = next_ct();
+        if (c1 >= 0) load1(1, c1);
+        asm volatile("" ::: "memory");
+        if (c2 < 0) break;
+        mul1(2);
+        c2 = next_ct();
+        if (c2 >= 0) load1(2, c2);
+      }
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    sTr[(kq + 4 * r) * 65 + 16 * wcolt + x] = tr[r];
-    sTi[(kq + 4 * r) * 65 + 16 * wcolt + x] = ti[r];
-  }
-  __syncthreads();
-  // ---- step 2: the l tiles this workgroup holds, dealt to the waves in order; the A operand (T) of the whole chunk
-  // stays in registers
-  double xr[16], xi[16];
+  for (int i = 0; i < DX; ++i)
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    xr[ks] = sTr[x * 65 + 4 * ks + kq];
-    xi[ks] = sTi[x * 65 + 4 * ks + kq];
-  }
+    for (int r = 0; r < 4; ++r) {
+      sTr[i][(kq + 4 * r) * 65 + 16 * wcolt + x] = tr[i][r];
+      sTi[i][(kq + 4 * r) * 65 + 16 * wcolt + x] = ti[i][r];
+    }
+  __syncthreads();
+  // ---- step 2: the l tiles this workgroup holds, dealt to the waves in order; the A operands (P_x) of the whole chunk
+  // stay in registers
+  double xr[DX][16], xi[DX][16];
+#pragma unroll
+  for (int i = 0; i < DX; ++i)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      xr[i][ks] = sTr[i][x * 65 + 4 * ks + kq];
+      xi[i][ks] = sTi[i][x * 65 + 4 * ks + kq];
+    }
   double dre = 0.0, dim = 0.0;
-  const double2* Rb = reinterpret_cast<const double2*>(g.Rt) + ((long long)b * g.Dr + 64 * kc + kq) * g.Dr + x;
+  const double2* Rb = reinterpret_cast<const double2*>(g.Rt) + ((long long)f * g.Dr + 64 * kc + kq) * g.Dr + x;
   double2* part = reinterpret_cast<double2*>(g.parts) + (long long)s * g.n;
-  // this wave's tiles: the (wave)-th, (wave + 8)-th, .. set bit of lts; two of them in flight
+  // this wave's tiles: the (wave)-th, (wave + 4)-th, .. set bit of lts; two of them in flight
   auto nth_tile = [&](unsigned long long m, int n) {      // position of the n-th set bit, or -1
     for (int i = 0; i < n && m; ++i) m &= m - 1;
     return m ? (int)__builtin_ctzll(m) : -1;
@@ -234,8 +282,8 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
   auto k_tiles = [&](int lt) {                             // k tiles of the chunk where R has data for l tile lt
     return (unsigned)__builtin_amdgcn_readlane((int)frn, lt);
   };
-  double2 rv[2][16], yv2[2][4];
-  auto load2 = [&](int slot, int lt, unsigned) {
+  double2 rv[2][16], yv2[2][DX][4];
+  auto load2 = [&](int slot, int lt) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
       // (unconditional: a load guarded by the tile flag becomes load + select, and the select waits for the load on the
@@ -245,29 +293,35 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
     }
     if (g.y) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        yv2[slot][r] = reinterpret_cast<const double2*>(g.y)[(long long)(a0 + kq + 4 * r) * g.Dr + 16 * lt + x];
+      for (int i = 0; i < DX; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          yv2[slot][i][r] =
+              reinterpret_cast<const double2*>(g.y)[((long long)(a0 + kq + 4 * r) * g.d + xo_wg) * g.Dr + 16 * lt + x];
     }
   };
   auto mul2 = [&](int slot, int lt, unsigned kts) {
-    v4d orr = {0, 0, 0, 0}, oi = {0, 0, 0, 0};
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      if ((kts >> (ks >> 2)) & 1u) {      // (uniform)
-        orr = mfma(xr[ks], rv[slot][ks].x, orr);
-        orr = mfma(-xi[ks], rv[slot][ks].y, orr);
-        oi = mfma(xr[ks], rv[slot][ks].y, oi);
-        oi = mfma(xi[ks], rv[slot][ks].x, oi);
+    for (int i = 0; i < DX; ++i) {
+      v4d orr = {0, 0, 0, 0}, oi = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if ((kts >> (ks >> 2)) & 1u) {      // (uniform)
+          orr = mfma(xr[i][ks], rv[slot][ks].x, orr);
+          orr = mfma(-xi[i][ks], rv[slot][ks].y, orr);
+          oi = mfma(xr[i][ks], rv[slot][ks].y, oi);
+          oi = mfma(xi[i][ks], rv[slot][ks].x, oi);
+        }
       }
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long e = (long long)(a0 + kq + 4 * r) * g.Dr + 16 * lt + x;
-      part[e] = make_double2(orr[r], oi[r]);
-      if (g.y) {
-        const double2 yv = yv2[slot][r];
-        dre += orr[r] * yv.x + oi[r] * yv.y;      // conj(o) y
-        dim += orr[r] * yv.y - oi[r] * yv.x;
+      for (int r = 0; r < 4; ++r) {
+        const long long e = ((long long)(a0 + kq + 4 * r) * g.d + xo_wg) * g.Dr + 16 * lt + x;
+        part[e] = make_double2(orr[r], oi[r]);
+        if (g.y) {
+          const double2 yv = yv2[slot][i][r];
+          dre += orr[r] * yv.x + oi[r] * yv.y;      // conj(o) y
+          dim += orr[r] * yv.y - oi[r] * yv.x;
+        }
       }
     }
   };
@@ -276,14 +330,14 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
   unsigned kt0 = 0, kt1 = 0;
   if (lt0 >= 0) {
     kt0 = k_tiles(lt0);
-    load2(0, lt0, kt0);
+    load2(0, lt0);
   }
   while (lt0 >= 0) {
     idx += NW;
     lt1 = nth_tile(lts, idx);
     if (lt1 >= 0) {
       kt1 = k_tiles(lt1);
-      load2(1, lt1, kt1);
+      load2(1, lt1);
     }
     asm volatile("" ::: "memory");     // (the next tile's operands are requested before this tile is multiplied)
     mul2(0, lt0, kt0);
@@ -292,7 +346,7 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
     lt0 = nth_tile(lts, idx);
     if (lt0 >= 0) {
       kt0 = k_tiles(lt0);
-      load2(0, lt0, kt0);
+      load2(0, lt0);
     }
     asm volatile("" ::: "memory");
     mul2(1, lt1, kt1);
@@ -320,22 +374,32 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
 
 }  // namespace
 
-// Number of parts the fused 0-site matvec would deliver for this operator (0: not eligible).  Eligible: complex bond
-// matrix between complex environments with equal bra / ket bonds, both bond dimensions multiples of 16 and large enough
-// that the plans' four launches are not already cheap, at most 64 parts.  MPSE_HEFF0=0 switches the path off.
+// Number of parts the fused matvec would deliver for this operator (0: not eligible).  Eligible: complex bond matrix
+// (nsite = 0) or complex one-site centre with a two-level physical index and a real MPO site (nsite = 1, d = 2) between
+// complex environments with equal bra / ket bonds, bond dimensions multiples of 16 (of 64 for the ket bond of a one-site
+// centre: the chunks of the centre mask) and large enough that the plans' launches are not already cheap, at most 64
+// parts.  MPSE_HEFF0=0 switches the path off.  (A one-site centre also needs the values of its MPO site on the host,
+// mpse_mpo_site_hint: heff0_fused_try declines without them.)
 int heff0_fused_parts(const mpse_heff* h, int dtype) {
   static const int mode = [] {
     const char* e = getenv("MPSE_HEFF0");
     return e ? atoi(e) : 1;
   }();
-  if (mode == 0 || h->nsite != 0 || dtype != MPSE_C128 || h->l_dtype != MPSE_C128 || h->r_dtype != MPSE_C128) return 0;
+  if (mode == 0 || dtype != MPSE_C128 || h->l_dtype != MPSE_C128 || h->r_dtype != MPSE_C128) return 0;
   const mpse_dims& d = h->dims;
-  const int64_t Dl = d.Dl_ket, Dr = d.Dr_ket, w = d.wl;
-  if ((d.Dl_bra > 0 && d.Dl_bra != Dl) || (d.Dr_bra > 0 && d.Dr_bra != Dr) || d.wr != w || d.danc > 1) return 0;
-  if (Dl % 16 || Dr % 16 || Dl > 1024 || Dr > 1024 || w < 1) return 0;     // (tile rows / columns index 64-bit words)
+  const int64_t Dl = d.Dl_ket, Dr = d.Dr_ket;
+  if (h->nsite == 0) {
+    if (d.wr != d.wl) return 0;
+  } else if (h->nsite == 1) {
+    if (d.d0 != 2 || h->w_dtype != MPSE_F64 || !h->W0 || Dr % 64) return 0;
+  } else {
+    return 0;
+  }
+  if ((d.Dl_bra > 0 && d.Dl_bra != Dl) || (d.Dr_bra > 0 && d.Dr_bra != Dr) || d.danc > 1) return 0;
+  if (Dl % 16 || Dr % 16 || Dl > 1024 || Dr > 1024 || d.wl < 1 || d.wr < 1 || d.wl > 16 || d.wr > 16) return 0;
   const int64_t min_d = mode >= 2 ? 16 : 128;            // (MPSE_HEFF0=2: every eligible shape - tests)
   if (Dl < min_d || Dr < min_d) return 0;
-  const int64_t nparts = w * ((Dr + 63) / 64);
+  const int64_t nparts = d.wr * ((Dr + 63) / 64);
   if (nparts > 64) return 0;
   return (int)nparts;
 }
@@ -346,83 +410,118 @@ void heff0_drop_cache(mpse_ctx* ctx) {
 }
 
 // Runs the fused matvec when the caller offered masked parts (mpse_ctx::parts_req.masked_ok) with room for all of them.
-int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, bool* taken) {
+// w_host: the MPO site (wl, d, d, wr) of a one-site centre as the host knows it (mpse_mpo_site_hint), else null.
+int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, const double* w_host, bool* taken) {
   *taken = false;
   mpse_ctx::PartsReq& pr = ctx->parts_req;
   const int nparts = heff0_fused_parts(h, dtype);
   if (nparts == 0 || !pr.ptr || !pr.masked_ok) return MPSE_OK;
-  const int Dl = (int)h->dims.Dl_ket, Dr = (int)h->dims.Dr_ket, w = (int)h->dims.wl;
-  const long long n = (long long)Dl * Dr;
+  const int Dl = (int)h->dims.Dl_ket, Dr = (int)h->dims.Dr_ket, wl = (int)h->dims.wl, wr = (int)h->dims.wr;
+  const int d = h->nsite == 1 ? (int)h->dims.d0 : 1;
+  if (h->nsite == 1 && !w_host) return MPSE_OK;
+  const long long n = (long long)Dl * d * Dr;
   if (pr.n != n || pr.cap_elems < (long long)nparts * n) return MPSE_OK;
   const int ntl = Dl / 16, ntr = Dr / 16, nkc = (Dr + 63) / 64;
   const int nwg = ntl * nparts;
-  if (ctx->dot_req.y && nwg > ctx->dot_req.cap) return MPSE_OK;
-  // the centre mask applies when it describes this shape: rows of C in 16s, columns in 64s
+  if (ctx->dot_req.y && nwg * d > ctx->dot_req.cap) return MPSE_OK;
+  // the terms of every right channel: the non-zero entries W[b, x, e, f] (a bond matrix: the channel itself, factor 1)
+  std::vector<F0Term> terms(size_t(wr) * F0_TMAX);
+  std::vector<int> nterm(wr, 0);
+  for (int f = 0; f < wr; ++f) {
+    if (h->nsite == 0) {
+      terms[size_t(f) * F0_TMAX] = F0Term{f, 0, 0, 0, 1.0};
+      nterm[f] = 1;
+      continue;
+    }
+    for (int b = 0; b < wl; ++b)
+      for (int x = 0; x < d; ++x)
+        for (int e = 0; e < d; ++e) {
+          const double v = w_host[((size_t(b) * d + x) * d + e) * wr + f];
+          if (v == 0.0) continue;
+          if (nterm[f] == F0_TMAX) return MPSE_OK;      // (a denser site than this path is built for)
+          terms[size_t(f) * F0_TMAX + nterm[f]++] = F0Term{b, e, x, 0, v};
+        }
+  }
+  // the centre mask applies when it describes this shape: rows of C in 16s, columns (e, k) in 64s
   const unsigned char* FC = nullptr;
   int fc_pitch = 0;
   {
     const long long nkw = (ntl + 7) / 8;
     const char* pc = static_cast<const char*>(C);
-    if (ctx->cmask.ptr && pc >= ctx->cmask.lo && pc < ctx->cmask.hi && ctx->cmask.bytes == (long long)nkc * nkw * 8) {
+    if (ctx->cmask.ptr && pc >= ctx->cmask.lo && pc < ctx->cmask.hi && ctx->cmask.bytes == (long long)d * nkc * nkw * 8) {
       FC = static_cast<const unsigned char*>(ctx->cmask.ptr);
       fc_pitch = (int)(nkw * 8);
     }
   }
-  // per-solve data: transposed right environment, tile flags of L and R, the part mask
-  const size_t rt_bytes = size_t(w) * Dr * Dr * 16;
-  const size_t fl_bytes = (size_t(ntl) * w * ntl + 15) & ~size_t(15), fr_bytes = (size_t(ntr) * w * ntr + 15) & ~size_t(15);
-  const size_t mk_bytes = size_t(ntl) * ntr * 8;
+  // per-solve data: transposed right environment, tile flags of L and R, the terms, the part mask
+  const size_t rt_bytes = size_t(wr) * Dr * Dr * 16;
+  const size_t fl_bytes = (size_t(ntl) * wl * ntl + 15) & ~size_t(15), fr_bytes = (size_t(ntr) * wr * ntr + 15) & ~size_t(15);
+  const size_t tm_bytes = terms.size() * sizeof(F0Term), nt_bytes = (size_t(wr) * sizeof(int) + 15) & ~size_t(15);
+  const size_t mk_bytes = size_t(ntl) * d * ntr * 8;
   const bool keep = ctx->occ_cache_on || ctx->small_rt_scope;
   if (!keep) return MPSE_OK;     // (outside a solve nothing would own the flags and the mask until the consumer has run)
   mpse_ctx::F0Cache& fc = ctx->f0;
   char* base = nullptr;
-  const bool hit = keep && fc.buf && fc.L == h->L && fc.R == h->R && fc.cmask == (const void*)FC && fc.Dl == Dl && fc.Dr == Dr &&
-                   fc.w == w;
+  const bool hit = fc.buf && fc.L == h->L && fc.R == h->R && fc.W == h->W0 && fc.cmask == (const void*)FC && fc.Dl == Dl &&
+                   fc.Dr == Dr && fc.w == wr && fc.nsite == h->nsite;
+  const size_t o_fl = rt_bytes, o_fr = o_fl + fl_bytes, o_tm = o_fr + fr_bytes, o_nt = o_tm + tm_bytes, o_mk = o_nt + nt_bytes;
   if (hit) {
     base = static_cast<char*>(fc.buf);
   } else {
     void* p = nullptr;
     heff0_drop_cache(ctx);
-    MPSE_TRY(mpse_malloc(ctx, rt_bytes + fl_bytes + fr_bytes + mk_bytes, &p));
-    fc.buf = p, fc.L = h->L, fc.R = h->R, fc.cmask = FC, fc.Dl = Dl, fc.Dr = Dr, fc.w = w;
+    MPSE_TRY(mpse_malloc(ctx, o_mk + mk_bytes, &p));
+    fc.buf = p, fc.L = h->L, fc.R = h->R, fc.W = h->W0, fc.cmask = FC, fc.Dl = Dl, fc.Dr = Dr, fc.w = wr, fc.nsite = h->nsite;
     base = static_cast<char*>(p);
-    const long long nel = (long long)w * Dr * Dr;
+    MPSE_TRY(stage_h2d(ctx, base + o_tm, terms.data(), tm_bytes));
+    MPSE_TRY(stage_h2d(ctx, base + o_nt, nterm.data(), size_t(wr) * sizeof(int)));
+    const long long nel = (long long)wr * Dr * Dr;
     int nb = (int)((nel + 255) / 256);
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(k_f0_transpose, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(base),
-                       static_cast<const double2*>(h->R), Dr, w, ctx->skip_flag);
-    hipLaunchKernelGGL(k_f0_flags, dim3(ntl, w), dim3(256), 0, ctx->stream, static_cast<const double2*>(h->L), Dl, w, ntl,
-                       reinterpret_cast<unsigned char*>(base + rt_bytes), ctx->skip_flag);
-    hipLaunchKernelGGL(k_f0_flags, dim3(ntr, w), dim3(256), 0, ctx->stream, static_cast<const double2*>(h->R), Dr, w, ntr,
-                       reinterpret_cast<unsigned char*>(base + rt_bytes + fl_bytes), ctx->skip_flag);
-    hipLaunchKernelGGL(k_f0_valid, dim3(1), dim3(1024), 0, ctx->stream,
-                       reinterpret_cast<const unsigned char*>(base + rt_bytes), FC,
-                       reinterpret_cast<const unsigned char*>(base + rt_bytes + fl_bytes), w, ntl, ntr, nkc, fc_pitch,
-                       reinterpret_cast<unsigned long long*>(base + rt_bytes + fl_bytes + fr_bytes), ctx->skip_flag);
+                       static_cast<const double2*>(h->R), Dr, wr, ctx->skip_flag);
+    hipLaunchKernelGGL(k_f0_flags, dim3(ntl, wl), dim3(256), 0, ctx->stream, static_cast<const double2*>(h->L), Dl, wl, ntl,
+                       reinterpret_cast<unsigned char*>(base + o_fl), ctx->skip_flag);
+    hipLaunchKernelGGL(k_f0_flags, dim3(ntr, wr), dim3(256), 0, ctx->stream, static_cast<const double2*>(h->R), Dr, wr, ntr,
+                       reinterpret_cast<unsigned char*>(base + o_fr), ctx->skip_flag);
+    hipLaunchKernelGGL(k_f0_valid, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const unsigned char*>(base + o_fl), FC,
+                       reinterpret_cast<const unsigned char*>(base + o_fr), reinterpret_cast<const F0Term*>(base + o_tm),
+                       reinterpret_cast<const int*>(base + o_nt), wl, wr, d, ntl, ntr, nkc, fc_pitch,
+                       reinterpret_cast<unsigned long long*>(base + o_mk), ctx->skip_flag);
   }
   F0Args g{};
   g.L = static_cast<const double*>(h->L);
   g.Rt = reinterpret_cast<const double*>(base);
   g.C = static_cast<const double*>(C);
   g.parts = static_cast<double*>(pr.ptr);
-  g.FL = reinterpret_cast<const unsigned char*>(base + rt_bytes);
+  g.FL = reinterpret_cast<const unsigned char*>(base + o_fl);
   g.FC = FC;
-  g.FR = reinterpret_cast<const unsigned char*>(base + rt_bytes + fl_bytes);
-  g.mask = reinterpret_cast<const unsigned long long*>(base + rt_bytes + fl_bytes + fr_bytes);
+  g.FR = reinterpret_cast<const unsigned char*>(base + o_fr);
+  g.terms = reinterpret_cast<const F0Term*>(base + o_tm);
+  g.nterm = reinterpret_cast<const int*>(base + o_nt);
+  g.mask = reinterpret_cast<const unsigned long long*>(base + o_mk);
   g.skip = ctx->skip_flag;
   g.n = n;
-  g.Dl = Dl, g.Dr = Dr, g.w = w, g.ntl = ntl, g.ntr = ntr, g.nkc = nkc, g.fc_pitch = fc_pitch;
+  g.Dl = Dl, g.Dr = Dr, g.wl = wl, g.wr = wr, g.d = d, g.ntl = ntl, g.ntr = ntr, g.nkc = nkc, g.fc_pitch = fc_pitch;
   if (ctx->dot_req.y) {
     g.y = static_cast<const double*>(ctx->dot_req.y);
     g.dot_part = ctx->dot_req.part;
-    ctx->dot_req.nb_out = nwg;
+    ctx->dot_req.nb_out = nwg * d;
   }
-  hipLaunchKernelGGL(k_heff0_fused, dim3(nwg), dim3(256), 0, ctx->stream, g);
+  hipLaunchKernelGGL(k_heff0_fused, dim3(nwg, d), dim3(256), 0, ctx->stream, g);
   MPSE_HIP(ctx, hipGetLastError());
+  ++ctx->f0_launches[h->nsite == 1 ? 1 : 0];
   pr.used = nparts;
   pr.mask = g.mask;
   pr.mask_row = Dr;
   pr.mask_tiles = ntr;
   *taken = true;
+  return MPSE_OK;
+}
+
+extern "C" int mpse_heff_fused_stats(mpse_ctx* ctx, int64_t* bond_launches, int64_t* site_launches) {
+  if (!ctx) return MPSE_ERR_ARG;
+  if (bond_launches) *bond_launches = ctx->f0_launches[0];
+  if (site_launches) *site_launches = ctx->f0_launches[1];
   return MPSE_OK;
 }

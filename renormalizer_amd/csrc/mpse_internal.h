@@ -167,9 +167,10 @@ struct mpse_ctx {
   // Per-solve data of the fused 0-site matvec (mpse_heff0.hip): transposed right environment, tile flags, part mask
   struct F0Cache {
     void* buf = nullptr;
-    const void *L = nullptr, *R = nullptr, *cmask = nullptr;
-    int Dl = 0, Dr = 0, w = 0;
+    const void *L = nullptr, *R = nullptr, *W = nullptr, *cmask = nullptr;
+    int Dl = 0, Dr = 0, w = 0, nsite = -1;
   } f0;
+  long long f0_launches[2] = {0, 0};   // fused matvec launches: bond matrices, two-level sites
   // mpse_block_qr: decompositions that took the Cholesky-QR path / that fell back from it to Householder
   long long qr_chol_calls = 0, qr_chol_fallbacks = 0, qr_calls = 0;
   // optimistic mode of the Cholesky-QR path (mpse_block_qr_optimistic): breakdowns raise this sticky device word
@@ -245,7 +246,7 @@ void heff_small_drop_cache(mpse_ctx* ctx);
 // Fused 0-site matvec for large complex bond matrices (mpse_heff0.hip): number of parts it would deliver (0 = not
 // eligible), the attempt itself (needs mpse_ctx::parts_req.masked_ok), and the release of its per-solve data
 int heff0_fused_parts(const mpse_heff* h, int dtype);
-int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, bool* taken);
+int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C, const double* w_host, bool* taken);
 void heff0_drop_cache(mpse_ctx* ctx);
 struct SmallRtScope {   // for the duration of one eigensolve: the right environment does not change
   mpse_ctx* c;

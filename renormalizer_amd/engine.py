@@ -92,6 +92,7 @@ _SIGNATURES = {
     "mpse_prof_get_svd_sweeps": [C.c_void_p, C.POINTER(C.c_int64)],
     "mpse_mpo_site_hint": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64],
     "mpse_block_qr_stats": [C.c_void_p] + [C.POINTER(C.c_int64)] * 3,
+    "mpse_heff_fused_stats": [C.c_void_p] + [C.POINTER(C.c_int64)] * 2,
     "mpse_block_qr_optimistic": [C.c_void_p, C.c_int],
     "mpse_block_qr_check": [C.c_void_p, C.POINTER(C.c_int)],
     "mpse_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
@@ -446,6 +447,12 @@ class Engine:
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         self._check(self.lib.mpse_block_qr_stats(self.ctx, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def heff_fused_stats(self):
+        """(bond-matrix, two-level-site) effective-Hamiltonian applications that ran as the fused launch."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.mpse_heff_fused_stats(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def block_qr_optimistic(self, on):
         """Optimistic mode of the Cholesky-QR path (``mpse_block_qr_optimistic``): breakdowns are not read back per

@@ -1359,7 +1359,7 @@ class Mps:
                 plan = svd_qn.block_plan(qnbigl, qnbigr, mps.qntot)
                 # large centres: the engine skips the empty tiles of the Krylov vectors by the pattern of their
                 # quantum numbers instead of scanning every vector (row / column grouping as the QR sees the site)
-                if use_cmask and len(shape) == 3 and shape[0] * shape[0] * shape[1] * shape[2] >= (1 << 26):
+                if use_cmask and len(shape) == 3 and shape[0] * shape[0] * shape[1] * shape[2] >= (1 << 22):
                     if mps.to_right:
                         ql, qr = qnbigl, qnbigr
                     else:               # sweeping left the QR groups the site as (a | sigma, b): regroup (a, sigma | b)
