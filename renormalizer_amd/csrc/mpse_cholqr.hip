@@ -1012,11 +1012,12 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
 
 }  // namespace
 
-// Eligible: every block at least as tall as wide (k = nn), at most 256 columns, and the tallest block tall enough for the
-// scheme to win: its cost is ~14 launches whose Cholesky / triangular-solve chains depend on the COLUMN count only
-// (0.30 - 0.50 ms at 100 - 180 columns), the Householder chain grows with the rows (0.32 ms at 256 rows, 0.78 ms at
-// 2 800: tools/qr_bench.py, profiles/r05_qr_cholqr.md).  MPSE_CHOLQR=0 switches the path off, MPSE_CHOLQR=2 takes every
-// eligible shape (tests); MPSE_CHOLQR_MINROWS moves the row threshold.
+// Eligible: every block at least as tall as wide (k = nn), at most 256 columns, and the tallest block of at least 256
+// rows and 32 columns: the cost of the scheme is ~14 launches whose Cholesky / triangular-solve chains depend on the
+// COLUMN count only (0.28 - 0.40 ms at 100 - 180 columns), the Householder chain grows with the rows (0.19 ms at 512 x 64,
+// 0.32 - 0.37 ms at 256 rows x 150 columns, 0.78 ms at 2 800 rows: tools/qr_bench.py, profiles/r05_qr_cholqr.md).
+// MPSE_CHOLQR=0 switches the path off, MPSE_CHOLQR=2 takes every eligible shape (tests); MPSE_CHOLQR_MINROWS moves the
+// row threshold.
 bool cholqr_eligible(const QrBlk* blks, int nblk) {
   static const int mode = [] {
     const char* e = getenv("MPSE_CHOLQR");
@@ -1024,7 +1025,7 @@ bool cholqr_eligible(const QrBlk* blks, int nblk) {
   }();
   static const int min_rows = [] {
     const char* e = getenv("MPSE_CHOLQR_MINROWS");
-    return e ? atoi(e) : 1024;
+    return e ? atoi(e) : 256;
   }();
   if (mode == 0 || nblk <= 0) return false;
   int max_mm = 0, max_nn = 0;
