@@ -332,6 +332,14 @@ int mpse_block_qr_stats(mpse_ctx* ctx, int64_t* calls, int64_t* chol_calls, int6
 int mpse_block_qr_optimistic(mpse_ctx* ctx, int on);
 int mpse_block_qr_check(mpse_ctx* ctx, int* tripped);
 
+/* Which kernels mpse_block_qr uses on this context: 0 Householder only (the column-by-column elimination of LAPACK's
+ * geqrf, mps/svd_qn.py:171-185 calls scipy.linalg.qr: the SAME isometry as the reference up to rounding, also in the
+ * directions of numerically zero singular values, where a QR factorisation is not unique), 1 Cholesky-QR for tall blocks
+ * from 256 rows on (default), 2 Cholesky-QR for every block shape it supports, -1 back to the MPSE_CHOLQR environment
+ * setting.  Both schemes return U @ Vt == coef and an isometry to rounding; they may differ by a rotation inside the
+ * numerical null space of a block.  No reference counterpart. */
+int mpse_block_qr_scheme(mpse_ctx* ctx, int scheme);
+
 /* Quantum-number blocked economic SVD by one-sided Jacobi, replaces mps/svd_qn.py:99-240
  * with QR=False, full_matrices=False (scipy.linalg.svd gesdd per block).  Same block
  * description; outputs U (nrow x K), Vt (K x ncol) (block order, NOT globally sorted) and

@@ -1017,12 +1017,13 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
 // COLUMN count only (0.28 - 0.40 ms at 100 - 180 columns), the Householder chain grows with the rows (0.19 ms at 512 x 64,
 // 0.32 - 0.37 ms at 256 rows x 150 columns, 0.78 ms at 2 800 rows: tools/qr_bench.py, profiles/r05_qr_cholqr.md).
 // MPSE_CHOLQR=0 switches the path off, MPSE_CHOLQR=2 takes every eligible shape (tests); MPSE_CHOLQR_MINROWS moves the
-// row threshold.
-bool cholqr_eligible(const QrBlk* blks, int nblk) {
-  static const int mode = [] {
+// row threshold; mpse_block_qr_scheme overrides MPSE_CHOLQR per context.
+bool cholqr_eligible(const mpse_ctx* ctx, const QrBlk* blks, int nblk) {
+  static const int env_mode = [] {
     const char* e = getenv("MPSE_CHOLQR");
     return e ? atoi(e) : 1;
   }();
+  const int mode = ctx->qr_scheme >= 0 ? ctx->qr_scheme : env_mode;
   static const int min_rows = [] {
     const char* e = getenv("MPSE_CHOLQR_MINROWS");
     return e ? atoi(e) : 256;

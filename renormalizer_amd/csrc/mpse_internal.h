@@ -176,6 +176,7 @@ struct mpse_ctx {
   // optimistic mode of the Cholesky-QR path (mpse_block_qr_optimistic): breakdowns raise this sticky device word
   // instead of being read back per decomposition
   bool qr_optimistic = false;
+  int qr_scheme = -1;            // mpse_block_qr_scheme: -1 environment default, 0 Householder only, 1 default rule, 2 every eligible shape
   int* qr_flag_dev = nullptr;
 };
 
@@ -338,7 +339,7 @@ int hh_qr_batched(mpse_ctx* ctx, bool cplx, double* ws, double* q, HhParam* prm,
 // Shifted Cholesky-QR of tall blocks on MFMA (mpse_cholqr.hip).  The blocks are factorised in place in their column-major
 // workspaces and scattered to U / Vt like mpse_block_qr does; *ok = false when a block was rank deficient or too ill
 // conditioned for the scheme (device flag, one read-back): the caller then runs the Householder path on fresh copies.
-bool cholqr_eligible(const QrBlk* blks, int nblk);
+bool cholqr_eligible(const mpse_ctx* ctx, const QrBlk* blks, int nblk);
 int cholqr_blocks(mpse_ctx* ctx, bool cplx, double* ws, const QrBlk* blks, int nblk, const long long* drows,
                   const long long* dcols, int herm, void* U, void* Vt, long long K, long long ncol, bool* ok);
 // zero fill of two ranges in one launch (8-byte aligned)

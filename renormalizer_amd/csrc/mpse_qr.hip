@@ -342,7 +342,7 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   // tall blocks of up to 256 columns: shifted Cholesky-QR on MFMA (mpse_cholqr.hip), all compute units instead of one
   // per block; a block it cannot decide (rank deficient, condition beyond ~1e15) raises a device flag and the whole
   // call is redone by the Householder kernels below on fresh copies of the blocks
-  if (cholqr_eligible(blks.data(), (int)blks.size())) {
+  if (cholqr_eligible(ctx, blks.data(), (int)blks.size())) {
     bool ok = false;
     MPSE_TRY(cholqr_blocks(ctx, CPLX, ws, blks.data(), (int)blks.size(), drows, dcols, herm, U, Vt, (long long)K,
                            (long long)ncol, &ok));
@@ -450,6 +450,12 @@ int mpse_block_qr_optimistic(mpse_ctx* ctx, int on) {
     MPSE_TRY(device_zero(ctx, ctx->qr_flag_dev, 16));
   }
   ctx->qr_optimistic = on != 0;
+  return MPSE_OK;
+}
+
+int mpse_block_qr_scheme(mpse_ctx* ctx, int scheme) {
+  if (!ctx || scheme < -1 || scheme > 2) return MPSE_ERR_ARG;
+  ctx->qr_scheme = scheme;
   return MPSE_OK;
 }
 

