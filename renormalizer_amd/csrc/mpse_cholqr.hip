@@ -463,18 +463,18 @@ __global__ __launch_bounds__(512) void k_cq_chol(const double* __restrict__ G, c
   }
 }
 
-// Right-looking form for blocks of up to 192 columns (P <= 12, T <= 78): every tile of the trailing matrix lives in
+// Right-looking form for blocks of up to 160 columns (P <= 10, T <= 55): every tile of the trailing matrix lives in
 // the MFMA accumulators of one of the 8 waves for the whole factorisation (tile t -> wave t mod 8, slot t / 8), the row
 // panel of a step goes through LDS (two buffers by parity) and is the operand of all updates of that step - no global
 // load sits inside the loop (the left-looking form above read its operands back from L2 in a loop of dependent round
 // trips: 100 us per factorisation at n = 145 against the ~35 us the chain diagonal factor -> row solve -> update needs).
-// NW waves, NS accumulator slots per wave (8 x 7: P <= 10; 16 x 5: P <= 12 - ten slots on eight waves spilled).  XLDS: the row solve re-reads its finished rows from LDS
-// instead of keeping them in 64 registers next to the 160 of ten slots (which spilled).
-template <bool CPLX, int NW, int NS, bool XLDS>
-__global__ __launch_bounds__(64 * NW) void k_cq_chol_rl(const double* __restrict__ G, const double* __restrict__ tinfo,
+// 8 waves with 7 accumulator slots each hold the 55 tiles of P <= 10 (160 columns); ten slots per wave, or 16 waves of
+// five, spilled and lost to the left-looking kernel, which keeps the blocks of 161 - 256 columns.
+template <bool CPLX>
+__global__ __launch_bounds__(512) void k_cq_chol_rl(const double* __restrict__ G, const double* __restrict__ tinfo,
                                                      double* __restrict__ R, const CqBlk* __restrict__ blks,
-                                                     int* __restrict__ status, int pass, int dbg, int* __restrict__ gflag) {
-  constexpr int E = CPLX ? 2 : 1, PMAX = 12, NT = 64 * NW;
+                                                     int* __restrict__ status, int pass, int* __restrict__ gflag) {
+  constexpr int E = CPLX ? 2 : 1, PMAX = 10, NW = 8, NS = 7, NT = 64 * NW;
   const CqBlk B = blks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15, kq = lane >> 4;
   const int P = B.P, T = B.T, nn = B.nn;
@@ -563,16 +563,14 @@ __global__ __launch_bounds__(64 * NW) void k_cq_chol_rl(const double* __restrict
       }
     __syncthreads();
     // ---- the row panel of the factor (diagonal factor + forward substitution in one elimination, see panel_eliminate)
-    if (!(dbg & 1)) {
-      int badp = 0;
-      panel_eliminate<CPLX>(sRow[buf], 16 * (P - p), p, P, nn, Rt, sDinv, pass, tid, &badp);
-      if (badp) bad = 1;
-    }
+    int badp = 0;
+    panel_eliminate<CPLX>(sRow[buf], 16 * (P - p), p, P, nn, Rt, sDinv, pass, tid, &badp);
+    if (badp) bad = 1;
     __syncthreads();
     // ---- updates: S(q, c) -= R(p, q)^H R(p, c) for this wave's tiles below the panel
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-      if (tq[s] > p && !(dbg & 4)) {
+      if (tq[s] > p) {
         const double2* ta = sRow[buf][tq[s] - p];
         const double2* tb = sRow[buf][tc[s] - p];
 #pragma unroll
@@ -601,7 +599,7 @@ __global__ __launch_bounds__(64 * NW) void k_cq_chol_rl(const double* __restrict
 //     by DPP row_share), stores X_q and publishes it through LDS as the A operand of the updates A_p -= X_q R(q, p).
 //     mode 1 (first-order factor R = I + U of pass 3): X_p = A_p - sum_{q<=p} A_q U(q, p), no dependent chain.
 //   the other workgroups: one tile each of Rout = Rcur . Rprev (the accumulated triangular factor).
-template <bool CPLX, int VAR>
+template <bool CPLX>
 __global__ __launch_bounds__(256) void k_cq_trsm(double* __restrict__ ws, const double* __restrict__ R,
                                                   const double* __restrict__ Rprev, double* __restrict__ Rout,
                                                   const CqBlk* __restrict__ blks, const int* __restrict__ status, int nrb_max,
@@ -728,31 +726,18 @@ __global__ __launch_bounds__(256) void k_cq_trsm(double* __restrict__ ws, const 
       if (wave + 4 * s < P) store_panel(wave + 4 * s, ar[s], ai[s]);
     return;
   }
-  // general mode.  VAR (development switch MPSE_CQ_TRSM): 0 = every operand loaded where it is used; 1 = the tile of the
-  // update on the critical path (panel q + 1) requested before the barrier; 2 = also the column of R_qq one step ahead
+  // general mode.  Every operand is loaded where it is used: requesting the tile of the critical update (panel q + 1)
+  // or the next diagonal column ahead of the barrier cost more registers (one workgroup per SIMD) than it hid latency
   double rr[16], ri[16];
   auto load_rcol = [&](int q) {
     const double* td = Rt + (long long)tile_index(q, q, P) * 256 * E;
 #pragma unroll
     for (int t = 0; t < 16; ++t) ld2<CPLX>(td, t * 16 + x, rr[t], ri[t]);
   };
-  if constexpr (VAR == 2) {
-    if (wave == 0) load_rcol(0);
-  }
   for (int q = 0; q < P; ++q) {
     const int owner = q & 3, slot = q >> 2, buf = q & 1;
-    const int pc = q + 1;
-    const bool crit = VAR >= 1 && pc < P && (pc & 3) == wave;
-    double ycr[4], yci[4];
-    if constexpr (VAR >= 1) {
-      if (crit) {
-        const double* tb = Rt + (long long)tile_index(q, pc, P) * 256 * E;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) ld2<CPLX>(tb, (4 * kk + kq) * 16 + x, ycr[kk], yci[kk]);
-      }
-    }
     if (wave == owner) {
-      if constexpr (VAR < 2) load_rcol(q);
+      load_rcol(q);
       asm volatile("" ::: "memory");   // (all sixteen loads are out before the first is consumed: left alone the
                                          // scheduler pairs each load with its use - sixteen dependent trips to L2)
       double dj = rr[0];
@@ -807,9 +792,6 @@ __global__ __launch_bounds__(256) void k_cq_trsm(double* __restrict__ ws, const 
       }
       store_panel(q, vr, vi);
     }
-    if constexpr (VAR == 2) {
-      if (pc < P && (pc & 3) == wave) load_rcol(pc);   // (this wave solves next: its rr / ri are free until then)
-    }
     lds_barrier();
     // updates of this wave's later panels: A_p -= X_q R(q, p)
 #pragma unroll
@@ -817,17 +799,9 @@ __global__ __launch_bounds__(256) void k_cq_trsm(double* __restrict__ ws, const 
       const int p = wave + 4 * s;
       if (p > q && p < P) {
         const double* tb = Rt + (long long)tile_index(q, p, P) * 256 * E;
-        const bool pre = VAR >= 1 && crit && p == pc;
         double yr[4], yi[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          if (pre) {
-            yr[kk] = ycr[kk];
-            yi[kk] = yci[kk];
-          } else {
-            ld2<CPLX>(tb, (4 * kk + kq) * 16 + x, yr[kk], yi[kk]);
-          }
-        }
+        for (int kk = 0; kk < 4; ++kk) ld2<CPLX>(tb, (4 * kk + kq) * 16 + x, yr[kk], yi[kk]);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -953,47 +927,22 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
   int* status = reinterpret_cast<int*>(base + db + pb + 6 * tb + ib);
   double* dstat = reinterpret_cast<double*>(base + db + pb + 6 * tb + ib + sb);
   const double* racc = nullptr;
-  static const int cq_dbg = [] {         // development: skip phases of the Cholesky kernel (wrong results, timings only)
-    const char* e = getenv("MPSE_CQ_DBG");
-    return e ? atoi(e) : 0;
-  }();
-  static const int chol12_var = [] {     // development switch: which Cholesky kernel takes 161 - 192 columns
-    const char* e = getenv("MPSE_CQ_CHOL12");
-    return e ? atoi(e) : 2;      // (2: the left-looking kernel - the ten-slot right-looking one spills)
-  }();
   for (int pass = 1; pass <= 3; ++pass) {
     double* Rcur = Rb[pass - 1];
     hipLaunchKernelGGL((k_cq_gram<CPLX>), dim3(max_gram, nblk), dim3(256), 0, ctx->stream, (const double*)ws, part, dblk,
                        status, pass == 1 ? nblk + 1 : 0);
     hipLaunchKernelGGL((k_cq_reduce<CPLX>), dim3(max_T, nblk), dim3(256), 0, ctx->stream, (const double*)part, G, tinfo, dblk);
     if (max_P <= 10)
-      hipLaunchKernelGGL((k_cq_chol_rl<CPLX, 8, 7, false>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G,
-                         (const double*)tinfo, Rcur, dblk, status, pass, cq_dbg, gflag);
-    else if (max_P <= 12 && chol12_var == 0)
-      hipLaunchKernelGGL((k_cq_chol_rl<CPLX, 8, 10, true>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G,
-                         (const double*)tinfo, Rcur, dblk, status, pass, cq_dbg, gflag);
-    else if (max_P <= 12 && chol12_var == 1)
-      hipLaunchKernelGGL((k_cq_chol_rl<CPLX, 16, 5, true>), dim3(nblk), dim3(1024), 0, ctx->stream, (const double*)G,
-                         (const double*)tinfo, Rcur, dblk, status, pass, cq_dbg, gflag);
+      hipLaunchKernelGGL((k_cq_chol_rl<CPLX>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G,
+                         (const double*)tinfo, Rcur, dblk, status, pass, gflag);
     else
       hipLaunchKernelGGL((k_cq_chol<CPLX>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G, (const double*)tinfo,
                          Rcur, dblk, status, pass, gflag);
     double* Rout = pass == 2 ? Rb[3] : Rb[4];
     const int rmul = pass >= 2 ? 1 : 0;
-    static const int trsm_var = [] {
-      const char* e = getenv("MPSE_CQ_TRSM");
-      return e ? atoi(e) : 0;
-    }();
     const dim3 tg(max_nrb + (rmul ? max_T : 0), nblk);
-    if (trsm_var == 1)
-      hipLaunchKernelGGL((k_cq_trsm<CPLX, 1>), tg, dim3(256), 0, ctx->stream, ws, (const double*)Rcur, racc, Rout, dblk,
-                         (const int*)status, max_nrb, rmul);
-    else if (trsm_var == 2)
-      hipLaunchKernelGGL((k_cq_trsm<CPLX, 2>), tg, dim3(256), 0, ctx->stream, ws, (const double*)Rcur, racc, Rout, dblk,
-                         (const int*)status, max_nrb, rmul);
-    else
-      hipLaunchKernelGGL((k_cq_trsm<CPLX, 0>), tg, dim3(256), 0, ctx->stream, ws, (const double*)Rcur, racc, Rout, dblk,
-                         (const int*)status, max_nrb, rmul);
+    hipLaunchKernelGGL((k_cq_trsm<CPLX>), tg, dim3(256), 0, ctx->stream, ws, (const double*)Rcur, racc, Rout, dblk,
+                       (const int*)status, max_nrb, rmul);
     racc = pass == 1 ? Rcur : Rout;
   }
   int nb = (int)((max_sc + 255) / 256);

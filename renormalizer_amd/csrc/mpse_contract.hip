@@ -485,7 +485,7 @@ extern "C" int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, con
   if (h->nsite == 1 && h->W0) {
     std::lock_guard<std::mutex> lock(ctx->pool_mu);
     auto it = ctx->wsite_info.find(h->W0);
-    if (it != ctx->wsite_info.end()) wi_keep = it->second;
+    if (it != ctx->wsite_info.end()) wi_keep = it->second.info;
   }
   // a caller that takes the result in two parts (mpse_ctx::y2_req, the Lanczos solve) lets the last product run as
   // halved tiles; `used` tells it whether the second part holds anything
@@ -528,7 +528,7 @@ extern "C" int mpse_mpo_site_hint(mpse_ctx* ctx, const void* W_dev, const double
   if (wl <= 0 || d <= 0 || wr <= 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "mpo_site_hint: empty MPO site");
   std::shared_ptr<void> info = std::make_shared<WSiteInfo>(analyse_mpo_site(W_host, wl, d, wr));
   std::lock_guard<std::mutex> lock(ctx->pool_mu);
-  ctx->wsite_info[W_dev] = info;
+  ctx->wsite_info[W_dev] = mpse_ctx::WSiteEntry{info, size_t(wl) * size_t(d) * size_t(d) * size_t(wr) * sizeof(double)};
   return MPSE_OK;
 }
 

@@ -465,6 +465,7 @@ int mpse_memcpy_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes
   if (!ctx || (bytes && (!dst || !src_host))) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
   if (!bytes) return MPSE_OK;
+  wsite_written(ctx, dst, bytes);
   MPSE_HIP(ctx, hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
   MPSE_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MPSE_OK;
@@ -483,6 +484,7 @@ int mpse_memcpy_d2d(mpse_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx || (bytes && (!dst || !src))) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
   if (!bytes) return MPSE_OK;
+  wsite_written(ctx, dst, bytes);
   // tensors are 16-byte aligned multiples of 8 bytes: a plain grid-stride kernel queues like any other launch, while
   // the runtime's device-to-device copy leaves ~15 us of idle time behind it on the stream (rocprofv3 trace)
   if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0 && (bytes & 15) == 0) {
@@ -503,6 +505,7 @@ int mpse_memcpy_2d(mpse_ctx* ctx, void* dst, size_t dpitch, const void* src, siz
   if (!ctx || ((width_bytes && height) && (!dst || !src))) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
   if (!width_bytes || !height) return MPSE_OK;
+  wsite_written(ctx, dst, dpitch * (height - 1) + width_bytes);
   MPSE_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDeviceToDevice, ctx->stream));
   return MPSE_OK;
 }
@@ -510,6 +513,7 @@ int mpse_memcpy_2d(mpse_ctx* ctx, void* dst, size_t dpitch, const void* src, siz
 int mpse_memset_zero(mpse_ctx* ctx, void* dst, size_t bytes) {
   if (!ctx || (bytes && !dst)) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
+  wsite_written(ctx, dst, bytes);
   return device_zero(ctx, dst, bytes);
 }
 

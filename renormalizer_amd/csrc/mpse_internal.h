@@ -84,8 +84,13 @@ struct mpse_ctx {
   // Krylov dimension of the last solve per problem class (number of sites, vector length): how far to run ahead
   std::unordered_map<unsigned long long, int> lz_hint;
   // Block structure of MPO sites the caller has described (mpse_mpo_site_hint), by device pointer: large one-site
-  // matvecs on such a site take the folded plan (mpse_plans.h).  Dropped when the buffer is freed.
-  std::unordered_map<const void*, std::shared_ptr<void>> wsite_info;   // -> mpse_plan::WSiteInfo
+  // matvecs on such a site take the folded plan (mpse_plans.h).  Dropped when the buffer is freed, and when one of
+  // the element-level entry points writes into it (wsite_written: copies, memset, scal, conj, axpy).
+  struct WSiteEntry {
+    std::shared_ptr<void> info;      // -> mpse_plan::WSiteInfo
+    size_t bytes = 0;                // extent of the described site on the device
+  };
+  std::unordered_map<const void*, WSiteEntry> wsite_info;
   // Deferred calls (mpse_defer_*): mpse_gemm / mpse_block_qr / mpse_env_update issued while a list is being recorded
   // are stored with copies of their arguments; an armed list runs at the end of the next mpse_expm_lanczos, right
   // after the solve has been enqueued to its end.  While a list is recorded or waiting, freed device blocks are held
@@ -193,12 +198,44 @@ inline int mpse_bind(mpse_ctx* ctx) {
 int stage_h2d(mpse_ctx* ctx, void* dst, const void* src_host, size_t bytes);
 // zero fill as a plain kernel on the context stream (8-byte aligned ranges; others go through hipMemsetAsync)
 int device_zero(mpse_ctx* ctx, void* dst, size_t bytes);
+// an entry point is about to write `bytes` at `dst`: a described MPO site (mpse_mpo_site_hint) that overlaps the range no
+// longer holds the values that were analysed - its description goes
+inline void wsite_written(mpse_ctx* ctx, const void* dst, size_t bytes) {
+  if (ctx->wsite_info.empty() || !dst || !bytes) return;
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
+  const char* lo = static_cast<const char*>(dst);
+  for (auto it = ctx->wsite_info.begin(); it != ctx->wsite_info.end();) {
+    const char* w = static_cast<const char*>(it->first);
+    if (lo < w + it->second.bytes && w < lo + bytes)
+      it = ctx->wsite_info.erase(it);
+    else
+      ++it;
+  }
+}
 // fold finished profiling records into the totals; call only when the stream is idle
 void prof_drain(mpse_ctx* ctx);
 // HIP-event bracket around a group of launches on the context stream; begin returns false when this call is not
 // sampled (profiling off or not the N-th call) or no event could be had
 bool prof_begin(mpse_ctx* ctx, int variant, double flops, double bytes, mpse_ctx::ProfRec* rec);
 void prof_end(mpse_ctx* ctx, const mpse_ctx::ProfRec& rec);
+// bracket that cannot leak its event pair: a scope left without end() (error return) hands the events back
+struct ProfScope {
+  mpse_ctx* ctx;
+  mpse_ctx::ProfRec rec;
+  bool on;
+  ProfScope(mpse_ctx* c, int variant, double flops, double bytes) : ctx(c), on(prof_begin(c, variant, flops, bytes, &rec)) {}
+  ProfScope(const ProfScope&) = delete;
+  ProfScope& operator=(const ProfScope&) = delete;
+  void end() {
+    if (on) prof_end(ctx, rec);
+    on = false;
+  }
+  ~ProfScope() {
+    if (!on) return;
+    ctx->prof_free_events.push_back(rec.e0);
+    ctx->prof_free_events.push_back(rec.e1);
+  }
+};
 
 #define MPSE_HIP(ctx, call)                                                              \
   do {                                                                                   \

@@ -315,8 +315,7 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
     qr_flops += (CPLX ? 4.0 : 1.0) * (4.0 * m * n * n - 4.0 * n * n * n / 3.0);
     qr_bytes += double(es) * (2.0 * B.mm * B.nn + double(B.mm) * B.k);
   }
-  mpse_ctx::ProfRec qrec;
-  const bool qpt = prof_begin(ctx, 5, qr_flops, qr_bytes, &qrec);
+  ProfScope qprof(ctx, 5, qr_flops, qr_bytes);
   // one upload: row index lists | column index lists | block descriptors
   const size_t ib = size_t(nri + nci) * sizeof(int64_t), db = blks.size() * sizeof(QrBlk);
   static_assert(sizeof(QrBlk) % 8 == 0, "descriptors follow the 8-byte index lists");
@@ -348,7 +347,7 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
                            (long long)ncol, &ok));
     ++ctx->qr_chol_calls;
     if (ok) {
-      if (qpt) prof_end(ctx, qrec);
+      qprof.end();
       return MPSE_OK;
     }
     ++ctx->qr_chol_fallbacks;
@@ -370,7 +369,7 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   hipLaunchKernelGGL((k_scatter_blocks<CPLX>), dim3(ew_blocks(max_sc), (unsigned)blks.size()), dim3(256), 0, ctx->stream,
                      (double*)U, (double*)Vt, (const double*)q, (const double*)ws, (long long)K, (long long)ncol, drows, dcols,
                      dblk, herm);
-  if (qpt) prof_end(ctx, qrec);
+  qprof.end();
   MPSE_HIP(ctx, hipGetLastError());
   return MPSE_OK;
 }

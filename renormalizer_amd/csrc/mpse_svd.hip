@@ -953,8 +953,8 @@ int block_svd_batched(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t nco
   }
   const int nblk = (int)tall.size();
   // whole-call timing for bench.py (variant 6): the algorithmic bytes depend on the sweep count, filled in below
-  mpse_ctx::ProfRec srec;
-  const bool spt = prof_begin(ctx, 6, 0.0, 0.0, &srec);
+  ProfScope sprof(ctx, 6, 0.0, 0.0);
+  const bool spt = sprof.on;
   int sweeps_done = 0;
   MPSE_TRY(mpse_memset_zero(ctx, U, size_t(nrow * KU) * es));
   MPSE_TRY(mpse_memset_zero(ctx, Vt, size_t(KV * ncol) * es));
@@ -1035,16 +1035,17 @@ int block_svd_batched(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t nco
     bool all = false;
     for (int sweep = 0; sweep < 60 && !all; ++sweep) {
       const size_t blk_lds = size_t(4) * JB_COLS * maxnn * es;      // X and V columns of a pair of column blocks
-      if (blk_lds <= size_t(150) * 1024) {
-        static const bool lds_attr = [] {     // beyond the default 64 KB of dynamic LDS (the CU has 160 KB)
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_block<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_block<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-          (void)hipGetLastError();
-          return true;
-        }();
-        (void)lds_attr;
+      // beyond the default 64 KB of dynamic LDS (the CU has 160 KB): asked for once; a runtime that refuses keeps the
+      // blocked kernel to the problems that fit 64 KB and sends the others through the column-pair kernels below
+      static const bool lds_attr = [] {
+        const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_block<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_block<false>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipGetLastError();
+        return a == hipSuccess && b == hipSuccess;
+      }();
+      if (blk_lds <= (lds_attr ? size_t(150) : size_t(64)) * 1024) {
         const int nbmax = ((maxnn + JB_COLS - 1) / JB_COLS + 1) & ~1;
         for (int step = 0; step < nbmax - 1; ++step)
           hipLaunchKernelGGL((k_jacobi_block<CPLX>), dim3(nbmax / 2, nblk), dim3(64 * JB_COLS), blk_lds, ctx->stream, xs,
@@ -1133,10 +1134,10 @@ int block_svd_batched(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t nco
                (CPLX ? 4.0 : 1.0) * (4.0 * B.mm * double(B.nn) * B.nn - 4.0 * double(B.nn) * B.nn * B.nn / 3.0) +
                (CPLX ? 8.0 : 2.0) * double(B.mm) * B.nn * B.nn;
     }
-    srec.bytes = bytes;
-    srec.flops = flops;
+    sprof.rec.bytes = bytes;
+    sprof.rec.flops = flops;
     ctx->prof_svd_sweeps += sweeps_done;
-    prof_end(ctx, srec);
+    sprof.end();
   }
   (void)E;
   return MPSE_OK;

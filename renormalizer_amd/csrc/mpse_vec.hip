@@ -1026,6 +1026,7 @@ int mpse_conj_inplace(mpse_ctx* ctx, void* x, int64_t n) {
   if (!ctx || (n && !x)) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
   if (n <= 0) return MPSE_OK;
+  wsite_written(ctx, x, size_t(n) * 16);
   hipLaunchKernelGGL(k_conj, dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)x, (long long)n);
   MPSE_HIP(ctx, hipGetLastError());
   return MPSE_OK;
@@ -1035,6 +1036,7 @@ int mpse_scal(mpse_ctx* ctx, int dtype, void* x, int64_t n, double a_re, double 
   if (!ctx || (n && !x)) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
   if (n <= 0) return MPSE_OK;
+  wsite_written(ctx, x, size_t(n) * dtype_size(dtype));
   if (dtype == MPSE_C128)
     hipLaunchKernelGGL((k_scal<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)x, (long long)n, a_re,
                        a_im);
@@ -1049,6 +1051,7 @@ int mpse_axpy(mpse_ctx* ctx, int dtype, void* y, const void* x, int64_t n, doubl
   if (!ctx || (n && (!x || !y))) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
   if (n <= 0) return MPSE_OK;
+  wsite_written(ctx, y, size_t(n) * dtype_size(dtype));
   if (dtype == MPSE_C128)
     hipLaunchKernelGGL((k_axpy<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)y, (const double*)x,
                        (long long)n, a_re, a_im);

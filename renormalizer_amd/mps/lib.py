@@ -92,6 +92,10 @@ def contract_one_site(environ, ms, mo, domain, ms_conj=None, canonical_mo_host=N
             out.unit = predict_unit_channel(canonical_mo_host, domain, environ.unit)
             if VERIFY_UNIT and oshape[0] >= UNIT_MIN_BOND and not deferred:
                 measured = find_unit_channel(out)
+                if measured != out.unit and eng.block_qr_check():
+                    # optimistic block QR (Mps._evolve_tdvp_ps): this site came out of a decomposition that broke down
+                    # and is no isometry - the step is going to be discarded and repeated, tell the driver now
+                    raise ArithmeticError("unit channel of an environment behind a block QR that broke down")
                 assert measured == out.unit, f"unit channel predicted {out.unit}, measured {measured}"
         elif oshape[0] >= UNIT_MIN_BOND and not deferred:
             # (a recorded update behind an environment without unit channel keeps unit = 0: an isometric site cannot

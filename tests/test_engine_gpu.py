@@ -655,6 +655,35 @@ def test_folded_one_site_matvec_block_sparse_vs_oracle(eng, cplx):
     assert _relerr(masked.to_host().ravel(), plain.to_host().ravel()) < 1e-13
 
 
+def test_described_mpo_site_follows_in_place_writes(eng):
+    """mpse_mpo_site_hint stores an analysis of the MPO site's values (which channels are zero / the identity) that the
+    folded one-site plan relies on: an entry point that writes into the described buffer (scal, copies into it, memset)
+    drops the description, so the product follows the new values instead of the stale analysis."""
+    rng = np.random.default_rng(33)
+    D, d = 256, 16
+    w = _holstein_like_site(rng, d)
+    l, r = _rand(rng, (D, w.shape[0], D), True), _rand(rng, (D, w.shape[3], D), True)
+    c = _rand(rng, (D, d, D), True)
+    hop = hop_expr(eng.asdevice(l), eng.asdevice(r), [w], c.shape)
+    cd = eng.asdevice(c)
+    assert _relerr(hop(cd).to_host().ravel(), orc.hop_apply(l, r, [w], c).ravel()) < 1e-12
+    # 1. scale in place: identity channels stop being identities
+    hop.cmo[0].scale_(0.5)
+    assert _relerr(hop(cd).to_host().ravel(), orc.hop_apply(l, r, [0.5 * w], c).ravel()) < 1e-12
+    # 2. overwrite with a dense site: channels the analysis saw as zero are now populated
+    w2 = rng.standard_normal(w.shape)
+    eng._check(eng.lib.mpse_mpo_site_hint(eng.ctx, hop.cmo[0].ptr, w.ctypes.data, *[int(x) for x in w.shape[:2]], int(w.shape[3])))
+    eng._check(eng.lib.mpse_memcpy_h2d(eng.ctx, hop.cmo[0].ptr, w2.ctypes.data, w2.nbytes))
+    assert _relerr(hop(cd).to_host().ravel(), orc.hop_apply(l, r, [w2], c).ravel()) < 1e-12
+    # 3. a partial write (one row block through a 2-D copy) drops it as well
+    eng.mpo_site_hint(hop.cmo[0], w2)
+    w3 = w2.copy()
+    w3[1] = rng.standard_normal(w3[1].shape)
+    flat = hop.cmo[0].reshape(w.shape[0], -1)
+    eng.copy_block(flat, 1, 0, eng.asdevice(w3[1].reshape(1, -1)))
+    assert _relerr(hop(cd).to_host().ravel(), orc.hop_apply(l, r, [w3], c).ravel()) < 1e-12
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 def test_matrix_module_tensordot_and_paths(eng, cplx):
     """renormalizer_amd.mps.matrix (the module-level names of SURVEY 8(b)): tensordot over device tensors against numpy
