@@ -311,7 +311,10 @@ int mpse_truncate_select(const double* sigma_host, const int64_t* block_id_host,
  * and columns col_idx_host[col_off_host[b]..col_off_host[b+1]); it contributes
  * min(rows,cols) columns.  Outputs (device, zero outside the blocks):
  *   U  (nrow x K)  and  Vt (K x ncol),  K = sum_b min(m_b,n_b),  coef == U @ Vt on the blocks;
- *   system 'L': U has orthonormal columns;  system 'R': Vt has orthonormal rows. */
+ *   system 'L': U has orthonormal columns;  system 'R': Vt has orthonormal rows.
+ * system_is_R: bit 0 = system 'R'; bit 1 = this decomposition by the Householder kernels whatever the context's scheme
+ * (mpse_block_qr_scheme) says - for a caller that knows the blocks to be rank deficient (a sweep that has seen this site
+ * break the Cholesky-QR path before). */
 int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int64_t ncol,
                   int nblocks, const int64_t* row_idx_host, const int64_t* row_off_host,
                   const int64_t* col_idx_host, const int64_t* col_off_host,

@@ -276,7 +276,8 @@ namespace {
 
 template <bool CPLX>
 int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, int nblocks, const int64_t* row_idx,
-                  const int64_t* row_off, const int64_t* col_idx, const int64_t* col_off, int herm, void* U, void* Vt,
+                  const int64_t* row_off, const int64_t* col_idx, const int64_t* col_off, int herm, bool hh_only, void* U,
+                  void* Vt,
                   int64_t K) {
   constexpr size_t es = CPLX ? 16 : 8;
   int64_t ktot = 0, ws_tot = 0, q_tot = 0;
@@ -341,7 +342,7 @@ int block_qr_impl(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t ncol, i
   // tall blocks of up to 256 columns: shifted Cholesky-QR on MFMA (mpse_cholqr.hip), all compute units instead of one
   // per block; a block it cannot decide (rank deficient, condition beyond ~1e15) raises a device flag and the whole
   // call is redone by the Householder kernels below on fresh copies of the blocks
-  if (cholqr_eligible(ctx, blks.data(), (int)blks.size())) {
+  if (!hh_only && cholqr_eligible(ctx, blks.data(), (int)blks.size())) {
     bool ok = false;
     MPSE_TRY(cholqr_blocks(ctx, CPLX, ws, blks.data(), (int)blks.size(), drows, dcols, herm, U, Vt, (long long)K,
                            (long long)ncol, &ok));
@@ -428,12 +429,13 @@ int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int6
   }
   MPSE_BIND(ctx);
   if (nblocks <= 0) return mpse_fail(ctx, MPSE_ERR_SHAPE, "Invalid quantum number");
+  if (system_is_R < 0 || system_is_R > 3) return mpse_fail(ctx, MPSE_ERR_ARG, "block_qr: system_is_R = %d", system_is_R);
   if (dtype == MPSE_C128)
     return block_qr_impl<true>(ctx, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host, col_off_host,
-                               system_is_R ? 1 : 0, U, Vt, K);
+                               system_is_R & 1, (system_is_R & 2) != 0, U, Vt, K);
   if (dtype == MPSE_F64)
     return block_qr_impl<false>(ctx, coef, nrow, ncol, nblocks, row_idx_host, row_off_host, col_idx_host,
-                                col_off_host, system_is_R ? 1 : 0, U, Vt, K);
+                                col_off_host, system_is_R & 1, (system_is_R & 2) != 0, U, Vt, K);
   return mpse_fail(ctx, MPSE_ERR_ARG, "block_qr: unknown dtype");
 }
 

@@ -1301,7 +1301,7 @@ class Mps:
         ``MPSE_QR_OPTIMISTIC=0``: verify every decomposition as it happens."""
         eng = get_engine()
         if os.environ.get("MPSE_QR_OPTIMISTIC", "1") == "0" or os.environ.get("MPSE_DEFER", "1") == "0":
-            return self._evolve_tdvp_ps_sweeps(mpo, evolve_dt)
+            return self._evolve_tdvp_ps_sweeps(mpo, evolve_dt, learn_qr=True)
         eng.block_qr_optimistic(True)
         try:
             new = self._evolve_tdvp_ps_sweeps(mpo, evolve_dt)
@@ -1317,10 +1317,13 @@ class Mps:
         if failed:
             clear_evolve_cache()
             _OPTIMISTIC_REDONE[0] += 1
-            new = self._evolve_tdvp_ps_sweeps(mpo, evolve_dt)
+            # the verified run notes WHICH sites sent the Cholesky-QR path back to the Householder kernels: the next
+            # steps decompose those sites by Householder from the start (the rank-deficient blocks next to the chain
+            # ends stay rank deficient for several steps - without the note every one of those steps ran twice)
+            new = self._evolve_tdvp_ps_sweeps(mpo, evolve_dt, learn_qr=True)
         return new
 
-    def _evolve_tdvp_ps_sweeps(self, mpo, evolve_dt) -> "Mps":
+    def _evolve_tdvp_ps_sweeps(self, mpo, evolve_dt, learn_qr=False) -> "Mps":
         """One-site TDVP with projector splitting, PhysRevB 94, 165116; order of operations of
         mps/mps.py:1267-1404: two half sweeps; per site a forward step -i dt/2 of the centre
         tensor (Lanczos), QR/RQ by quantum-number block, one environment update, a backward
@@ -1344,6 +1347,15 @@ class Mps:
             environ = Environ(mps, mpo, ahead)
         local_steps = []
         q = len(mps.qntot)
+        hh_sites = _householder_sites(mps)         # (site, direction) whose block QR broke the Cholesky-QR path before
+        qr_redone = [eng.block_qr_stats()[2]]
+
+        def note_qr(imps):
+            if learn_qr:
+                now = eng.block_qr_stats()[2]
+                if now != qr_redone[0]:
+                    hh_sites.add((imps, mps.to_right))
+                qr_redone[0] = now
 
         use_cmask = os.environ.get("MPSE_CENTRE_MASK", "1") != "0"
 
@@ -1375,7 +1387,8 @@ class Mps:
             hop, _, qnbigl, qnbigr, plan = ready
             l_array, r_array = hop.l, hop.r
             u, qnlset, v, qnrset = svd_qn.svd_qn(centre, qnbigl, qnbigr, mps.qntot, QR=True,
-                                                 system="L" if mps.to_right else "R", full_matrices=False, plan=plan)
+                                                 system="L" if mps.to_right else "R", full_matrices=False, plan=plan,
+                                                 householder=(imps, mps.to_right) in hh_sites)
             vt = v.T
             if not mps.to_right:
                 mps[imps] = vt.reshape([-1] + shape[1:])
@@ -1435,6 +1448,7 @@ class Mps:
                         mps_t, j = _local_propagate(cfg, hop, -1j * evolve_dt / 2, centre)
                         local_steps.append(j)
                         hop_b, bond, nbr = split_site(imps, mps_t, ready, shape)
+                        note_qr(imps)
                         ready = prepare(nbr, list(mps[nbr].shape[:-1]) + [bond.shape[1]] if not mps.to_right
                                         else [bond.shape[0]] + list(mps[nbr].shape[1:]))
                         b_t, j = _local_propagate(cfg, hop_b, 1j * evolve_dt / 2, bond)
@@ -1445,6 +1459,7 @@ class Mps:
                     eng.arm(0)
                     _, j = expm_krylov(hop, -1j * evolve_dt / 2, centre, out=out)       # + QR, environment update
                     local_steps.append(j)
+                    note_qr(imps)
                     b_out = eng.empty(bond.shape, bond.dtype)
                     with eng.recording(1):
                         new_centre = absorb(b_out, nbr)
@@ -1472,6 +1487,18 @@ class Mps:
 
 # steps the optimistic block QR had to repeat (diagnostics; bench.py reports it)
 _OPTIMISTIC_REDONE = [0]
+
+# Per host thread (= per trajectory): the (site, sweep direction) pairs of the chain being evolved whose block QR sent the
+# Cholesky-QR path back to the Householder kernels in a verified run.  Keyed by the shape of the chain: another chain in
+# the same thread starts with an empty note.  A stale entry costs a slower decomposition, never correctness.
+_QR_NOTES = threading.local()
+
+
+def _householder_sites(mps):
+    key = (len(mps), tuple(mps.bond_dims), tuple(int(x) for x in mps.pbond_dims))
+    if getattr(_QR_NOTES, "key", None) != key:
+        _QR_NOTES.key, _QR_NOTES.sites = key, set()
+    return _QR_NOTES.sites
 
 # One slot per host thread (= per trajectory): the environments ahead of the next half sweep, as the last TDVP-PS step
 # left them, with the objects they were computed from.  Bounded: a new step replaces the slot.

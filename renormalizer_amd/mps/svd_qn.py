@@ -94,11 +94,12 @@ def _p64(a):
 
 
 def svd_qn(coef_array, qnbigl, qnbigr, qntot, QR=False, system=None, full_matrices=True, opt_full_matrices=True,
-           plan=None):
+           plan=None, householder=False):
     """Block decomposition of the centre tensor.  Returns ``(u, new_qnl, v, new_qnr)`` for QR and
     ``(u, su, new_qnl, v, sv, new_qnr)`` for SVD with ``coef == u @ diag(s) @ v.T`` (``v.T`` is
     available as ``v.T``, a device tensor).  ``plan``: the result of ``block_plan`` for these quantum numbers when
-    the caller has it already (the sweeps prepare it while the GPU is still busy with the preceding solve)."""
+    the caller has it already (the sweeps prepare it while the GPU is still busy with the preceding solve).
+    ``householder`` (QR only): this decomposition by the Householder kernels (bit 1 of ``system_is_R``)."""
     eng = get_engine()
     coef = eng.asdevice(coef_array)
     qntot = np.asarray(qntot)
@@ -119,7 +120,8 @@ def svd_qn(coef_array, qnbigl, qnbigr, qntot, QR=False, system=None, full_matric
         u = eng.empty((nrow, K), coef.dtype)
         vt = eng.empty((K, ncol), coef.dtype)
         eng._check(eng.lib.mpse_block_qr(eng.ctx, coef.code, coef.ptr, nrow, ncol, len(blocks), _p64(rows), _p64(roff),
-                                         _p64(cols), _p64(coff), int(system == "R"), u.ptr, vt.ptr, K))
+                                         _p64(cols), _p64(coff), int(system == "R") | (2 if householder else 0), u.ptr,
+                                         vt.ptr, K))
         return u, new_qnl, TransposedView(vt), new_qnr
     s = np.zeros(K)
     sp = s.ctypes.data_as(C.POINTER(C.c_double))

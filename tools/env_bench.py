@@ -22,8 +22,13 @@ def main():
     out = sys.argv[2] if len(sys.argv) > 2 else None
     eng = get_engine()
     state = os.environ.get("ENV_BENCH_STATE", "/tmp/state.npz")
-    model, mpo, mps = bench.build_workload(25, 16, 256, 0, "physical", state_file=state)
-    mps = mps.evolve(mpo, 10.0)                   # a generic complex state with filled bonds
+    evolved = state + ".evolved.npz"             # a generic complex state with filled bonds: one evolve, kept on disk so
+    if os.path.exists(evolved):                   # that a profiled run holds environment updates only
+        model, mpo, mps = bench.build_workload(25, 16, 256, 0, "physical", state_file=evolved)
+    else:
+        model, mpo, mps = bench.build_workload(25, 16, 256, 0, "physical", state_file=state)
+        mps = mps.evolve(mpo, 10.0)
+        mps.dump(evolved)
     dims, pd, wd = list(mps.bond_dims), [int(x) for x in mps.pbond_dims], list(mpo.bond_dims)
     n = len(pd)
 

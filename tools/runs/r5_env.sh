@@ -5,4 +5,4 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o b -- python tools/env
 python tools/rocpd_summary.py $O/prof/b_results.db $O/kernel_stats.md > /dev/null; rm -rf $O/prof
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc -o p -- python tools/env_bench.py 1 > $O/pmc.log 2>&1
 python tools/pmc_mfma_util.py $O/pmc/p_results.db $O/pmc_mfma_util.md > /dev/null 2> $O/pmc.err; rm -rf $O/pmc
-cat $O/env_bench.out | cut -c1-400; head -30 $O/kernel_stats.md | cut -c1-130; cat $O/pmc_mfma_util.md | cut -c1-200
+cat $O/env_bench.out | cut -c1-400; head -14 $O/kernel_stats.md | cut -c1-130; cat $O/pmc_mfma_util.md | cut -c1-200
