@@ -243,10 +243,16 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
                                                                   double* __restrict__ partial,
                                                                   const int* __restrict__ done,
                                                                   const unsigned long long* __restrict__ pmask,
-                                                                  int prow, int ptiles) {
+                                                                  int prow, int ptiles,
+                                                                  const unsigned char* __restrict__ cmask, int crow,
+                                                                  int ckw) {
   // pmask (complex vectors, VEC): the parts hold only some 16 x 16 tiles of the result viewed as rows of prow elements
   // (fused 0-site matvec, mpse_heff0.hip): word [tile row * ptiles + tile column], bit s = part s holds the tile; the
-  // parts named there are added in part order, the others were never written
+  // parts named there are added in part order, the others were never written.
+  // cmask (complex vectors, VEC, no pmask): the caller's structural pattern of the centre (mpse_expm_centre_mask; rows of
+  // crow elements, crow a multiple of 64, byte [(column / 64) * ckw + row / 16]): every vector of the solve is exactly
+  // zero in the tiles it leaves out - nothing is read there and zeros are written (a wave works on 64 consecutive
+  // elements of one row: the test is uniform over the wave)
   if (done && *done) return;
   double araw, a_im, cur2, z;
   sum_partials(a_partial, a_nb, araw, a_im);
@@ -295,6 +301,44 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
         };
         ya = gather(i);
         yb = h1 ? gather(i1) : zz;
+      } else if (cmask) {
+        auto live = [&](long long e) {
+          const unsigned ee = (unsigned)e, row = ee / (unsigned)crow, col = ee - row * (unsigned)crow;
+          return cmask[(col >> 6) * ckw + (row >> 4)] != 0;
+        };
+        const bool la = live(i), lb = h1 && live(i1);
+        double2 va = zz, ua = zz, vb = zz, ub = zz;
+        ya = yb = zz;
+        if (la) {
+          ya = py[i];
+          va = p1[i];
+          if (u0) ua = p0[i];
+        }
+        if (lb) {
+          yb = py[i1];
+          vb = p1[i1];
+          if (u0) ub = p0[i1];
+        }
+        for (int s = 1; s < nparts; ++s) {
+          const double2* ps = py + s * (part_stride >> 1);
+          if (la) {
+            const double2 ta = ps[i];
+            ya.x += ta.x, ya.y += ta.y;
+          }
+          if (lb) {
+            const double2 tb = ps[i1];
+            yb.x += tb.x, yb.y += tb.y;
+          }
+        }
+        const double2 xa = make_double2(c_y * ya.x - (c_1 * va.x + c_0 * ua.x), c_y * ya.y - (c_1 * va.y + c_0 * ua.y));
+        const double2 xb = make_double2(c_y * yb.x - (c_1 * vb.x + c_0 * ub.x), c_y * yb.y - (c_1 * vb.y + c_0 * ub.y));
+        o2[i] = la ? xa : zz;
+        if (la) s += xa.x * xa.x + xa.y * xa.y;
+        if (h1) {
+          o2[i1] = lb ? xb : zz;
+          if (lb) s += xb.x * xb.x + xb.y * xb.y;
+        }
+        continue;
       } else {
         ya = py[i], yb = h1 ? py[i1] : zz;
         for (int s = 1; s < nparts; ++s) {
@@ -620,7 +664,8 @@ template <bool CPLX>
 __global__ void k_lincomb_dev(double* __restrict__ res, const double* __restrict__ V, long long n, int m,
                               const double* __restrict__ coef, const double* __restrict__ prev, double rtol, double atol,
                               unsigned int* __restrict__ flag, unsigned int gen, const LzCtl* __restrict__ ctl,
-                              int m_early) {
+                              int m_early, const unsigned char* __restrict__ cmask, int crow, int ckw) {
+  // cmask: as in k_lanczos_update_u - the basis vectors (and the earlier estimate) are exactly zero outside it
   if (ctl->done || ctl->need_host) return;
   __shared__ double cr[LZ_MAXM], ci[LZ_MAXM], er[LZ_MAXM], ei[LZ_MAXM];
   if (threadIdx.x < LZ_MAXM) {
@@ -634,6 +679,13 @@ __global__ void k_lincomb_dev(double* __restrict__ res, const double* __restrict
   bool bad = false;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     if (CPLX) {
+      if (cmask) {
+        const unsigned ee = (unsigned)i, row = ee / (unsigned)crow, col = ee - row * (unsigned)crow;
+        if (!cmask[(col >> 6) * ckw + (row >> 4)]) {
+          reinterpret_cast<double2*>(res)[i] = make_double2(0.0, 0.0);
+          continue;
+        }
+      }
       double xr = 0, xi = 0, pr = 0, pi = 0;
       for (int jj = 0; jj < m; ++jj) {
         if (cr[jj] == 0.0 && ci[jj] == 0.0 && !(jj < m_early)) continue;   // past a breakdown: never touched
@@ -844,6 +896,24 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
     ~CMaskScope() { c->cmask = mpse_ctx::CMask(); }
   } cmask_scope(ctx);
 
+  // the structural mask of the centre also serves the vector kernels of this solve (square operators on complex vectors
+  // whose rows are whole multiples of 64 elements)
+  const unsigned char* vmask = nullptr;
+  int vm_row = 0, vm_kw = 0;
+  static const bool vmask_on = [] {
+    const char* e = getenv("MPSE_VEC_MASK");
+    return !(e && e[0] == '0');
+  }();
+  if (vmask_on && vec16 && cplx && ctx->cmask.ptr && h->dims.Dl_ket > 0 && h->dims.Dl_bra == h->dims.Dl_ket &&
+      h->dims.Dr_bra == h->dims.Dr_ket && n < (int64_t(1) << 31)) {
+    const int64_t Dl = h->dims.Dl_ket, N = n / Dl;
+    const int64_t nkw = ((Dl + 15) / 16 + 7) / 8;
+    if (N * Dl == n && N % 64 == 0 && ctx->cmask.bytes == (N / 64) * nkw * 8) {
+      vmask = static_cast<const unsigned char*>(ctx->cmask.ptr);
+      vm_row = (int)N;
+      vm_kw = (int)(nkw * 8);
+    }
+  }
   auto bracket = [&](double bytes, auto&& launch) {
     mpse_ctx::ProfRec rec;
     const bool pt = prof_begin(ctx, 4, 0.0, bytes, &rec);
@@ -938,13 +1008,13 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
                            W.as<const double>(), nparts, (long long)nd, (const double*)vec(j),
                            j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
                            (const double*)part_a, a_nb, scal + 4 + 4 * j, (const double*)cur_part, nb, cur_out, prev2,
-                           new_part, done, pmask, prow, ptiles);
+                           new_part, done, pmask, prow, ptiles, pmask ? nullptr : vmask, vm_row, vm_kw);
       else
         hipLaunchKernelGGL(k_lanczos_update_u<false>, dim3(nb), dim3(RED_THREADS), 0, ctx->stream, (double*)vec(j + 1),
                            W.as<const double>(), nparts, (long long)nd, (const double*)vec(j),
                            j > 0 ? (const double*)vec(j - 1) : (const double*)nullptr, (long long)nd,
                            (const double*)part_a, a_nb, scal + 4 + 4 * j, (const double*)cur_part, nb, cur_out, prev2,
-                           new_part, done, pmask, prow, ptiles);
+                           new_part, done, pmask, prow, ptiles, pmask ? nullptr : vmask, vm_row, vm_kw);
     });
     bool check = (j > 3 && j % 2 == 0);                // krylov.py:76-81
     const bool last = (j + 1 >= limit);
@@ -970,11 +1040,11 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
       if (cplx)
         hipLaunchKernelGGL((k_lincomb_dev<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst,
                            V.as<double>(), (long long)n, j + 1, (const double*)coef, (const double*)prev, rtol, atol,
-                           dflag, gen, (const LzCtl*)ctl, merged ? j - 1 : 0);
+                           dflag, gen, (const LzCtl*)ctl, merged ? j - 1 : 0, vmask, vm_row, vm_kw);
       else
         hipLaunchKernelGGL((k_lincomb_dev<false>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst,
                            V.as<double>(), (long long)n, j + 1, (const double*)coef, (const double*)prev, rtol, atol,
-                           dflag, gen, (const LzCtl*)ctl, merged ? j - 1 : 0);
+                           dflag, gen, (const LzCtl*)ctl, merged ? j - 1 : 0, vmask, vm_row, vm_kw);
       const bool wait_here = j >= wait_from || waited || last;
       const bool self_pub = wait_here && ctx->pinned_dev != nullptr;
       const double seq = self_pub ? double(++ctx->publish_seq) : 0.0;
