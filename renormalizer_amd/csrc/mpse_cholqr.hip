@@ -6,8 +6,11 @@
 // Gram-matrix schemes put the m n^2 work on all compute units:
 //   pass i:  G = A^H A            (k_cq_gram: MFMA, fragments straight from L2, row chunks -> partial sums;
 //                                  k_cq_reduce: fixed-order sum of the chunks, per-tile |G - I| and trace)
-//            R_i = chol(G [+ s I]) (k_cq_chol: one workgroup per block, left-looking by 16-row panels, the panel
-//                                  update on MFMA, the 16 x 16 diagonal factor in registers of one wave)
+//            R_i = chol(G [+ s I]) (one workgroup per block.  k_cq_chol_rl, up to 160 columns: right-looking, every
+//                                  tile of the trailing matrix stays in the MFMA accumulators of one of 8 waves, the row
+//                                  panel of a step goes through LDS; k_cq_chol, 161 - 256 columns: left-looking by
+//                                  16-row panels.  Both eliminate a row panel - diagonal factor and forward
+//                                  substitution at once - with a thread per column, panel_eliminate)
 //            A <- A R_i^-1         (k_cq_trsm: one workgroup per 16 rows, right-looking over 16-column panels,
 //                                  substitution inside a diagonal block by DPP row broadcasts - backward stable, an
 //                                  explicit inverse would leave a residual u kappa(R))
@@ -19,9 +22,13 @@
 //
 // Rank-deficient / too ill-conditioned blocks (the 1e-10 padding of expand_bond_dimension in the first steps of a
 // run: profiles/r05_qr_cond_step2.md - 4 of 98 decompositions; none of 98 at step 13) make a pivot of pass 2 / 3
-// non-positive or leave the pivots of pass 3 outside [1/4, 4]: the kernels raise a device flag, the host reads it
-// after the last launch (one mapped-memory read-back) and mpse_block_qr runs the Householder path on those inputs.
-// Householder therefore still decides every case Cholesky cannot: results are an exact isometry either way.
+// non-positive or leave the pivots of pass 3 outside [1/4, 4]: the kernels raise a device flag.  Either the host reads it
+// after the last launch (one mapped-memory read-back) and mpse_block_qr runs the Householder path on those inputs, or -
+// optimistic mode, mpse_block_qr_optimistic, for callers that can repeat a whole step - the flag is a sticky device word
+// read once at the end of the step (the read-back idles the GPU for ~80 us per decomposition).
+// Householder therefore still decides every case Cholesky cannot: results are an exact isometry either way.  The two
+// schemes agree up to the phases of the columns where the block has full numerical rank; inside a numerical null space
+// every QR is a different, equally valid completion (profiles/r05_qr_gauge.md).
 #include <type_traits>
 
 #include "mpse_device.h"

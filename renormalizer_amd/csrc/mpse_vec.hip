@@ -280,6 +280,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
       const long long i1 = i + stride;
       const bool h1 = i1 < n2;
       double2 ya, yb;
+      bool la = true, lb = h1;      // element i / i1 lies in a tile the centre mask keeps (always, without a mask)
       if (pmask) {
         auto gather = [&](long long e) {
           const unsigned ee = (unsigned)e, row = ee / (unsigned)prow, col = ee - row * (unsigned)prow;
@@ -301,54 +302,25 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
         };
         ya = gather(i);
         yb = h1 ? gather(i1) : zz;
-      } else if (cmask) {
-        auto live = [&](long long e) {
-          const unsigned ee = (unsigned)e, row = ee / (unsigned)crow, col = ee - row * (unsigned)crow;
-          return cmask[(col >> 6) * ckw + (row >> 4)] != 0;
-        };
-        const bool la = live(i), lb = h1 && live(i1);
-        double2 va = zz, ua = zz, vb = zz, ub = zz;
-        ya = yb = zz;
-        if (la) {
-          ya = py[i];
-          va = p1[i];
-          if (u0) ua = p0[i];
-        }
-        if (lb) {
-          yb = py[i1];
-          vb = p1[i1];
-          if (u0) ub = p0[i1];
-        }
-        for (int s = 1; s < nparts; ++s) {
-          const double2* ps = py + s * (part_stride >> 1);
-          if (la) {
-            const double2 ta = ps[i];
-            ya.x += ta.x, ya.y += ta.y;
-          }
-          if (lb) {
-            const double2 tb = ps[i1];
-            yb.x += tb.x, yb.y += tb.y;
-          }
-        }
-        const double2 xa = make_double2(c_y * ya.x - (c_1 * va.x + c_0 * ua.x), c_y * ya.y - (c_1 * va.y + c_0 * ua.y));
-        const double2 xb = make_double2(c_y * yb.x - (c_1 * vb.x + c_0 * ub.x), c_y * yb.y - (c_1 * vb.y + c_0 * ub.y));
-        o2[i] = la ? xa : zz;
-        if (la) s += xa.x * xa.x + xa.y * xa.y;
-        if (h1) {
-          o2[i1] = lb ? xb : zz;
-          if (lb) s += xb.x * xb.x + xb.y * xb.y;
-        }
-        continue;
       } else {
-        ya = py[i], yb = h1 ? py[i1] : zz;
+        // (one arithmetic path with and without the mask: the same expression trees, so the same fused multiply-adds)
+        if (cmask) {
+          auto live = [&](long long e) {
+            const unsigned ee = (unsigned)e, row = ee / (unsigned)crow, col = ee - row * (unsigned)crow;
+            return cmask[(col >> 6) * ckw + (row >> 4)] != 0;
+          };
+          la = live(i);
+          lb = h1 && live(i1);
+        }
+        ya = la ? py[i] : zz, yb = lb ? py[i1] : zz;
         for (int s = 1; s < nparts; ++s) {
           const double2* ps = py + s * (part_stride >> 1);
-          const double2 ta = ps[i], tb = h1 ? ps[i1] : zz;
+          const double2 ta = la ? ps[i] : zz, tb = lb ? ps[i1] : zz;
           ya.x += ta.x, ya.y += ta.y, yb.x += tb.x, yb.y += tb.y;
         }
       }
-      const double2 va = p1[i], ua = u0 ? p0[i] : zz;
-      const double2 vb = h1 ? p1[i1] : zz, ub = (h1 && u0) ? p0[i1] : zz;
+      const double2 va = la ? p1[i] : zz, ua = (la && u0) ? p0[i] : zz;
+      const double2 vb = lb ? p1[i1] : zz, ub = (lb && u0) ? p0[i1] : zz;
       const double2 xa = make_double2(c_y * ya.x - (c_1 * va.x + c_0 * ua.x), c_y * ya.y - (c_1 * va.y + c_0 * ua.y));
       const double2 xb = make_double2(c_y * yb.x - (c_1 * vb.x + c_0 * ub.x), c_y * yb.y - (c_1 * vb.y + c_0 * ub.y));
       o2[i] = xa;

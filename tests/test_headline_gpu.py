@@ -188,6 +188,10 @@ _SWITCHES = {
     "MPSE_SPLIT2=0": False,           # products with R as one workgroup per tile (other summation order)
     "MPSE_WFOLD=0": False,            # one-site matvec as the three-step chain (L.C, MPO step, .R) instead of the folded plan
     "MPSE_SMALL=0": False,            # the small centres at the chain ends through the plans instead of the one-launch matvec
+    "MPSE_HEFF0=0": False,            # bond and two-level-site matvecs through the plans instead of the fused launch
+    "MPSE_CHOLQR=0": False,           # every block QR by the Householder kernels (same isometry up to column phases)
+    "MPSE_QR_OPTIMISTIC=0": True,     # every Cholesky-QR verified as it happens (same decompositions, same fallbacks)
+    "MPSE_VEC_MASK=0": True,          # the vector kernels of a solve read and write the structurally empty tiles too
 }
 
 
