@@ -969,7 +969,8 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
 }  // namespace
 
 // Eligible: every block at least as tall as wide (k = nn), at most 256 columns, and the tallest block of at least 256
-// rows and 32 columns: the cost of the scheme is ~14 launches whose Cholesky / triangular-solve chains depend on the
+// rows and the widest of at least 96 columns (inside a sweep the scheme loses to the Householder chain at 64 columns:
+// spin-boson chain, D = 64, 512 x 64 centres: 24.0 against 22.5 ms per evolve, profiles/r05_vs_r4_side_configs.md): the cost of the scheme is ~14 launches whose Cholesky / triangular-solve chains depend on the
 // COLUMN count only (0.28 - 0.40 ms at 100 - 180 columns), the Householder chain grows with the rows (0.19 ms at 512 x 64,
 // 0.32 - 0.37 ms at 256 rows x 150 columns, 0.78 ms at 2 800 rows: tools/qr_bench.py, profiles/r05_qr_cholqr.md).
 // MPSE_CHOLQR=0 switches the path off, MPSE_CHOLQR=2 takes every eligible shape (tests); MPSE_CHOLQR_MINROWS moves the
@@ -992,7 +993,7 @@ bool cholqr_eligible(const mpse_ctx* ctx, const QrBlk* blks, int nblk) {
     max_nn = std::max(max_nn, blks[b].nn);
   }
   if (mode >= 2) return true;
-  return max_mm >= min_rows && max_nn >= 32;
+  return max_mm >= min_rows && max_nn >= 96;
 }
 
 int cholqr_blocks(mpse_ctx* ctx, bool cplx, double* ws, const QrBlk* blks, int nblk, const long long* drows,

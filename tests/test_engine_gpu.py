@@ -456,6 +456,72 @@ def test_block_qr_many_ragged_blocks_tree_shapes(eng, cplx):
             k0 += k
 
 
+def _with_cond(rng, m, n, cond, cplx, rank=None):
+    a = _rand(rng, (m, n), cplx)
+    u, _, v = np.linalg.svd(a, full_matrices=False)
+    sv = np.logspace(0, -np.log10(cond), n) if cond > 1 else np.ones(n)
+    if rank is not None:
+        sv[rank:] = 0.0
+    return (u * sv) @ v
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_block_qr_cholesky_path(eng, cplx):
+    """The Cholesky-QR kernels of mpse_block_qr (mpse_cholqr.hip; default for tall blocks of 96 - 256 columns, here also
+    forced onto every shape they support, mpse_block_qr_scheme 2) against the same contract as the Householder path:
+    reconstruction and isometry to 1e-13, exactly triangular other factor - for two-block layouts like the headline's
+    sites, condition numbers up to 1e12 (three real passes), a well-conditioned input (first-order third pass), odd
+    sizes and column counts on both sides of the right-looking / left-looking Cholesky kernels (<= 160 / <= 256 columns);
+    rank-deficient and kappa = 1e18 inputs have to raise the device flag and come back through the Householder kernels.
+    Which path ran is read from mpse_block_qr_stats."""
+    rng = np.random.default_rng(77)
+    cases = [  # rows of block 0 / 1, columns of block 0 / 1, condition, rank of block 0 (None = full), expected path
+        (2816, 1280, 145, 111, 1e6, None, "chol"), (2816, 1280, 145, 111, 1e12, None, "chol"),
+        (256, 256, 150, 106, 1e7, None, "chol"), (2608, 1488, 182, 74, 1e7, None, "chol"),
+        (4096, 0, 256, 0, 1e4, None, "chol"), (1001, 333, 77, 19, 1e8, None, "chol"), (2816, 1280, 145, 111, 3, None, "chol"),
+        (2816, 1280, 145, 111, 1e3, 100, "fallback"), (2816, 1280, 145, 111, 1e18, None, "fallback"),
+        (700, 300, 33, 17, 1e5, None, "chol")]
+    try:
+        for scheme in (2, 1):
+            eng.block_qr_scheme(scheme)
+            for m0, m1, n0, n1, cond, rank, expect in cases:
+                m, n = m0 + m1, n0 + n1
+                qnl = np.concatenate([np.zeros(m0, int), np.ones(m1, int)])[rng.permutation(m)]
+                qnr = np.concatenate([np.zeros(n0, int), np.ones(n1, int)])[rng.permutation(n)]
+                a = np.zeros((m, n), dtype=complex if cplx else float)
+                a[np.ix_(qnl == 0, qnr == 0)] = _with_cond(rng, m0, n0, cond, cplx, rank)
+                if m1 and n1:
+                    a[np.ix_(qnl == 1, qnr == 1)] = _with_cond(rng, m1, n1, cond, cplx)
+                for system in ("L", "R"):
+                    x = a if system == "L" else np.ascontiguousarray(a.conj().T)
+                    ql, qr = (qnl, qnr) if system == "L" else (qnr, qnl)
+                    s0 = eng.block_qr_stats()
+                    u, vt, blocks = dev_block_qr(eng, x, ql[:, None], -qr[:, None], np.array([0]), system)
+                    s1 = eng.block_qr_stats()
+                    tag = (scheme, m0, m1, n0, n1, cond, rank, system)
+                    assert _relerr(u @ vt, x) < 1e-13, tag
+                    iso = u if system == "L" else vt.conj().T
+                    assert np.abs(iso.conj().T @ iso - np.eye(iso.shape[1])).max() < 1e-13, tag
+                    k0 = 0
+                    for _, _, rows, cols in blocks:
+                        k = min(len(rows), len(cols))
+                        if system == "L":
+                            assert np.abs(np.tril(vt[k0:k0 + k][:, cols], -1)).max() == 0, tag
+                        else:
+                            assert np.abs(np.triu(u[rows][:, k0:k0 + k], 1)).max() == 0, tag
+                        k0 += k
+                    took = s1[1] - s0[1], s1[2] - s0[2]
+                    wide_enough = scheme == 2 or (max(m0, m1) >= 256 and max(n0, n1) >= 96)
+                    if not wide_enough:
+                        assert took == (0, 0), (tag, took)             # default rule: Householder from the start
+                    elif expect == "chol":
+                        assert took == (1, 0), (tag, took)
+                    else:
+                        assert took == (1, 1), (tag, took)             # tried, flagged on the device, redone
+    finally:
+        eng.block_qr_scheme(-1)
+
+
 # -------------------------------------------------------------- block SVD
 
 def dev_block_svd(eng, c, qnbigl, qnbigr, qntot):
