@@ -479,10 +479,22 @@ def main():
                             "alg_bytes_per_launch": vv["bytes"] / max(1, vv["launches"])})
         if qq["ms"] > 0:
             tf = qq["flops"] / (qq["ms"] * 1e-3) / 1e12
-            classes.append({"kernel": "block QR / RQ (Householder panels, whole mpse_block_qr calls)", "bound": "latency (FP64 vector)",
+            classes.append({"kernel": "block QR / RQ (whole mpse_block_qr calls: Cholesky-QR on MFMA for tall blocks, Householder "
+                                      "panels otherwise)", "bound": "latency (chain of dependent launches, one workgroup per block "
+                                                                    "in the Cholesky factor)",
                             "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                             "timed_calls": qq["launches"], "avg_call_ms": qq["ms"] / max(1, qq["launches"]),
                             "alg_flops_per_call": qq["flops"] / max(1, qq["launches"])})
+        ff = prof.get("heff_fused", {"ms": 0})
+        if ff["ms"] > 0:
+            tf = ff["flops"] / (ff["ms"] * 1e-3) / 1e12
+            classes.append({"kernel": "k_heff0_fused (bond and two-level-site matvecs in one MFMA launch each)",
+                            "bound": "latency (one 4-wave workgroup per compute unit, dependent loads)",
+                            "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                            "achieved_note": "algorithmic (dense-formula) flops of the matvec over its launch time; the kernel "
+                                             "skips the quantum-number zero blocks, so the MFMA work issued is smaller",
+                            "timed_launches": ff["launches"], "avg_launch_ms": ff["ms"] / max(1, ff["launches"]),
+                            "alg_flops_per_launch": ff["flops"] / max(1, ff["launches"])})
         ss = prof.get("block_svd", {"ms": 0})
         if ss["ms"] > 0:
             gbs = ss["bytes"] / (ss["ms"] * 1e-3) / 1e9

@@ -75,6 +75,9 @@ int mpse_prof_get_ktiles(mpse_ctx* ctx, int variant, int64_t* ktiles);
  * the traffic and the arithmetic of sweeps x all column pairs (an upper bound: converged pairs are not rotated);
  * mpse_prof_get_svd_sweeps: Jacobi sweeps summed over the timed calls. */
 int mpse_prof_get_svd_sweeps(mpse_ctx* ctx, int64_t* sweeps);
+/* variant 7 of mpse_prof_get = the fused bond / two-level-site matvec launches (k_heff0_fused): total_flops are the
+ * algorithmic flops of the matvec (dense formula of the contraction, no credit for skipped zero blocks), total_bytes the
+ * operands read once plus the result written once. */
 int mpse_prof_enable(mpse_ctx* ctx, int on);
 int mpse_prof_reset(mpse_ctx* ctx);
 int mpse_prof_get(mpse_ctx* ctx, int variant, double* total_ms, double* total_flops, double* total_bytes,

@@ -508,7 +508,17 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
     g.dot_part = ctx->dot_req.part;
     ctx->dot_req.nb_out = nwg * d;
   }
-  hipLaunchKernelGGL(k_heff0_fused, dim3(nwg, d), dim3(256), 0, ctx->stream, g);
+  {
+    // sampled HIP-event bracket (variant 7 of mpse_prof_get): algorithmic flops of SURVEY.md 8(d) for this matvec
+    // (8 real flops per complex multiply-add; 4 for the real MPO site), bytes = operands read once + parts written
+    const double fl = h->nsite == 0 ? 8.0 * wr * double(Dl) * Dr * (double(Dl) + Dr)
+                                    : 8.0 * double(Dl) * Dl * wl * d * Dr + 4.0 * double(Dl) * Dr * wl * wr * d * d +
+                                          8.0 * double(Dl) * Dr * Dr * wr * d;
+    const double by = 16.0 * (double(Dl) * wl * Dl + double(Dr) * wr * Dr + 2.0 * double(n));
+    ProfScope fprof(ctx, 7, fl, by);
+    hipLaunchKernelGGL(k_heff0_fused, dim3(nwg, d), dim3(256), 0, ctx->stream, g);
+    fprof.end();
+  }
   MPSE_HIP(ctx, hipGetLastError());
   ++ctx->f0_launches[h->nsite == 1 ? 1 : 0];
   pr.used = nparts;

@@ -45,7 +45,8 @@ struct mpse_ctx {
   long long prof_counter = 0;
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_free_events;
-  static constexpr int PROF_NVAR = 7;     // 0-3: contraction kernel by operand types, 4: Lanczos vector kernels, 5: block QR, 6: block SVD
+  static constexpr int PROF_NVAR = 8;     // 0-3: contraction kernel by operand types, 4: Lanczos vector kernels, 5: block QR, 6: block SVD,
+                                          // 7: fused bond / two-level-site matvec (k_heff0_fused)
   int64_t prof_svd_sweeps = 0;            // Jacobi sweeps of the timed mpse_block_svd calls (largest block of each call)
   double prof_ms[PROF_NVAR] = {0};
   double prof_flops[PROF_NVAR] = {0};

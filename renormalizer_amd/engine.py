@@ -472,7 +472,8 @@ class Engine:
 
     def prof_get(self):
         """{variant: dict(ms, flops, bytes, launches)} for the contraction kernel variants."""
-        names = {0: "f64xf64", 1: "c128xf64", 2: "f64xc128", 3: "c128xc128", 4: "lanczos_vec", 5: "block_qr", 6: "block_svd"}
+        names = {0: "f64xf64", 1: "c128xf64", 2: "f64xc128", 3: "c128xc128", 4: "lanczos_vec", 5: "block_qr", 6: "block_svd",
+                 7: "heff_fused"}
         issued_per_mac = {0: 2.0, 1: 4.0, 2: 4.0, 3: 6.0}     # real flops the MFMA units execute per multiply-add
         out = {}
         for v, nm in names.items():

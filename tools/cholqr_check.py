@@ -2,7 +2,7 @@
 """Cholesky-QR path of mpse_block_qr against NumPy on shapes and conditionings of the sweeps (GPU box).
 
 For every case: |U Vt - A| / |A|, |iso^H iso - I|_max, exact triangularity of the other factor, which path ran
-(mpse_block_qr_stats), time per call.  Exit status 1 when a case misses 1e-13.
+(mpse_block_qr_stats), median time per call (each call synchronised).  Exit status 1 when a case misses 1e-13.
     python tools/cholqr_check.py [out.md]"""
 import os
 import sys
@@ -37,12 +37,15 @@ def run(a, blocks, system, reps=10):
                                          p64(coff), int(system == "R"), u.ptr, vt.ptr, K))
     call()
     s1 = eng.block_qr_stats()
+    call()
     eng.sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    times = []
+    for _ in range(reps):       # median of individually timed calls: a pool growth (one device allocation of tens of ms)
+        t0 = time.perf_counter()    # now and then lands in one of them
         call()
-    eng.sync()
-    dt = (time.perf_counter() - t0) / reps
+        eng.sync()
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     uh, vh = u.to_host(), vt.to_host()
     mask = np.zeros(a.shape, bool)
     for r, c in blocks:
