@@ -177,11 +177,15 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
   }
   const int lc = min(lane, g.ntl - 1);
   const int nt = g.nterm[f];
-  v4d tr[DX], ti[DX];
+  // complex products as three real ones (3M): P1 = sum ar br, P2 = sum ai bi, P3 = sum (ar + ai)(br + bi);
+  // re = P1 - P2, im = P3 - P1 - P2 - a quarter fewer MFMAs on the chain of the heaviest workgroups, which set the
+  // duration of the launch (the contraction kernel of mpse_gemm.hip forms its complex products the same way)
+  v4d t1[DX], t2[DX], t3[DX];
 #pragma unroll
   for (int i = 0; i < DX; ++i) {
-    tr[i] = v4d{0, 0, 0, 0};
-    ti[i] = v4d{0, 0, 0, 0};
+    t1[i] = v4d{0, 0, 0, 0};
+    t2[i] = v4d{0, 0, 0, 0};
+    t3[i] = v4d{0, 0, 0, 0};
   }
   // operands of three c tiles in flight (the tensors come from the memory-side cache: ~1.5 us away, and a workgroup has
   // no neighbour on its compute unit to hide that behind)
@@ -212,10 +216,9 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
 #pragma unroll
         for (int i = 0; i < DX; ++i) {
           {
-            tr[i] = mfma(ar, bv[slot][kk].x, tr[i]);
-            tr[i] = mfma(-ai, bv[slot][kk].y, tr[i]);
-            ti[i] = mfma(ar, bv[slot][kk].y, ti[i]);
-            ti[i] = mfma(ai, bv[slot][kk].x, ti[i]);
+            t1[i] = mfma(ar, bv[slot][kk].x, t1[i]);
+            t2[i] = mfma(ai, bv[slot][kk].y, t2[i]);
+            t3[i] = mfma(ar + ai, bv[slot][kk].x + bv[slot][kk].y, t3[i]);
           }
         }
       }
@@ -257,8 +260,8 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
   for (int i = 0; i < DX; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      sTr[i][(kq + 4 * r) * 65 + 16 * wcolt + x] = tr[i][r];
-      sTi[i][(kq + 4 * r) * 65 + 16 * wcolt + x] = ti[i][r];
+      sTr[i][(kq + 4 * r) * 65 + 16 * wcolt + x] = t1[i][r] - t2[i][r];
+      sTi[i][(kq + 4 * r) * 65 + 16 * wcolt + x] = t3[i][r] - t1[i][r] - t2[i][r];
     }
   __syncthreads();
   // ---- step 2: the l tiles this workgroup holds, dealt to the waves in order; the A operands (P_x) of the whole chunk
@@ -303,16 +306,16 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
   auto mul2 = [&](int slot, int lt, unsigned kts) {
 #pragma unroll
     for (int i = 0; i < DX; ++i) {
-      v4d orr = {0, 0, 0, 0}, oi = {0, 0, 0, 0};
+      v4d o1 = {0, 0, 0, 0}, o2 = {0, 0, 0, 0}, o3 = {0, 0, 0, 0};
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         if ((kts >> (ks >> 2)) & 1u) {      // (uniform)
-          orr = mfma(xr[i][ks], rv[slot][ks].x, orr);
-          orr = mfma(-xi[i][ks], rv[slot][ks].y, orr);
-          oi = mfma(xr[i][ks], rv[slot][ks].y, oi);
-          oi = mfma(xi[i][ks], rv[slot][ks].x, oi);
+          o1 = mfma(xr[i][ks], rv[slot][ks].x, o1);
+          o2 = mfma(xi[i][ks], rv[slot][ks].y, o2);
+          o3 = mfma(xr[i][ks] + xi[i][ks], rv[slot][ks].x + rv[slot][ks].y, o3);
         }
       }
+      const v4d orr = o1 - o2, oi = o3 - o1 - o2;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long e = ((long long)(a0 + kq + 4 * r) * g.d + xo_wg) * g.Dr + 16 * lt + x;

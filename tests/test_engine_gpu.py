@@ -18,6 +18,9 @@ def eng():
     return E.get_engine()
 
 
+_FUSED_ON = os.environ.get("MPSE_HEFF0", "1") != "0" and os.environ.get("MPSE_LANCZOS_ASYNC", "1") != "0"
+
+
 def _rand(rng, shape, cplx):
     a = rng.standard_normal(shape)
     return a + 1j * rng.standard_normal(shape) if cplx else a
@@ -870,7 +873,9 @@ def test_fused_bond_matvec_in_lanczos(eng, Dl, Dr, w, masked, monkeypatch):
         out, nv = expm_krylov(hop, dt, eng.asdevice(c))
         outs.append(out.to_host())
         assert nv == nref
-    if min(Dl, Dr) >= 128 or os.environ.get("MPSE_HEFF0") == "2":
+    # (the fused launch serves the asynchronous solve - the one that takes its result as tile-masked parts; centres of
+    # up to 32 768 elements belong to the one-launch kernel of mpse_small.hip whatever MPSE_HEFF0 says)
+    if min(Dl, Dr) >= 128 and _FUSED_ON:
         assert eng.heff_fused_stats()[0] - n0 == 3 * nref          # every matvec of the three solves ran fused
     assert _relerr(outs[0].ravel(), ref) < 1e-10
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
@@ -920,7 +925,8 @@ def test_fused_two_level_site_matvec_in_lanczos(eng, Dl, Dr, w, masked):
         out, nv = expm_krylov(hop, dt, eng.asdevice(c))
         outs.append(out.to_host())
         assert nv == nref
-    assert eng.heff_fused_stats()[1] - n0 == 3 * nref              # every matvec of the three solves ran fused
+    if _FUSED_ON:
+        assert eng.heff_fused_stats()[1] - n0 == 3 * nref          # every matvec of the three solves ran fused
     assert _relerr(outs[0].ravel(), ref) < 1e-10
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert np.abs(outs[0] * (sl[:, None, None] != sr[None, None, :])).max() == 0
