@@ -133,7 +133,10 @@ __global__ __launch_bounds__(1024) void k_f0_valid(const unsigned char* __restri
 
 // blockIdx.y = the value x of the physical index of the result this workgroup forms (0 for a bond matrix): the terms
 // of the other x are another workgroup's - half the chain of the heaviest workgroups, which set the duration of the launch
-__global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
+// Two workgroups per compute unit (256 registers per lane, 24 bytes of scratch): the launch of a two-level site has 640
+// workgroups for 256 compute units and is as long as the sum of their chains, not as the longest one - a second
+// workgroup's MFMAs fill the first one's waits (site launch 54 -> 45 us, 382 -> 375 ms of kernels per two steps).
+__global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
   constexpr int DX = 1;
   const int xo_wg = blockIdx.y;
   constexpr int NW = 4;   // waves per workgroup (eight - two groups splitting the c tiles of step 1, added up in LDS -
@@ -266,14 +269,8 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
   __syncthreads();
   // ---- step 2: the l tiles this workgroup holds, dealt to the waves in order; the A operands (P_x) of the whole chunk
   // stay in registers
-  double xr[DX][16], xi[DX][16];
-#pragma unroll
-  for (int i = 0; i < DX; ++i)
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      xr[i][ks] = sTr[i][x * 65 + 4 * ks + kq];
-      xi[i][ks] = sTi[i][x * 65 + 4 * ks + kq];
-    }
+  // (the A operands of step 2 are read from LDS where they are used: sixty-four registers less per lane, which is what
+  // lets two workgroups share a compute unit)
   double dre = 0.0, dim = 0.0;
   const double2* Rb = reinterpret_cast<const double2*>(g.Rt) + ((long long)f * g.Dr + 64 * kc + kq) * g.Dr + x;
   double2* part = reinterpret_cast<double2*>(g.parts) + (long long)s * g.n;
@@ -310,9 +307,10 @@ __global__ __launch_bounds__(256) void k_heff0_fused(const F0Args g) {
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {
         if ((kts >> (ks >> 2)) & 1u) {      // (uniform)
-          o1 = mfma(xr[i][ks], rv[slot][ks].x, o1);
-          o2 = mfma(xi[i][ks], rv[slot][ks].y, o2);
-          o3 = mfma(xr[i][ks] + xi[i][ks], rv[slot][ks].x + rv[slot][ks].y, o3);
+          const double xr = sTr[i][x * 65 + 4 * ks + kq], xi = sTi[i][x * 65 + 4 * ks + kq];
+          o1 = mfma(xr, rv[slot][ks].x, o1);
+          o2 = mfma(xi, rv[slot][ks].y, o2);
+          o3 = mfma(xr + xi, rv[slot][ks].x + rv[slot][ks].y, o3);
         }
       }
       const v4d orr = o1 - o2, oi = o3 - o1 - o2;
