@@ -551,7 +551,17 @@ extern "C" int mpse_env_update(mpse_ctx* ctx, int dtype, int domain, const mpse_
     if (dims->Dl_bra != dims->Dl_ket || dims->Dr_bra != dims->Dr_ket)
       return mpse_fail(ctx, MPSE_ERR_SHAPE, "env_update: bra==NULL needs equal bonds");
   }
-  Plan p = plan_env(dtype, domain, *dims, env_dtype, w_dtype, bra_conj);
+  std::shared_ptr<void> wi_keep;     // the site as the caller described it (mpse_mpo_site_hint): elementwise MPO step
+  {
+    static const bool fold_on = [] {
+      const char* e = getenv("MPSE_ENV_WFOLD");
+      return !(e && e[0] == '0');
+    }();
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    auto it = ctx->wsite_info.find(W);
+    if (fold_on && it != ctx->wsite_info.end()) wi_keep = it->second.info;
+  }
+  Plan p = plan_env(dtype, domain, *dims, env_dtype, w_dtype, bra_conj, static_cast<const WSiteInfo*>(wi_keep.get()));
   const void* bufs[B_COUNT] = {nullptr};
   bufs[B_L] = env;
   bufs[B_W0] = W;

@@ -541,8 +541,69 @@ inline Plan plan_heff1_fold(int dtype, const mpse_heff& h, const WSiteInfo& wi, 
 
 // Environment update, mps/lib.py:169-250.  Buffers: B_L = incoming environment (either
 // domain), B_C = ket site, B_BRA = bra site, B_W0 = mpo site, B_OUT = new environment.
-inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, int w_dtype, int bra_conj) {
+// MPO step of an environment update as the elementwise pass of the folded matvec (K_WMIX) instead of a batched
+// real x complex product: for a large physical index and a site the caller has described (mpse_mpo_site_hint) the
+// product moves ~130 MB to apply a handful of identity / diagonal / tridiagonal blocks.  in_left: the incoming channel is
+// the LEFT index of W (domain L); otherwise the right one (domain R).  Tensors: src[a, (channel), e, k] / dst[a, (channel),
+// dd, k] through the offsets and strides given per channel.  Returns false (nothing pushed) when the site does not fit the pass.
+inline bool push_env_wmix(Plan& p, const WSiteInfo& wi, bool in_left, int dtype, int w_dtype, int tin, int tout, int64_t Da,
+                          int64_t Dk, int64_t src_ch_stride, int64_t src_sa, int64_t src_sd, int64_t dst_ch_stride,
+                          int64_t dst_sa, int64_t dst_sd) {
+  const int64_t d = wi.d, wl = wi.wl, wr = wi.wr, nout = in_left ? wr : wl;
+  const int64_t nchunk = (d + WM_CHUNK - 1) / WM_CHUNK;
+  if (d > 32 || nchunk > WM_MAXCHUNKS) return false;
+  std::vector<std::vector<const WBlock*>> by_out(nout);
+  int64_t nslot = 0;
+  for (const WBlock& k : wi.blocks) {
+    by_out[in_left ? k.f : k.b].push_back(&k);
+    nslot += k.ident ? 0 : 1;
+  }
+  for (auto& v : by_out)
+    if ((int)v.size() > WM_MAXTERM) return false;
+  if (nslot * d * d > 8192) return false;          // 64 KB of LDS for the dense blocks
+  std::vector<Step> steps;
+  Step mix{};
+  auto fresh = [&] {
+    mix = Step{};
+    mix.kind = K_WMIX;
+    mix.b = B_W0;
+    mix.dta = dtype, mix.dtb = w_dtype;
+    mix.wp_Da = Da, mix.wp_d = d, mix.wp_Dk = Dk, mix.wp_wr = wr;
+  };
+  fresh();
+  for (int64_t o = 0; o < nout; ++o) {
+    WMixDst q;
+    q.dst = tout, q.dst_off = o * dst_ch_stride, q.s_a = dst_sa, q.s_d = dst_sd;
+    for (const WBlock* k : by_out[o]) {
+      WMixTerm& t = q.term[q.nterm++];
+      t.b = k->b, t.f = k->f, t.ident = k->ident;
+      t.src = tin, t.src_off = (in_left ? k->b : k->f) * src_ch_stride;
+      t.s_a = src_sa, t.s_d = src_sd;
+      for (int64_t c = 0; c < nchunk; ++c) {
+        int64_t lo = d, hi = 0;
+        for (int64_t x = c * WM_CHUNK; x < std::min<int64_t>(d, (c + 1) * WM_CHUNK); ++x)
+          for (int64_t e = 0; e < d; ++e)
+            if (wi.w[((k->b * d + x) * d + e) * wr + k->f] != 0.0) lo = std::min(lo, e), hi = std::max(hi, e + 1);
+        t.e_lo[c] = (unsigned char)(hi > lo ? lo : 0), t.e_hi[c] = (unsigned char)(hi > lo ? hi : 0);
+      }
+    }
+    mix.mix.push_back(q);          // (a channel without blocks: nterm = 0, the pass writes zeros)
+    if ((int)mix.mix.size() == WM_MAXDST) {
+      steps.push_back(mix);
+      fresh();
+    }
+  }
+  if (!mix.mix.empty()) steps.push_back(mix);
+  for (Step& st : steps) p.steps.push_back(st);
+  return true;
+}
+
+inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, int w_dtype, int bra_conj,
+                     const WSiteInfo* wi = nullptr) {
   Plan p;
+  // the described site takes the elementwise MPO step where the batched product is the expensive way (large d, no ancilla)
+  const bool wfold = wi && dtype == MPSE_C128 && w_dtype == MPSE_F64 && s.d0 >= 8 && (s.danc <= 1) && wi->wl == s.wl &&
+                     wi->d == s.d0 && wi->wr == s.wr;
   const int64_t d = s.d0, wl = s.wl, wr = s.wr;
   const int64_t anc = s.danc > 0 ? s.danc : 1;
   const int64_t Dlb = s.Dl_bra, Dlk = s.Dl_ket, Drb = s.Dr_bra, Drk = s.Dr_ket;
@@ -554,7 +615,9 @@ inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, i
     // X[a,b,(e,g,h)] = sum_c L[(a,b),c] A[c,(e,g,h)]
     push_env_times(p, B_L, env_dtype, B_C, dtype, B_T1, Dlb, wl, Dlk, N, s.env_unit, true);
     // Y[a,d,f,(g,h)] = sum_{b,e} W[b,d,e,f] X[a,b,e,(g,h)]
-    push_w(p, B_W0, w_dtype, B_T1, B_T2, dtype, Dlb, wl, d, wr, anc * Drk);
+    if (!(wfold && push_env_wmix(p, *wi, true, dtype, w_dtype, B_T1, B_T2, Dlb, Drk, /*src X[b, a, e, h]: channel b*/ Dlb * d * Drk, d * Drk, Drk,
+                                 /*dst: channel f*/ Drk, d * wr * Drk, wr * Drk)))
+      push_w(p, B_W0, w_dtype, B_T1, B_T2, dtype, Dlb, wl, d, wr, anc * Drk);
     // out[p,(f,h)] = sum_{a,d,g} bra*[(a,d,g),p] Y[a,d,f,g,h]
     //   A = bra^T: m = p (stride 1), k = (a,d,g) (stride Drb)
     //   B = Y: k = ((a,d) | g): s_hi = wr*anc*Drk, s_lo = Drk ; n = (f | h): s_hi = anc*Drk, s_lo = 1
@@ -583,6 +646,9 @@ inline Plan plan_env(int dtype, int domain, const mpse_dims& s, int env_dtype, i
       }
     }
     // Y[h,q,d,g,a] = sum_{e,b} W[q,d,e,b] X[h,e,g,b,a] ; batch h ; one step per ancilla value g
+    if (wfold && push_env_wmix(p, *wi, false, dtype, w_dtype, B_T1, B_T2, Dlk, Drb, /*src: channel b*/ Drb, d * wr * Drb, wr * Drb,
+                               /*dst: channel q*/ d * Drb, wl * d * Drb, Drb)) {
+    } else
     for (int64_t g = 0; g < anc; ++g)
       push(p, B_W0, 0, w_dtype, 0, B_T1, g * wr * Drb, dtype, 0, B_T2, g * Drb,
            /*A=W: m=(q,d), k=(e,b)*/ i1(wl * d, d * wr), i1(d * wr, 1),

@@ -198,6 +198,40 @@ def test_env_update_golden(eng, golden_dir):
         assert _relerr(dev_env_update(eng, g("env"), g("ms"), g("mo"), dom), g("out_self")) < 1e-12
 
 
+@pytest.mark.parametrize("dom", ["L", "R"])
+def test_env_update_described_site_elementwise_mpo_step(eng, dom):
+    """Environment update behind a described MPO site (mpse_mpo_site_hint) with a large physical index: the MPO step runs
+    as the elementwise pass of the folded matvec (mpse_plans.h push_env_wmix) instead of a batched real x complex product.
+    Holstein-like site (identity, diagonal and tridiagonal blocks; a channel that receives nothing; five planes on the
+    R side = two passes), block-sparse environment with a unit channel, bra = ket and a separate bra, against the oracle
+    and against the same call without the description (the product path)."""
+    rng = np.random.default_rng(41)
+    D, d = 128, 16
+    w = _holstein_like_site(rng, d)                      # (5, d, d, 4)
+    wl, wr = w.shape[0], w.shape[3]
+    ket = _rand(rng, (D, d, D), True)
+    bra = _rand(rng, (D, d, D), True)
+    we = wl if dom == "L" else wr
+    env = _rand(rng, (D, we, D), True)
+    env[:, 0, :] = np.eye(D)
+    for other in (None, bra):
+        ref = orc.contract_one_site(env, ket, w, dom, ms_conj=None if other is None else other.conj())
+        K, Ev, W = eng.asdevice(ket), eng.asdevice(env), eng.asdevice(w)
+        Bt = None if other is None else eng.asdevice(other)
+        dd = _dims(ket, w, other)
+        oshape = (dd.Dr_bra, dd.wr, dd.Dr_ket) if dom == "L" else (dd.Dl_bra, dd.wl, dd.Dl_ket)
+        outs = []
+        for described in (False, True):
+            if described:
+                eng.mpo_site_hint(W, w)
+            out = eng.empty(oshape, np.complex128)
+            eng._check(eng.lib.mpse_env_update(eng.ctx, out.code, 0 if dom == "L" else 1, C.byref(dd), Ev.ptr, Ev.code, K.ptr,
+                                               None if Bt is None else Bt.ptr, 1, W.ptr, W.code, out.ptr))
+            outs.append(out.to_host())
+            assert _relerr(outs[-1], ref) < 1e-12, (dom, other is None, described)
+        assert _relerr(outs[1], outs[0]) < 1e-13
+
+
 def test_heff_apply_golden(eng, golden_dir):
     z = np.load(os.path.join(golden_dir, "seams.npz"))
     for k in range(int(z["hop_n"])):

@@ -192,6 +192,7 @@ _SWITCHES = {
     "MPSE_CHOLQR=0": False,           # every block QR by the Householder kernels (same isometry up to column phases)
     "MPSE_QR_OPTIMISTIC=0": True,     # every Cholesky-QR verified as it happens (same decompositions, same fallbacks)
     "MPSE_VEC_MASK=0": True,          # the vector kernels of a solve read and write the structurally empty tiles too
+    "MPSE_ENV_WFOLD=0": False,        # MPO step of the d = 16 environment updates as a batched product instead of the elementwise pass
 }
 
 

@@ -31,7 +31,7 @@ python bench.py --steps 1 --warmup 1 --cpu-updates 0 $S > /dev/null 2>&1
 (timeout 300 python tools/cholqr_check.py $O/cholqr_check.md > $O/cholqr_check.out 2>&1; echo "exit $?" >> $O/cholqr_check.out)
 (timeout 300 python tools/qr_bench.py > $O/qr_bench_chol.txt 2>&1); (MPSE_CHOLQR=0 timeout 300 python tools/qr_bench.py > $O/qr_bench_hh.txt 2>&1)
 (timeout 300 python tools/qr_trip_pattern.py > $O/qr_trip_pattern.txt 2>&1)
-for v in "MPSE_CHOLQR=0" "MPSE_CHOLQR=1" "MPSE_HEFF0=0" "MPSE_HEFF0=1" "MPSE_QR_OPTIMISTIC=0" "MPSE_QR_OPTIMISTIC=1" "MPSE_VEC_MASK=0" "MPSE_VEC_MASK=1" "MPSE_CHOLQR=0" "MPSE_CHOLQR=1" "MPSE_HEFF0=0" "MPSE_HEFF0=1"; do
+for v in "MPSE_CHOLQR=0" "MPSE_CHOLQR=1" "MPSE_HEFF0=0" "MPSE_HEFF0=1" "MPSE_QR_OPTIMISTIC=0" "MPSE_QR_OPTIMISTIC=1" "MPSE_VEC_MASK=0" "MPSE_VEC_MASK=1" "MPSE_ENV_WFOLD=0" "MPSE_ENV_WFOLD=1" "MPSE_CHOLQR=0" "MPSE_CHOLQR=1" "MPSE_HEFF0=0" "MPSE_HEFF0=1"; do
   env $v python bench.py --steps 5 --warmup 3 --cpu-updates 0 $S 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'switch': '$v', 'value': round(d['value'],1), 'ms_per_step': round(d['ms_per_step'],2), 'block_qr': d['config']['block_qr']}))" >> $O/ab_switches.jsonl
 done
 bash tools/runs/r5_env.sh $T/env > /dev/null 2>&1
