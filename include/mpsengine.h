@@ -248,7 +248,9 @@ int mpse_heff_apply(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
  * its own (same result: the reference's single expression mps/hop_expr.py:75-79).  The contents of W_dev must not
  * change while the hint stands: mpse_free(W_dev), a call with W_host == NULL, and every element-level entry point that
  * writes into the described range (mpse_memcpy_h2d / _d2d / _2d, mpse_memset_zero, mpse_scal, mpse_conj_inplace,
- * mpse_axpy) drop it; a caller that uses W_dev as the OUTPUT of a contraction has to drop it itself.  No device work. */
+ * mpse_axpy) drop it; a caller that uses W_dev as the OUTPUT of a contraction has to drop it itself.
+ * mpse_env_update on a described site with d >= 8 runs its MPO step as an elementwise pass over the site's non-zero
+ * blocks as well.  No device work. */
 int mpse_mpo_site_hint(mpse_ctx* ctx, const void* W_dev, const double* W_host_f64, int64_t wl, int64_t d, int64_t wr);
 
 /* How many effective-Hamiltonian applications of this context ran as the single fused launch of mpse_heff0.hip (inside
