@@ -61,13 +61,12 @@ struct F0Args {
   int Dl, Dr, wl, wr, d, ntl, ntr, nkc, fc_pitch;
 };
 
-// Rt[(b, k), l] = R[l, b, k]
-__global__ __launch_bounds__(256) void k_f0_transpose(double2* __restrict__ rt, const double2* __restrict__ r, int D, int w,
-                                                       const int* __restrict__ skip) {
-  if (skip && *skip) return;
+// Rt[(b, k), l] = R[l, b, k]  (block `blk` of `nblk`)
+__device__ __forceinline__ void f0_transpose(double2* __restrict__ rt, const double2* __restrict__ r, int D, int w, int blk,
+                                             int nblk) {
   const long long n = (long long)D * w * D;
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+  const long long stride = (long long)nblk * 256;
+  for (long long i = (long long)blk * 256 + threadIdx.x; i < n; i += stride) {
     const int l = (int)(i % D);
     const long long bk = i / D;
     rt[i] = r[(long long)l * w * D + bk];
@@ -75,12 +74,11 @@ __global__ __launch_bounds__(256) void k_f0_transpose(double2* __restrict__ rt, 
 }
 
 // flags of the 16 x 16 tiles of an environment E (D, w, D) viewed per channel: F[(rt * w + b) * nt + ct] = any non-zero in
-// rows [16 rt, 16 rt + 16), channel b, columns [16 ct, 16 ct + 16).  grid (nt, w), 256 threads = one tile row.
-__global__ __launch_bounds__(256) void k_f0_flags(const double2* __restrict__ E, int D, int w, int nt,
-                                                   unsigned char* __restrict__ F, const int* __restrict__ skip) {
-  if (skip && *skip) return;
+// rows [16 rt, 16 rt + 16), channel b, columns [16 ct, 16 ct + 16).  One block of 256 threads = one tile row (rt, b).
+__device__ __forceinline__ void f0_flags(const double2* __restrict__ E, int D, int w, int nt, unsigned char* __restrict__ F,
+                                         int rt, int b) {
   __shared__ int s_f[64];
-  const int rt = blockIdx.x, b = blockIdx.y, row = threadIdx.x >> 4, col = threadIdx.x & 15;
+  const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
   if (threadIdx.x < 64) s_f[threadIdx.x] = 0;
   __syncthreads();
   const double2* base = E + ((long long)(16 * rt + row) * w + b) * D;
@@ -90,6 +88,28 @@ __global__ __launch_bounds__(256) void k_f0_flags(const double2* __restrict__ E,
   }
   __syncthreads();
   if ((int)threadIdx.x < nt) F[((long long)rt * w + b) * nt + threadIdx.x] = s_f[threadIdx.x] ? 1 : 0;
+}
+
+// Per-solve preparation in ONE launch (three before): blocks [0, ntl wl) flag the tiles of L, the next ntr wr blocks those
+// of R, the rest transpose R - the three jobs do not depend on each other, and a launch at the head of a solve is ~8 us
+// of latency in front of its first matvec.
+__global__ __launch_bounds__(256) void k_f0_prepare(const double2* __restrict__ L, const double2* __restrict__ R,
+                                                     double2* __restrict__ rt, unsigned char* __restrict__ FL,
+                                                     unsigned char* __restrict__ FR, int Dl, int Dr, int wl, int wr, int ntl,
+                                                     int ntr, const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  int blk = blockIdx.x;
+  if (blk < ntl * wl) {
+    f0_flags(L, Dl, wl, ntl, FL, blk / wl, blk % wl);
+    return;
+  }
+  blk -= ntl * wl;
+  if (blk < ntr * wr) {
+    f0_flags(R, Dr, wr, ntr, FR, blk / wr, blk % wr);
+    return;
+  }
+  blk -= ntr * wr;
+  f0_transpose(rt, R, Dr, wr, blk, (int)gridDim.x - ntl * wl - ntr * wr);
 }
 
 // which parts hold which output tile: bit s = f * nkc + kc of the word of (bra tile row at, l tile lt) is set when step 1
@@ -479,12 +499,10 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
     const long long nel = (long long)wr * Dr * Dr;
     int nb = (int)((nel + 255) / 256);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(k_f0_transpose, dim3(nb), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(base),
-                       static_cast<const double2*>(h->R), Dr, wr, ctx->skip_flag);
-    hipLaunchKernelGGL(k_f0_flags, dim3(ntl, wl), dim3(256), 0, ctx->stream, static_cast<const double2*>(h->L), Dl, wl, ntl,
-                       reinterpret_cast<unsigned char*>(base + o_fl), ctx->skip_flag);
-    hipLaunchKernelGGL(k_f0_flags, dim3(ntr, wr), dim3(256), 0, ctx->stream, static_cast<const double2*>(h->R), Dr, wr, ntr,
-                       reinterpret_cast<unsigned char*>(base + o_fr), ctx->skip_flag);
+    hipLaunchKernelGGL(k_f0_prepare, dim3(ntl * wl + ntr * wr + nb), dim3(256), 0, ctx->stream,
+                       static_cast<const double2*>(h->L), static_cast<const double2*>(h->R), reinterpret_cast<double2*>(base),
+                       reinterpret_cast<unsigned char*>(base + o_fl), reinterpret_cast<unsigned char*>(base + o_fr), Dl, Dr, wl,
+                       wr, ntl, ntr, ctx->skip_flag);
     hipLaunchKernelGGL(k_f0_valid, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const unsigned char*>(base + o_fl), FC,
                        reinterpret_cast<const unsigned char*>(base + o_fr), reinterpret_cast<const F0Term*>(base + o_tm),
                        reinterpret_cast<const int*>(base + o_nt), wl, wr, d, ntl, ntr, nkc, fc_pitch,
