@@ -1300,6 +1300,7 @@ class Mps:
         with every decomposition verified (Householder where needed) - ``self`` is untouched until the step returns.
         ``MPSE_QR_OPTIMISTIC=0``: verify every decomposition as it happens."""
         eng = get_engine()
+        _householder_sites(self).tick()          # one evolve less on the Householder kernels for every noted site
         if os.environ.get("MPSE_QR_OPTIMISTIC", "1") == "0" or os.environ.get("MPSE_DEFER", "1") == "0":
             return self._evolve_tdvp_ps_sweeps(mpo, evolve_dt, learn_qr=True)
         eng.block_qr_optimistic(True)
@@ -1354,7 +1355,7 @@ class Mps:
             if learn_qr:
                 now = eng.block_qr_stats()[2]
                 if now != qr_redone[0]:
-                    hh_sites.add((imps, mps.to_right))
+                    hh_sites.note((imps, mps.to_right))
                 qr_redone[0] = now
 
         use_cmask = os.environ.get("MPSE_CENTRE_MASK", "1") != "0"
@@ -1494,10 +1495,34 @@ _OPTIMISTIC_REDONE = [0]
 _QR_NOTES = threading.local()
 
 
+class _QrNotes:
+    """(site, direction) -> [evolves left on the Householder kernels, patience].  A noted site goes back to the Cholesky-QR
+    path after ``patience`` evolves (the rank-deficient blocks of a freshly expanded state fill up within a few steps:
+    profiles/r05_qr_trips.md); if it breaks down again its patience doubles."""
+    FIRST = 8
+
+    def __init__(self):
+        self.d = {}
+
+    def __contains__(self, key):
+        e = self.d.get(key)
+        return e is not None and e[0] > 0
+
+    def note(self, key):
+        e = self.d.get(key)
+        patience = min(2 * e[1], 1 << 20) if e else self.FIRST
+        self.d[key] = [patience, patience]
+
+    def tick(self):
+        for e in self.d.values():
+            if e[0] > 0:
+                e[0] -= 1
+
+
 def _householder_sites(mps):
     key = (len(mps), tuple(mps.bond_dims), tuple(int(x) for x in mps.pbond_dims))
     if getattr(_QR_NOTES, "key", None) != key:
-        _QR_NOTES.key, _QR_NOTES.sites = key, set()
+        _QR_NOTES.key, _QR_NOTES.sites = key, _QrNotes()
     return _QR_NOTES.sites
 
 # One slot per host thread (= per trajectory): the environments ahead of the next half sweep, as the last TDVP-PS step
