@@ -494,8 +494,12 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
     MPSE_TRY(mpse_malloc(ctx, o_mk + mk_bytes, &p));
     fc.buf = p, fc.L = h->L, fc.R = h->R, fc.W = h->W0, fc.cmask = FC, fc.Dl = Dl, fc.Dr = Dr, fc.w = wr, fc.nsite = h->nsite;
     base = static_cast<char*>(p);
-    MPSE_TRY(stage_h2d(ctx, base + o_tm, terms.data(), tm_bytes));
-    MPSE_TRY(stage_h2d(ctx, base + o_nt, nterm.data(), size_t(wr) * sizeof(int)));
+    {   // terms | term counts: adjacent in the buffer, one upload
+      std::vector<char> up(tm_bytes + nt_bytes, 0);
+      memcpy(up.data(), terms.data(), tm_bytes);
+      memcpy(up.data() + tm_bytes, nterm.data(), size_t(wr) * sizeof(int));
+      MPSE_TRY(stage_h2d(ctx, base + o_tm, up.data(), up.size()));
+    }
     const long long nel = (long long)wr * Dr * Dr;
     int nb = (int)((nel + 255) / 256);
     if (nb > 2048) nb = 2048;
