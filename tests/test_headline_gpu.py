@@ -151,7 +151,9 @@ def test_headline_five_evolves_conserve(headline):
         assert list(cur.bond_dims) == dims0
     # optimistic block QR: the rank-deficient blocks next to the chain ends break the Cholesky-QR path in each of these
     # early steps; the first such step is repeated and notes the sites, the following ones send them to Householder
-    assert _m._OPTIMISTIC_REDONE[0] - redone0 <= 1, _m._OPTIMISTIC_REDONE[0] - redone0
+    # (a note expires after eight evolves of this chain shape in this thread - earlier tests count - and a site that
+    # breaks down again is noted anew with doubled patience: at most two repeats in five evolves, never one per evolve)
+    assert _m._OPTIMISTIC_REDONE[0] - redone0 <= 2, _m._OPTIMISTIC_REDONE[0] - redone0
 
 
 _VARIANT = r"""
