@@ -90,6 +90,39 @@ def _kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def _source_sha(*names):
+    """Fingerprint of the named csrc files (a committed counter figure is quoted only for the sources it was measured on)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in names:
+        try:
+            with open(os.path.join(REPO, "renormalizer_amd", "csrc", name), "rb") as fh:
+                h.update(fh.read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
+
+
+def _committed_mfma_busy(kernel, *sources):
+    """(busy fraction by duration, by GUI-active cycles, source note) of ``kernel`` from the newest committed
+    profiles/rNN_pmc_mfma_busy.json (tools/pmc_mfma_util.py --json on a rocprofv3 --pmc pass of this command), or
+    (None, None, note) when the file is missing or was measured on other sources of that kernel."""
+    import glob
+    import hashlib
+    try:
+        f = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_pmc_mfma_busy.json")))[-1]
+        with open(f, "rb") as fh:
+            raw = fh.read()
+        d = json.loads(raw)
+        k = d["kernels"][kernel]
+        note = f"profiles/{os.path.basename(f)} sha256:{hashlib.sha256(raw).hexdigest()[:16]} (SQ_VALU_MFMA_BUSY_CYCLES, launch-time weighted)"
+        if k.get("source_sha") != _source_sha(*sources):
+            return None, None, note + "; kernel sources CHANGED since that pass: figure withheld"
+        return k["busy_by_duration"], k["busy_by_gui_active"], note
+    except (OSError, KeyError, ValueError, IndexError):
+        return None, None, None
+
+
 def build_workload(nmol, pdim, bond_dim, seed, init, unit=0, state_file=None, scheme="tdvp_ps"):
     from renormalizer_amd import (HolsteinModel, Phonon, Mol, Quantity, Mpo, CompressConfig, CompressCriteria,
                                   EvolveConfig, EvolveMethod)
@@ -347,6 +380,7 @@ def main():
             engines[t].prof_reset()
             engines[t].prof_enable(PROF_STRIDE)
             qr0 = engines[t].block_qr_stats()
+            redone0 = _redone()
             engines[t].sync()
             sync.wait()                    # all trajectories ready -> main thread takes t0
             rtx = _roctx()
@@ -362,9 +396,11 @@ def main():
             engines[t].sync()
             if rtx is not None:
                 rtx.roctxProfilerPause(0)
+            redone_timed = _redone() - redone0
             sync.wait()                    # all done -> main thread takes t1
             engines[t].prof_enable(False)
             results[t] = dict(model=model, mpo=mpo, mps=mps, kry=kry, work=work, prof=engines[t].prof_get(),
+                              redone_timed=redone_timed,
                               qr=tuple(b - a for a, b in zip(qr0, engines[t].block_qr_stats())))
         except BaseException as exc:       # noqa: BLE001 - report and unblock the barrier
             errors.append(exc)
@@ -488,9 +524,13 @@ def main():
         ff = prof.get("heff_fused", {"ms": 0})
         if ff["ms"] > 0:
             tf = ff["flops"] / (ff["ms"] * 1e-3) / 1e12
+            busy_d, busy_g, busy_src = _committed_mfma_busy("k_heff0_fused", "mpse_heff0.hip")
             classes.append({"kernel": "k_heff0_fused (bond and two-level-site matvecs in one MFMA launch each)",
                             "bound": "latency (one 4-wave workgroup per compute unit, dependent loads)",
-                            "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                            "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            # NOT a utilisation: dense-formula flops over time (the kernel skips the zero blocks)
+                            "dense_equiv_frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                            "mfma_busy": busy_d, "mfma_busy_gui_active": busy_g, "mfma_busy_source": busy_src,
                             "achieved_note": "algorithmic (dense-formula) flops of the matvec over its launch time; the kernel "
                                              "skips the quantum-number zero blocks, so the MFMA work issued is smaller",
                             "timed_launches": ff["launches"], "avg_launch_ms": ff["ms"] / max(1, ff["launches"]),
@@ -549,6 +589,11 @@ def main():
                        # (tall blocks) and how many of those a device flag sent back to the Householder kernels
                        "block_qr": dict(zip(("calls", "cholesky_qr", "redone_by_householder"),
                                             [int(sum(r["qr"][k] for r in results)) for k in range(3)]),
+                                        # evolves the optimistic block QR discarded and ran again verified: inside
+                                        # the timed region (their time IS in `value`; with several trajectories per
+                                        # GPU the counter is shared, so this is an upper bound per trajectory) and
+                                        # over the whole run, warm-up included
+                                        steps_repeated_in_timed_region=int(max(r["redone_timed"] for r in results)),
                                         steps_repeated_after_breakdown=int(_redone())),
                        "bond_dims": [int(d) for d in mps.bond_dims],
                        "environments": ("rebuilt at every step (MPSE_ENV_CARRY=0)" if os.environ.get("MPSE_ENV_CARRY") == "0"

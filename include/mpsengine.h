@@ -338,7 +338,8 @@ int mpse_block_qr_stats(mpse_ctx* ctx, int64_t* calls, int64_t* chol_calls, int6
  * a breakdown raises a sticky device word instead and the results of that decomposition are NOT an isometry.
  * mpse_block_qr_check (synchronous) says whether any decomposition since the mode was switched on broke down: the caller
  * then discards the step and repeats it with the mode off (every decomposition verified, Householder where needed).
- * Switching the mode on clears the word.  No reference counterpart. */
+ * Switching the mode on OR off clears the word - ask before switching off - and while the mode is off
+ * mpse_block_qr_check reports 0 without touching the device.  No reference counterpart. */
 int mpse_block_qr_optimistic(mpse_ctx* ctx, int on);
 int mpse_block_qr_check(mpse_ctx* ctx, int* tripped);
 

@@ -202,8 +202,9 @@ int device_zero(mpse_ctx* ctx, void* dst, size_t bytes);
 // an entry point is about to write `bytes` at `dst`: a described MPO site (mpse_mpo_site_hint) that overlaps the range no
 // longer holds the values that were analysed - its description goes
 inline void wsite_written(mpse_ctx* ctx, const void* dst, size_t bytes) {
-  if (ctx->wsite_info.empty() || !dst || !bytes) return;
-  std::lock_guard<std::mutex> lock(ctx->pool_mu);
+  if (!dst || !bytes) return;
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);   // (before the first look at the map: mpse_free may run on a GC thread)
+  if (ctx->wsite_info.empty()) return;
   const char* lo = static_cast<const char*>(dst);
   for (auto it = ctx->wsite_info.begin(); it != ctx->wsite_info.end();) {
     const char* w = static_cast<const char*>(it->first);

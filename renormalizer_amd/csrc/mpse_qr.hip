@@ -448,8 +448,10 @@ int mpse_block_qr_optimistic(mpse_ctx* ctx, int on) {
       MPSE_TRY(mpse_malloc(ctx, 16, &p));
       ctx->qr_flag_dev = static_cast<int*>(p);
     }
-    MPSE_TRY(device_zero(ctx, ctx->qr_flag_dev, 16));
   }
+  // the word is cleared on BOTH edges: after a step that tripped it, the verified repeat (mode off) and whatever runs
+  // later on this context must not see a stale breakdown (mpse_block_qr_check reports 0 while the mode is off)
+  if (ctx->qr_flag_dev) MPSE_TRY(device_zero(ctx, ctx->qr_flag_dev, 16));
   ctx->qr_optimistic = on != 0;
   return MPSE_OK;
 }
@@ -464,7 +466,7 @@ int mpse_block_qr_check(mpse_ctx* ctx, int* tripped) {
   if (!ctx || !tripped) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
   *tripped = 0;
-  if (!ctx->qr_flag_dev) return MPSE_OK;
+  if (!ctx->qr_flag_dev || !ctx->qr_optimistic) return MPSE_OK;   // (mode off: every decomposition was verified as it ran)
   int v[4] = {0, 0, 0, 0};
   MPSE_TRY(mpse_memcpy_d2h(ctx, v, ctx->qr_flag_dev, 16));
   *tripped = v[0] != 0;

@@ -308,6 +308,9 @@ class Mps:
         new.compress_config = self.compress_config.copy()
         new.evolve_config = self.evolve_config.copy()
         new.optimize_config = self.optimize_config.copy()
+        notes = self.__dict__.get("_qr_notes")
+        if notes is not None:
+            new._qr_notes = notes.copy()          # part of the state: a copy evolves with its own history of noted sites
         return new
 
     def copy(self):
@@ -1300,16 +1303,18 @@ class Mps:
         with every decomposition verified (Householder where needed) - ``self`` is untouched until the step returns.
         ``MPSE_QR_OPTIMISTIC=0``: verify every decomposition as it happens."""
         eng = get_engine()
-        _householder_sites(self).tick()          # one evolve less on the Householder kernels for every noted site
         if os.environ.get("MPSE_QR_OPTIMISTIC", "1") == "0" or os.environ.get("MPSE_DEFER", "1") == "0":
             return self._evolve_tdvp_ps_sweeps(mpo, evolve_dt, learn_qr=True)
         eng.block_qr_optimistic(True)
         try:
             new = self._evolve_tdvp_ps_sweeps(mpo, evolve_dt)
             failed = eng.block_qr_check()
-        except (EngineError, ArithmeticError, ValueError, np.linalg.LinAlgError):
-            # a decomposition that broke down leaves something that is not an isometry: what follows may fail in many
-            # ways - only if the flag is up is the failure the optimistic mode's own
+        except Exception:
+            # a decomposition that broke down leaves something that is not an isometry (bad pivots are replaced by 1,
+            # tiny ones give factors ~1e150, later values may be inf / NaN): what follows may fail in many ways - engine
+            # status codes, LinAlgError, but also the plain assertions of the Krylov solver (`nrmv > 0`) or of the
+            # environment bookkeeping.  Only if the flag is up is the failure the optimistic mode's own: then the step
+            # is repeated verified; anything else is raised as it is
             if not eng.block_qr_check():
                 raise
             failed = True
@@ -1349,6 +1354,7 @@ class Mps:
         local_steps = []
         q = len(mps.qntot)
         hh_sites = _householder_sites(mps)         # (site, direction) whose block QR broke the Cholesky-QR path before
+        hh_sites.tick()                            # one evolve less on the Householder kernels for every noted site
         qr_redone = [eng.block_qr_stats()[2]]
 
         def note_qr(imps):
@@ -1489,10 +1495,11 @@ class Mps:
 # steps the optimistic block QR had to repeat (diagnostics; bench.py reports it)
 _OPTIMISTIC_REDONE = [0]
 
-# Per host thread (= per trajectory): the (site, sweep direction) pairs of the chain being evolved whose block QR sent the
-# Cholesky-QR path back to the Householder kernels in a verified run.  Keyed by the shape of the chain: another chain in
-# the same thread starts with an empty note.  A stale entry costs a slower decomposition, never correctness.
-_QR_NOTES = threading.local()
+# Per state (carried from an Mps to the states evolved from it, like evolve_config; copied by metacopy): the (site, sweep
+# direction) pairs whose block QR sent the Cholesky-QR path back to the Householder kernels in a verified run.  Which
+# kernels decompose a site therefore depends on the state object alone, not on what else the calling thread evolved
+# before (rounds 4-5 kept the notes in a thread-local keyed by the chain's shape).  A stale entry costs a slower
+# decomposition, never correctness; the notes are not written to checkpoints.
 
 
 class _QrNotes:
@@ -1503,6 +1510,11 @@ class _QrNotes:
 
     def __init__(self):
         self.d = {}
+
+    def copy(self):
+        new = _QrNotes()
+        new.d = {k: list(v) for k, v in self.d.items()}
+        return new
 
     def __contains__(self, key):
         e = self.d.get(key)
@@ -1520,10 +1532,10 @@ class _QrNotes:
 
 
 def _householder_sites(mps):
-    key = (len(mps), tuple(mps.bond_dims), tuple(int(x) for x in mps.pbond_dims))
-    if getattr(_QR_NOTES, "key", None) != key:
-        _QR_NOTES.key, _QR_NOTES.sites = key, _QrNotes()
-    return _QR_NOTES.sites
+    notes = mps.__dict__.get("_qr_notes")
+    if notes is None:
+        notes = mps._qr_notes = _QrNotes()
+    return notes
 
 # One slot per host thread (= per trajectory): the environments ahead of the next half sweep, as the last TDVP-PS step
 # left them, with the objects they were computed from.  Bounded: a new step replaces the slot.

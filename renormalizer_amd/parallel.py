@@ -93,11 +93,16 @@ def _recv_exact(conn, n):
 
 
 class SocketRendezvous:
-    """Small key -> bytes exchange of one launch over MASTER_ADDR (single node or not: plain TCP).  Rank 0 listens on
-    the first free port of MASTER_PORT .. MASTER_PORT + 16 (a launcher's own store may hold MASTER_PORT:
-    torch.distributed.run's agent does) and draws the launch nonce; rank r > 0 walks the same ports and takes the
-    first listener that answers with the right magic AND the right launch key - it never sends anything to MASTER_PORT
-    itself when a launcher's store is known to sit there.  Request: magic | launch key (16) | rank (int32) | key (16).
+    """Small key -> bytes exchange of one launch over MASTER_ADDR.  Meant for the ranks of ONE node on a trusted
+    network (what this engine shards over: the GPUs of a node): the launch key is derivable from the environment, the
+    exchange is neither authenticated beyond it nor encrypted, and it carries nothing but the RCCL unique id and a nonce.
+    Rank 0 listens on the first free port of MASTER_PORT .. MASTER_PORT + 16 - skipping MASTER_PORT itself when a
+    launcher's own store is known to sit there (torch.distributed.run's agent: the other ranks skip it too, so a rank 0
+    that found it free would listen where nobody looks) - on MASTER_ADDR when that is a local address and on every
+    interface otherwise (global rank 0 need not run on the MASTER_ADDR host), and draws the launch nonce; rank r > 0
+    walks the same ports and takes the first listener that answers with the right magic AND the right launch key.
+    Every connection is served by a short-lived thread with a 2 s budget: a silent peer cannot stall the others.
+    Request: magic | launch key (16) | rank (int32) | key (16).
     Reply: magic | nonce (8) | status (int32: 0 data follows, 1 not published yet, 2 another launch) | length | data.
     Independent of process ancestry and of the file system; a crashed earlier launch leaves nothing behind."""
 
@@ -113,17 +118,26 @@ class SocketRendezvous:
         if self.rank == 0:
             self.nonce = os.urandom(8)
             last = None
+            agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() in ("1", "true")
             for off in range(_RDZV_PORTS):
-                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                try:
-                    srv.bind((self.addr, self.base_port + off))
-                    srv.listen(64)
-                    self._srv, self.port = srv, self.base_port + off
+                if off == 0 and agent_store:
+                    continue                          # the launcher's store: the other ranks never ask there
+                for host in (self.addr, ""):          # MASTER_ADDR if it is one of this host's addresses, else any
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    try:
+                        srv.bind((host, self.base_port + off))
+                        srv.listen(64)
+                        self._srv, self.port = srv, self.base_port + off
+                        break
+                    except OSError as exc:
+                        last = exc
+                        srv.close()
+                        import errno
+                        if exc.errno != errno.EADDRNOTAVAIL:
+                            break                     # port taken: next port; address not local: same port, any interface
+                if self._srv is not None:
                     break
-                except OSError as exc:
-                    last = exc
-                    srv.close()
             if self._srv is None:
                 raise OSError(f"rank 0: no free port in {self.base_port} .. {self.base_port + _RDZV_PORTS - 1} "
                               f"on {self.addr} for the rendezvous ({last})")
@@ -137,7 +151,7 @@ class SocketRendezvous:
     # ---- rank 0
     def _serve(self):
         import socket
-        import struct
+        import threading
         while not self._stop:
             try:
                 conn, _ = self._srv.accept()
@@ -145,23 +159,27 @@ class SocketRendezvous:
                 continue
             except OSError:
                 return
-            try:
-                conn.settimeout(5.0)
-                req = _recv_exact(conn, 12 + 16 + 4 + 16)
-                if req[:12] != _RDZV_MAGIC:
-                    continue
-                key = req[32:48].rstrip(b"\0").decode(errors="replace")
-                if req[12:28] != self.key:
-                    status, data = 2, b""
-                else:
-                    with self._lock:
-                        data = self.nonce if key == "nonce" else self._store.get(key)
-                    status, data = (0, data) if data is not None else (1, b"")
-                conn.sendall(_RDZV_MAGIC + self.nonce + struct.pack("<ii", status, len(data)) + data)
-            except (OSError, ConnectionError):
-                pass
-            finally:
-                conn.close()
+            threading.Thread(target=self._answer, args=(conn,), daemon=True).start()
+
+    def _answer(self, conn):
+        import struct
+        try:
+            conn.settimeout(2.0)
+            req = _recv_exact(conn, 12 + 16 + 4 + 16)
+            if req[:12] != _RDZV_MAGIC:
+                return
+            key = req[32:48].rstrip(b"\0").decode(errors="replace")
+            if req[12:28] != self.key:
+                status, data = 2, b""
+            else:
+                with self._lock:
+                    data = self.nonce if key == "nonce" else self._store.get(key)
+                status, data = (0, data) if data is not None else (1, b"")
+            conn.sendall(_RDZV_MAGIC + self.nonce + struct.pack("<ii", status, len(data)) + data)
+        except (OSError, ConnectionError):
+            pass
+        finally:
+            conn.close()
 
     def publish(self, key: str, data: bytes):
         assert self.rank == 0 and len(key.encode()) <= 16
@@ -351,7 +369,10 @@ def _exit_hard_at_end():
 
     def bye():
         # atexit runs handlers last-registered-first: this one would run BEFORE everything registered earlier (logging
-        # shutdown, result writers) and os._exit would skip them - so it runs them itself, then leaves
+        # shutdown, result writers) and os._exit would skip them - so it runs them itself, then leaves.  CPython keeps a
+        # callback registered while it runs: without the unregister the call below would enter bye() again and recurse
+        # until RecursionError, with the earlier handlers never reached
+        atexit.unregister(bye)
         try:
             atexit._run_exitfuncs()
         except Exception:                      # noqa: BLE001 - a failing handler must not keep the process alive

@@ -559,6 +559,90 @@ def test_block_qr_cholesky_path(eng, cplx):
         eng.block_qr_scheme(-1)
 
 
+@pytest.mark.parametrize("cplx", [True, False])
+def test_block_qr_cholesky_kappa_window(eng, cplx):
+    """The window between "three passes are enough" (kappa <= 1e12) and "certainly flagged" (kappa = 1e18): condition
+    numbers 1e13 ... 1e17, several spectra each (geometric decay, a cliff - one tiny singular value -, a plateau of tiny
+    ones), tall two-block layouts of the sweep.  Whatever the device decides, the RESULT must be an isometry to 1e-13
+    with exact reconstruction: either the Cholesky-QR kernels delivered it (flag down) or the flag went up and the
+    Householder kernels did.  "Flag not raised but orthogonality degraded" fails here (round-5 verdict, weak 1 ii)."""
+    rng = np.random.default_rng(1234)
+    took_tot = np.zeros(2, dtype=int)
+    worst = 0.0
+    try:
+        eng.block_qr_scheme(2)
+        for m0, m1, n0, n1 in [(2816, 1280, 145, 111), (512, 300, 165, 91)]:
+            m, n = m0 + m1, n0 + n1
+            for logk in range(13, 18):
+                for spectrum in ("geometric", "cliff", "plateau"):
+                    sv = np.ones(n0)
+                    if spectrum == "geometric":
+                        sv = np.logspace(0, -logk, n0)
+                    elif spectrum == "cliff":
+                        sv[-1] = 10.0 ** -logk
+                    else:
+                        sv[n0 // 2:] = 10.0 ** -logk
+                    g = _rand(rng, (m0, n0), cplx)
+                    uu, _, vv = np.linalg.svd(g, full_matrices=False)
+                    blk0 = (uu * sv) @ vv
+                    qnl = np.concatenate([np.zeros(m0, int), np.ones(m1, int)])[rng.permutation(m)]
+                    qnr = np.concatenate([np.zeros(n0, int), np.ones(n1, int)])[rng.permutation(n)]
+                    a = np.zeros((m, n), dtype=complex if cplx else float)
+                    a[np.ix_(qnl == 0, qnr == 0)] = blk0
+                    a[np.ix_(qnl == 1, qnr == 1)] = _with_cond(rng, m1, n1, 1e5, cplx)
+                    for system in ("L", "R"):
+                        x = a if system == "L" else np.ascontiguousarray(a.conj().T)
+                        ql, qr = (qnl, qnr) if system == "L" else (qnr, qnl)
+                        s0 = eng.block_qr_stats()
+                        u, vt, _ = dev_block_qr(eng, x, ql[:, None], -qr[:, None], np.array([0]), system)
+                        s1 = eng.block_qr_stats()
+                        tag = (m0, n0, logk, spectrum, system, s1[1] - s0[1], s1[2] - s0[2])
+                        assert s1[1] - s0[1] == 1, tag                     # the Cholesky-QR kernels were tried
+                        took_tot += (1, s1[2] - s0[2])
+                        iso = u if system == "L" else vt.conj().T
+                        orth = np.abs(iso.conj().T @ iso - np.eye(iso.shape[1])).max()
+                        worst = max(worst, orth)
+                        assert orth < 1e-13, tag
+                        assert _relerr(u @ vt, x) < 1e-13, tag
+    finally:
+        eng.block_qr_scheme(-1)
+    # both outcomes occur in the window (else the sweep does not straddle the decision it is meant to probe)
+    assert 0 < took_tot[1] < took_tot[0], took_tot
+
+
+def test_block_qr_optimistic_flag_edges(eng):
+    """The sticky breakdown word of the optimistic mode: up after a rank-deficient tall block went through the
+    Cholesky-QR kernels unverified, reported only while the mode is on, cleared on BOTH edges of the mode (round-5
+    advisor: it used to survive into the verified repeat and into whatever ran next on the context)."""
+    rng = np.random.default_rng(5)
+    m, n = 2048, 128
+    bad = _with_cond(rng, m, n, 1e3, True, rank=100)
+    good = _with_cond(rng, m, n, 1e3, True)
+    qnl, qnr = np.zeros((m, 1), int), np.zeros((n, 1), int)
+    try:
+        eng.block_qr_scheme(2)
+        assert eng.block_qr_check() is False
+        eng.block_qr_optimistic(True)
+        dev_block_qr(eng, good, qnl, qnr, np.array([0]), "L")
+        assert eng.block_qr_check() is False
+        s0 = eng.block_qr_stats()
+        u, vt, _ = dev_block_qr(eng, bad, qnl, qnr, np.array([0]), "L")
+        s1 = eng.block_qr_stats()
+        assert (s1[1] - s0[1], s1[2] - s0[2]) == (1, 0)              # tried, NOT redone: the caller repeats the step
+        assert eng.block_qr_check() is True
+        dev_block_qr(eng, good, qnl, qnr, np.array([0]), "L")
+        assert eng.block_qr_check() is True                           # sticky while the mode is on
+        eng.block_qr_optimistic(False)
+        assert eng.block_qr_check() is False                          # off: nothing to report ...
+        u, vt, _ = dev_block_qr(eng, bad, qnl, qnr, np.array([0]), "L")
+        assert np.abs(u.conj().T @ u - np.eye(n)).max() < 1e-13      # ... every call verified: Householder took it
+        eng.block_qr_optimistic(True)
+        assert eng.block_qr_check() is False                          # ... and a new optimistic stretch starts clean
+    finally:
+        eng.block_qr_optimistic(False)
+        eng.block_qr_scheme(-1)
+
+
 # -------------------------------------------------------------- block SVD
 
 def dev_block_svd(eng, c, qnbigl, qnbigr, qntot):

@@ -49,24 +49,31 @@ def test_headline_bond_dims(headline):
     assert all(len(q) == d for q, d in zip(mps.qn, dims))
 
 
-def test_headline_one_evolve_vs_oracle(headline):
-    """One evolve at the headline size on the device and in the oracle from the same tensors: electronic
-    occupations and <H> within 1e-8 (north_star: 1e-6 relative), integer bookkeeping exact, same number of Krylov
-    solves, |<psi_oracle|psi_device>| = 1."""
-    model, mpo, mps, _ = headline
-    sites = mps.to_arrays()
-    ost = orc.MpsState(sites, [q.copy() for q in mps.qn], mps.qnidx, mps.qntot.copy(), mps.to_right,
-                       [np.array(b.sigmaqn) for b in model.basis], complex(mps.coeff))
+def _solve_sites(nsite, to_right):
+    """(centre site, neighbour the bond factor goes to or None) of every local solve of one TDVP-PS evolve, in the order
+    the driver and the oracle run them: per half sweep and site a forward solve of the site, then - unless it is the last
+    site of the half sweep - a backward solve of the bond factor between the site and its neighbour."""
+    out = []
+    for _ in range(2):
+        order = list(range(nsite)) if to_right else list(range(nsite - 1, -1, -1))
+        for k, i in enumerate(order):
+            out.append((i, None))
+            if k != nsite - 1:
+                out.append((i, i + 1 if to_right else i - 1))
+        to_right = not to_right
+    return out
+
+
+def _compare_evolve(model, mpo, dev0, dev, ost0, ost, sing):
+    """Device evolve dev0 -> dev against oracle evolve ost0 -> ost (both of the same physical state).  ``sing``: the
+    singular values of every bond of dev0 (rows padded with zeros), for the gauge argument below."""
     w_host = [mpo[i] for i in range(len(mpo))]
-    e0 = mps.expectation(mpo)
-    dev = mps.evolve(mpo, 10.0)
-    ost = orc.tdvp_ps_step(ost, w_host, 10.0)
     occ_dev = np.asarray(dev.e_occupations)
     occ_orc = np.array([orc.expectation(ost.sites, [m[i] for i in range(len(m))]).real
                         for m in model.mpos["e_occupations"]])
     assert np.abs(occ_dev - occ_orc).max() < 1e-8, np.abs(occ_dev - occ_orc).max()
     e_dev, e_orc = dev.expectation(mpo), orc.expectation(ost.sites, w_host)
-    assert abs(e_dev - e_orc) < 1e-8 and abs(e_dev - e0) < 1e-6
+    assert abs(e_dev - e_orc) < 1e-8
     assert abs(dev.mp_norm - 1.0) < 1e-12
     # integer bookkeeping: bit exact
     assert list(dev.bond_dims) == list(ost.bond_dims)
@@ -74,7 +81,7 @@ def test_headline_one_evolve_vs_oracle(headline):
     for a, b in zip(dev.qn, ost.qn):
         assert np.array_equal(_sorted_rows(a), _sorted_rows(b))
     st = dev.evolve_config.stat
-    assert st["nobs"] == len(ost.krylov_dims) == 2 * (2 * len(mps) - 1)
+    assert st["nobs"] == len(ost.krylov_dims) == 2 * (2 * len(dev) - 1)
     # solve by solve: the same Krylov dimension, except where the oracle's own stopping test was marginal.  The test is
     # np.allclose on the ELEMENTS of the local tensor (largest |res - new_res| / (atol + rtol |new_res|) <= 1), and the
     # elements depend on the gauge of the neighbouring isometries: where a block of a site matrix has numerically zero
@@ -84,17 +91,79 @@ def test_headline_one_evolve_vs_oracle(headline):
     # up to sqrt(k).  Observed: the oracle passes checks at 0.63 / 0.68 / 0.89 that the device fails and fails one at
     # 1.08 that the device passes (profiles/r05_qr_gauge.md: from the same start state the device's two QR schemes give
     # the same dimensions in all 198 solves and states with overlap 1 - 3e-15).  A solve whose oracle ratio lies within
-    # a factor 2 of 1 may differ by one check (2 vectors); every other solve has to agree exactly
+    # a factor 2 of 1 may differ by one check (2 vectors); every other solve has to agree exactly.  Round 6 makes the
+    # gauge argument checkable: at most FOUR solves may differ, and each of them must sit next to a bond whose spectrum
+    # is numerically rank deficient (sigma_min / sigma_max < 1e-14) - a wrong residual estimate on a full-rank bond fails
     dev_dims, orc_dims = list(st["steps"]), list(ost.krylov_dims)
     assert len(dev_dims) == len(orc_dims) == len(ost.krylov_margins)
     marginal = [any(0.5 <= m <= 2.0 for m in ms) for ms in ost.krylov_margins]
     differ = [i for i, (a, b) in enumerate(zip(dev_dims, orc_dims)) if a != b]
     assert all(marginal[i] and abs(dev_dims[i] - orc_dims[i]) <= 2 for i in differ), \
         [(i, dev_dims[i], orc_dims[i], ost.krylov_margins[i]) for i in differ]
-    assert len(differ) <= 6, differ
+    assert len(differ) <= 4, differ
+    where = _solve_sites(len(dev), bool(ost0.to_right))
+    assert len(where) == len(dev_dims)
+
+    def deficient(bond):           # bond b joins sites b - 1 and b; 0 and nsite are the dummy edges
+        if bond <= 0 or bond >= len(dev):
+            return False
+        sv = np.asarray(sing[bond - 1], dtype=float)
+        sv = sv[: dev0.bond_dims[bond]]
+        return sv.min() < 1e-14 * sv.max()
+
+    for i in differ:
+        site, nbr = where[i]
+        bonds = {site, site + 1} if nbr is None else {site, site + 1, nbr, nbr + 1}
+        assert any(deficient(b) for b in bonds), (i, where[i], dev_dims[i], orc_dims[i])
     assert abs(st["mean"] - float(np.mean(orc_dims))) < 0.1
     ov = orc.mps_dot([s.conj() for s in ost.sites], dev.to_arrays())
     assert abs(abs(ov) - 1.0) < 1e-9, abs(ov)
+    return len(differ)
+
+
+def _oracle_state(model, mps):
+    return orc.MpsState(mps.to_arrays(), [q.copy() for q in mps.qn], mps.qnidx, mps.qntot.copy(), mps.to_right,
+                        [np.array(b.sigmaqn) for b in model.basis], complex(mps.coeff))
+
+
+@pytest.fixture(scope="module")
+def first_evolve(headline):
+    """One evolve of the benchmark state on the device and in the oracle from the same tensors (~65 s of host time)."""
+    model, mpo, mps, _ = headline
+    ost0 = _oracle_state(model, mps)
+    sing = mps.calc_bond_singular_values()
+    dev = mps.evolve(mpo, 10.0)
+    ost = orc.tdvp_ps_step(ost0, [mpo[i] for i in range(len(mpo))], 10.0)
+    return dev, ost0, ost, sing
+
+
+def test_headline_one_evolve_vs_oracle(headline, first_evolve):
+    """One evolve at the headline size on the device and in the oracle from the same tensors: electronic
+    occupations and <H> within 1e-8 (north_star: 1e-6 relative), integer bookkeeping exact, same number of Krylov
+    solves, |<psi_oracle|psi_device>| = 1."""
+    model, mpo, mps, _ = headline
+    dev, ost0, ost, sing = first_evolve
+    assert abs(dev.expectation(mpo) - mps.expectation(mpo)) < 1e-6
+    _compare_evolve(model, mpo, mps, dev, ost0, ost, sing)
+
+
+def test_headline_three_evolves_vs_oracle(headline, first_evolve):
+    """Evolves two and three against the ORACLE as well (round-5 verdict: they were pinned only against a file this
+    engine wrote).  Each side continues from its own state - same physics, different gauge - so the optimistic repeat of
+    the first evolve, the noted sites of the second and third and the carried environments are all on the device's path.
+    Every evolve: occupations and <H> to 1e-8, bookkeeping exact, Krylov dimensions solve by solve (marginal rule),
+    overlap 1 to 1e-9."""
+    model, mpo, mps, _ = headline
+    dev, _, ost, _ = first_evolve
+    w_host = [mpo[i] for i in range(len(mpo))]
+    total = 0
+    for _ in range(2):
+        sing = dev.calc_bond_singular_values()
+        dev_next = dev.evolve(mpo, 10.0)
+        ost_next = orc.tdvp_ps_step(ost, w_host, 10.0)
+        total += _compare_evolve(model, mpo, dev, dev_next, ost, ost_next, sing)
+        dev, ost = dev_next, ost_next
+    assert total <= 6, total
 
 
 def test_headline_qr_schemes_agree(headline):
@@ -150,9 +219,10 @@ def test_headline_five_evolves_conserve(headline):
         assert abs(cur.expectation(mpo) - e0) < 1e-6 * 0.12, (step, cur.expectation(mpo) - e0)   # 4 J = 0.12 a.u.
         assert list(cur.bond_dims) == dims0
     # optimistic block QR: the rank-deficient blocks next to the chain ends break the Cholesky-QR path in each of these
-    # early steps; the first such step is repeated and notes the sites, the following ones send them to Householder
-    # (a note expires after eight evolves of this chain shape in this thread - earlier tests count - and a site that
-    # breaks down again is noted anew with doubled patience: at most two repeats in five evolves, never one per evolve)
+    # early steps; the first such step is repeated and notes the sites ON THE STATE (round 6: the notes travel with the
+    # Mps, whatever other tests evolved before in this thread), the following ones send them to Householder (a note
+    # expires after eight evolves; a site that breaks down again is noted anew with doubled patience): at most two
+    # repeats in five evolves, never one per evolve
     assert _m._OPTIMISTIC_REDONE[0] - redone0 <= 2, _m._OPTIMISTIC_REDONE[0] - redone0
 
 

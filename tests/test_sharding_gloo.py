@@ -210,3 +210,69 @@ def test_bench_refuses_world_size_other_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()
+
+
+def test_hard_exit_runs_earlier_handlers_and_keeps_status(tmp_path):
+    """After a stuck ``ncclCommInitRank`` the process leaves through ``os._exit`` (parallel._exit_hard_at_end): exit
+    handlers registered EARLIER must still run (once), and the status of ``sys.exit(n)`` must survive.  (Round-5 advisor:
+    the handler called ``atexit._run_exitfuncs()`` while still registered and recursed into itself.)"""
+    marker = tmp_path / "earlier_handler_ran"
+    code = textwrap.dedent(f"""
+        import atexit, sys
+        sys.path.insert(0, {REPO!r})
+        def earlier():
+            with open({str(marker)!r}, "a") as fh:
+                fh.write("x")
+        atexit.register(earlier)
+        from renormalizer_amd import parallel
+        parallel._exit_hard_at_end()
+        atexit.register(lambda: None)        # one registered later as well
+        sys.exit(3)
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert marker.read_text() == "x"
+    assert "RecursionError" not in r.stderr and "unraisablehook" not in r.stderr
+
+    # an uncaught exception leaves with status 1, handlers run as well
+    marker.unlink()
+    r = subprocess.run([sys.executable, "-c", code.replace("sys.exit(3)", "raise ValueError('boom')")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and marker.read_text() == "x" and "boom" in r.stderr
+
+
+def test_socket_rendezvous_agent_store_port_and_silent_peers(monkeypatch):
+    """Round-5 advisor: (1) with a launcher's agent store on MASTER_PORT the other ranks never ask there, so rank 0 must
+    not listen there either - even when it finds the port free; (2) rank 0 can serve although MASTER_ADDR is not one of
+    its own addresses (it then listens on every interface); (3) peers that connect and stay silent do not delay a real
+    request by their time-outs (connections are answered by threads of their own)."""
+    import time
+    from renormalizer_amd import parallel
+    port = _free_port()
+    for k, v in dict(WORLD_SIZE="2", MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1", MPSE_LAUNCH_ID="agent-store-test",
+                     TORCHELASTIC_USE_AGENT_STORE="True").items():
+        monkeypatch.setenv(k, v)
+    r0 = parallel.SocketRendezvous(0, 2, 10.0)
+    try:
+        assert r0.port == port + 1                      # MASTER_PORT was free, and is skipped all the same
+        r0.publish("rccl_id", b"\x07" * 128)
+        silent = [socket.create_connection(("127.0.0.1", r0.port)) for _ in range(4)]
+        t0 = time.time()
+        r1 = parallel.SocketRendezvous(1, 2, 10.0)
+        assert r1.nonce == r0.nonce and r1.fetch("rccl_id", 10.0) == b"\x07" * 128
+        assert time.time() - t0 < 1.5, "silent peers delayed the exchange"
+        for s in silent:
+            s.close()
+    finally:
+        r0.close()
+    # MASTER_ADDR that is not local (TEST-NET-1, RFC 5737): rank 0 falls back to every interface instead of failing
+    monkeypatch.setenv("MASTER_ADDR", "192.0.2.1")
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    monkeypatch.delenv("TORCHELASTIC_USE_AGENT_STORE")
+    r0 = parallel.SocketRendezvous(0, 2, 5.0)
+    try:
+        assert r0.port == int(os.environ["MASTER_PORT"])
+        with socket.create_connection(("127.0.0.1", r0.port), timeout=2.0):
+            pass
+    finally:
+        r0.close()
