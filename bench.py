@@ -380,6 +380,7 @@ def main():
             engines[t].prof_reset()
             engines[t].prof_enable(PROF_STRIDE)
             qr0 = engines[t].block_qr_stats()
+            qp0 = engines[t].block_qr_pass_stats()
             redone0 = _redone()
             engines[t].sync()
             sync.wait()                    # all trajectories ready -> main thread takes t0
@@ -397,10 +398,11 @@ def main():
             if rtx is not None:
                 rtx.roctxProfilerPause(0)
             redone_timed = _redone() - redone0
+            qp1 = engines[t].block_qr_pass_stats()
             sync.wait()                    # all done -> main thread takes t1
             engines[t].prof_enable(False)
             results[t] = dict(model=model, mpo=mpo, mps=mps, kry=kry, work=work, prof=engines[t].prof_get(),
-                              redone_timed=redone_timed,
+                              redone_timed=redone_timed, qr_pass=(qp1[0] - qp0[0], qp1[1] - qp0[1]),
                               qr=tuple(b - a for a, b in zip(qr0, engines[t].block_qr_stats())))
         except BaseException as exc:       # noqa: BLE001 - report and unblock the barrier
             errors.append(exc)
@@ -593,6 +595,10 @@ def main():
                                         # the timed region (their time IS in `value`; with several trajectories per
                                         # GPU the counter is shared, so this is an upper bound per trajectory) and
                                         # over the whole run, warm-up included
+                                        # quantum-number blocks the Cholesky-QR kernels factorised in the timed steps and
+                                        # how many of them the device ended after two passes (adaptive pass count)
+                                        cholesky_qr_blocks=int(sum(r["qr_pass"][0] for r in results)),
+                                        cholesky_qr_blocks_two_passes=int(sum(r["qr_pass"][1] for r in results)),
                                         steps_repeated_in_timed_region=int(max(r["redone_timed"] for r in results)),
                                         steps_repeated_after_breakdown=int(_redone())),
                        "bond_dims": [int(d) for d in mps.bond_dims],

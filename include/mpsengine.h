@@ -343,6 +343,13 @@ int mpse_block_qr_stats(mpse_ctx* ctx, int64_t* calls, int64_t* chol_calls, int6
 int mpse_block_qr_optimistic(mpse_ctx* ctx, int on);
 int mpse_block_qr_check(mpse_ctx* ctx, int* tripped);
 
+/* Pass counts of the Cholesky-QR path since the context was created (synchronous read of two device counters): quantum-
+ * number blocks factorised by those kernels, and how many of them ended after TWO passes - the kernels decide per block,
+ * on the device, whether the Gram matrix of the second pass is close enough to the identity for its factor to leave an
+ * isometry to rounding (n max|G - I| <= 0.1); the third pass of such a block is skipped.  No reference counterpart
+ * (diagnostics; bench.py reports the rate).  Either pointer may be NULL. */
+int mpse_block_qr_pass_stats(mpse_ctx* ctx, int64_t* blocks, int64_t* two_pass);
+
 /* Which kernels mpse_block_qr uses on this context: 0 Householder only (the column-by-column elimination of LAPACK's
  * geqrf, mps/svd_qn.py:171-185 calls scipy.linalg.qr: the SAME isometry as the reference up to rounding, also in the
  * directions of numerically zero singular values, where a QR factorisation is not unique), 1 Cholesky-QR for tall blocks

@@ -102,10 +102,13 @@ __device__ __forceinline__ void st2(double* p, long long i, double re, double im
 // Four operand loads feed sixteen MFMAs; the loads of two row steps are in flight ahead of the arithmetic.
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_cq_gram(const double* __restrict__ ws, double* __restrict__ part,
-                                                  const CqBlk* __restrict__ blks, int* __restrict__ status, int nstat) {
+                                                  const CqBlk* __restrict__ blks, int* __restrict__ status, int nstat,
+                                                  const int* __restrict__ done) {
   constexpr int E = CPLX ? 2 : 1;
+  if (done && done[blockIdx.y]) return;     // (pass 3 of a block whose second pass was the last one)
   const CqBlk B = blks[blockIdx.y];
-  if (nstat > 0 && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < nstat) status[threadIdx.x] = 0;
+  if (nstat > 0 && blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < nstat; i += 256) status[i] = 0;
   const int P2 = (B.P + 1) >> 1, T2 = P2 * (P2 + 1) / 2;
   const int nmacro = (B.nchunk + 3) >> 2;
   const int macro = blockIdx.x / T2, t2 = blockIdx.x - macro * T2;
@@ -213,8 +216,10 @@ __global__ __launch_bounds__(256) void k_cq_gram(const double* __restrict__ ws, 
 // the tile's valid entries, sum of the real diagonal of a diagonal tile)
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_cq_reduce(const double* __restrict__ part, double* __restrict__ G,
-                                                    double* __restrict__ tinfo, const CqBlk* __restrict__ blks) {
+                                                    double* __restrict__ tinfo, const CqBlk* __restrict__ blks,
+                                                    const int* __restrict__ done) {
   constexpr int E = CPLX ? 2 : 1;
+  if (done && done[blockIdx.y]) return;
   const CqBlk B = blks[blockIdx.y];
   const int t = blockIdx.x;
   if (t >= B.T) return;
@@ -274,13 +279,23 @@ __global__ __launch_bounds__(256) void k_cq_reduce(const double* __restrict__ pa
 // measured by switching the phases off: a dependent chain of FP64 operations on a single wave) by 15 short steps on
 // all columns at once.  Called by every thread of the workgroup (the barriers are workgroup barriers); threads past
 // the panel width only keep the barriers.  Pivots are checked at the end: status |= 1 (through *bad).
+//
+// Pivot shift (pass 1 with a per-pivot shift, `thr` != nullptr): a pivot that has lost all but a fraction theta of its
+// diagonal entry of G (d_k <= thr[k] = theta G_kk) counts as d_k + shift (shift = sDinv[16]) - the factor is that of
+// G + D with a diagonal 0 <= D <= shift I chosen on the way.  The eigenvalues of Q1^H Q1 = R1^-H G R1^-1 then still lie
+// in [lambda_min / (lambda_min + shift), 1] (D <= shift I is all the bound of the fully shifted scheme uses), so
+// passes 2 and 3 see nothing worse than before, while a block that is well conditioned up to column scaling is not
+// shifted at all and leaves pass 1 orthogonal to ~u kappa^2: its second pass can be the last (cholqr_run).
+// Every thread applies the rule to the pivot it reads (the published tile keeps the unshifted value): no thread is
+// singled out inside the steps.  sDinv: [0, 16) 1 / sqrt(pivot), [16] the shift, [17, 33) sqrt(pivot).
 template <bool CPLX>
 __device__ __forceinline__ void panel_eliminate(double2 (*tiles)[256], int W, int p, int P, int nn_unused, double* Rt,
-                                                double* sDinv, int pass, int tid, int* bad) {
+                                                double* sDinv, bool window, int tid, int* bad, const double* thr) {
   (void)nn_unused;
   constexpr int E = CPLX ? 2 : 1;
   const bool act = tid < W;
   const int ct = tid >> 4, col = tid & 15;
+  const bool dyn = thr != nullptr;
   double cr[16], ci[16];
   if (act) {
 #pragma unroll
@@ -293,7 +308,9 @@ __device__ __forceinline__ void panel_eliminate(double2 (*tiles)[256], int W, in
   auto step = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     if (act) {
-      const double inv = fast_rcp(tiles[0][k * 16 + k].x);     // (a bad pivot makes garbage here; flagged below)
+      double piv = tiles[0][k * 16 + k].x;                       // (a bad pivot makes garbage here; flagged below)
+      if (dyn) piv = piv > thr[k] ? piv : piv + sDinv[16];
+      const double inv = fast_rcp(piv);
       const double tr = cr[k] * inv, ti = ci[k] * inv;
 #pragma unroll
       for (int i = k + 1; i < 16; ++i) {
@@ -320,14 +337,17 @@ __device__ __forceinline__ void panel_eliminate(double2 (*tiles)[256], int W, in
   step(std::integral_constant<int, 12>{});
   step(std::integral_constant<int, 13>{});
   step(std::integral_constant<int, 14>{});
-  // pivots s_ii (row i as published): checks and 1 / sqrt
+  // pivots s_ii (row i as published, shifted by the same rule): checks, 1 / sqrt and sqrt
   if (tid < 16) {
     double d = tiles[0][tid * 16 + tid].x;
+    if (dyn) d = d > thr[tid] ? d : d + sDinv[16];
     bool ok = d > 0.0 && d < 1e300;
-    if (pass == 3 && !(d >= 0.25 && d <= 4.0)) ok = false;
+    if (window && !(d >= 0.25 && d <= 4.0)) ok = false;         // (last pass: the Gram matrix was the identity to O(0.1))
     if (!(d > 0.0 && d < 1e300)) d = 1.0;
     if (!ok) *bad = 1;
-    sDinv[tid] = fast_rsqrt(d);
+    const double rs = fast_rsqrt(d);
+    sDinv[tid] = rs;
+    sDinv[17 + tid] = d * rs;
   }
   lds_barrier();
   if (act) {
@@ -338,7 +358,10 @@ __device__ __forceinline__ void panel_eliminate(double2 (*tiles)[256], int W, in
       double vr = cr[i] * rs, vi = ci[i] * rs;
       if (ct == 0) {
         if (i > col) vr = vi = 0.0;
-        if (i == col) vi = 0.0;
+        if (i == col) {
+          vr = sDinv[17 + i];
+          vi = 0.0;
+        }
       }
       tiles[ct][i * 16 + col] = make_double2(vr, vi);
       st2<CPLX>(td, i * 16 + col, vr, vi);
@@ -356,16 +379,24 @@ __device__ __forceinline__ void panel_eliminate(double2 (*tiles)[256], int W, in
 template <bool CPLX>
 __global__ __launch_bounds__(512) void k_cq_chol(const double* __restrict__ G, const double* __restrict__ tinfo,
                                                   double* __restrict__ R, const CqBlk* __restrict__ blks,
-                                                  int* __restrict__ status, int pass, int* __restrict__ gflag) {
+                                                  int* __restrict__ status, int pass, int* __restrict__ gflag, int nblk,
+                                                  double theta, double tau) {
   constexpr int E = CPLX ? 2 : 1;
+  int* const donep = status + 1 + nblk + blockIdx.x;
+  if (pass == 3 && *donep) return;      // the second pass of this block was the last one
   const CqBlk B = blks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15, kq = lane >> 4;
   const int P = B.P, T = B.T, nn = B.nn;
   const double* Gt = G + B.t_off * 256 * E;
   double* Rt = R + B.t_off * 256 * E;
   __shared__ double2 sS[16][256];
-  __shared__ double sDinv[16];
+  __shared__ double sDinv[33];     // [0, 16) 1 / sqrt(pivot) of the panel, [16] the shift of pass 1, [17, 33) sqrt(pivot)
   __shared__ double s_red[2][512];
+  __shared__ double sThr[256];
+  const bool dyn = pass == 1 && theta > 0.0;
+  if (dyn)     // pivot thresholds theta G_kk (padding rows: none)
+    for (int i = tid; i < 16 * P; i += 512)
+      sThr[i] = i < nn ? theta * Gt[((long long)tile_index(i >> 4, i >> 4, P) * 256 + (i & 15) * 17) * E] : -1.0;
   // trace and max |G - I| of the block (fixed order)
   {
     double m = 0.0, tr = 0.0;
@@ -386,7 +417,12 @@ __global__ __launch_bounds__(512) void k_cq_chol(const double* __restrict__ G, c
   }
   const double maxdev = s_red[0][0], trace = s_red[1][0];
   const double shift = pass == 1 ? 11.0 * ((double)B.mm * nn + (double)nn * (nn + 1)) * 1.1102230246251565e-16 * trace : 0.0;
-  if (pass == 3 && (double)nn * maxdev <= 1e-9) {
+  if (tid == 0) sDinv[16] = shift;     // (visible after the barriers ahead of the first panel_eliminate)
+  // adaptive pass count: when the Gram matrix of pass 2 is the identity to within tau, the factor of this pass leaves an
+  // isometry to rounding (u kappa(Q1)^2 with kappa(Q1)^2 <= (1 + tau) / (1 - tau)) and pass 3 is skipped for the block
+  const bool last = pass == 3 || (pass == 2 && (double)nn * maxdev <= tau);
+  if (pass == 2 && tid == 0) *donep = last ? 1 : 0;
+  if (pass >= 2 && (double)nn * maxdev <= 1e-9) {
     // first-order factor of G = I + E:  R = I + striu(E) + diag(E) / 2   (error O(|E|^2) <= 1e-18)
     for (int t = 0; t < T; ++t) {
       int q, c;
@@ -426,7 +462,7 @@ __global__ __launch_bounds__(512) void k_cq_chol(const double* __restrict__ G, c
           ld2<CPLX>(g0, row * 16 + x, gr, gi);
           if (c == p && row == x) {
             gi = 0.0;
-            gr = 16 * p + row < nn ? gr + shift : 1.0;
+            gr = 16 * p + row < nn ? (dyn ? gr : gr + shift) : 1.0;
           }
           ar[r] = gr;
           ai[r] = gi;
@@ -459,7 +495,7 @@ __global__ __launch_bounds__(512) void k_cq_chol(const double* __restrict__ G, c
     // ---- the row panel of the factor (diagonal factor + forward substitution in one elimination, see panel_eliminate)
     {
       int badp = 0;
-      panel_eliminate<CPLX>(sS, 16 * (P - p), p, P, nn, Rt, sDinv, pass, tid, &badp);
+      panel_eliminate<CPLX>(sS, 16 * (P - p), p, P, nn, Rt, sDinv, last, tid, &badp, dyn ? sThr + 16 * p : nullptr);
       if (badp) bad = 1;
     }
     __syncthreads();   // the tiles of row panel p are visible to the MFMA loads of the next panels
@@ -480,16 +516,24 @@ __global__ __launch_bounds__(512) void k_cq_chol(const double* __restrict__ G, c
 template <bool CPLX>
 __global__ __launch_bounds__(512) void k_cq_chol_rl(const double* __restrict__ G, const double* __restrict__ tinfo,
                                                      double* __restrict__ R, const CqBlk* __restrict__ blks,
-                                                     int* __restrict__ status, int pass, int* __restrict__ gflag) {
+                                                     int* __restrict__ status, int pass, int* __restrict__ gflag, int nblk,
+                                                     double theta, double tau) {
   constexpr int E = CPLX ? 2 : 1, PMAX = 10, NW = 8, NS = 7, NT = 64 * NW;
+  int* const donep = status + 1 + nblk + blockIdx.x;
+  if (pass == 3 && *donep) return;      // the second pass of this block was the last one
   const CqBlk B = blks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15, kq = lane >> 4;
   const int P = B.P, T = B.T, nn = B.nn;
   const double* Gt = G + B.t_off * 256 * E;
   double* Rt = R + B.t_off * 256 * E;
   __shared__ double2 sRow[2][PMAX][256];
-  __shared__ double sDinv[16];
+  __shared__ double sDinv[33];     // [0, 16) 1 / sqrt(pivot) of the panel, [16] the shift of pass 1, [17, 33) sqrt(pivot)
+  __shared__ double sThr[16 * PMAX];
   double* s_red = reinterpret_cast<double*>(&sRow[0][0][0]);   // scratch of the reductions before the loop
+  const bool dyn = pass == 1 && theta > 0.0;
+  if (dyn)     // pivot thresholds theta G_kk (padding rows: none)
+    for (int i = tid; i < 16 * P; i += NT)
+      sThr[i] = i < nn ? theta * Gt[((long long)tile_index(i >> 4, i >> 4, P) * 256 + (i & 15) * 17) * E] : -1.0;
   {
     double m = 0.0, tr = 0.0;
     for (int t = tid; t < T; t += NT) {
@@ -510,7 +554,10 @@ __global__ __launch_bounds__(512) void k_cq_chol_rl(const double* __restrict__ G
   const double maxdev = s_red[0], trace = s_red[NT];
   __syncthreads();
   const double shift = pass == 1 ? 11.0 * ((double)B.mm * nn + (double)nn * (nn + 1)) * 1.1102230246251565e-16 * trace : 0.0;
-  if (pass == 3 && (double)nn * maxdev <= 1e-9) {
+  if (tid == 0) sDinv[16] = shift;     // (visible after the barriers ahead of the first panel_eliminate)
+  const bool last = pass == 3 || (pass == 2 && (double)nn * maxdev <= tau);     // (adaptive pass count: see k_cq_chol)
+  if (pass == 2 && tid == 0) *donep = last ? 1 : 0;
+  if (pass >= 2 && (double)nn * maxdev <= 1e-9) {
     for (int t = 0; t < T; ++t) {
       int q, c;
       tile_decode(t, P, q, c);
@@ -551,7 +598,7 @@ __global__ __launch_bounds__(512) void k_cq_chol_rl(const double* __restrict__ G
         ld2<CPLX>(g0, row * 16 + x, gr, gi);
         if (tq[s] == tc[s] && row == x) {
           gi = 0.0;
-          gr = 16 * tq[s] + row < nn ? gr + shift : 1.0;
+          gr = 16 * tq[s] + row < nn ? (dyn ? gr : gr + shift) : 1.0;
         }
         ar[s][r] = gr;
         ai[s][r] = gi;
@@ -571,7 +618,7 @@ __global__ __launch_bounds__(512) void k_cq_chol_rl(const double* __restrict__ G
     __syncthreads();
     // ---- the row panel of the factor (diagonal factor + forward substitution in one elimination, see panel_eliminate)
     int badp = 0;
-    panel_eliminate<CPLX>(sRow[buf], 16 * (P - p), p, P, nn, Rt, sDinv, pass, tid, &badp);
+    panel_eliminate<CPLX>(sRow[buf], 16 * (P - p), p, P, nn, Rt, sDinv, last, tid, &badp, dyn ? sThr + 16 * p : nullptr);
     if (badp) bad = 1;
     __syncthreads();
     // ---- updates: S(q, c) -= R(p, q)^H R(p, c) for this wave's tiles below the panel
@@ -610,8 +657,9 @@ template <bool CPLX>
 __global__ __launch_bounds__(256) void k_cq_trsm(double* __restrict__ ws, const double* __restrict__ R,
                                                   const double* __restrict__ Rprev, double* __restrict__ Rout,
                                                   const CqBlk* __restrict__ blks, const int* __restrict__ status, int nrb_max,
-                                                  int rmul) {
+                                                  int rmul, const int* __restrict__ done) {
   constexpr int E = CPLX ? 2 : 1;
+  if (done && done[blockIdx.y]) return;     // (pass 3 of a block whose second pass was the last one)
   const CqBlk B = blks[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15, kq = lane >> 4;
   const int P = B.P, nn = B.nn;
@@ -829,14 +877,25 @@ __global__ __launch_bounds__(256) void k_cq_trsm(double* __restrict__ ws, const 
 // herm: Vt[koff + c, cols[r]] = conj(Q[r, c]), U[rows[c], koff + i] = conj(R[i, c]).  The last workgroup-independent
 // job: status word as a double for the host (dstat[0] = status[0]).
 template <bool CPLX>
-__global__ void k_cq_scatter(double* U, double* Vt, const double* __restrict__ ws, const double* __restrict__ R, long long K,
+__global__ void k_cq_scatter(double* U, double* Vt, const double* __restrict__ ws, const double* __restrict__ R,
+                             const double* __restrict__ R2, long long K,
                              long long ncol, const long long* __restrict__ drows, const long long* __restrict__ dcols,
-                             const CqBlk* __restrict__ blks, int herm, const int* __restrict__ status, double* dstat) {
+                             const CqBlk* __restrict__ blks, int herm, const int* __restrict__ status, double* dstat,
+                             const int* __restrict__ done, int* __restrict__ words) {
   constexpr int E = CPLX ? 2 : 1;
   const CqBlk B = blks[blockIdx.y];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dstat[0] = (double)status[0];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    dstat[0] = (double)status[0];
+    int n2 = 0;                                      // blocks that ended after two passes (diagnostics)
+    for (int b = 0; b < (int)gridDim.y; ++b) n2 += done[b] != 0;
+    dstat[1] = (double)n2;
+    if (words) {       // the context's running counts (mpse_block_qr_pass_stats): blocks factorised, of them in two passes
+      atomicAdd(words + 2, (int)gridDim.y);
+      atomicAdd(words + 3, n2);
+    }
+  }
   const double* q = ws + B.ws_off * E;
-  const double* Rt = R + B.t_off * 256 * E;
+  const double* Rt = (done[blockIdx.y] ? R2 : R) + B.t_off * 256 * E;      // R2 R1, or R3 R2 R1
   const long long* rows = drows + B.row_off;
   const long long* cols = dcols + B.col_off;
   const int mm = B.mm, nn = B.nn, k = B.nn;
@@ -873,7 +932,8 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
                int herm, void* U, void* Vt, long long K, long long ncol, bool* ok) {
   // optimistic mode (mpse_block_qr_optimistic): no read-back here - a breakdown sets the context's sticky device flag,
   // which the caller of the sweep reads once at its end (and then repeats the step on the Householder kernels)
-  int* gflag = ctx->qr_optimistic ? ctx->qr_flag_dev : nullptr;
+  MPSE_TRY(qr_words(ctx));
+  int* gflag = ctx->qr_optimistic ? ctx->qr_words_dev : nullptr;
   constexpr size_t es = CPLX ? 16 : 8;
   std::vector<CqBlk> cb(nblk);
   long long part_tot = 0, t_tot = 0;
@@ -920,7 +980,7 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
   // one allocation: descriptors | partial sums | G | five sets of R tiles (R1, R2, R3, R2 R1, R3 R2 R1) | tile infos | status
   const size_t db = (size_t(nblk) * sizeof(CqBlk) + 15) & ~size_t(15);
   const size_t pb = size_t(part_tot) * es, tb = size_t(t_tot) * 256 * es, ib = size_t(t_tot) * 2 * sizeof(double);
-  const size_t sb = ((size_t(nblk) + 1) * sizeof(int) + 15) & ~size_t(15);
+  const size_t sb = ((2 * size_t(nblk) + 1) * sizeof(int) + 15) & ~size_t(15);   // flag | trsm mode per block | done per block
   TmpBuf M(ctx);
   MPSE_TRY(M.alloc(db + pb + 6 * tb + ib + sb + 16));
   char* base = static_cast<char*>(M.p);
@@ -932,30 +992,46 @@ int cholqr_run(mpse_ctx* ctx, double* ws, const QrBlk* blks, int nblk, const lon
   for (int i = 0; i < 5; ++i) Rb[i] = reinterpret_cast<double*>(base + db + pb + (1 + i) * tb);
   double* tinfo = reinterpret_cast<double*>(base + db + pb + 6 * tb);
   int* status = reinterpret_cast<int*>(base + db + pb + 6 * tb + ib);
+  const int* done = status + 1 + nblk;
   double* dstat = reinterpret_cast<double*>(base + db + pb + 6 * tb + ib + sb);
+  // Adaptive pass count (round 6).  theta: pass 1 shifts a pivot only when it has lost all but theta of its diagonal
+  // entry (0 = the shift on the whole diagonal, the round-5 scheme); tau: pass 2 is the last pass of a block whose Gram
+  // matrix deviates from the identity by n max|G - I| <= tau (0 = always three passes).  Both are decided on the device,
+  // per block, from the data of the call alone; pass 3's launches return at once for the blocks that are done.
+  static const double theta = [] {
+    const char* e = getenv("MPSE_CHOLQR_THETA");
+    return e ? atof(e) : 1e-12;
+  }();
+  static const double tau = [] {
+    const char* e = getenv("MPSE_CHOLQR_TAU");
+    return e ? atof(e) : 0.1;
+  }();
   const double* racc = nullptr;
   for (int pass = 1; pass <= 3; ++pass) {
     double* Rcur = Rb[pass - 1];
+    const int* dn = pass == 3 ? done : nullptr;
     hipLaunchKernelGGL((k_cq_gram<CPLX>), dim3(max_gram, nblk), dim3(256), 0, ctx->stream, (const double*)ws, part, dblk,
-                       status, pass == 1 ? nblk + 1 : 0);
-    hipLaunchKernelGGL((k_cq_reduce<CPLX>), dim3(max_T, nblk), dim3(256), 0, ctx->stream, (const double*)part, G, tinfo, dblk);
+                       status, pass == 1 ? 2 * nblk + 1 : 0, dn);
+    hipLaunchKernelGGL((k_cq_reduce<CPLX>), dim3(max_T, nblk), dim3(256), 0, ctx->stream, (const double*)part, G, tinfo, dblk,
+                       dn);
     if (max_P <= 10)
       hipLaunchKernelGGL((k_cq_chol_rl<CPLX>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G,
-                         (const double*)tinfo, Rcur, dblk, status, pass, gflag);
+                         (const double*)tinfo, Rcur, dblk, status, pass, gflag, nblk, theta, tau);
     else
       hipLaunchKernelGGL((k_cq_chol<CPLX>), dim3(nblk), dim3(512), 0, ctx->stream, (const double*)G, (const double*)tinfo,
-                         Rcur, dblk, status, pass, gflag);
+                         Rcur, dblk, status, pass, gflag, nblk, theta, tau);
     double* Rout = pass == 2 ? Rb[3] : Rb[4];
     const int rmul = pass >= 2 ? 1 : 0;
     const dim3 tg(max_nrb + (rmul ? max_T : 0), nblk);
     hipLaunchKernelGGL((k_cq_trsm<CPLX>), tg, dim3(256), 0, ctx->stream, ws, (const double*)Rcur, racc, Rout, dblk,
-                       (const int*)status, max_nrb, rmul);
+                       (const int*)status, max_nrb, rmul, dn);
     racc = pass == 1 ? Rcur : Rout;
   }
   int nb = (int)((max_sc + 255) / 256);
   if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL((k_cq_scatter<CPLX>), dim3(nb, nblk), dim3(256), 0, ctx->stream, (double*)U, (double*)Vt, (const double*)ws,
-                     racc, K, ncol, drows, dcols, dblk, herm, (const int*)status, dstat);
+                     (const double*)Rb[4], (const double*)Rb[3], K, ncol, drows, dcols, dblk, herm, (const int*)status, dstat,
+                     done, ctx->qr_words_dev);
   MPSE_HIP(ctx, hipGetLastError());
   if (gflag) {
     *ok = true;

@@ -59,6 +59,7 @@ struct F0Args {
   const int* skip;
   long long n;
   int Dl, Dr, wl, wr, d, ntl, ntr, nkc, fc_pitch;
+  int nsplit;             // workgroups per (bra tile row, channel, ket chunk) unit: each takes every nsplit-th l tile of step 2
 };
 
 // Rt[(b, k), l] = R[l, b, k]  (block `blk` of `nblk`)
@@ -172,11 +173,23 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
   // chunk-major 32 against 29.)
   const int nparts = g.wr * g.nkc;
   const int wg0 = blockIdx.x;
-  const int wg = wg0 * g.d + xo_wg;                 // slot of the dot partials
+  const int zs = blockIdx.z;                          // which share of the unit's l tiles
+  const int wg = (wg0 * g.d + xo_wg) * g.nsplit + zs; // slot of the dot partials
   const int at = wg0 / nparts, s = wg0 - at * nparts, f = s / g.nkc, kc = s - f * g.nkc;
   // which output tiles this workgroup holds (the mask is the single statement of that rule): lane lt looks at tile lt
-  const unsigned long long lts =
+  unsigned long long lts =
       __ballot(lane < g.ntr && ((g.mask[(long long)at * g.d * g.ntr + min(lane, g.ntr - 1)] >> s) & 1ull));
+  // The chain of a unit is step 1 (its T: up to 16 c tiles x 12 MFMAs per wave) followed by step 2 (its l tiles dealt to
+  // the four waves: up to 4 x 48 MFMAs per wave), and the launch lasts as long as its heaviest unit while most of the
+  // chip idles (MFMA-busy 0.10 - 0.20, profiles/r05_pmc_mfma_util_fused.md).  nsplit workgroups share a unit: each forms
+  // the unit's T itself (operands from the caches, MFMA time the chip has to spare) and multiplies every nsplit-th of
+  // the unit's l tiles - the same tiles of the same part, written once: no further plane, no further mask bit.
+  if (g.nsplit > 1) {
+    unsigned long long keep = 0, m = lts;
+    for (int rank = 0; m; ++rank, m &= m - 1)
+      if (rank % g.nsplit == zs) keep |= m & (~m + 1);
+    lts = keep;
+  }
   if (lts == 0) {
     if (g.dot_part && tid == 0) {
       g.dot_part[2 * wg] = 0.0;
@@ -444,7 +457,15 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
   if (pr.n != n || pr.cap_elems < (long long)nparts * n) return MPSE_OK;
   const int ntl = Dl / 16, ntr = Dr / 16, nkc = (Dr + 63) / 64;
   const int nwg = ntl * nparts;
-  if (ctx->dot_req.y && nwg * d > ctx->dot_req.cap) return MPSE_OK;
+  // workgroups per unit (see k_heff0_fused): MPSE_F0_SPLIT, default 2
+  static const int nsplit_env = [] {
+    const char* e = getenv("MPSE_F0_SPLIT");
+    const int v = e ? atoi(e) : 2;
+    return v < 1 ? 1 : (v > 4 ? 4 : v);
+  }();
+  int nsplit = nsplit_env;
+  while (nsplit > 1 && ctx->dot_req.y && nwg * d * nsplit > ctx->dot_req.cap) nsplit >>= 1;
+  if (ctx->dot_req.y && nwg * d * nsplit > ctx->dot_req.cap) return MPSE_OK;
   // the terms of every right channel: the non-zero entries W[b, x, e, f] (a bond matrix: the channel itself, factor 1)
   std::vector<F0Term> terms(size_t(wr) * F0_TMAX);
   std::vector<int> nterm(wr, 0);
@@ -526,10 +547,11 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
   g.skip = ctx->skip_flag;
   g.n = n;
   g.Dl = Dl, g.Dr = Dr, g.wl = wl, g.wr = wr, g.d = d, g.ntl = ntl, g.ntr = ntr, g.nkc = nkc, g.fc_pitch = fc_pitch;
+  g.nsplit = nsplit;
   if (ctx->dot_req.y) {
     g.y = static_cast<const double*>(ctx->dot_req.y);
     g.dot_part = ctx->dot_req.part;
-    ctx->dot_req.nb_out = nwg * d;
+    ctx->dot_req.nb_out = nwg * d * nsplit;
   }
   {
     // sampled HIP-event bracket (variant 7 of mpse_prof_get): algorithmic flops of SURVEY.md 8(d) for this matvec
@@ -539,7 +561,7 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
                                           8.0 * double(Dl) * Dr * Dr * wr * d;
     const double by = 16.0 * (double(Dl) * wl * Dl + double(Dr) * wr * Dr + 2.0 * double(n));
     ProfScope fprof(ctx, 7, fl, by);
-    hipLaunchKernelGGL(k_heff0_fused, dim3(nwg, d), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL(k_heff0_fused, dim3(nwg, d, nsplit), dim3(256), 0, ctx->stream, g);
     fprof.end();
   }
   MPSE_HIP(ctx, hipGetLastError());

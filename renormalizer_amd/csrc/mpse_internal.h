@@ -183,8 +183,11 @@ struct mpse_ctx {
   // instead of being read back per decomposition
   bool qr_optimistic = false;
   int qr_scheme = -1;            // mpse_block_qr_scheme: -1 environment default, 0 Householder only, 1 default rule, 2 every eligible shape
-  int* qr_flag_dev = nullptr;
+  // four device words of the block QR: [0] sticky breakdown flag of the optimistic mode, [2] blocks factorised by the
+  // Cholesky-QR kernels, [3] of them finished after two passes (mpse_block_qr_pass_stats); allocated by qr_words()
+  int* qr_words_dev = nullptr;
 };
+int qr_words(mpse_ctx* ctx);     // allocate + zero ctx->qr_words_dev once (mpse_qr.hip)
 
 int mpse_fail(mpse_ctx* ctx, int code, const char* fmt, ...);
 // Makes ctx->device the calling thread's current HIP device (a new thread starts on device 0; allocations and

@@ -259,6 +259,14 @@ int hh_factor_colmajor(mpse_ctx* ctx, bool cplx, double* ws, int mm, int nn, int
   return MPSE_OK;
 }
 
+int qr_words(mpse_ctx* ctx) {
+  if (ctx->qr_words_dev) return MPSE_OK;
+  void* p = nullptr;
+  MPSE_TRY(mpse_malloc(ctx, 16, &p));
+  ctx->qr_words_dev = static_cast<int*>(p);
+  return device_zero(ctx, ctx->qr_words_dev, 16);
+}
+
 // explicit Q (mm x k, column-major) from a factored workspace
 int hh_formq_colmajor(mpse_ctx* ctx, bool cplx, double* q, const double* ws, int mm, int k, const HhParam* prm,
                       int nq) {
@@ -442,16 +450,10 @@ int mpse_block_qr(mpse_ctx* ctx, int dtype, const void* coef, int64_t nrow, int6
 int mpse_block_qr_optimistic(mpse_ctx* ctx, int on) {
   if (!ctx) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
-  if (on) {
-    if (!ctx->qr_flag_dev) {
-      void* p = nullptr;
-      MPSE_TRY(mpse_malloc(ctx, 16, &p));
-      ctx->qr_flag_dev = static_cast<int*>(p);
-    }
-  }
+  MPSE_TRY(qr_words(ctx));
   // the word is cleared on BOTH edges: after a step that tripped it, the verified repeat (mode off) and whatever runs
   // later on this context must not see a stale breakdown (mpse_block_qr_check reports 0 while the mode is off)
-  if (ctx->qr_flag_dev) MPSE_TRY(device_zero(ctx, ctx->qr_flag_dev, 16));
+  MPSE_TRY(device_zero(ctx, ctx->qr_words_dev, 8));
   ctx->qr_optimistic = on != 0;
   return MPSE_OK;
 }
@@ -466,10 +468,20 @@ int mpse_block_qr_check(mpse_ctx* ctx, int* tripped) {
   if (!ctx || !tripped) return MPSE_ERR_ARG;
   MPSE_BIND(ctx);
   *tripped = 0;
-  if (!ctx->qr_flag_dev || !ctx->qr_optimistic) return MPSE_OK;   // (mode off: every decomposition was verified as it ran)
+  if (!ctx->qr_words_dev || !ctx->qr_optimistic) return MPSE_OK;   // (mode off: every decomposition was verified as it ran)
   int v[4] = {0, 0, 0, 0};
-  MPSE_TRY(mpse_memcpy_d2h(ctx, v, ctx->qr_flag_dev, 16));
+  MPSE_TRY(mpse_memcpy_d2h(ctx, v, ctx->qr_words_dev, 16));
   *tripped = v[0] != 0;
+  return MPSE_OK;
+}
+
+int mpse_block_qr_pass_stats(mpse_ctx* ctx, int64_t* blocks, int64_t* two_pass) {
+  if (!ctx) return MPSE_ERR_ARG;
+  MPSE_BIND(ctx);
+  int v[4] = {0, 0, 0, 0};
+  if (ctx->qr_words_dev) MPSE_TRY(mpse_memcpy_d2h(ctx, v, ctx->qr_words_dev, 16));
+  if (blocks) *blocks = v[2];
+  if (two_pass) *two_pass = v[3];
   return MPSE_OK;
 }
 

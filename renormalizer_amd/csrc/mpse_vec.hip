@@ -847,7 +847,11 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
   double* coef = scal + SC_COEF;
   const int* done = &ctl->done;
   const int nb = red_blocks(nd);
-  double* part_a = ctx->dscratch;
+  // <H U_j, U_j> partials: room for 4096 producers (the fused bond / two-level-site matvec has up to
+  // (D / 16) w (D / 64) d workgroups per unit share, mpse_heff0.hip), above the areas of the norm partials
+  constexpr int DOT_CAP = 4096;
+  double* part_a = ctx->dscratch + 16 * RED_MAX_BLOCKS;
+  static_assert(16 * RED_MAX_BLOCKS + 2 * DOT_CAP < (1 << 16) - 8, "dot partials fit the device scratch");
   double* part_b = ctx->dscratch + 4 * RED_MAX_BLOCKS;
   const bool vec16 = (cplx || n % 2 == 0) && (reinterpret_cast<uintptr_t>(Cin) & 15) == 0;
   const double vbytes = double(n) * double(es);
@@ -934,7 +938,7 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
     // nb_out = 0 and the reduction runs as a pass of its own
     ctx->dot_req.y = vec(j);
     ctx->dot_req.part = part_a;
-    ctx->dot_req.cap = 2 * RED_MAX_BLOCKS;
+    ctx->dot_req.cap = DOT_CAP;
     ctx->dot_req.nb_out = 0;
     ctx->cmask.lo = V.as<char>();
     ctx->cmask.hi = V.as<char>() + size_t(cap) * n * es;

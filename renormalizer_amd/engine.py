@@ -96,6 +96,7 @@ _SIGNATURES = {
     "mpse_block_qr_optimistic": [C.c_void_p, C.c_int],
     "mpse_block_qr_scheme": [C.c_void_p, C.c_int],
     "mpse_block_qr_check": [C.c_void_p, C.POINTER(C.c_int)],
+    "mpse_block_qr_pass_stats": [C.c_void_p] + [C.POINTER(C.c_int64)] * 2,
     "mpse_malloc": [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)],
     "mpse_free": [C.c_void_p, C.c_void_p],
     "mpse_pool_trim": [C.c_void_p],
@@ -469,6 +470,12 @@ class Engine:
         v = C.c_int(0)
         self._check(self.lib.mpse_block_qr_check(self.ctx, C.byref(v)))
         return bool(v.value)
+
+    def block_qr_pass_stats(self):
+        """(blocks factorised by the Cholesky-QR kernels, of them finished after two passes) - synchronous."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.mpse_block_qr_pass_stats(self.ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def prof_get(self):
         """{variant: dict(ms, flops, bytes, launches)} for the contraction kernel variants."""

@@ -509,15 +509,16 @@ def test_block_qr_cholesky_path(eng, cplx):
     reconstruction and isometry to 1e-13, exactly triangular other factor - for two-block layouts like the headline's
     sites, condition numbers up to 1e12 (three real passes), a well-conditioned input (first-order third pass), odd
     sizes and column counts on both sides of the right-looking / left-looking Cholesky kernels (<= 160 / <= 256 columns);
-    rank-deficient and kappa = 1e18 inputs have to raise the device flag and come back through the Householder kernels.
+    an exactly zero column has to raise the device flag and come back through the Householder kernels; rank-deficient
+    and kappa = 1e18 inputs may do either (the result is held to the same contract).
     Which path ran is read from mpse_block_qr_stats."""
     rng = np.random.default_rng(77)
     cases = [  # rows of block 0 / 1, columns of block 0 / 1, condition, rank of block 0 (None = full), expected path
         (2816, 1280, 145, 111, 1e6, None, "chol"), (2816, 1280, 145, 111, 1e12, None, "chol"),
         (256, 256, 150, 106, 1e7, None, "chol"), (2608, 1488, 182, 74, 1e7, None, "chol"),
         (4096, 0, 256, 0, 1e4, None, "chol"), (1001, 333, 77, 19, 1e8, None, "chol"), (2816, 1280, 145, 111, 3, None, "chol"),
-        (2816, 1280, 145, 111, 1e3, 100, "fallback"), (2816, 1280, 145, 111, 1e18, None, "fallback"),
-        (700, 300, 33, 17, 1e5, None, "chol")]
+        (2816, 1280, 145, 111, 1e3, 100, "either"), (2816, 1280, 145, 111, 1e18, None, "either"),
+        (2816, 1280, 145, 111, 1e3, -7, "fallback"), (700, 300, 33, 17, 1e5, None, "chol")]
     try:
         for scheme in (2, 1):
             eng.block_qr_scheme(scheme)
@@ -526,7 +527,10 @@ def test_block_qr_cholesky_path(eng, cplx):
                 qnl = np.concatenate([np.zeros(m0, int), np.ones(m1, int)])[rng.permutation(m)]
                 qnr = np.concatenate([np.zeros(n0, int), np.ones(n1, int)])[rng.permutation(n)]
                 a = np.zeros((m, n), dtype=complex if cplx else float)
-                a[np.ix_(qnl == 0, qnr == 0)] = _with_cond(rng, m0, n0, cond, cplx, rank)
+                blk0 = _with_cond(rng, m0, n0, cond, cplx, rank if rank is None or rank > 0 else None)
+                if rank is not None and rank < 0:
+                    blk0[:, -rank] = 0                     # an exactly zero column: nothing to normalise in pass 2
+                a[np.ix_(qnl == 0, qnr == 0)] = blk0
                 if m1 and n1:
                     a[np.ix_(qnl == 1, qnr == 1)] = _with_cond(rng, m1, n1, cond, cplx)
                 for system in ("L", "R"):
@@ -553,8 +557,14 @@ def test_block_qr_cholesky_path(eng, cplx):
                         assert took == (0, 0), (tag, took)             # default rule: Householder from the start
                     elif expect == "chol":
                         assert took == (1, 0), (tag, took)
-                    else:
+                    elif expect == "fallback":
                         assert took == (1, 1), (tag, took)             # tried, flagged on the device, redone
+                    else:
+                        # rank-deficient / kappa = 1e18 blocks: since round 6 pass 1 shifts the pivots that collapsed
+                        # (not the whole diagonal), and the columns it cannot determine may come out as an orthonormal
+                        # completion without a breakdown - or the flag goes up and Householder decides.  Either way the
+                        # result was checked above
+                        assert took in ((1, 0), (1, 1)), (tag, took)
     finally:
         eng.block_qr_scheme(-1)
 
@@ -606,17 +616,19 @@ def test_block_qr_cholesky_kappa_window(eng, cplx):
                         assert _relerr(u @ vt, x) < 1e-13, tag
     finally:
         eng.block_qr_scheme(-1)
-    # both outcomes occur in the window (else the sweep does not straddle the decision it is meant to probe)
-    assert 0 < took_tot[1] < took_tot[0], took_tot
+    # (round 5, shift on the whole diagonal: both outcomes occurred in this window; round 6, shift per pivot: the
+    # Cholesky-QR kernels may decide all of it - what is pinned is the contract above, for every case)
+    assert took_tot[0] == 2 * 5 * 3 * 2 and 0 <= took_tot[1] <= took_tot[0], took_tot
 
 
 def test_block_qr_optimistic_flag_edges(eng):
-    """The sticky breakdown word of the optimistic mode: up after a rank-deficient tall block went through the
+    """The sticky breakdown word of the optimistic mode: up after a tall block with a zero column went through the
     Cholesky-QR kernels unverified, reported only while the mode is on, cleared on BOTH edges of the mode (round-5
     advisor: it used to survive into the verified repeat and into whatever ran next on the context)."""
     rng = np.random.default_rng(5)
     m, n = 2048, 128
-    bad = _with_cond(rng, m, n, 1e3, True, rank=100)
+    bad = _with_cond(rng, m, n, 1e3, True)
+    bad[:, 7] = 0                                  # an exactly zero column: pass 2 has nothing to normalise -> flag
     good = _with_cond(rng, m, n, 1e3, True)
     qnl, qnr = np.zeros((m, 1), int), np.zeros((n, 1), int)
     try:
