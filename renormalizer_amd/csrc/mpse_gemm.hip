@@ -35,6 +35,16 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// debug timeline buffer of the contraction kernel: only inside the profiled (timed) region; MPSE_GEMM_TRACE_ONLY=f0
+// leaves the buffer to the records of the fused bond / two-level-site matvec (mpse_heff0.hip)
+static unsigned long long* gemm_trace_ptr(const mpse_ctx* ctx) {
+  static const bool f0_only = [] {
+    const char* e = getenv("MPSE_GEMM_TRACE_ONLY");
+    return e && e[0] == 'f';
+  }();
+  return (ctx->prof_on && !f0_only) ? ctx->gemm_trace : nullptr;
+}
+
 namespace {
 
 struct IdxMap {
@@ -1301,7 +1311,7 @@ static int gemm_impl(mpse_ctx* ctx, const mpse_gemm_desc* d, const void* A, cons
       }
     }
   }
-  g.trace = ctx->prof_on ? ctx->gemm_trace : nullptr;    // only inside the profiled (timed) region
+  g.trace = gemm_trace_ptr(ctx);
   TmpBuf WSB(ctx), MSK(ctx);
   bool leave_slices = false;
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
@@ -1619,7 +1629,7 @@ int gemm_grouped(mpse_ctx* ctx, const GroupedDesc& d) {
   g.ksplit = 1;
   g.skip = ctx->skip_flag;
   g.skew = 1;
-  g.trace = ctx->prof_on ? ctx->gemm_trace : nullptr;
+  g.trace = gemm_trace_ptr(ctx);
   GemmGroups& gg = g.gg;
   gg.ngrp = d.ngrp, gg.tiles_m_grp = g.mtiles_m, gg.nkt_seg = g.K / BK;
   gg.am_pitch = d.am_pitch, gg.bm_pitch = d.bm_pitch;

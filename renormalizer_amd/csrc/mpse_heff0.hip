@@ -59,7 +59,7 @@ struct F0Args {
   const int* skip;
   long long n;
   int Dl, Dr, wl, wr, d, ntl, ntr, nkc, fc_pitch;
-  int nsplit;             // workgroups per (bra tile row, channel, ket chunk) unit: each takes every nsplit-th l tile of step 2
+  unsigned long long* trace;   // debug timeline (mpse_ctx::gemm_trace, MPSE_GEMM_TRACE), null normally
 };
 
 // Rt[(b, k), l] = R[l, b, k]  (block `blk` of `nblk`)
@@ -167,34 +167,49 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
   __shared__ double sTr[DX][16 * 65], sTi[DX][16 * 65];
   __shared__ double s_dot[8];
   if (g.skip && *g.skip) return;
+  // debug timeline (tools/f0_trace.py): entry, flags in hand, end of step 1, end of step 2, exit - shader cycles
+  unsigned long long tr[4] = {0, 0, 0, 0};
+  const unsigned long long rt0 = g.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  if (g.trace) tr[0] = __builtin_readcyclecounter();
+  int tr_ct = 0, tr_lt = 0;
+  auto trace_out = [&]() {
+    if (g.trace && tid == 0) {
+      const unsigned long long slot = atomicAdd(g.trace, 1ull);
+      if (slot < GEMM_TRACE_CAP) {
+        unsigned long long* r = g.trace + 1 + slot * GEMM_TRACE_WORDS;
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        r[0] = ((unsigned long long)gridDim.x << 32) | (unsigned long long)blockIdx.x;
+        r[1] = (1ull << 63) | ((unsigned long long)g.d << 32) | (unsigned long long)blockIdx.y;
+        r[2] = (unsigned long long)(unsigned)tr_ct | ((unsigned long long)(unsigned)tr_lt << 16) |
+               ((unsigned long long)(((xc & 0xf) << 16) | (hw & 0xffff)) << 32);
+        r[3] = tr[0], r[4] = tr[1], r[5] = tr[2], r[6] = tr[3];
+        r[7] = __builtin_readcyclecounter();
+        r[8] = rt0;
+        r[9] = __builtin_amdgcn_s_memrealtime();
+      }
+    }
+  };
+  // (Round 6, measured and dropped: several workgroups per unit, each forming the unit's T itself and multiplying every
+  // n-th of its l tiles - the verdict's reading was that the launch lasts as long as the chain of its heaviest unit.  It
+  // does not: 546 -> 517 site-updates/s with two workgroups per unit, 458 with four, alternating runs on one box,
+  // profiles/r06_ab_qr_f0split.txt - the launch is bound by what its workgroups do in total, not by the longest one.)
   // Launch position -> (bra tile row, part), plain order.  (Measured and dropped: a die - launch position mod 8, one L2
   // each - taking whole parts, so that its L2 holds only the panels of C and Rt its workgroups share.  Dealt channel-major
   // the heavy parts - ket chunks that straddle two quantum-number sectors - piled up on two dies: 39 us against 33; dealt
   // chunk-major 32 against 29.)
   const int nparts = g.wr * g.nkc;
   const int wg0 = blockIdx.x;
-  const int zs = blockIdx.z;                          // which share of the unit's l tiles
-  const int wg = (wg0 * g.d + xo_wg) * g.nsplit + zs; // slot of the dot partials
+  const int wg = wg0 * g.d + xo_wg;                 // slot of the dot partials
   const int at = wg0 / nparts, s = wg0 - at * nparts, f = s / g.nkc, kc = s - f * g.nkc;
   // which output tiles this workgroup holds (the mask is the single statement of that rule): lane lt looks at tile lt
-  unsigned long long lts =
+  const unsigned long long lts =
       __ballot(lane < g.ntr && ((g.mask[(long long)at * g.d * g.ntr + min(lane, g.ntr - 1)] >> s) & 1ull));
-  // The chain of a unit is step 1 (its T: up to 16 c tiles x 12 MFMAs per wave) followed by step 2 (its l tiles dealt to
-  // the four waves: up to 4 x 48 MFMAs per wave), and the launch lasts as long as its heaviest unit while most of the
-  // chip idles (MFMA-busy 0.10 - 0.20, profiles/r05_pmc_mfma_util_fused.md).  nsplit workgroups share a unit: each forms
-  // the unit's T itself (operands from the caches, MFMA time the chip has to spare) and multiplies every nsplit-th of
-  // the unit's l tiles - the same tiles of the same part, written once: no further plane, no further mask bit.
-  if (g.nsplit > 1) {
-    unsigned long long keep = 0, m = lts;
-    for (int rank = 0; m; ++rank, m &= m - 1)
-      if (rank % g.nsplit == zs) keep |= m & (~m + 1);
-    lts = keep;
-  }
   if (lts == 0) {
     if (g.dot_part && tid == 0) {
       g.dot_part[2 * wg] = 0.0;
       g.dot_part[2 * wg + 1] = 0.0;
     }
+    trace_out();
     return;
   }
   // ---- step 1: P_x[a, k] for this wave's 16 columns k of the chunk
@@ -259,6 +274,10 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
         }
       }
     };
+    if (g.trace) {
+      if (!tr[1]) tr[1] = __builtin_readcyclecounter();
+      tr_ct += __builtin_popcountll(cts);
+    }
     if (wcol && cts) {
       // Three c tiles in flight, slots used in a fixed rotation.  The compiler barriers keep the order "request the tile
       // after next, THEN multiply the oldest": without them the scheduler sinks every batch of loads to just before its
@@ -291,6 +310,10 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
         if (c2 >= 0) load1(2, c2);
       }
     }
+  }
+  if (g.trace) {
+    tr[2] = __builtin_readcyclecounter();
+    tr_lt = __builtin_popcountll(lts);
   }
 #pragma unroll
   for (int i = 0; i < DX; ++i)
@@ -385,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
     asm volatile("" ::: "memory");
     mul2(1, lt1, kt1);
   }
+  if (g.trace) tr[3] = __builtin_readcyclecounter();
   if (g.dot_part) {
     dre = wave_sum(dre);
     dim = wave_sum(dim);
@@ -404,6 +428,7 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
       g.dot_part[2 * wg + 1] = ai;
     }
   }
+  trace_out();
 }
 
 }  // namespace
@@ -457,15 +482,7 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
   if (pr.n != n || pr.cap_elems < (long long)nparts * n) return MPSE_OK;
   const int ntl = Dl / 16, ntr = Dr / 16, nkc = (Dr + 63) / 64;
   const int nwg = ntl * nparts;
-  // workgroups per unit (see k_heff0_fused): MPSE_F0_SPLIT, default 2
-  static const int nsplit_env = [] {
-    const char* e = getenv("MPSE_F0_SPLIT");
-    const int v = e ? atoi(e) : 2;
-    return v < 1 ? 1 : (v > 4 ? 4 : v);
-  }();
-  int nsplit = nsplit_env;
-  while (nsplit > 1 && ctx->dot_req.y && nwg * d * nsplit > ctx->dot_req.cap) nsplit >>= 1;
-  if (ctx->dot_req.y && nwg * d * nsplit > ctx->dot_req.cap) return MPSE_OK;
+  if (ctx->dot_req.y && nwg * d > ctx->dot_req.cap) return MPSE_OK;
   // the terms of every right channel: the non-zero entries W[b, x, e, f] (a bond matrix: the channel itself, factor 1)
   std::vector<F0Term> terms(size_t(wr) * F0_TMAX);
   std::vector<int> nterm(wr, 0);
@@ -545,13 +562,13 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
   g.nterm = reinterpret_cast<const int*>(base + o_nt);
   g.mask = reinterpret_cast<const unsigned long long*>(base + o_mk);
   g.skip = ctx->skip_flag;
+  g.trace = ctx->prof_on ? ctx->gemm_trace : nullptr;
   g.n = n;
   g.Dl = Dl, g.Dr = Dr, g.wl = wl, g.wr = wr, g.d = d, g.ntl = ntl, g.ntr = ntr, g.nkc = nkc, g.fc_pitch = fc_pitch;
-  g.nsplit = nsplit;
   if (ctx->dot_req.y) {
     g.y = static_cast<const double*>(ctx->dot_req.y);
     g.dot_part = ctx->dot_req.part;
-    ctx->dot_req.nb_out = nwg * d * nsplit;
+    ctx->dot_req.nb_out = nwg * d;
   }
   {
     // sampled HIP-event bracket (variant 7 of mpse_prof_get): algorithmic flops of SURVEY.md 8(d) for this matvec
@@ -561,7 +578,7 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
                                           8.0 * double(Dl) * Dr * Dr * wr * d;
     const double by = 16.0 * (double(Dl) * wl * Dl + double(Dr) * wr * Dr + 2.0 * double(n));
     ProfScope fprof(ctx, 7, fl, by);
-    hipLaunchKernelGGL(k_heff0_fused, dim3(nwg, d, nsplit), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL(k_heff0_fused, dim3(nwg, d), dim3(256), 0, ctx->stream, g);
     fprof.end();
   }
   MPSE_HIP(ctx, hipGetLastError());

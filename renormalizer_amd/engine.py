@@ -537,6 +537,18 @@ class Engine:
         self._check(self.lib.mpse_memcpy_2d(self.ctx, dst.ptr + (dst_row0 * dst.shape[1] + dst_col0) * es,
                                             dst.shape[1] * es, src.ptr, cols * es, cols * es, rows))
 
+    def copy_sub(self, dst, dst_row0, dst_col0, src, src_row0, src_col0, rows, cols):
+        """dst[dst_row0 + r, dst_col0 + c] = src[src_row0 + r, src_col0 + c], r < rows, c < cols (2-D, same dtype)."""
+        assert dst.dtype == src.dtype and dst.ndim == 2 and src.ndim == 2
+        assert dst_row0 + rows <= dst.shape[0] and dst_col0 + cols <= dst.shape[1]
+        assert src_row0 + rows <= src.shape[0] and src_col0 + cols <= src.shape[1]
+        if rows == 0 or cols == 0:
+            return
+        es = dst.dtype.itemsize
+        self._check(self.lib.mpse_memcpy_2d(self.ctx, dst.ptr + (dst_row0 * dst.shape[1] + dst_col0) * es,
+                                            dst.shape[1] * es, src.ptr + (src_row0 * src.shape[1] + src_col0) * es,
+                                            src.shape[1] * es, cols * es, rows))
+
     def ones(self, shape, dtype=np.float64):
         return self.asdevice(np.ones(shape, dtype=dtype))
 

@@ -80,15 +80,15 @@ def eigh_direct(mps, qn_mask, ltensor, rtensor, cmo, twolayer=False):
     entries, diagonalised on the host with LAPACK like the reference.  Returns (e, c) with c as device tensor(s) of the
     centre's shape."""
     eng = get_engine()
-    if mps.optimize_config.inverse != 1.0:
-        raise NotImplementedError("optimize_config.inverse != 1")
     cshape = qn_mask.shape
     hop = hop_expr(ltensor, rtensor, cmo, cshape, twolayer)
     ham = hop.dense()
     flat = qn_mask.ravel()
     ham = ham[flat][:, flat]
     ham = (ham + ham.conj().T) / 2
-    w, v = np.linalg.eigh(ham)
+    # gs.py:397-398: the spectrum of inverse * H (inverse = -1: the HIGHEST state of H; the value returned is that of
+    # the scaled operator, as in the reference)
+    w, v = np.linalg.eigh(ham * float(mps.optimize_config.inverse))
     nroots = mps.optimize_config.nroots
 
     def expand(col):
@@ -115,9 +115,14 @@ def eigh_iterative(mps, qn_mask, ltensor, rtensor, cmo, cguess, twolayer=False):
                 (``shift`` large against ``e`` is not available, so x / (hdiag - e + 1e-4) is kept: same fixed
                 point).  Same eigenpairs to the solver tolerance; iteration counts differ from the library's."""
     eng = get_engine()
-    inverse = mps.optimize_config.inverse
+    inverse = float(mps.optimize_config.inverse)
     if inverse != 1.0:
-        raise NotImplementedError("optimize_config.inverse != 1")
+        # gs.py:470, 521: hdiag and every H c are multiplied by ``inverse`` - the operator is linear in its first MPO
+        # site, so a scaled copy of that site gives inverse * H_eff for the matvec, the diagonal and the preconditioner
+        # alike.  (Two layers are (H - omega)^2 with the SAME sites in both: a scaled copy would enter squared.)
+        if twolayer:
+            raise NotImplementedError("optimize_config.inverse != 1 with omega (two-layer environments)")
+        cmo = [cmo[0].copy().scale_(inverse)] + list(cmo[1:])
     algo = mps.optimize_config.algo
     if algo not in ("davidson", "primme"):
         raise ValueError(f"optimize_config.algo = {algo!r}: 'davidson', 'primme' (iterative) or 'direct'")

@@ -536,17 +536,18 @@ class Mps:
         lenv = sentinel
         for i in range(n):
             ms = self[i]
-            if ms.ndim != 3:
-                raise NotImplementedError("calc_1site_rdm: density-operator (4-leg) sites")
             if i in idx:
-                Dl, d, Dr = ms.shape
+                # density-operator sites (Dl, d, d_anc, Dr): the ancilla leg is traced with the bonds
+                # (mps/mps.py:1590-1593) - for the products below it is part of the right bond
+                Dl, d, Dr = ms.shape[0], ms.shape[1], int(np.prod(ms.shape[2:]))
+                Dr1 = ms.shape[-1]
                 L = lenv.reshape(lenv.shape[0], lenv.shape[2])
                 R = renv[i + 1].reshape(renv[i + 1].shape[0], renv[i + 1].shape[2])
-                # X[a', (p, b)] = sum_a L[a, a'] conj(A)[a, (p, b)] ; Y[(a', p), b'] = sum_b X[(a', p), b] R[b, b']
+                # X[a', (p, g, b)] = sum_a L[a, a'] conj(A)[a, (p, g, b)] ; Y[(a', p, g), b'] = sum_b X[(a', p, g), b] R[b, b']
                 x = eng.matmul(L, ms.reshape(Dl, d * Dr), trans_a=True, conj_b=True)
-                y = eng.matmul(x.reshape(Dl * d, Dr), R)
+                y = eng.matmul(x.reshape(Dl * d * (Dr // Dr1), Dr1), R)
                 a = ms.to_complex() if y.is_complex and not ms.is_complex else ms
-                # rdm[p, p'] = sum_{a', b'} Y[a', p, b'] A[a', p', b']
+                # rdm[p, p'] = sum_{a', g, b'} Y[a', p, g, b'] A[a', p', g, b']
                 out = eng.empty((d, d), np.complex128 if (y.is_complex or a.is_complex) else np.float64)
                 eng.gemm(y, a, out, idx1(d, Dr), idx2(Dl, Dr, d * Dr, 1), idx2(Dl, Dr, d * Dr, 1), idx1(d, Dr),
                          idx1(d, d), idx1(d, 1))
@@ -564,8 +565,8 @@ class Mps:
         from ..engine import idx1, idx2
         eng = get_engine()
         n = self.site_num
-        if any(ms.ndim != 3 for ms in self):
-            raise NotImplementedError("calc_2site_rdm: density-operator (4-leg) sites")
+        # density-operator sites (Dl, d, d_anc, Dr): the ancilla leg g is traced wherever a site meets its conjugate
+        # (mps/mps.py:1624-1627, 1634-1637, 1648-1651); ``da`` below is 1 for a pure state
         ident = [eng.asdevice(np.eye(self[i].shape[1]).reshape(1, self[i].shape[1], self[i].shape[1], 1))
                  for i in range(n)]
         sentinel = eng.ones((1, 1, 1), np.float64)
@@ -582,33 +583,38 @@ class Mps:
         def left_component(i):
             """T[(p,p'),(b,b')] = sum_{a,a'} L[a,a'] conj(A)[a,p,b] A[a',p',b']"""
             a = self[i]
-            Dl, d, Dr = a.shape
+            Dl, d, Dr = a.shape[0], a.shape[1], a.shape[-1]
+            da = a.size // (Dl * d * Dr)
             L = lenv[i - 1].reshape(Dl, Dl)
-            x = eng.matmul(L, a.reshape(Dl, d * Dr), trans_a=True, conj_b=True)          # [a', (p, b)]
+            x = eng.matmul(L, a.reshape(Dl, d * da * Dr), trans_a=True, conj_b=True)     # [a', (p, g, b)]
             t = eng.empty((d * d, Dr * Dr), np.complex128 if (x.is_complex or a.is_complex) else np.float64)
             a2 = a.to_complex() if t.is_complex else a
             x2 = x.to_complex() if t.is_complex else x
-            eng.gemm(x2, a2, t, idx1(d * Dr, 1), idx1(Dl, d * Dr), idx1(Dl, d * Dr), idx1(d * Dr, 1),
-                     idx2(d, Dr, d * Dr * Dr, Dr), idx2(d, Dr, Dr * Dr, 1))
+            # M = (p, b), K = (a', g), N = (p', b')
+            eng.gemm(x2, a2, t, idx2(d, Dr, da * Dr, 1), idx2(Dl, da, d * da * Dr, Dr), idx2(Dl, da, d * da * Dr, Dr),
+                     idx2(d, Dr, da * Dr, 1), idx2(d, Dr, d * Dr * Dr, Dr), idx2(d, Dr, Dr * Dr, 1))
             return t
 
         def right_component(j):
             """Rc[(a,a'),(q,q')] = sum_{c,c'} conj(A)[a,q,c] R[c,c'] A[a',q',c']"""
             a = self[j]
-            Dl, d, Dr = a.shape
+            Dl, d, Dr = a.shape[0], a.shape[1], a.shape[-1]
+            da = a.size // (Dl * d * Dr)
             R = renv[j + 1].reshape(Dr, Dr)
-            y = eng.matmul(a.reshape(Dl * d, Dr), R, conj_a=True)                         # [(a, q), c']
+            y = eng.matmul(a.reshape(Dl * d * da, Dr), R, conj_a=True)                    # [(a, q, g), c']
             rc = eng.empty((Dl * Dl, d * d), np.complex128 if (y.is_complex or a.is_complex) else np.float64)
             a2 = a.to_complex() if rc.is_complex else a
             y2 = y.to_complex() if rc.is_complex else y
-            eng.gemm(y2, a2, rc, idx1(Dl * d, Dr), idx1(Dr, 1), idx1(Dr, 1), idx1(Dl * d, Dr),
+            # M = (a, q), K = (g, c') (contiguous), N = (a', q')
+            eng.gemm(y2, a2, rc, idx1(Dl * d, da * Dr), idx1(da * Dr, 1), idx1(da * Dr, 1), idx1(Dl * d, da * Dr),
                      idx2(Dl, d, Dl * d * d, d), idx2(Dl, d, d * d, 1))
             return rc
 
         def transfer(t, k, dd):
-            """T'[(pp'),(c,c')] = sum_{b,b',s} T[(pp'),(b,b')] conj(A_k)[b,s,c] A_k[b',s,c']"""
+            """T'[(pp'),(c,c')] = sum_{b,b',s} T[(pp'),(b,b')] conj(A_k)[b,s,c] A_k[b',s,c'] (s: physical and ancilla leg)"""
             a = self[k]
-            D, dk, Dc = a.shape
+            D, Dc = a.shape[0], a.shape[-1]
+            dk = a.size // (D * Dc)
             cdt = np.complex128 if (t.is_complex or a.is_complex) else np.float64
             a2 = a.to_complex() if cdt == np.complex128 else a
             t2 = t.to_complex() if cdt == np.complex128 else t

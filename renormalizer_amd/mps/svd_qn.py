@@ -113,8 +113,6 @@ def svd_qn(coef_array, qnbigl, qnbigr, qntot, QR=False, system=None, full_matric
     rows, cols, roff, coff = plan["rows"], plan["cols"], plan["roff"], plan["coff"]
     new_qnl, new_qnr = list(plan["new_qnl"]), list(plan["new_qnr"])
     if QR:
-        if full_matrices:
-            raise NotImplementedError("full_matrices QR is not used by the sweep algorithms")
         if system not in ("L", "R"):
             raise ValueError("system must be 'L' or 'R' for QR")
         u = eng.empty((nrow, K), coef.dtype)
@@ -122,7 +120,50 @@ def svd_qn(coef_array, qnbigl, qnbigr, qntot, QR=False, system=None, full_matric
         eng._check(eng.lib.mpse_block_qr(eng.ctx, coef.code, coef.ptr, nrow, ncol, len(blocks), _p64(rows), _p64(roff),
                                          _p64(cols), _p64(coff), int(system == "R") | (2 if householder else 0), u.ptr,
                                          vt.ptr, K))
-        return u, new_qnl, TransposedView(vt), new_qnr
+        if not full_matrices:
+            return u, new_qnl, TransposedView(vt), new_qnr
+        # full_matrices (svd_qn.py:194-197, ``scipy.linalg.qr / rq(mode="full")`` per block; no caller in the reference's
+        # sweeps): the isometry of every block is completed to a square unitary - the extra vectors span the orthogonal
+        # complement of the block's range, which is also what the full SVD of the block appends, so they are taken from
+        # ``mpse_block_svd_full`` (Householder completion on the device) - and the triangular factor gets zero rows /
+        # columns to match, listed after the economic part with the block's quantum number like the reference's
+        # ``blockappend``.  (For RQ of a block with fewer rows than columns LAPACK's full mode puts the triangle at the
+        # right edge of R and the reference then files its leading columns under "non-zero": here the economic factors
+        # always come first.)
+        iso_rows = system == "L"
+        extra = np.zeros(len(blocks), dtype=np.int64)
+        qn_iso0, qn_tri0 = [], []
+        for ib, (b, k) in enumerate(zip(blocks, dims)):
+            m, n = len(b[2]), len(b[3])
+            ex = (m - k) if iso_rows else (n - k)
+            if ex > 0:
+                extra[ib] = ex
+                qn_iso0 += [(b[0] if iso_rows else b[1]).tolist()] * ex
+                qn_tri0 += [(b[1] if iso_rows else b[0]).tolist()] * ex
+        nex = int(extra.sum())
+        if nex == 0:
+            return u, new_qnl, TransposedView(vt), new_qnr
+        # (an isometry side that needs completing IS the taller side of its block: mpse_block_svd_full appends exactly
+        # ``extra[ib]`` completion vectors to that side and none to the other)
+        s = np.zeros(K)
+        su = eng.empty((nrow, K + (nex if iso_rows else 0)), coef.dtype)
+        svt = eng.empty((K + (0 if iso_rows else nex), ncol), coef.dtype)
+        eng._check(eng.lib.mpse_block_svd_full(eng.ctx, coef.code, coef.ptr, nrow, ncol, len(blocks), _p64(rows),
+                                               _p64(roff), _p64(cols), _p64(coff), _p64(extra), su.ptr, su.shape[1],
+                                               svt.ptr, svt.shape[0], s.ctypes.data_as(C.POINTER(C.c_double)), K))
+        if iso_rows:
+            uf = eng.empty((nrow, K + nex), coef.dtype)
+            eng.copy_block(uf, 0, 0, u)
+            eng.copy_sub(uf, 0, K, su, 0, K, nrow, nex)
+            vtf = eng.zeros((K + nex, ncol), coef.dtype)
+            eng.copy_block(vtf, 0, 0, vt)
+            return uf, new_qnl + qn_iso0, TransposedView(vtf), new_qnr + qn_tri0
+        vtf = eng.empty((K + nex, ncol), coef.dtype)
+        eng.copy_block(vtf, 0, 0, vt)
+        eng.copy_block(vtf, K, 0, svt.row_block(K, K + nex))
+        uf = eng.zeros((nrow, K + nex), coef.dtype)
+        eng.copy_block(uf, 0, 0, u)
+        return uf, new_qnl + qn_tri0, TransposedView(vtf), new_qnr + qn_iso0
     s = np.zeros(K)
     sp = s.ctypes.data_as(C.POINTER(C.c_double))
     if full_matrices:

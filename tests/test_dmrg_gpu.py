@@ -103,6 +103,56 @@ def test_h2o_dmrg_with_fermionic_on_the_fly_swapping(golden_dir):
     assert abs(energy_in_own_order(opt) - fci) < 5e-3
 
 
+@pytest.mark.parametrize("method", ["2site", "1site"])
+def test_optimize_config_inverse(method):
+    """``optimize_config.inverse = -1`` (utils/configs.py:292-294; gs.py:397-398, 470, 521): the centre problems are those
+    of -H, i.e. the sweep climbs to the HIGHEST state of the sector, and the values returned are eigenvalues of the scaled
+    operator.  Pinned three ways on a model small enough for a dense spectrum: (i) against DMRG of the negated MPO with
+    inverse = +1 (the plain path), (ii) against the largest eigenvalue of the dense Hamiltonian restricted to the
+    one-exciton sector, (iii) <H> of the returned state.  Both the dense centre solver (centres below 1000 elements) and
+    the Davidson iteration (bond dimension 16 -> larger centres) are on the path."""
+    from renormalizer_amd.mps.gs import optimize_mps
+    from renormalizer_amd.mps.mps import Mps
+    # four molecules x one mode x four levels: 4096 states in all, 1024 in the one-exciton sector; at M = 16 the centres
+    # of the middle of the chain have 1024 (one-site) / 2048 (two-site) elements: Davidson; the outer ones are dense
+    ph = [Phonon.simple_phonon(Quantity(1555.55, "cm^{-1}"), Quantity(8.7729), 4)]
+    j = np.zeros((4, 4))
+    for a in range(3):
+        j[a, a + 1] = j[a + 1, a] = -0.1 * (a + 1) / constant.au2ev
+    model = HolsteinModel([Mol(Quantity(2.67, "eV"), ph, 15.45)] * 4, j, 3)
+    mpo = Mpo(model)
+    procedure = [[16, 0.4], [16, 0.2], [16, 0.1], [16, 0], [16, 0], [16, 0]]
+
+    def run(op, inverse):
+        mps = Mps.random(model, 1, 16, rng=np.random.default_rng(11))
+        mps.optimize_config.procedure = procedure
+        mps.optimize_config.method = method
+        mps.optimize_config.inverse = inverse
+        return optimize_mps(mps, op)
+
+    e_inv, top = run(mpo, -1.0)
+    e_neg, top2 = run(mpo.scale(-1.0), 1.0)
+    assert min(e_inv) == pytest.approx(min(e_neg), abs=1e-8)
+    # <H> of the state the inverse sweep returns: the highest level, so -<H> is the converged value
+    assert -top.expectation(mpo) == pytest.approx(min(e_inv), abs=1e-7)
+    assert abs(top.mp_norm - 1.0) < 1e-10
+    # the plain sweep finds the other end of the spectrum
+    e_gs, _ = run(mpo, 1.0)
+    assert min(e_gs) < -min(e_inv) - 1e-3
+    # dense spectrum of the one-exciton sector: electronic occupation numbers are diagonal in the product basis
+    dense = mpo.todense()
+    nex = np.zeros(dense.shape[0])
+    dims = [int(d) for d in model.pbond_list]
+    idx = np.indices(dims).reshape(len(dims), -1)
+    for site, b in enumerate(model.basis):
+        sq = np.asarray(b.sigmaqn).reshape(dims[site], -1)[:, 0]
+        nex += sq[idx[site]]
+    sector = nex == 1
+    w = np.linalg.eigvalsh(dense[np.ix_(sector, sector)])
+    assert -min(e_inv) == pytest.approx(w[-1], abs=1e-6)
+    assert min(e_gs) == pytest.approx(w[0], abs=1e-6)
+
+
 @pytest.mark.parametrize("nroots", [1, 3])
 def test_primme_style_solver_option(nroots):
     """optimize_config.algo = "primme" (gs.py:552-569: the reference hands the centre problems to PRIMME with

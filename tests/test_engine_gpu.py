@@ -655,6 +655,46 @@ def test_block_qr_optimistic_flag_edges(eng):
         eng.block_qr_scheme(-1)
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_svd_qn_qr_full_matrices(eng, cplx):
+    """``svd_qn(QR=True, full_matrices=True)`` (mps/svd_qn.py:194-197: scipy's ``mode="full"`` per block): the isometry
+    side completed to a square unitary per block, the triangular factor padded with zeros, ``u @ v.T`` still the input,
+    and the quantum numbers of the extra vectors those of their block.  Tall, wide and square blocks, both systems."""
+    from renormalizer_amd.mps import svd_qn as sq
+    rng = np.random.default_rng(17)
+    heights, widths = [40, 7, 12, 3], [9, 20, 12, 3]
+    qnl = np.concatenate([np.full(h, b) for b, h in enumerate(heights)])
+    qnr = np.concatenate([np.full(w, b) for b, w in enumerate(widths)])
+    qnl, qnr = qnl[rng.permutation(len(qnl))], qnr[rng.permutation(len(qnr))]
+    a = _rand(rng, (len(qnl), len(qnr)), cplx) * ((qnl[:, None] - qnr[None, :]) == 0)
+    for system in ("L", "R"):
+        u, ql, v, qr = sq.svd_qn(eng.asdevice(a), qnl[:, None], -qnr[:, None], np.array([0]), QR=True, system=system,
+                                 full_matrices=True)
+        ue, qle, ve, qre = sq.svd_qn(eng.asdevice(a), qnl[:, None], -qnr[:, None], np.array([0]), QR=True, system=system,
+                                     full_matrices=False)
+        uh, vth, K = u.to_host(), v.T.to_host(), ue.shape[1]
+        nex = sum(max(h - w, 0) for h, w in zip(heights, widths)) if system == "L" else \
+            sum(max(w - h, 0) for h, w in zip(heights, widths))
+        assert uh.shape == (len(qnl), K + nex) and vth.shape == (K + nex, len(qnr))
+        assert len(ql) == len(qr) == K + nex and ql[:K] == qle and qr[:K] == qre
+        assert _relerr(uh @ vth, a) < 1e-13
+        assert np.array_equal(uh[:, :K], ue.to_host()) and np.array_equal(vth[:K], ve.T.to_host())
+        iso = uh if system == "L" else vth.conj().T
+        assert np.abs(iso.conj().T @ iso - np.eye(K + nex)).max() < 1e-13
+        tri_extra = vth[K:] if system == "L" else uh[:, K:]
+        assert np.abs(tri_extra).max() == 0
+        # block by block the completed isometry is SQUARE on its own rows (columns): a unitary of the block
+        own = qnl if system == "L" else qnr
+        lab = np.array([q[0] for q in (ql if system == "L" else qr)])
+        lab = lab if system == "L" else -lab
+        for b, (h, w) in enumerate(zip(heights, widths)):
+            side = h if system == "L" else w
+            blk = iso[np.ix_(own == b, lab == b)]
+            if (h >= w) == (system == "L") or h == w:
+                assert blk.shape == (side, side)
+                assert np.abs(blk @ blk.conj().T - np.eye(side)).max() < 1e-13
+
+
 # -------------------------------------------------------------- block SVD
 
 def dev_block_svd(eng, c, qnbigl, qnbigr, qntot):

@@ -227,3 +227,53 @@ def test_mpdm_right_apply_and_evolve_exact():
     ev = gs.evolve_exact(h, dt, "GS")
     dense_h = h.todense() - model.gs_zpe * np.eye(h.todense().shape[0])
     assert np.abs(ev.todense() - gs.todense() @ scipy.linalg.expm(-1j * dt * dense_h)).max() < 1e-12
+
+
+def test_reduced_density_matrices_of_a_density_operator():
+    """``calc_1site_rdm`` / ``calc_2site_rdm`` on 4-leg (density-operator) sites, mps/mps.py:1547-1655 (the ancilla leg is
+    traced together with the bonds): a cooled MpDm of a small Holstein dimer against the brute-force contraction of its
+    own site tensors on the host, and the traces / one-site marginals against each other."""
+    from renormalizer_amd.mps import MpDm
+    ph = [Phonon.simple_phonon(Quantity(1555.55, "cm^{-1}"), Quantity(8.7729), 3)]
+    j = np.array([[0.0, -0.1], [-0.1, 0.0]]) / constant.au2ev
+    model = HolsteinModel([Mol(Quantity(2.67, "eV"), ph, 15.45)] * 2, j, 3)
+    init = MpDm.max_entangled_ex(model)
+    init.compress_config = CompressConfig(CompressCriteria.fixed, max_bonddim=8)
+    beta = Quantity(298, "K").to_beta()
+    rho, *_ = _cool(init, model, EvolveConfig(EvolveMethod.tdvp_ps, adaptive=False, guess_dt=0.1 / 1j), beta / 2j / 4, 4)
+    arrs = rho.to_arrays()
+    assert all(a.ndim == 4 for a in arrs)
+    n = len(arrs)
+    # |rho>> as a dense tensor psi[p0, g0, p1, g1, ...]; rdm over the physical legs with every ancilla leg traced
+    psi = arrs[0]
+    for a in arrs[1:]:
+        psi = np.tensordot(psi, a, axes=([-1], [0]))
+    psi = psi.reshape(psi.shape[1:-1])
+    phys = [2 * k for k in range(n)]
+    norm = np.vdot(psi, psi).real
+
+    def brute(sites):
+        keep = [2 * k for k in sites]
+        rest = [ax for ax in range(psi.ndim) if ax not in keep]
+        m = np.transpose(psi, keep + rest).reshape(int(np.prod([psi.shape[k] for k in keep])), -1)
+        # reference convention (mps/mps.py:1585-1595): rdm[p, p'] = sum conj(A)[.., p, ..] A[.., p', ..]
+        return m.conj() @ m.T
+
+    r1 = rho.calc_1site_rdm()
+    assert sorted(r1) == list(range(n))
+    for i in range(n):
+        assert np.abs(r1[i] - brute([i])).max() < 1e-12, i
+        assert abs(np.trace(r1[i]).real - norm) < 1e-12
+    only = rho.calc_1site_rdm(idx=[1, 3])
+    assert sorted(only) == [1, 3] and np.abs(only[3] - r1[3]).max() < 1e-14
+    r2 = rho.calc_2site_rdm()
+    assert sorted(r2) == [(i, jj) for i in range(n) for jj in range(i + 1, n)]
+    for (i, jj), m in r2.items():
+        assert np.abs(m - brute([i, jj])).max() < 1e-12, (i, jj)
+        di, dj = arrs[i].shape[1], arrs[jj].shape[1]
+        marg = np.einsum("pqrq->pr", m.reshape(di, dj, di, dj))
+        assert np.abs(marg - r1[i]).max() < 1e-12, (i, jj)
+    # the electronic populations are the diagonal of the electronic sites' one-site matrices
+    e_sites = [k for k, b in enumerate(model.basis) if b.is_electron]
+    occ = np.array([r1[k][1, 1].real for k in e_sites]) / norm
+    assert np.abs(occ - np.asarray(rho.e_occupations)).max() < 1e-10
