@@ -1068,8 +1068,12 @@ bool cholqr_eligible(const mpse_ctx* ctx, const QrBlk* blks, int nblk) {
     max_mm = std::max(max_mm, blks[b].mm);
     max_nn = std::max(max_nn, blks[b].nn);
   }
+  static const int min_cols = [] {
+    const char* e = getenv("MPSE_CHOLQR_MINCOLS");
+    return e ? atoi(e) : 96;
+  }();
   if (mode >= 2) return true;
-  return max_mm >= min_rows && max_nn >= 96;
+  return max_mm >= min_rows && max_nn >= min_cols;
 }
 
 int cholqr_blocks(mpse_ctx* ctx, bool cplx, double* ws, const QrBlk* blks, int nblk, const long long* drows,

@@ -43,6 +43,19 @@ struct F0Term {
   int b, e, x, pad;
   double w;
 };
+// What a launch position needs to start, in ONE read (k_f0_order): before round 6 a workgroup went to memory four times in a
+// row before its first operand load - part mask, term count, terms, tile flags, ~1.5 us each and nothing to hide them
+// behind (the timeline of profiles/r06_f0_trace.md: 4 - 6 k cycles of prelude).  The compact form holds for bonds of up to
+// 256 (16 tiles a side) and at most four terms per (channel, x); other shapes keep nt = -1 and read the tables.
+struct F0Info {
+  int unit;                // (at * nparts + s) * d + x: also the slot of the dot partials
+  int nt;                  // terms of (f, x) listed below (0 .. 4), or -1
+  unsigned long long lts;  // bit lt: the unit holds output tile lt
+  unsigned long long frn;  // 4 bits per l tile: k tiles of the chunk where R has data
+  unsigned long long cts;  // 16 bits per term: c tiles where L and C both hold data
+  unsigned bpack, epack;   // 8 bits per term: left channel b, physical index e of the centre
+  double w[4];
+};
 struct F0Args {
   const double* L;        // (Dl, wl, Dl)
   const double* Rt;       // (wr, Dr, Dr): Rt[f, k, l] = R[l, f, k]
@@ -57,6 +70,8 @@ struct F0Args {
   const F0Term* terms;    // [f * F0_TMAX + t]
   const int* nterm;       // [f]
   const int* skip;
+  int prefetch2;          // request the first l tile of step 2 ahead of the barrier between the steps
+  const F0Info* info;     // launch position -> unit, heaviest first, with what it needs to start (k_f0_order); null: plain order
   long long n;
   int Dl, Dr, wl, wr, d, ntl, ntr, nkc, fc_pitch;
   unsigned long long* trace;   // debug timeline (mpse_ctx::gemm_trace, MPSE_GEMM_TRACE), null normally
@@ -152,34 +167,127 @@ __global__ __launch_bounds__(1024) void k_f0_valid(const unsigned char* __restri
   }
 }
 
-// blockIdx.y = the value x of the physical index of the result this workgroup forms (0 for a bond matrix): the terms
-// of the other x are another workgroup's - half the chain of the heaviest workgroups, which set the duration of the launch
+// Launch order of the units of a solve (one workgroup, once per solve like the flags).  Why: the dispatcher deals launch
+// positions to the dies round robin and, on a die, gives every compute unit one workgroup before any gets a second; a third
+// of the units have no work and return at once.  In plain order a bond launch of 320 units left 90 compute units with
+// nothing but empty units while 31 held TWO working ones - and a working workgroup that shares its unit's MFMA pipes
+// lives 25 us instead of 20 (profiles/r06_f0_trace.md).  Order: the n_cu heaviest units first, heaviest first (one compute
+// unit each); then the other working units LIGHTEST first (position n_cu + k joins the unit of position k: the heaviest
+// gets the lightest partner); the empty units last.  Weight = c tiles of step 1 + l tiles of step 2 (the fit of the
+// timeline gives both ~0.6 us).  Only the schedule changes: every unit writes the same tiles of the same part and the same
+// dot-partial slot as before.
+__global__ __launch_bounds__(1024) void k_f0_order(const unsigned char* __restrict__ FL, const unsigned char* __restrict__ FC,
+                                                    const unsigned long long* __restrict__ mask, const F0Term* __restrict__ terms,
+                                                    const int* __restrict__ nterm, int wl, int wr, int d, int ntl, int ntr,
+                                                    int nkc, int fc_pitch, int n_cu, F0Info* __restrict__ info,
+                                                    unsigned short* __restrict__ wts, const unsigned char* __restrict__ FR,
+                                                    int compact, const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  constexpr int WMAX = 512;
+  __shared__ int hist[WMAX], start[WMAX], s_nw;
+  const int tid = threadIdx.x, nparts = wr * nkc, nu = ntl * nparts * d;
+  for (int i = tid; i < WMAX; i += 1024) hist[i] = 0;
+  if (tid == 0) s_nw = 0;
+  __syncthreads();
+  for (int u = tid; u < nu; u += 1024) {
+    const int x = u % d, wg0 = u / d, at = wg0 / nparts, sp = wg0 - at * nparts, f = sp / nkc, kc = sp - f * nkc;
+    int nlt = 0;
+    for (int lt = 0; lt < ntr; ++lt) nlt += (int)((mask[(long long)at * d * ntr + lt] >> sp) & 1ull);
+    int nct = 0;
+    if (nlt)
+      for (int q = 0; q < nterm[f]; ++q) {
+        const F0Term tm = terms[f * F0_TMAX + q];
+        if (tm.x != x) continue;
+        for (int ct = 0; ct < ntl; ++ct)
+          nct += (FL[((long long)at * wl + tm.b) * ntl + ct] && (!FC || FC[(long long)(tm.e * nkc + kc) * fc_pitch + ct])) ? 1 : 0;
+      }
+    const int w = nlt ? min(WMAX - 1, 1 + nct + nlt) : 0;
+    wts[u] = (unsigned short)w;
+    atomicAdd(&hist[w], 1);
+    if (w) atomicAdd(&s_nw, 1);
+  }
+  __syncthreads();
+  if (tid == 0) {            // descending weights: start[w] = units heavier than w
+    int acc = 0;
+    for (int w = WMAX - 1; w >= 0; --w) {
+      start[w] = acc;
+      acc += hist[w];
+    }
+  }
+  __syncthreads();
+  const int nw = s_nw;
+  for (int u = tid; u < nu; u += 1024) {
+    const int w = wts[u];
+    const int rank = start[w] + atomicAdd(&hist[w], -1) - 1;       // (any order among equal weights: only the schedule)
+    int pos = rank;
+    if (rank >= n_cu && rank < nw) pos = n_cu + (nw - 1 - rank);
+    F0Info I{};
+    I.unit = u;
+    I.nt = -1;
+    if (compact) {
+      const int x = u % d, wg0 = u / d, at = wg0 / nparts, sp = wg0 - at * nparts, f = sp / nkc, kc = sp - f * nkc;
+      for (int lt = 0; lt < ntr; ++lt) {
+        if ((mask[(long long)at * d * ntr + lt] >> sp) & 1ull) I.lts |= 1ull << lt;
+        for (int jj = 0; jj < 4; ++jj) {
+          const int kt = 4 * kc + jj;
+          if (kt < ntr && FR[((long long)lt * wr + f) * ntr + kt]) I.frn |= 1ull << (4 * lt + jj);
+        }
+      }
+      int nt = 0;
+      for (int q = 0; q < nterm[f]; ++q) {
+        const F0Term tm = terms[f * F0_TMAX + q];
+        if (tm.x != x) continue;
+        unsigned long long c = 0;
+        for (int ct = 0; ct < ntl; ++ct)
+          if (FL[((long long)at * wl + tm.b) * ntl + ct] && (!FC || FC[(long long)(tm.e * nkc + kc) * fc_pitch + ct])) c |= 1ull << ct;
+        I.cts |= c << (16 * nt);
+        I.bpack |= (unsigned)tm.b << (8 * nt), I.epack |= (unsigned)tm.e << (8 * nt), I.w[nt] = tm.w;
+        ++nt;
+      }
+      I.nt = nt;
+    }
+    info[pos] = I;
+  }
+}
+
+// A unit = (bra tile row, part, value x of the physical index of the result - 0 for a bond matrix): the terms of the other
+// x are another workgroup's - half the chain of the heaviest workgroups, which set the duration of the launch.  Launch
+// positions map to units through g.info (k_f0_order: heaviest first).
 // Two workgroups per compute unit (256 registers per lane, 24 bytes of scratch): the launch of a two-level site has 640
 // workgroups for 256 compute units and is as long as the sum of their chains, not as the longest one - a second
 // workgroup's MFMAs fill the first one's waits (site launch 54 -> 45 us, 382 -> 375 ms of kernels per two steps).
 __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
   constexpr int DX = 1;
-  const int xo_wg = blockIdx.y;
   constexpr int NW = 4;   // waves per workgroup (eight - two groups splitting the c tiles of step 1, added up in LDS -
                           // spilled registers and lost: 495 against 510 site-updates/s)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15,
             kq = lane >> 4;
   __shared__ double sTr[DX][16 * 65], sTi[DX][16 * 65];
   __shared__ double s_dot[8];
+  // this position's record: the unit and - compact form - everything it needs before its first operand load.  Requested
+  // ahead of the skip word of the solve: the two reads travel together instead of one after the other
+  F0Info I;
+  if (g.info) {
+    I = g.info[blockIdx.x];
+  } else {
+    I.unit = (int)blockIdx.x;
+    I.nt = -1;
+  }
+  asm volatile("" ::: "memory");
   if (g.skip && *g.skip) return;
   // debug timeline (tools/f0_trace.py): entry, flags in hand, end of step 1, end of step 2, exit - shader cycles
   unsigned long long tr[4] = {0, 0, 0, 0};
   const unsigned long long rt0 = g.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   if (g.trace) tr[0] = __builtin_readcyclecounter();
-  int tr_ct = 0, tr_lt = 0;
+  int tr_ct = 0, tr_lt = 0, tr_x = 0;
   auto trace_out = [&]() {
     if (g.trace && tid == 0) {
       const unsigned long long slot = atomicAdd(g.trace, 1ull);
       if (slot < GEMM_TRACE_CAP) {
         unsigned long long* r = g.trace + 1 + slot * GEMM_TRACE_WORDS;
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        r[0] = ((unsigned long long)gridDim.x << 32) | (unsigned long long)blockIdx.x;
-        r[1] = (1ull << 63) | ((unsigned long long)g.d << 32) | (unsigned long long)blockIdx.y;
+        r[0] = ((unsigned long long)(gridDim.x / g.d) << 32) | (unsigned long long)blockIdx.x;
+        r[1] = (1ull << 63) | ((unsigned long long)g.d << 32) | (unsigned long long)tr_x;
         r[2] = (unsigned long long)(unsigned)tr_ct | ((unsigned long long)(unsigned)tr_lt << 16) |
                ((unsigned long long)(((xc & 0xf) << 16) | (hw & 0xffff)) << 32);
         r[3] = tr[0], r[4] = tr[1], r[5] = tr[2], r[6] = tr[3];
@@ -191,19 +299,25 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
   };
   // (Round 6, measured and dropped: several workgroups per unit, each forming the unit's T itself and multiplying every
   // n-th of its l tiles - the verdict's reading was that the launch lasts as long as the chain of its heaviest unit.  It
-  // does not: 546 -> 517 site-updates/s with two workgroups per unit, 458 with four, alternating runs on one box,
-  // profiles/r06_ab_qr_f0split.txt - the launch is bound by what its workgroups do in total, not by the longest one.)
+  // does, and splitting still lost: 546 -> 517 site-updates/s with two workgroups per unit, 458 with four, alternating runs
+  // on one box, profiles/r06_ab_qr_f0split.txt - the extra workgroups land on compute units that already hold a working one,
+  // and two working workgroups on a unit share its MFMA pipes (25 against 20 us of life, profiles/r06_f0_trace.md).  What
+  // helped is WHERE the working workgroups run: k_f0_order.)
   // Launch position -> (bra tile row, part), plain order.  (Measured and dropped: a die - launch position mod 8, one L2
   // each - taking whole parts, so that its L2 holds only the panels of C and Rt its workgroups share.  Dealt channel-major
   // the heavy parts - ket chunks that straddle two quantum-number sectors - piled up on two dies: 39 us against 33; dealt
   // chunk-major 32 against 29.)
   const int nparts = g.wr * g.nkc;
-  const int wg0 = blockIdx.x;
-  const int wg = wg0 * g.d + xo_wg;                 // slot of the dot partials
+  const bool compact = I.nt >= 0;                    // (uniform)
+  const int wg = I.unit;                             // also the slot of its dot partials
+  const int wg0 = wg / g.d;
+  const int xo_wg = wg - wg0 * g.d;                  // the value x of the physical index of the result this workgroup forms
+  tr_x = xo_wg;
   const int at = wg0 / nparts, s = wg0 - at * nparts, f = s / g.nkc, kc = s - f * g.nkc;
   // which output tiles this workgroup holds (the mask is the single statement of that rule): lane lt looks at tile lt
   const unsigned long long lts =
-      __ballot(lane < g.ntr && ((g.mask[(long long)at * g.d * g.ntr + min(lane, g.ntr - 1)] >> s) & 1ull));
+      compact ? I.lts
+              : __ballot(lane < g.ntr && ((g.mask[(long long)at * g.d * g.ntr + min(lane, g.ntr - 1)] >> s) & 1ull));
   if (lts == 0) {
     if (g.dot_part && tid == 0) {
       g.dot_part[2 * wg] = 0.0;
@@ -219,7 +333,9 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
   // (every flag this workgroup will consult is requested here, together: a dependent trip to memory costs ~1.5 us, and
   // a workgroup has no neighbour on its compute unit to hide it behind)
   unsigned frn = 0;          // lane lt: bit j = R has data in rows lt, channel f, k tile 4 kc + j
-  if (lane < g.ntr) {
+  if (compact) {
+    frn = lane < 16 ? (unsigned)((I.frn >> (4 * lane)) & 0xfull) : 0u;
+  } else if (lane < g.ntr) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int kt = 4 * kc + jj;
@@ -227,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
     }
   }
   const int lc = min(lane, g.ntl - 1);
-  const int nt = g.nterm[f];
+  const int nt = compact ? I.nt : g.nterm[f];
   // complex products as three real ones (3M): P1 = sum ar br, P2 = sum ai bi, P3 = sum (ar + ai)(br + bi);
   // re = P1 - P2, im = P3 - P1 - P2 - a quarter fewer MFMAs on the chain of the heaviest workgroups, which set the
   // duration of the launch (the contraction kernel of mpse_gemm.hip forms its complex products the same way)
@@ -242,15 +358,22 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
   // no neighbour on its compute unit to hide that behind)
   double2 av[3][4], bv[3][4];
   for (int q = 0; q < nt; ++q) {
-    const F0Term tm = g.terms[f * F0_TMAX + q];
-    const int b = tm.b;
-    const double wv = tm.w;
-    if (tm.x != xo_wg) continue;      // (uniform)
-    const unsigned long long cts =
-        __ballot(lane < g.ntl && g.FL[((long long)at * g.wl + b) * g.ntl + lc] &&
-                 (!g.FC || g.FC[(long long)(tm.e * g.nkc + kc) * g.fc_pitch + lc]));
+    int b, te;
+    double wv;
+    unsigned long long cts;
+    if (compact) {                      // (the record lists the terms of this x only)
+      b = (int)((I.bpack >> (8 * q)) & 0xffu), te = (int)((I.epack >> (8 * q)) & 0xffu);
+      wv = q == 0 ? I.w[0] : q == 1 ? I.w[1] : q == 2 ? I.w[2] : I.w[3];
+      cts = (I.cts >> (16 * q)) & 0xffffull;
+    } else {
+      const F0Term tm = g.terms[f * F0_TMAX + q];
+      b = tm.b, te = tm.e, wv = tm.w;
+      if (tm.x != xo_wg) continue;      // (uniform)
+      cts = __ballot(lane < g.ntl && g.FL[((long long)at * g.wl + b) * g.ntl + lc] &&
+                     (!g.FC || g.FC[(long long)(te * g.nkc + kc) * g.fc_pitch + lc]));
+    }
     const double2* La = reinterpret_cast<const double2*>(g.L) + ((long long)(a0 + x) * g.wl + b) * g.Dl + kq;   // + c
-    const double2* Cb = reinterpret_cast<const double2*>(g.C) + ((long long)kq * g.d + tm.e) * g.Dr + (wcol ? k0 : 0) + x;
+    const double2* Cb = reinterpret_cast<const double2*>(g.C) + ((long long)kq * g.d + te) * g.Dr + (wcol ? k0 : 0) + x;
     const long long cstride = (long long)g.d * g.Dr;                                                    // + c * d * Dr
     auto load1 = [&](int slot, int ct) {
 #pragma unroll
@@ -315,14 +438,6 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
     tr[2] = __builtin_readcyclecounter();
     tr_lt = __builtin_popcountll(lts);
   }
-#pragma unroll
-  for (int i = 0; i < DX; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      sTr[i][(kq + 4 * r) * 65 + 16 * wcolt + x] = t1[i][r] - t2[i][r];
-      sTi[i][(kq + 4 * r) * 65 + 16 * wcolt + x] = t3[i][r] - t1[i][r] - t2[i][r];
-    }
-  __syncthreads();
   // ---- step 2: the l tiles this workgroup holds, dealt to the waves in order; the A operands (P_x) of the whole chunk
   // stay in registers
   // (the A operands of step 2 are read from LDS where they are used: sixty-four registers less per lane, which is what
@@ -387,8 +502,21 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
   unsigned kt0 = 0, kt1 = 0;
   if (lt0 >= 0) {
     kt0 = k_tiles(lt0);
-    load2(0, lt0);
+    if (g.prefetch2) load2(0, lt0);
   }
+  // The operands of this wave's first l tile are on their way BEFORE T goes through LDS and the workgroup meets at the
+  // barrier: the trip to memory (~1.5 us) runs under the barrier instead of after it.  (Round 5 measured this neutral;
+  // with the working workgroups spread over the compute units by k_f0_order the trip is what a wave waits for.)
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < DX; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sTr[i][(kq + 4 * r) * 65 + 16 * wcolt + x] = t1[i][r] - t2[i][r];
+      sTi[i][(kq + 4 * r) * 65 + 16 * wcolt + x] = t3[i][r] - t1[i][r] - t2[i][r];
+    }
+  __syncthreads();
+  if (!g.prefetch2 && lt0 >= 0) load2(0, lt0);
   while (lt0 >= 0) {
     idx += NW;
     lt1 = nth_tile(lts, idx);
@@ -517,6 +645,24 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
   const size_t fl_bytes = (size_t(ntl) * wl * ntl + 15) & ~size_t(15), fr_bytes = (size_t(ntr) * wr * ntr + 15) & ~size_t(15);
   const size_t tm_bytes = terms.size() * sizeof(F0Term), nt_bytes = (size_t(wr) * sizeof(int) + 15) & ~size_t(15);
   const size_t mk_bytes = size_t(ntl) * d * ntr * 8;
+  const size_t nu = size_t(nwg) * d;
+  const size_t od_bytes = (nu * sizeof(F0Info) + 15) & ~size_t(15), wt_bytes = (nu * sizeof(unsigned short) + 15) & ~size_t(15);
+  // compact records (F0Info): at most 16 tiles a side and four terms per (channel, x)
+  static const bool compact_on = [] {
+    const char* e = getenv("MPSE_F0_COMPACT");
+    return !(e && e[0] == '0');
+  }();
+  static const int prefetch2 = [] {
+    const char* e = getenv("MPSE_F0_PREFETCH");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  bool compact = compact_on && ntl <= 16 && ntr <= 16 && wl <= 255 && d <= 255;
+  for (int f = 0; f < wr && compact; ++f)
+    for (int x = 0; x < d; ++x) {
+      int c = 0;
+      for (int q = 0; q < nterm[f]; ++q) c += terms[size_t(f) * F0_TMAX + q].x == x;
+      if (c > 4) compact = false;
+    }
   const bool keep = ctx->occ_cache_on || ctx->small_rt_scope;
   if (!keep) return MPSE_OK;     // (outside a solve nothing would own the flags and the mask until the consumer has run)
   mpse_ctx::F0Cache& fc = ctx->f0;
@@ -524,12 +670,18 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
   const bool hit = fc.buf && fc.L == h->L && fc.R == h->R && fc.W == h->W0 && fc.cmask == (const void*)FC && fc.Dl == Dl &&
                    fc.Dr == Dr && fc.w == wr && fc.nsite == h->nsite;
   const size_t o_fl = rt_bytes, o_fr = o_fl + fl_bytes, o_tm = o_fr + fr_bytes, o_nt = o_tm + tm_bytes, o_mk = o_nt + nt_bytes;
+  const size_t o_od = o_mk + mk_bytes, o_wt = o_od + od_bytes, tot_bytes = o_wt + wt_bytes;
+  // MPSE_F0_ORDER=0: launch positions in plain unit order (as before round 6)
+  static const bool order_on = [] {
+    const char* e = getenv("MPSE_F0_ORDER");
+    return !(e && e[0] == '0');
+  }();
   if (hit) {
     base = static_cast<char*>(fc.buf);
   } else {
     void* p = nullptr;
     heff0_drop_cache(ctx);
-    MPSE_TRY(mpse_malloc(ctx, o_mk + mk_bytes, &p));
+    MPSE_TRY(mpse_malloc(ctx, tot_bytes, &p));
     fc.buf = p, fc.L = h->L, fc.R = h->R, fc.W = h->W0, fc.cmask = FC, fc.Dl = Dl, fc.Dr = Dr, fc.w = wr, fc.nsite = h->nsite;
     base = static_cast<char*>(p);
     {   // terms | term counts: adjacent in the buffer, one upload
@@ -549,6 +701,13 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
                        reinterpret_cast<const unsigned char*>(base + o_fr), reinterpret_cast<const F0Term*>(base + o_tm),
                        reinterpret_cast<const int*>(base + o_nt), wl, wr, d, ntl, ntr, nkc, fc_pitch,
                        reinterpret_cast<unsigned long long*>(base + o_mk), ctx->skip_flag);
+    if (order_on)
+      hipLaunchKernelGGL(k_f0_order, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const unsigned char*>(base + o_fl),
+                         FC, reinterpret_cast<const unsigned long long*>(base + o_mk),
+                         reinterpret_cast<const F0Term*>(base + o_tm), reinterpret_cast<const int*>(base + o_nt), wl, wr, d, ntl,
+                         ntr, nkc, fc_pitch, ctx->n_cu > 0 ? ctx->n_cu : 256, reinterpret_cast<F0Info*>(base + o_od),
+                         reinterpret_cast<unsigned short*>(base + o_wt), reinterpret_cast<const unsigned char*>(base + o_fr),
+                         compact ? 1 : 0, ctx->skip_flag);
   }
   F0Args g{};
   g.L = static_cast<const double*>(h->L);
@@ -562,6 +721,8 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
   g.nterm = reinterpret_cast<const int*>(base + o_nt);
   g.mask = reinterpret_cast<const unsigned long long*>(base + o_mk);
   g.skip = ctx->skip_flag;
+  g.prefetch2 = prefetch2;
+  g.info = order_on ? reinterpret_cast<const F0Info*>(base + o_od) : nullptr;
   g.trace = ctx->prof_on ? ctx->gemm_trace : nullptr;
   g.n = n;
   g.Dl = Dl, g.Dr = Dr, g.wl = wl, g.wr = wr, g.d = d, g.ntl = ntl, g.ntr = ntr, g.nkc = nkc, g.fc_pitch = fc_pitch;
@@ -578,7 +739,7 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
                                           8.0 * double(Dl) * Dr * Dr * wr * d;
     const double by = 16.0 * (double(Dl) * wl * Dl + double(Dr) * wr * Dr + 2.0 * double(n));
     ProfScope fprof(ctx, 7, fl, by);
-    hipLaunchKernelGGL(k_heff0_fused, dim3(nwg, d), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL(k_heff0_fused, dim3(nwg * d), dim3(256), 0, ctx->stream, g);
     fprof.end();
   }
   MPSE_HIP(ctx, hipGetLastError());

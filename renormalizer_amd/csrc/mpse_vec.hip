@@ -632,13 +632,6 @@ __global__ __launch_bounds__(64) void k_lz_coefs(double* __restrict__ scal, int 
 // the decision of the check at iteration j (its estimate went to buffer `which`).  ``pub`` != null: the host waits at this
 // check - the control block goes to the mapped pinned buffer and the sequence number after it (a k_publish launch did
 // that before: one launch and its latency less per wait).
-struct LzDecide {
-  unsigned int* counter;       // null: the decision is a launch of its own (k_lz_decide)
-  int has_prev, j, which;
-  double* pub;
-  volatile double* seq_slot;
-  double seq;
-};
 __device__ __forceinline__ void lz_decide(LzCtl* ctl, const unsigned int* flag, unsigned int gen, int has_prev, int j,
                                           int which, double* pub, volatile double* seq_slot, double seq) {
   if (!(ctl->done || ctl->need_host)) {
@@ -646,9 +639,7 @@ __device__ __forceinline__ void lz_decide(LzCtl* ctl, const unsigned int* flag, 
       ctl->done = 1;
       ctl->nvec = ctl->forced_m;
       ctl->which = which;
-    } else if (has_prev && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
-      // (an atomic load: inside the launch that raises the word, a plain or scalar load could be served from a cache
-      // the other workgroups' atomics never touched)
+    } else if (has_prev && *flag != gen) {
       ctl->done = 1;
       ctl->nvec = j + 1;
       ctl->which = which;
@@ -668,24 +659,18 @@ __global__ void k_lz_decide(LzCtl* ctl, const unsigned int* __restrict__ flag, u
 }
 
 // res = sum_{i<m} coef_i V_i with the coefficients in device memory; optional closeness flag as in k_lincomb
-// ``dec.counter`` != null: the decision of the check rides on this launch - the workgroup that finishes last (a counter
-// in device memory, reset by that workgroup) takes it once every workgroup's closeness verdict is in the flag word:
-// one dependent launch less per check (k_lz_decide: ~4.6 us each, 2 % of the kernel time of a headline step with
-// k_lz_coefs).
+// (Round 6, measured and dropped: the decision of the check riding on this launch - the workgroup that finishes last, by a
+// counter in device memory, takes it - to save the k_lz_decide launch, ~4.6 us per check.  4 096 workgroups counting
+// on one address cost far more than the launch: 539 -> 434 site-updates/s, profiles/r06_ab_lz_fuse.txt.)
 // ``m_early`` > 0: the estimate of the (deferred) first check, sum_{i < m_early} coef2_i V_i with coef2 = coef + 2 LZ_MAXM,
 // is formed in the same pass over the basis and takes the place of ``prev``.
 template <bool CPLX>
 __global__ void k_lincomb_dev(double* __restrict__ res, const double* __restrict__ V, long long n, int m,
                               const double* __restrict__ coef, const double* __restrict__ prev, double rtol, double atol,
-                              unsigned int* __restrict__ flag, unsigned int gen, LzCtl* __restrict__ ctl,
-                              int m_early, const unsigned char* __restrict__ cmask, int crow, int ckw, const LzDecide dec) {
+                              unsigned int* __restrict__ flag, unsigned int gen, const LzCtl* __restrict__ ctl,
+                              int m_early, const unsigned char* __restrict__ cmask, int crow, int ckw) {
   // cmask: as in k_lanczos_update_u - the basis vectors (and the earlier estimate) are exactly zero outside it
-  if (ctl->done || ctl->need_host) {
-    // (uniform over the launch: no workgroup counts; the host may still be waiting for the publication)
-    if (dec.counter && blockIdx.x == 0 && threadIdx.x == 0)
-      lz_decide(ctl, flag, gen, dec.has_prev, dec.j, dec.which, dec.pub, dec.seq_slot, dec.seq);
-    return;
-  }
+  if (ctl->done || ctl->need_host) return;
   __shared__ double cr[LZ_MAXM], ci[LZ_MAXM], er[LZ_MAXM], ei[LZ_MAXM];
   if (threadIdx.x < LZ_MAXM) {
     cr[threadIdx.x] = coef[threadIdx.x];
@@ -744,18 +729,6 @@ __global__ void k_lincomb_dev(double* __restrict__ res, const double* __restrict
     }
   }
   if ((prev || m_early > 0) && bad) atomicMax(flag, gen);
-  if (dec.counter) {
-    __shared__ int s_last;
-    __threadfence();                 // this thread's verdict (and its part of the estimate) before its workgroup counts
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(dec.counter, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) {
-      __threadfence();
-      *dec.counter = 0;              // every other workgroup has counted: ready for the next check
-      lz_decide(ctl, flag, gen, dec.has_prev, dec.j, dec.which, dec.pub, dec.seq_slot, dec.seq);
-    }
-  }
 }
 
 // Start of an asynchronous solve in one launch (three before: zero fill of the control block, copy of the start vector,
@@ -1047,32 +1020,20 @@ int expm_lanczos_async(mpse_ctx* ctx, int dtype, const mpse_heff* h, std::comple
           gen = ++ctx->flag_gen;
         }
       }
-      const bool wait_here = j >= wait_from || waited || last;
-      const bool self_pub = wait_here && ctx->pinned_dev != nullptr;
-      const double seq = self_pub ? double(++ctx->publish_seq) : 0.0;
-      // the decision rides on the launch that forms the estimate (its last workgroup takes it); MPSE_LZ_FUSE=0: a launch
-      // of its own, as before round 6
-      static const bool fuse_decide = [] {
-        const char* e = getenv("MPSE_LZ_FUSE");
-        return !(e && e[0] == '0');
-      }();
-      LzDecide dec{};
-      dec.counter = fuse_decide ? dflag + 2 : nullptr;
-      dec.has_prev = (prev || merged) ? 1 : 0, dec.j = j, dec.which = dst == out ? 0 : 1;
-      dec.pub = self_pub ? ctx->pinned_dev + 24 : (double*)nullptr;
-      dec.seq_slot = (volatile double*)(self_pub ? ctx->pinned_dev + 4095 : nullptr);
-      dec.seq = seq;
       if (cplx)
         hipLaunchKernelGGL((k_lincomb_dev<true>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst,
                            V.as<double>(), (long long)n, j + 1, (const double*)coef, (const double*)prev, rtol, atol,
-                           dflag, gen, ctl, merged ? j - 1 : 0, vmask, vm_row, vm_kw, dec);
+                           dflag, gen, (const LzCtl*)ctl, merged ? j - 1 : 0, vmask, vm_row, vm_kw);
       else
         hipLaunchKernelGGL((k_lincomb_dev<false>), dim3(ew_blocks(n)), dim3(256), 0, ctx->stream, (double*)dst,
                            V.as<double>(), (long long)n, j + 1, (const double*)coef, (const double*)prev, rtol, atol,
-                           dflag, gen, ctl, merged ? j - 1 : 0, vmask, vm_row, vm_kw, dec);
-      if (!fuse_decide)
-        hipLaunchKernelGGL(k_lz_decide, dim3(1), dim3(1), 0, ctx->stream, ctl, (const unsigned int*)dflag, gen,
-                           dec.has_prev, j, dec.which, dec.pub, dec.seq_slot, seq);
+                           dflag, gen, (const LzCtl*)ctl, merged ? j - 1 : 0, vmask, vm_row, vm_kw);
+      const bool wait_here = j >= wait_from || waited || last;
+      const bool self_pub = wait_here && ctx->pinned_dev != nullptr;
+      const double seq = self_pub ? double(++ctx->publish_seq) : 0.0;
+      hipLaunchKernelGGL(k_lz_decide, dim3(1), dim3(1), 0, ctx->stream, ctl, (const unsigned int*)dflag, gen,
+                         (prev || merged) ? 1 : 0, j, dst == out ? 0 : 1, self_pub ? ctx->pinned_dev + 24 : (double*)nullptr,
+                         (volatile double*)(self_pub ? ctx->pinned_dev + 4095 : nullptr), seq);
       prev = dst;
       MPSE_HIP(ctx, hipGetLastError());
       if (wait_here) {

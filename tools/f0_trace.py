@@ -55,6 +55,51 @@ for key in sorted(set(zip(grid.tolist(), d.tolist()))):
     a = np.median(np.array(rows), axis=0)
     lines.append(f"| {key[0]} x {key[1]} | {len(rows)} | {a[0]:.0f} | {a[1]:.0f} | {a[2]:.1f} | {a[3]:.1f} | {a[4]:.1f} | {a[5]:.1f} | "
                  f"{a[6]:.0f} | {a[7]:.0f} | {a[8]:.0f} | {a[9]:.0f} | {a[10]:.0f} | {a[11]:.1f} | {a[12]:.1f} | {a[13]:.2f} |")
+# Does a heavy workgroup run slower when another WORKING workgroup shares its compute unit?  Heavy = top quartile of
+# (c tiles + 4 l tiles) within its launch; "shared" = another workgroup with work on the same (die, HW_ID[15:8]) whose life
+# overlaps more than half of this one's.
+hwid = (r[:, 2] >> np.uint64(32)).astype(np.int64)
+cu = ((hwid >> 16) & 0xF) * 256 + ((hwid >> 8) & 0xFF)
+lines += ["", "| grid x d | heavy workgroups | alone on their CU: n, median life us | sharing it with a working workgroup: n, median life us | CUs with 0 / 1 / 2+ working workgroups (median per launch) |",
+          "|---|---|---|---|---|"]
+for key in sorted(set(zip(grid.tolist(), d.tolist()))):
+    m = (grid == key[0]) & (d == key[1])
+    alone, shared, occ = [], [], []
+    for L in np.unique(launch[m])[:60]:
+        k = np.nonzero(m & (launch == L))[0]
+        if len(k) < key[0] * key[1] // 2:
+            continue
+        w = nct[k] + 4 * nlt[k]
+        work = nlt[k] > 0
+        if work.sum() < 4:
+            continue
+        heavy = work & (w >= np.quantile(w[work], 0.75))
+        cnt = np.bincount(cu[k][work], minlength=4096)
+        used = np.unique(cu[k])
+        occ.append((int((cnt[used] == 0).sum()), int((cnt[used] == 1).sum()), int((cnt[used] >= 2).sum())))
+        for i in np.nonzero(heavy)[0]:
+            same = (cu[k] == cu[k][i]) & work
+            same[i] = False
+            ov = np.minimum(rt1[k][same], rt1[k][i]) - np.maximum(rt0[k][same], rt0[k][i])
+            life_i = (rt1[k][i] - rt0[k][i]) / 100.0
+            (shared if (ov > 0.5 * (rt1[k][i] - rt0[k][i])).any() else alone).append(life_i)
+    if alone or shared:
+        o = np.median(np.array(occ), axis=0) if occ else (0, 0, 0)
+        lines.append(f"| {key[0]} x {key[1]} | {len(alone) + len(shared)} | {len(alone)}, {np.median(alone) if alone else 0:.1f} | "
+                     f"{len(shared)}, {np.median(shared) if shared else 0:.1f} | {o[0]:.0f} / {o[1]:.0f} / {o[2]:.0f} |")
+# What a workgroup's life is made of: least squares  life = fixed + a (c tiles of step 1) + b (l tiles of step 2)  over the
+# workgroups with work (a c tile = 12 MFMAs per wave = 768 MFMA cycles; an l tile, dealt to four waves, 48 MFMAs of one
+# wave = 3072 cycles, i.e. 768 per l tile of the workgroup)
+lines += ["", "| grid x d | workgroups fitted | fixed us | per c tile us | per l tile us | residual rms us |", "|---|---|---|---|---|---|"]
+for key in sorted(set(zip(grid.tolist(), d.tolist()))):
+    m = (grid == key[0]) & (d == key[1]) & (nlt > 0)
+    if m.sum() < 100:
+        continue
+    A = np.stack([np.ones(m.sum()), nct[m], nlt[m]], 1).astype(float)
+    y = (rt1[m] - rt0[m]) / 100.0
+    coef, *_ = np.linalg.lstsq(A, y, rcond=None)
+    res = np.sqrt(np.mean((A @ coef - y) ** 2))
+    lines.append(f"| {key[0]} x {key[1]} | {m.sum()} | {coef[0]:.2f} | {coef[1]:.3f} | {coef[2]:.3f} | {res:.2f} |")
 out = "\n".join(lines) + f"\n\n{len(r)} workgroup records of k_heff0_fused; medians over the launches of a class\n"
 print(out)
 if len(sys.argv) > 2:

@@ -13,7 +13,10 @@ Two normalisations of the same busy counter (round 5: the judge found them to di
                     LONGEST launch in the pass (where the command-processor share is negligible).
 Calibration: `tools/ubench/mfma_f64_peak` (every SIMD issuing MFMAs back to back) must read ~1.0 in all columns.
 Launches are grouped by (kernel, grid size) = one GEMM shape.  Third argument: substring the kernel name must contain
-(default k_gemm)."""
+(default k_gemm).  Fourth argument (optional): a JSON file that receives / is updated with the launch-time weighted busy
+fractions per kernel ({"kernels": {name: {"busy_by_duration", "busy_by_gui_active", "launches", "source_sha"}}}) -
+bench.py quotes them (`mfma_busy`) while the kernel's sources are the ones of that pass; fifth: the csrc file(s) of the
+kernel, comma separated, for that fingerprint."""
 import os
 import re
 import sqlite3
@@ -57,6 +60,29 @@ def main():
     print(out)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(out + "\n")
+    if len(sys.argv) > 4:
+        import hashlib
+        import json
+        repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        h = hashlib.sha256()
+        for name in (sys.argv[5].split(",") if len(sys.argv) > 5 else []):
+            with open(os.path.join(repo, "renormalizer_amd", "csrc", name), "rb") as fh:
+                h.update(fh.read())
+        try:
+            with open(sys.argv[4]) as fh:
+                doc = json.load(fh)
+        except (OSError, ValueError):
+            doc = {"counter": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x time)", "kernels": {}}
+        per_kernel = defaultdict(list)
+        for (short, grid), ds in groups.items():
+            per_kernel[short] += ds
+        for short, ds in per_kernel.items():
+            busy = sum(x["SQ_VALU_MFMA_BUSY_CYCLES"] for x in ds)
+            doc["kernels"][short] = {"busy_by_duration": busy / (1024 * sum(x["dur"] for x in ds) * ghz),
+                                     "busy_by_gui_active": busy / (1024 * sum(x["GRBM_GUI_ACTIVE"] for x in ds) / 8),
+                                     "launches": len(ds), "clock_ghz_assumed": ghz, "source_sha": h.hexdigest()[:16]}
+        with open(sys.argv[4], "w") as fh:
+            json.dump(doc, fh, indent=1)
 
 
 if __name__ == "__main__":
