@@ -70,7 +70,6 @@ struct F0Args {
   const F0Term* terms;    // [f * F0_TMAX + t]
   const int* nterm;       // [f]
   const int* skip;
-  int prefetch2;          // request the first l tile of step 2 ahead of the barrier between the steps
   const F0Info* info;     // launch position -> unit, heaviest first, with what it needs to start (k_f0_order); null: plain order
   long long n;
   int Dl, Dr, wl, wr, d, ntl, ntr, nkc, fc_pitch;
@@ -167,85 +166,136 @@ __global__ __launch_bounds__(1024) void k_f0_valid(const unsigned char* __restri
   }
 }
 
-// Launch order of the units of a solve (one workgroup, once per solve like the flags).  Why: the dispatcher deals launch
-// positions to the dies round robin and, on a die, gives every compute unit one workgroup before any gets a second; a third
-// of the units have no work and return at once.  In plain order a bond launch of 320 units left 90 compute units with
-// nothing but empty units while 31 held TWO working ones - and a working workgroup that shares its unit's MFMA pipes
-// lives 25 us instead of 20 (profiles/r06_f0_trace.md).  Order: the n_cu heaviest units first, heaviest first (one compute
-// unit each); then the other working units LIGHTEST first (position n_cu + k joins the unit of position k: the heaviest
-// gets the lightest partner); the empty units last.  Weight = c tiles of step 1 + l tiles of step 2 (the fit of the
-// timeline gives both ~0.6 us).  Only the schedule changes: every unit writes the same tiles of the same part and the same
-// dot-partial slot as before.
-__global__ __launch_bounds__(1024) void k_f0_order(const unsigned char* __restrict__ FL, const unsigned char* __restrict__ FC,
-                                                    const unsigned long long* __restrict__ mask, const F0Term* __restrict__ terms,
-                                                    const int* __restrict__ nterm, int wl, int wr, int d, int ntl, int ntr,
-                                                    int nkc, int fc_pitch, int n_cu, F0Info* __restrict__ info,
-                                                    unsigned short* __restrict__ wts, const unsigned char* __restrict__ FR,
-                                                    int compact, const int* __restrict__ skip) {
+// Part mask AND launch order of the units of a solve in one launch (one workgroup, once per solve like the flags;
+// MPSE_F0_ORDER=0: k_f0_valid alone, units in index order).
+// Why an order: the dispatcher deals launch positions to the dies round robin and, on a die, gives every compute unit one
+// workgroup before any gets a second; a third of the units have no work and return at once.  In plain order a bond launch of
+// 320 units left 90 compute units with nothing but empty units while 31 held TWO working ones - and a working workgroup
+// that shares its unit's MFMA pipes lives 25 us instead of 20 (profiles/r06_f0_trace.md).  Order: the n_cu heaviest units
+// first, heaviest first (one compute unit each); then the other working units LIGHTEST first (position n_cu + k joins the
+// unit of position k: the heaviest gets the lightest partner); the empty units last.  Weight = c tiles of step 1 + l tiles
+// of step 2 (the fit of the timeline gives both ~0.6 us).  Only the schedule changes: every unit writes the same tiles of
+// the same part and the same dot-partial slot as before.
+// The tile flags and the term table are staged in LDS first (one trip to memory; the first version read them from global
+// memory per unit, twice, and cost 30 us per solve - 2.3 % of the kernel time of a step, most of what the order gained).
+__global__ __launch_bounds__(1024) void k_f0_plan(const unsigned char* __restrict__ FL, const unsigned char* __restrict__ FC,
+                                                   const unsigned char* __restrict__ FR, const F0Term* __restrict__ terms,
+                                                   const int* __restrict__ nterm, int wl, int wr, int d, int ntl, int ntr,
+                                                   int nkc, int fc_pitch, unsigned long long* __restrict__ mask, int n_cu,
+                                                   F0Info* __restrict__ info, int compact, const int* __restrict__ skip) {
   if (skip && *skip) return;
-  constexpr int WMAX = 512;
+  constexpr int WMAX = 256, STAGE = 8192;
+  __shared__ unsigned long long s1[64], s2[64];    // per bra tile row / per l tile: bit s
   __shared__ int hist[WMAX], start[WMAX], s_nw;
-  const int tid = threadIdx.x, nparts = wr * nkc, nu = ntl * nparts * d;
+  __shared__ unsigned char sFL[STAGE], sFR[STAGE], sFC[STAGE];
+  __shared__ F0Term sT[16 * F0_TMAX];
+  __shared__ int sNT[16];
+  const int nparts = wr * nkc, tid = threadIdx.x, nu = ntl * nparts * d;
+  const int nfl = ntl * wl * ntl, nfr = ntr * wr * ntr, nfc = FC ? d * nkc * fc_pitch : 0;
+  const bool staged = nfl <= STAGE && nfr <= STAGE && nfc <= STAGE && wr <= 16;
+  if (staged) {
+    for (int i = tid; i < nfl; i += 1024) sFL[i] = FL[i];
+    for (int i = tid; i < nfr; i += 1024) sFR[i] = FR[i];
+    for (int i = tid; i < nfc; i += 1024) sFC[i] = FC[i];
+    for (int i = tid; i < wr * F0_TMAX; i += 1024) sT[i] = terms[i];
+    if (tid < wr) sNT[tid] = nterm[tid];
+  }
+  if (tid < 64) s1[tid] = s2[tid] = 0;
   for (int i = tid; i < WMAX; i += 1024) hist[i] = 0;
   if (tid == 0) s_nw = 0;
   __syncthreads();
-  for (int u = tid; u < nu; u += 1024) {
+  const unsigned char* pFL = staged ? sFL : FL;
+  const unsigned char* pFR = staged ? sFR : FR;
+  const unsigned char* pFC = FC ? (staged ? sFC : FC) : nullptr;
+  const F0Term* pT = staged ? sT : terms;
+  const int* pNT = staged ? sNT : nterm;
+  auto c_tiles = [&](int at, const F0Term& tm, int kc) {       // c tiles where L (rows at, channel b) and C (e, chunk kc) hold data
+    unsigned long long c = 0;
+    for (int ct = 0; ct < ntl; ++ct)
+      if (pFL[(at * wl + tm.b) * ntl + ct] && (!pFC || pFC[(tm.e * nkc + kc) * fc_pitch + ct])) c |= 1ull << ct;
+    return c;
+  };
+  // ---- the part mask (as k_f0_valid)
+  for (int t = tid; t < ntl * nparts; t += 1024) {
+    const int at = t / nparts, sp = t - at * nparts, f = sp / nkc, kc = sp - f * nkc;
+    bool any = false;
+    for (int q = 0; q < pNT[f]; ++q) any = any || c_tiles(at, pT[f * F0_TMAX + q], kc) != 0;
+    if (any) atomicOr(&s1[at], 1ull << sp);
+  }
+  for (int t = tid; t < ntr * nparts; t += 1024) {
+    const int lt = t / nparts, sp = t - lt * nparts, f = sp / nkc, kc = sp - f * nkc;
+    bool any = false;
+    for (int j = 0; j < 4; ++j) {
+      const int kt = 4 * kc + j;
+      if (kt < ntr) any = any || pFR[(lt * wr + f) * ntr + kt];
+    }
+    if (any) atomicOr(&s2[lt], 1ull << sp);
+  }
+  __syncthreads();
+  for (int t = tid; t < ntl * d * ntr; t += 1024) {
+    const int row = t / ntr, lt = t - row * ntr;
+    mask[t] = s1[row / d] & s2[lt];
+  }
+  // ---- a unit's record and weight (everything from LDS)
+  auto record = [&](int u, F0Info& I) {
     const int x = u % d, wg0 = u / d, at = wg0 / nparts, sp = wg0 - at * nparts, f = sp / nkc, kc = sp - f * nkc;
-    int nlt = 0;
-    for (int lt = 0; lt < ntr; ++lt) nlt += (int)((mask[(long long)at * d * ntr + lt] >> sp) & 1ull);
-    int nct = 0;
+    I = F0Info{};
+    I.unit = u;
+    I.nt = -1;
+    int nlt = 0, nct = 0, nt = 0;
+    if ((s1[at] >> sp) & 1ull)
+      for (int lt = 0; lt < ntr; ++lt)
+        if ((s2[lt] >> sp) & 1ull) {
+          ++nlt;
+          if (lt < 64) I.lts |= 1ull << lt;
+          if (lt < 16)
+            for (int jj = 0; jj < 4; ++jj) {
+              const int kt = 4 * kc + jj;
+              if (kt < ntr && pFR[(lt * wr + f) * ntr + kt]) I.frn |= 1ull << (4 * lt + jj);
+            }
+        }
     if (nlt)
-      for (int q = 0; q < nterm[f]; ++q) {
-        const F0Term tm = terms[f * F0_TMAX + q];
+      for (int q = 0; q < pNT[f]; ++q) {
+        const F0Term tm = pT[f * F0_TMAX + q];
         if (tm.x != x) continue;
-        for (int ct = 0; ct < ntl; ++ct)
-          nct += (FL[((long long)at * wl + tm.b) * ntl + ct] && (!FC || FC[(long long)(tm.e * nkc + kc) * fc_pitch + ct])) ? 1 : 0;
+        const unsigned long long c = c_tiles(at, tm, kc);
+        nct += __builtin_popcountll(c);
+        if (compact && nt < 4) {
+          I.cts |= (c & 0xffffull) << (16 * nt);
+          I.bpack |= (unsigned)tm.b << (8 * nt), I.epack |= (unsigned)tm.e << (8 * nt), I.w[nt] = tm.w;
+        }
+        ++nt;
       }
-    const int w = nlt ? min(WMAX - 1, 1 + nct + nlt) : 0;
-    wts[u] = (unsigned short)w;
+    if (compact) I.nt = nt;
+    return nlt ? min(WMAX - 1, 1 + nct + nlt) : 0;
+  };
+  F0Info mine;                       // (launches of up to 1024 units: the record stays in registers across the sort)
+  int myw = 0;
+  for (int u = tid; u < nu; u += 1024) {
+    F0Info I;
+    const int w = record(u, I);
+    if (u == tid) mine = I, myw = w;
     atomicAdd(&hist[w], 1);
     if (w) atomicAdd(&s_nw, 1);
   }
   __syncthreads();
-  if (tid == 0) {            // descending weights: start[w] = units heavier than w
+  if (tid < WMAX) {                  // descending weights: start[w] = units heavier than w
     int acc = 0;
-    for (int w = WMAX - 1; w >= 0; --w) {
-      start[w] = acc;
-      acc += hist[w];
-    }
+    for (int w = tid + 1; w < WMAX; ++w) acc += hist[w];
+    start[tid] = acc;
   }
   __syncthreads();
   const int nw = s_nw;
   for (int u = tid; u < nu; u += 1024) {
-    const int w = wts[u];
+    F0Info I;
+    int w;
+    if (u == tid)
+      I = mine, w = myw;
+    else
+      w = record(u, I);
     const int rank = start[w] + atomicAdd(&hist[w], -1) - 1;       // (any order among equal weights: only the schedule)
     int pos = rank;
     if (rank >= n_cu && rank < nw) pos = n_cu + (nw - 1 - rank);
-    F0Info I{};
-    I.unit = u;
-    I.nt = -1;
-    if (compact) {
-      const int x = u % d, wg0 = u / d, at = wg0 / nparts, sp = wg0 - at * nparts, f = sp / nkc, kc = sp - f * nkc;
-      for (int lt = 0; lt < ntr; ++lt) {
-        if ((mask[(long long)at * d * ntr + lt] >> sp) & 1ull) I.lts |= 1ull << lt;
-        for (int jj = 0; jj < 4; ++jj) {
-          const int kt = 4 * kc + jj;
-          if (kt < ntr && FR[((long long)lt * wr + f) * ntr + kt]) I.frn |= 1ull << (4 * lt + jj);
-        }
-      }
-      int nt = 0;
-      for (int q = 0; q < nterm[f]; ++q) {
-        const F0Term tm = terms[f * F0_TMAX + q];
-        if (tm.x != x) continue;
-        unsigned long long c = 0;
-        for (int ct = 0; ct < ntl; ++ct)
-          if (FL[((long long)at * wl + tm.b) * ntl + ct] && (!FC || FC[(long long)(tm.e * nkc + kc) * fc_pitch + ct])) c |= 1ull << ct;
-        I.cts |= c << (16 * nt);
-        I.bpack |= (unsigned)tm.b << (8 * nt), I.epack |= (unsigned)tm.e << (8 * nt), I.w[nt] = tm.w;
-        ++nt;
-      }
-      I.nt = nt;
-    }
     info[pos] = I;
   }
 }
@@ -502,11 +552,12 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
   unsigned kt0 = 0, kt1 = 0;
   if (lt0 >= 0) {
     kt0 = k_tiles(lt0);
-    if (g.prefetch2) load2(0, lt0);
+    load2(0, lt0);
   }
   // The operands of this wave's first l tile are on their way BEFORE T goes through LDS and the workgroup meets at the
-  // barrier: the trip to memory (~1.5 us) runs under the barrier instead of after it.  (Round 5 measured this neutral;
-  // with the working workgroups spread over the compute units by k_f0_order the trip is what a wave waits for.)
+  // barrier: the trip to memory (~1.5 us) runs under the barrier instead of after it (step 2 of the heaviest workgroups
+  // 22.5 - 25 k -> 21 - 22.4 k cycles in the timeline; neutral on the headline within the scatter of a box,
+  // profiles/r06_ab_f0_compact_prefetch.txt).
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int i = 0; i < DX; ++i)
@@ -516,7 +567,6 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
       sTi[i][(kq + 4 * r) * 65 + 16 * wcolt + x] = t3[i][r] - t1[i][r] - t2[i][r];
     }
   __syncthreads();
-  if (!g.prefetch2 && lt0 >= 0) load2(0, lt0);
   while (lt0 >= 0) {
     idx += NW;
     lt1 = nth_tile(lts, idx);
@@ -646,17 +696,9 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
   const size_t tm_bytes = terms.size() * sizeof(F0Term), nt_bytes = (size_t(wr) * sizeof(int) + 15) & ~size_t(15);
   const size_t mk_bytes = size_t(ntl) * d * ntr * 8;
   const size_t nu = size_t(nwg) * d;
-  const size_t od_bytes = (nu * sizeof(F0Info) + 15) & ~size_t(15), wt_bytes = (nu * sizeof(unsigned short) + 15) & ~size_t(15);
+  const size_t od_bytes = (nu * sizeof(F0Info) + 15) & ~size_t(15);
   // compact records (F0Info): at most 16 tiles a side and four terms per (channel, x)
-  static const bool compact_on = [] {
-    const char* e = getenv("MPSE_F0_COMPACT");
-    return !(e && e[0] == '0');
-  }();
-  static const int prefetch2 = [] {
-    const char* e = getenv("MPSE_F0_PREFETCH");
-    return (e && e[0] == '0') ? 0 : 1;
-  }();
-  bool compact = compact_on && ntl <= 16 && ntr <= 16 && wl <= 255 && d <= 255;
+  bool compact = ntl <= 16 && ntr <= 16 && wl <= 255 && d <= 255;
   for (int f = 0; f < wr && compact; ++f)
     for (int x = 0; x < d; ++x) {
       int c = 0;
@@ -670,7 +712,7 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
   const bool hit = fc.buf && fc.L == h->L && fc.R == h->R && fc.W == h->W0 && fc.cmask == (const void*)FC && fc.Dl == Dl &&
                    fc.Dr == Dr && fc.w == wr && fc.nsite == h->nsite;
   const size_t o_fl = rt_bytes, o_fr = o_fl + fl_bytes, o_tm = o_fr + fr_bytes, o_nt = o_tm + tm_bytes, o_mk = o_nt + nt_bytes;
-  const size_t o_od = o_mk + mk_bytes, o_wt = o_od + od_bytes, tot_bytes = o_wt + wt_bytes;
+  const size_t o_od = o_mk + mk_bytes, tot_bytes = o_od + od_bytes;
   // MPSE_F0_ORDER=0: launch positions in plain unit order (as before round 6)
   static const bool order_on = [] {
     const char* e = getenv("MPSE_F0_ORDER");
@@ -697,17 +739,17 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
                        static_cast<const double2*>(h->L), static_cast<const double2*>(h->R), reinterpret_cast<double2*>(base),
                        reinterpret_cast<unsigned char*>(base + o_fl), reinterpret_cast<unsigned char*>(base + o_fr), Dl, Dr, wl,
                        wr, ntl, ntr, ctx->skip_flag);
-    hipLaunchKernelGGL(k_f0_valid, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const unsigned char*>(base + o_fl), FC,
-                       reinterpret_cast<const unsigned char*>(base + o_fr), reinterpret_cast<const F0Term*>(base + o_tm),
-                       reinterpret_cast<const int*>(base + o_nt), wl, wr, d, ntl, ntr, nkc, fc_pitch,
-                       reinterpret_cast<unsigned long long*>(base + o_mk), ctx->skip_flag);
     if (order_on)
-      hipLaunchKernelGGL(k_f0_order, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const unsigned char*>(base + o_fl),
-                         FC, reinterpret_cast<const unsigned long long*>(base + o_mk),
-                         reinterpret_cast<const F0Term*>(base + o_tm), reinterpret_cast<const int*>(base + o_nt), wl, wr, d, ntl,
-                         ntr, nkc, fc_pitch, ctx->n_cu > 0 ? ctx->n_cu : 256, reinterpret_cast<F0Info*>(base + o_od),
-                         reinterpret_cast<unsigned short*>(base + o_wt), reinterpret_cast<const unsigned char*>(base + o_fr),
-                         compact ? 1 : 0, ctx->skip_flag);
+      hipLaunchKernelGGL(k_f0_plan, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const unsigned char*>(base + o_fl), FC,
+                         reinterpret_cast<const unsigned char*>(base + o_fr), reinterpret_cast<const F0Term*>(base + o_tm),
+                         reinterpret_cast<const int*>(base + o_nt), wl, wr, d, ntl, ntr, nkc, fc_pitch,
+                         reinterpret_cast<unsigned long long*>(base + o_mk), ctx->n_cu > 0 ? ctx->n_cu : 256,
+                         reinterpret_cast<F0Info*>(base + o_od), compact ? 1 : 0, ctx->skip_flag);
+    else
+      hipLaunchKernelGGL(k_f0_valid, dim3(1), dim3(1024), 0, ctx->stream, reinterpret_cast<const unsigned char*>(base + o_fl), FC,
+                         reinterpret_cast<const unsigned char*>(base + o_fr), reinterpret_cast<const F0Term*>(base + o_tm),
+                         reinterpret_cast<const int*>(base + o_nt), wl, wr, d, ntl, ntr, nkc, fc_pitch,
+                         reinterpret_cast<unsigned long long*>(base + o_mk), ctx->skip_flag);
   }
   F0Args g{};
   g.L = static_cast<const double*>(h->L);
@@ -721,7 +763,6 @@ int heff0_fused_try(mpse_ctx* ctx, int dtype, const mpse_heff* h, const void* C,
   g.nterm = reinterpret_cast<const int*>(base + o_nt);
   g.mask = reinterpret_cast<const unsigned long long*>(base + o_mk);
   g.skip = ctx->skip_flag;
-  g.prefetch2 = prefetch2;
   g.info = order_on ? reinterpret_cast<const F0Info*>(base + o_od) : nullptr;
   g.trace = ctx->prof_on ? ctx->gemm_trace : nullptr;
   g.n = n;
