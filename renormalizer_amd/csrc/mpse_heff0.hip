@@ -184,52 +184,54 @@ __global__ __launch_bounds__(1024) void k_f0_plan(const unsigned char* __restric
                                                    int nkc, int fc_pitch, unsigned long long* __restrict__ mask, int n_cu,
                                                    F0Info* __restrict__ info, int compact, const int* __restrict__ skip) {
   if (skip && *skip) return;
-  constexpr int WMAX = 256, STAGE = 8192;
+  // (the caller guarantees ntl, ntr <= 64, wl, wr <= 16 and at most MROWS flag rows of each kind: heff0_fused_parts)
+  constexpr int WMAX = 256, STAGE = 16384, MROWS = 1024;
   __shared__ unsigned long long s1[64], s2[64];    // per bra tile row / per l tile: bit s
   __shared__ int hist[WMAX], start[WMAX], s_nw;
-  __shared__ unsigned char sFL[STAGE], sFR[STAGE], sFC[STAGE];
+  __shared__ unsigned char sB[STAGE];              // flag bytes on their way to the row masks below
+  __shared__ unsigned long long mL[MROWS], mR[MROWS], mC[64];   // rows of FL / FR / FC as bit masks over their tiles
   __shared__ F0Term sT[16 * F0_TMAX];
   __shared__ int sNT[16];
-  const int nparts = wr * nkc, tid = threadIdx.x, nu = ntl * nparts * d;
-  const int nfl = ntl * wl * ntl, nfr = ntr * wr * ntr, nfc = FC ? d * nkc * fc_pitch : 0;
-  const bool staged = nfl <= STAGE && nfr <= STAGE && nfc <= STAGE && wr <= 16;
-  if (staged) {
-    for (int i = tid; i < nfl; i += 1024) sFL[i] = FL[i];
-    for (int i = tid; i < nfr; i += 1024) sFR[i] = FR[i];
-    for (int i = tid; i < nfc; i += 1024) sFC[i] = FC[i];
-    for (int i = tid; i < wr * F0_TMAX; i += 1024) sT[i] = terms[i];
-    if (tid < wr) sNT[tid] = nterm[tid];
-  }
+  const int nparts = wr * nkc, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nu = ntl * nparts * d;
+  // a flag row (nt bytes) -> one word: staged through LDS (one coalesced trip to memory per kind), a wave per row
+  auto rows_to_masks = [&](const unsigned char* F, int nrows, int nt, int pitch, unsigned long long* out) {
+    for (int r0 = 0; r0 < nrows; r0 += STAGE / 64) {
+      const int nr = min(nrows - r0, STAGE / 64);
+      for (int i = tid; i < nr * nt; i += 1024) sB[(i / nt) * 64 + i % nt] = F[(long long)(r0 + i / nt) * pitch + i % nt];
+      __syncthreads();
+      for (int r = wave; r < nr; r += 16) {
+        const unsigned long long m = __ballot(lane < nt && sB[r * 64 + lane] != 0);
+        if (lane == 0) out[r0 + r] = m;
+      }
+      __syncthreads();
+    }
+  };
+  rows_to_masks(FL, ntl * wl, ntl, ntl, mL);
+  rows_to_masks(FR, ntr * wr, ntr, ntr, mR);
+  if (FC) rows_to_masks(FC, d * nkc, ntl, fc_pitch, mC);
+  for (int i = tid; i < wr * F0_TMAX; i += 1024) sT[i] = terms[i];
+  if (tid < wr) sNT[tid] = nterm[tid];
   if (tid < 64) s1[tid] = s2[tid] = 0;
   for (int i = tid; i < WMAX; i += 1024) hist[i] = 0;
   if (tid == 0) s_nw = 0;
   __syncthreads();
-  const unsigned char* pFL = staged ? sFL : FL;
-  const unsigned char* pFR = staged ? sFR : FR;
-  const unsigned char* pFC = FC ? (staged ? sFC : FC) : nullptr;
-  const F0Term* pT = staged ? sT : terms;
-  const int* pNT = staged ? sNT : nterm;
+  const unsigned long long all_c = ntl >= 64 ? ~0ull : ((1ull << ntl) - 1);
   auto c_tiles = [&](int at, const F0Term& tm, int kc) {       // c tiles where L (rows at, channel b) and C (e, chunk kc) hold data
-    unsigned long long c = 0;
-    for (int ct = 0; ct < ntl; ++ct)
-      if (pFL[(at * wl + tm.b) * ntl + ct] && (!pFC || pFC[(tm.e * nkc + kc) * fc_pitch + ct])) c |= 1ull << ct;
-    return c;
+    return mL[at * wl + tm.b] & (FC ? mC[tm.e * nkc + kc] : all_c);
+  };
+  auto k_tiles = [&](int lt, int f, int kc) {                  // 4 bits: k tiles of chunk kc where R (rows lt, channel f) holds data
+    return (unsigned)((mR[lt * wr + f] >> (4 * kc)) & 0xfull);
   };
   // ---- the part mask (as k_f0_valid)
   for (int t = tid; t < ntl * nparts; t += 1024) {
     const int at = t / nparts, sp = t - at * nparts, f = sp / nkc, kc = sp - f * nkc;
     bool any = false;
-    for (int q = 0; q < pNT[f]; ++q) any = any || c_tiles(at, pT[f * F0_TMAX + q], kc) != 0;
+    for (int q = 0; q < sNT[f]; ++q) any = any || c_tiles(at, sT[f * F0_TMAX + q], kc) != 0;
     if (any) atomicOr(&s1[at], 1ull << sp);
   }
   for (int t = tid; t < ntr * nparts; t += 1024) {
     const int lt = t / nparts, sp = t - lt * nparts, f = sp / nkc, kc = sp - f * nkc;
-    bool any = false;
-    for (int j = 0; j < 4; ++j) {
-      const int kt = 4 * kc + j;
-      if (kt < ntr) any = any || pFR[(lt * wr + f) * ntr + kt];
-    }
-    if (any) atomicOr(&s2[lt], 1ull << sp);
+    if (k_tiles(lt, f, kc)) atomicOr(&s2[lt], 1ull << sp);
   }
   __syncthreads();
   for (int t = tid; t < ntl * d * ntr; t += 1024) {
@@ -247,16 +249,12 @@ __global__ __launch_bounds__(1024) void k_f0_plan(const unsigned char* __restric
       for (int lt = 0; lt < ntr; ++lt)
         if ((s2[lt] >> sp) & 1ull) {
           ++nlt;
-          if (lt < 64) I.lts |= 1ull << lt;
-          if (lt < 16)
-            for (int jj = 0; jj < 4; ++jj) {
-              const int kt = 4 * kc + jj;
-              if (kt < ntr && pFR[(lt * wr + f) * ntr + kt]) I.frn |= 1ull << (4 * lt + jj);
-            }
+          I.lts |= 1ull << lt;
+          if (lt < 16) I.frn |= (unsigned long long)k_tiles(lt, f, kc) << (4 * lt);
         }
     if (nlt)
-      for (int q = 0; q < pNT[f]; ++q) {
-        const F0Term tm = pT[f * F0_TMAX + q];
+      for (int q = 0; q < sNT[f]; ++q) {
+        const F0Term tm = sT[f * F0_TMAX + q];
         if (tm.x != x) continue;
         const unsigned long long c = c_tiles(at, tm, kc);
         nct += __builtin_popcountll(c);

@@ -13,9 +13,14 @@
 namespace {
 
 constexpr int RED_MAX_BLOCKS = 512;  // two blocks per CU; consumers of the partials re-sum all of them per block
+                                     // (1 024 / 2 048 measured: 586 / 582 against 589 site-updates/s, r06_ab_red_blocks.txt)
 
+// Two doubles per thread - one complex element - up to the cap.  Rounds 1 - 5 gave a thread eight: the vectors of the bond
+// and two-level-site solves (1 - 2 MB) then ran on 64 - 128 workgroups whose threads made two to four PASSES of dependent
+// trips to memory (mask word -> parts -> store) - latency bound by their own grid.  One pass per thread: k_lanczos_update_u
+// 45.9 -> 33.8 ms per two steps at four doubles already, +4.7 % on the headline at two (profiles/r06_ab_red_blocks.txt).
 inline int red_blocks(int64_t n_doubles) {
-  int64_t b = (n_doubles + RED_THREADS * 8 - 1) / (RED_THREADS * 8);
+  int64_t b = (n_doubles + RED_THREADS * 2 - 1) / (RED_THREADS * 2);
   if (b < 1) b = 1;
   if (b > RED_MAX_BLOCKS) b = RED_MAX_BLOCKS;
   return (int)b;
@@ -254,6 +259,71 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
   // zero in the tiles it leaves out - nothing is read there and zeros are written (a wave works on 64 consecutive
   // elements of one row: the test is uniform over the wave)
   if (done && *done) return;
+  // The first pair of elements of this thread is requested BEFORE the scalars of the step are summed: its loads (mask
+  // word, parts, U_j, U_{j-1}) do not depend on them, and the two block reductions of sum_partials otherwise stand in
+  // front of every trip to memory of a kernel that is nothing but such trips.  Same arithmetic, same order.
+  const long long stride = (long long)gridDim.x * RED_THREADS;
+  const long long n2v = n_doubles >> 1;
+  const double2 zz0 = make_double2(0.0, 0.0);
+  struct Pair {
+    double2 ya, yb, va, ua, vb, ub;
+    bool h1;
+  };
+  auto fetch = [&](long long i) {
+    Pair q;
+    const double2* py = reinterpret_cast<const double2*>(y);
+    const double2* p1 = reinterpret_cast<const double2*>(u1);
+    const double2* p0 = reinterpret_cast<const double2*>(u0);
+    const long long i1 = i + stride;
+    q.h1 = i1 < n2v;
+    bool la = true, lb = q.h1;      // element i / i1 lies in a tile the centre mask keeps (always, without a mask)
+    if (pmask) {
+      auto gather = [&](long long e) {
+        const unsigned ee = (unsigned)e, row = ee / (unsigned)prow, col = ee - row * (unsigned)prow;
+        unsigned long long m = pmask[(row >> 4) * ptiles + (col >> 4)];
+        double2 acc = zz0;
+        while (m) {          // four parts per round: their loads are in flight together, added in part order
+          int sp[4];
+          double2 t[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            sp[u] = m ? __builtin_ctzll(m) : -1;
+            m &= m - (m ? 1 : 0);
+            t[u] = sp[u] >= 0 ? py[(long long)sp[u] * (part_stride >> 1) + e] : zz0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc.x += t[u].x, acc.y += t[u].y;
+        }
+        return acc;
+      };
+      q.ya = gather(i);
+      q.yb = q.h1 ? gather(i1) : zz0;
+    } else {
+      // (one arithmetic path with and without the mask: the same expression trees, so the same fused multiply-adds)
+      if (cmask) {
+        auto live = [&](long long e) {
+          const unsigned ee = (unsigned)e, row = ee / (unsigned)crow, col = ee - row * (unsigned)crow;
+          return cmask[(col >> 6) * ckw + (row >> 4)] != 0;
+        };
+        la = live(i);
+        lb = q.h1 && live(i1);
+      }
+      q.ya = la ? py[i] : zz0, q.yb = lb ? py[i1] : zz0;
+      for (int s = 1; s < nparts; ++s) {
+        const double2* ps = py + s * (part_stride >> 1);
+        const double2 ta = la ? ps[i] : zz0, tb = lb ? ps[i1] : zz0;
+        q.ya.x += ta.x, q.ya.y += ta.y, q.yb.x += tb.x, q.yb.y += tb.y;
+      }
+    }
+    q.va = la ? p1[i] : zz0, q.ua = (la && u0) ? p0[i] : zz0;
+    q.vb = lb ? p1[i1] : zz0, q.ub = (lb && u0) ? p0[i1] : zz0;
+    return q;
+  };
+  const long long i_first = (long long)blockIdx.x * RED_THREADS + threadIdx.x;
+  Pair first;
+  first.h1 = false;
+  if (VEC && i_first < n2v) first = fetch(i_first);
+  asm volatile("" ::: "memory");
   double araw, a_im, cur2, z;
   sum_partials(a_partial, a_nb, araw, a_im);
   sum_partials(cur_partial, cur_nb, cur2, z);
@@ -268,64 +338,16 @@ __global__ __launch_bounds__(RED_THREADS) void k_lanczos_update_u(double* __rest
   const double c_y = s1, c_1 = a * s1;
   const double c_0 = u0 ? sqrt(cur2) / sqrt(*prev2) : 0.0;   // beta_{j-1} s_{j-1}
   double s = 0, zero = 0;
-  const long long stride = (long long)gridDim.x * RED_THREADS;
   if (VEC) {
-    const long long n2 = n_doubles >> 1;
     double2* o2 = reinterpret_cast<double2*>(u_next);
-    const double2* py = reinterpret_cast<const double2*>(y);
-    const double2* p1 = reinterpret_cast<const double2*>(u1);
-    const double2* p0 = reinterpret_cast<const double2*>(u0);
-    const double2 zz = make_double2(0.0, 0.0);
-    for (long long i = (long long)blockIdx.x * RED_THREADS + threadIdx.x; i < n2; i += 2 * stride) {
+    for (long long i = i_first; i < n2v; i += 2 * stride) {
+      const Pair q = i == i_first ? first : fetch(i);
       const long long i1 = i + stride;
-      const bool h1 = i1 < n2;
-      double2 ya, yb;
-      bool la = true, lb = h1;      // element i / i1 lies in a tile the centre mask keeps (always, without a mask)
-      if (pmask) {
-        auto gather = [&](long long e) {
-          const unsigned ee = (unsigned)e, row = ee / (unsigned)prow, col = ee - row * (unsigned)prow;
-          unsigned long long m = pmask[(row >> 4) * ptiles + (col >> 4)];
-          double2 acc = zz;
-          while (m) {          // four parts per round: their loads are in flight together, added in part order
-            int sp[4];
-            double2 t[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              sp[u] = m ? __builtin_ctzll(m) : -1;
-              m &= m - (m ? 1 : 0);
-              t[u] = sp[u] >= 0 ? py[(long long)sp[u] * (part_stride >> 1) + e] : zz;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc.x += t[u].x, acc.y += t[u].y;
-          }
-          return acc;
-        };
-        ya = gather(i);
-        yb = h1 ? gather(i1) : zz;
-      } else {
-        // (one arithmetic path with and without the mask: the same expression trees, so the same fused multiply-adds)
-        if (cmask) {
-          auto live = [&](long long e) {
-            const unsigned ee = (unsigned)e, row = ee / (unsigned)crow, col = ee - row * (unsigned)crow;
-            return cmask[(col >> 6) * ckw + (row >> 4)] != 0;
-          };
-          la = live(i);
-          lb = h1 && live(i1);
-        }
-        ya = la ? py[i] : zz, yb = lb ? py[i1] : zz;
-        for (int s = 1; s < nparts; ++s) {
-          const double2* ps = py + s * (part_stride >> 1);
-          const double2 ta = la ? ps[i] : zz, tb = lb ? ps[i1] : zz;
-          ya.x += ta.x, ya.y += ta.y, yb.x += tb.x, yb.y += tb.y;
-        }
-      }
-      const double2 va = la ? p1[i] : zz, ua = (la && u0) ? p0[i] : zz;
-      const double2 vb = lb ? p1[i1] : zz, ub = (lb && u0) ? p0[i1] : zz;
-      const double2 xa = make_double2(c_y * ya.x - (c_1 * va.x + c_0 * ua.x), c_y * ya.y - (c_1 * va.y + c_0 * ua.y));
-      const double2 xb = make_double2(c_y * yb.x - (c_1 * vb.x + c_0 * ub.x), c_y * yb.y - (c_1 * vb.y + c_0 * ub.y));
+      const double2 xa = make_double2(c_y * q.ya.x - (c_1 * q.va.x + c_0 * q.ua.x), c_y * q.ya.y - (c_1 * q.va.y + c_0 * q.ua.y));
+      const double2 xb = make_double2(c_y * q.yb.x - (c_1 * q.vb.x + c_0 * q.ub.x), c_y * q.yb.y - (c_1 * q.vb.y + c_0 * q.ub.y));
       o2[i] = xa;
       s += xa.x * xa.x + xa.y * xa.y;
-      if (h1) {
+      if (q.h1) {
         o2[i1] = xb;
         s += xb.x * xb.x + xb.y * xb.y;
       }
