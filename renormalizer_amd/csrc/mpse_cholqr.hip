@@ -1068,12 +1068,10 @@ bool cholqr_eligible(const mpse_ctx* ctx, const QrBlk* blks, int nblk) {
     max_mm = std::max(max_mm, blks[b].mm);
     max_nn = std::max(max_nn, blks[b].nn);
   }
-  static const int min_cols = [] {
-    const char* e = getenv("MPSE_CHOLQR_MINCOLS");
-    return e ? atoi(e) : 96;
-  }();
   if (mode >= 2) return true;
-  return max_mm >= min_rows && max_nn >= min_cols;
+  // (96 columns: with the two-pass scheme of round 6 a threshold of 48 was measured again on the spin-boson chain, the
+  // D = 64 Holstein chain and the 497-site FMO chain - within the scatter of the box either way, profiles/r06_small_mincols.txt)
+  return max_mm >= min_rows && max_nn >= 96;
 }
 
 int cholqr_blocks(mpse_ctx* ctx, bool cplx, double* ws, const QrBlk* blks, int nblk, const long long* drows,

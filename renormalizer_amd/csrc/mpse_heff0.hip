@@ -185,25 +185,29 @@ __global__ __launch_bounds__(1024) void k_f0_plan(const unsigned char* __restric
                                                    F0Info* __restrict__ info, int compact, const int* __restrict__ skip) {
   if (skip && *skip) return;
   // (the caller guarantees ntl, ntr <= 64, wl, wr <= 16 and at most MROWS flag rows of each kind: heff0_fused_parts)
-  constexpr int WMAX = 256, STAGE = 16384, MROWS = 1024;
+  constexpr int WMAX = 256, MROWS = 1024;
   __shared__ unsigned long long s1[64], s2[64];    // per bra tile row / per l tile: bit s
   __shared__ int hist[WMAX], start[WMAX], s_nw;
-  __shared__ unsigned char sB[STAGE];              // flag bytes on their way to the row masks below
   __shared__ unsigned long long mL[MROWS], mR[MROWS], mC[64];   // rows of FL / FR / FC as bit masks over their tiles
   __shared__ F0Term sT[16 * F0_TMAX];
   __shared__ int sNT[16];
   const int nparts = wr * nkc, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nu = ntl * nparts * d;
-  // a flag row (nt bytes) -> one word: staged through LDS (one coalesced trip to memory per kind), a wave per row
+  // a flag row (nt <= 64 bytes) -> one word: a wave per row, a lane per tile, straight from global memory; the rows a wave
+  // takes are requested together (four at a time), so that all three kinds of flags cost about one trip to memory
   auto rows_to_masks = [&](const unsigned char* F, int nrows, int nt, int pitch, unsigned long long* out) {
-    for (int r0 = 0; r0 < nrows; r0 += STAGE / 64) {
-      const int nr = min(nrows - r0, STAGE / 64);
-      for (int i = tid; i < nr * nt; i += 1024) sB[(i / nt) * 64 + i % nt] = F[(long long)(r0 + i / nt) * pitch + i % nt];
-      __syncthreads();
-      for (int r = wave; r < nr; r += 16) {
-        const unsigned long long m = __ballot(lane < nt && sB[r * 64 + lane] != 0);
-        if (lane == 0) out[r0 + r] = m;
+    for (int r0 = wave; r0 < nrows; r0 += 64) {
+      unsigned char v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = r0 + 16 * j;
+        v[j] = (r < nrows && lane < nt) ? F[(long long)r * pitch + lane] : (unsigned char)0;
       }
-      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = r0 + 16 * j;
+        const unsigned long long m = __ballot(v[j] != 0);
+        if (r < nrows && lane == 0) out[r] = m;
+      }
     }
   };
   rows_to_masks(FL, ntl * wl, ntl, ntl, mL);
