@@ -103,7 +103,8 @@ class _MarginalSolves:
 
 
 def _oracle_step(ost, w_host):
-    with _MarginalSolves() as spy:
+    from conftest import oracle_threads
+    with _MarginalSolves() as spy, oracle_threads():
         nxt = orc.tdvp_ps_step(ost, w_host, 10.0)
     return nxt, spy.rec
 
@@ -143,14 +144,17 @@ def _compare_evolve(model, mpo, dev, ost, solves):
     solves ``solves`` as recorded by ``_MarginalSolves``)."""
     from test_engine_gpu import dev_expm
     from renormalizer_amd.engine import get_engine
+    from conftest import oracle_threads
     w_host = [mpo[i] for i in range(len(mpo))]
     occ_dev = np.asarray(dev.e_occupations)
     occ_mpos = model.mpos["e_occupations"]
-    occ_orc = _oracle_local_expectations(ost.sites, occ_mpos)
-    k = len(occ_mpos) // 2                                  # (the fast path against the oracle's own routine, one operator)
-    assert abs(occ_orc[k] - orc.expectation(ost.sites, [occ_mpos[k][i] for i in range(len(occ_mpos[k]))]).real) < 1e-12
+    with oracle_threads():
+        occ_orc = _oracle_local_expectations(ost.sites, occ_mpos)
+        k = len(occ_mpos) // 2                              # (the fast path against the oracle's own routine, one operator)
+        assert abs(occ_orc[k] - orc.expectation(ost.sites, [occ_mpos[k][i] for i in range(len(occ_mpos[k]))]).real) < 1e-12
+        e_orc = orc.expectation(ost.sites, w_host)
     assert np.abs(occ_dev - occ_orc).max() < 1e-8, np.abs(occ_dev - occ_orc).max()
-    e_dev, e_orc = dev.expectation(mpo), orc.expectation(ost.sites, w_host)
+    e_dev = dev.expectation(mpo)
     assert abs(e_dev - e_orc) < 1e-8
     assert abs(dev.mp_norm - 1.0) < 1e-12
     # integer bookkeeping: bit exact

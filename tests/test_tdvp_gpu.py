@@ -326,13 +326,17 @@ def test_config4_full_size_invariants():
             ost = orc.MpsState(psi.to_arrays(), [q.copy() for q in psi.qn], psi.qnidx, psi.qntot.copy(), psi.to_right,
                                [np.array(b.sigmaqn) for b in model.basis], complex(psi.coeff))
             w_host = [mpo[i] for i in range(len(mpo))]
-            ost = orc.tdvp_ps_step(ost, w_host, 160.0)
+            from conftest import oracle_threads
+            with oracle_threads():           # (tiny products: 64 BLAS threads on a 256-core host only get in each other's way)
+                ost = orc.tdvp_ps_step(ost, w_host, 160.0)
         psi = psi.evolve(mpo, 160.0)
         if unit == 0:
-            occ_orc = np.array([orc.expectation(ost.sites, [m[i] for i in range(len(m))]).real
-                                for m in model.mpos["e_occupations"]])
+            with oracle_threads():
+                occ_orc = np.array([orc.expectation(ost.sites, [m[i] for i in range(len(m))]).real
+                                    for m in model.mpos["e_occupations"]])
+                e_orc = orc.expectation(ost.sites, w_host)
             assert np.abs(np.asarray(psi.e_occupations) - occ_orc).max() < 1e-8
-            assert abs(psi.expectation(mpo) - orc.expectation(ost.sites, w_host)) < 1e-8
+            assert abs(psi.expectation(mpo) - e_orc) < 1e-8
             assert list(psi.bond_dims) == list(ost.bond_dims) and psi.qnidx == ost.qnidx and psi.to_right == ost.to_right
             for qa, qb in zip(psi.qn, ost.qn):
                 assert np.array_equal(np.sort(np.asarray(qa).ravel()), np.sort(np.asarray(qb).ravel()))
