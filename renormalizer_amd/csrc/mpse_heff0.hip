@@ -43,7 +43,7 @@ struct F0Term {
   int b, e, x, pad;
   double w;
 };
-// What a launch position needs to start, in ONE read (k_f0_order): before round 6 a workgroup went to memory four times in a
+// What a launch position needs to start, in ONE read (k_f0_plan): before round 6 a workgroup went to memory four times in a
 // row before its first operand load - part mask, term count, terms, tile flags, ~1.5 us each and nothing to hide them
 // behind (the timeline of profiles/r06_f0_trace.md: 4 - 6 k cycles of prelude).  The compact form holds for bonds of up to
 // 256 (16 tiles a side) and at most four terms per (channel, x); other shapes keep nt = -1 and read the tables.
@@ -70,7 +70,7 @@ struct F0Args {
   const F0Term* terms;    // [f * F0_TMAX + t]
   const int* nterm;       // [f]
   const int* skip;
-  const F0Info* info;     // launch position -> unit, heaviest first, with what it needs to start (k_f0_order); null: plain order
+  const F0Info* info;     // launch position -> unit, heaviest first, with what it needs to start (k_f0_plan); null: plain order
   long long n;
   int Dl, Dr, wl, wr, d, ntl, ntr, nkc, fc_pitch;
   unsigned long long* trace;   // debug timeline (mpse_ctx::gemm_trace, MPSE_GEMM_TRACE), null normally
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(1024) void k_f0_plan(const unsigned char* __restric
 
 // A unit = (bra tile row, part, value x of the physical index of the result - 0 for a bond matrix): the terms of the other
 // x are another workgroup's - half the chain of the heaviest workgroups, which set the duration of the launch.  Launch
-// positions map to units through g.info (k_f0_order: heaviest first).
+// positions map to units through g.info (k_f0_plan: heaviest first).
 // Two workgroups per compute unit (256 registers per lane, 24 bytes of scratch): the launch of a two-level site has 640
 // workgroups for 256 compute units and is as long as the sum of their chains, not as the longest one - a second
 // workgroup's MFMAs fill the first one's waits (site launch 54 -> 45 us, 382 -> 375 ms of kernels per two steps).
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void k_heff0_fused(const F0Args g) {
   // does, and splitting still lost: 546 -> 517 site-updates/s with two workgroups per unit, 458 with four, alternating runs
   // on one box, profiles/r06_ab_qr_f0split.txt - the extra workgroups land on compute units that already hold a working one,
   // and two working workgroups on a unit share its MFMA pipes (25 against 20 us of life, profiles/r06_f0_trace.md).  What
-  // helped is WHERE the working workgroups run: k_f0_order.)
+  // helped is WHERE the working workgroups run: k_f0_plan.)
   // Launch position -> (bra tile row, part), plain order.  (Measured and dropped: a die - launch position mod 8, one L2
   // each - taking whole parts, so that its L2 holds only the panels of C and Rt its workgroups share.  Dealt channel-major
   // the heavy parts - ket chunks that straddle two quantum-number sectors - piled up on two dies: 39 us against 33; dealt
