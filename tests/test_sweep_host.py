@@ -80,3 +80,33 @@ def test_centre_tile_mask_matches_the_allowed_pattern():
         assert np.array_equal(m.view(np.uint8).reshape(ntn, nkw * 8), ref)
         assert H.centre_tile_mask(eng, ql, qnr, qt, (Dl, d, Dr)) is m        # cached
     assert H.centre_tile_mask(eng, ql, qnr, qt, (Dl + 1, d, Dr)) is None      # quantum numbers of another shape
+
+
+def test_qr_notes_travel_with_the_state():
+    """The (site, direction) pairs whose block QR fell back to the Householder kernels are noted ON the state (round 6;
+    rounds 4-5 kept them in a thread-local keyed by the chain's shape, so that an evolve depended on what the thread had
+    evolved before): a copy starts from its parent's notes and evolves its own, a note expires after its patience, and a
+    site that breaks down again is noted with doubled patience."""
+    class Dummy:
+        pass
+
+    a = Dummy()
+    notes = M._householder_sites(a)
+    assert notes is M._householder_sites(a) and (3, True) not in notes
+    notes.note((3, True))
+    assert (3, True) in notes and (3, False) not in notes
+    b = Dummy()
+    b._qr_notes = notes.copy()                    # what Mps.metacopy does
+    for _ in range(M._QrNotes.FIRST):
+        M._householder_sites(b).tick()
+    assert (3, True) not in M._householder_sites(b) and (3, True) in notes      # the copy's clock, not the parent's
+    M._householder_sites(b).note((3, True))       # breaks down again: twice the patience
+    for _ in range(M._QrNotes.FIRST):
+        M._householder_sites(b).tick()
+    assert (3, True) in M._householder_sites(b)
+    for _ in range(M._QrNotes.FIRST):
+        M._householder_sites(b).tick()
+    assert (3, True) not in M._householder_sites(b)
+    # the real class copies them in metacopy
+    import inspect
+    assert "_qr_notes" in inspect.getsource(M.Mps.metacopy)
