@@ -19,9 +19,11 @@ def select_basis_indices(sset, qnlist, Mmax, percent=0.0):
     n = len(sset)
     ids = None
     if percent != 0:
-        qn_t = [tuple(int(x) for x in np.atleast_1d(qn)) for qn in qnlist]
-        rank = {b: i for i, b in enumerate(sorted(set(qn_t)))}
-        ids = np.ascontiguousarray([rank[q] for q in qn_t], dtype=np.int64)
+        # block id of every state = rank of its quantum number among the distinct ones in lexicographic order (rows of an
+        # integer array: np.unique sorts them that way)
+        qn_a = np.asarray(qnlist, dtype=np.int64).reshape(n, -1)
+        _, inv = np.unique(qn_a, axis=0, return_inverse=True)
+        ids = np.ascontiguousarray(np.asarray(inv).reshape(-1), dtype=np.int64)
     picked = np.empty(max(n, 1), dtype=np.int64)
     npicked = C.c_int64(0)
     st = _LIB.mpse_truncate_select(sset.ctypes.data_as(C.POINTER(C.c_double)),
@@ -29,6 +31,6 @@ def select_basis_indices(sset, qnlist, Mmax, percent=0.0):
                                    float(percent), picked.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(npicked))
     if st != 0:
         raise ValueError(f"mpse_truncate_select failed with status {st}")
-    out = [int(i) for i in picked[:npicked.value]]
+    out = picked[:npicked.value].tolist()
     assert len(set(out)) == len(out)
     return out
