@@ -37,6 +37,10 @@ def main():
         return 8.0 * dl * dl * wl * d * dr + 4.0 * dl * dr * wl * wr * d * d + 8.0 * dl * dr * dr * wr * d
 
     res = {}
+    tracing = bool(os.environ.get("MPSE_GEMM_TRACE"))     # per-workgroup timeline of these launches (tools/gemm_trace.py)
+    if tracing:
+        eng.prof_reset()
+        eng.prof_enable(1)
     for dom in ("L", "R"):
         sites = range(0, n - 1) if dom == "L" else range(n - 1, 0, -1)
         fl = sum(flops(i) for i in sites)
@@ -49,6 +53,9 @@ def main():
         dt = (time.perf_counter() - t0) / reps
         res[dom] = dict(ms=dt * 1e3, updates=len(list(sites)), gflop=fl / 1e9, tflops=fl / dt / 1e12,
                         frac_of_78_6=fl / dt / 78.6e12)
+    if tracing:
+        eng.prof_get()                                     # (writes the trace file)
+        eng.prof_enable(False)
     res["bond_dims"] = dims
     print(json.dumps(res))
     if out:
