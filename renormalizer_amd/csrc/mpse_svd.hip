@@ -747,6 +747,394 @@ __global__ __launch_bounds__(64 * JB_COLS) void k_jacobi_block(double* ws, doubl
   if (lane == 0 && rotations) atomicAdd(nrot + b, rotations);
 }
 
+// Block step on the Gram matrix (round 6): a pair of JG-column blocks of X and V is rotated through its 2 JG x 2 JG Gram
+// matrix instead of through its columns - the step for blocks too wide for the column kernel above (its LDS holds
+// 4 JB_COLS columns of nn rows: nn <= 256 complex), where the alternative is one launch per rotation step.
+//   1. G = Y^H Y of the 2 JG = 32 columns Y of the pair, on MFMA straight from memory (rows dealt to the 4 waves, partial
+//      sums added through LDS in a fixed order).  Only the first launch of a sweep forms all three tiles: the diagonal
+//      tiles of a column block travel with it (dgin / dgout: what the rotations of the previous launch made of them),
+//      the later launches form the tile of the cross products;
+//   2. the inner round robin runs on G alone: two-sided rotations G <- J^H G J in LDS (thread (k, l) owns the 2 x 2 block
+//      of column pair k against column pair l and forms both rotations itself from the diagonal blocks - one barrier per
+//      inner step, two copies of G by parity), U <- U J accumulated one step behind.  The rotation of a pair is the one
+//      the column kernels form from the same three Gram entries; what differs is that the entries are carried through
+//      the inner steps by the rotation formulas instead of being recomputed from the columns - two-sided Jacobi on a
+//      positive definite matrix keeps the accuracy relative to the scaled matrix (Demmel / Veselic, SIAM J. Matrix
+//      Anal. Appl. 13 (1992) 1204), and every sweep starts from fresh entries;
+//   3. [X; V](:, pair) <- [X; V](:, pair) U on MFMA, 16-row tiles, transposed form so that loads and stores run along
+//      the columns.
+// The products are 6 nn 32^2 complex multiply-adds per launch and FP64 MFMA runs at the vector rate on this part
+// (64 cycles per 16 x 16 x 4 step): ~20 us on ONE compute unit at nn = 256, so the rows of step 3 are dealt to R
+// workgroups per pair (each repeats steps 1 - 2: same inputs, same bits).  That needs the launch to read one copy of
+// X, V and write another (a workgroup must not overwrite rows a neighbour still reads for its Gram matrix): every
+// workgroup writes its rows of its columns in EVERY launch - converged blocks, steps past a block's last one and pairs
+// without a rotation copy them - so that the current copy is the same for all blocks.
+// Measured (profiles/r06_svd_gram_step.md): an inner step with all 16 rotations live costs ~4 600 cycles (rotation
+// parameters ~1 100, the 2 x 2 blocks ~1 600, U ~1 000, barrier ~400: one wave per SIMD, every LDS round trip and FP64
+// chain exposed), a launch at nn = 256 ~50 us for 256 cross pairs where the column kernel takes 28 us for 64: the sweep
+// costs the same (17 launches against 33) and whole runs are within +-2 %, so the column kernel keeps the blocks it
+// fits; at nn = 512 (one block of a 512 x 4096 centre) the decomposition takes 28 ms against 58 with a launch per step.
+constexpr int JG = 16;
+typedef double jg_v4d __attribute__((ext_vector_type(4)));
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_jacobi_gram(const double* __restrict__ xin, double* __restrict__ xout,
+                                                     const double* __restrict__ vin, double* __restrict__ vout,
+                                                     const double2* __restrict__ dgin, double2* __restrict__ dgout,
+                                                     int nbmax, const SvdBlk* __restrict__ blks, int step, int R,
+                                                     const double* __restrict__ null2v, int* nrot,
+                                                     const int* __restrict__ done) {
+  constexpr int NC = 2 * JG;
+  extern __shared__ double s_dyn[];
+  double2* sG0 = reinterpret_cast<double2*>(s_dyn);     // G by parity of the inner step: 2 x [32][32]
+  double2* sG1 = sG0 + NC * NC;
+  constexpr int NCP = NC + 1;                           // pitch of U: stored by COLUMN (a rotation step reads two columns
+  double2* sU = sG1 + NC * NC;                          // at 32 consecutive rows), padded against bank conflicts in step 3
+  double* sPart = reinterpret_cast<double*>(sU + NC * NCP);   // 2 slots x 3 tiles x (re, im) x 4 x 64
+  __shared__ int s_cnt;
+  const int b = blockIdx.y;
+  const SvdBlk B = blks[b];
+  const int nn = B.nn;
+  const int nb = ((nn + JG - 1) / JG + 1) & ~1;         // column blocks, padded to an even number
+  const int kk = blockIdx.x / R, slab = blockIdx.x - kk * R;
+  if (kk >= nb / 2) return;
+  const bool active = !done[b] && step < nb - 1;
+  const int pstep = active ? step : 0;                  // (idle launches copy by the pairing of step 0)
+  int bp, bq;
+  if (kk == 0) {
+    bp = pstep % (nb - 1);
+    bq = nb - 1;
+  } else {
+    bp = (pstep + kk) % (nb - 1);
+    bq = (pstep - kk + (nb - 1)) % (nb - 1);
+  }
+  if (bp > bq) {
+    const int t = bp;
+    bp = bq;
+    bq = t;
+  }
+  if (bp * JG >= nn) return;                            // both blocks are padding
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), x = lane & 15, kq = lane >> 4;
+  const double* X = xin + B.ws_off * Cx<CPLX>::E;
+  const double* V = vin + B.v_off * Cx<CPLX>::E;
+  double* Xo = xout + B.ws_off * Cx<CPLX>::E;
+  double* Vo = vout + B.v_off * Cx<CPLX>::E;
+  const double2* dgp_in = dgin + ((long long)b * nbmax + bp) * 256;
+  const double2* dgq_in = dgin + ((long long)b * nbmax + bq) * 256;
+  double2* dgp_out = dgout + ((long long)b * nbmax + bp) * 256;
+  double2* dgq_out = dgout + ((long long)b * nbmax + bq) * 256;
+  auto gcol = [&](int c) { return (c < JG ? bp : bq) * JG + (c & (JG - 1)); };   // local column -> column of X
+  if (tid == 0) s_cnt = 0;
+  for (int t = tid; t < NC * NC; t += 256) sU[(t >> 5) * NCP + (t & 31)] = make_double2((t >> 5) == (t & 31) ? 1.0 : 0.0, 0.0);
+  int rotated = 0;
+  if (active) {
+    // ---- 1. Gram matrix.  First launch of a sweep: all three tiles from the columns.  Later launches: the tile of the
+    // cross products only - the diagonal tiles are what the previous launch's rotations made of them (dgin: every
+    // launch leaves the diagonal tiles of its final G for the two column blocks it rotated).  Wave w takes the row
+    // steps w, w + 4, .. (four rows each); all loads of a wave go out before its first MFMA.
+    const bool fresh = step == 0;
+    double2 dg_p = make_double2(0.0, 0.0), dg_q = dg_p;
+    if (!fresh) {
+      dg_p = dgp_in[tid];
+      dg_q = dgq_in[tid];
+    }
+    jg_v4d gr[3], gi[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gr[i] = gi[i] = jg_v4d{0, 0, 0, 0};
+    {
+      const int c0 = gcol(x), c1 = gcol(JG + x);
+      const bool ok0 = c0 < nn, ok1 = c1 < nn;
+      const long long o0 = (long long)(ok0 ? c0 : 0) * nn, o1 = (long long)(ok1 ? c1 : 0) * nn;
+      const int nks = (nn + 3) >> 2;
+      for (int base = wave; base < nks; base += 64) {
+        double2 va[16], vb[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int ks = base + 4 * i;
+          va[i] = vb[i] = make_double2(0.0, 0.0);
+          if (ks < nks) {
+            const int r = min(4 * ks + kq, nn - 1);
+            va[i] = Cx<CPLX>::ld(X, o0 + r);
+            vb[i] = Cx<CPLX>::ld(X, o1 + r);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int ks = base + 4 * i;
+          if (ks >= nks) break;
+          const bool okr = 4 * ks + kq < nn;
+          const double ar = okr && ok0 ? va[i].x : 0.0, ai = okr && ok0 ? va[i].y : 0.0;
+          const double br = okr && ok1 ? vb[i].x : 0.0, bi = okr && ok1 ? vb[i].y : 0.0;
+          // conj(a) b = (ar br + ai bi) + i (ar bi - ai br)
+          gr[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, gr[1], 0, 0, 0);
+          if constexpr (CPLX) {
+            gr[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, gr[1], 0, 0, 0);
+            gi[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, bi, gi[1], 0, 0, 0);
+            gi[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, br, gi[1], 0, 0, 0);
+          }
+          if (fresh) {
+            gr[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, ar, gr[0], 0, 0, 0);
+            gr[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(br, br, gr[2], 0, 0, 0);
+            if constexpr (CPLX) {
+              gr[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, ai, gr[0], 0, 0, 0);
+              gr[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi, bi, gr[2], 0, 0, 0);
+              gi[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, ai, gi[0], 0, 0, 0);
+              gi[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, ar, gi[0], 0, 0, 0);
+              gi[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(br, bi, gi[2], 0, 0, 0);
+              gi[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-bi, br, gi[2], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // partial sums of the 4 waves in a fixed tree: (w, w + 2), then (0, 1); wave 1 writes into the slot it has consumed
+    auto put = [&](int slot) {
+      double* p = sPart + slot * 1536;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[(i * 8 + r) * 64 + lane] = gr[i][r];
+          p[(i * 8 + 4 + r) * 64 + lane] = gi[i][r];
+        }
+    };
+    auto add = [&](int slot) {
+      const double* p = sPart + slot * 1536;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gr[i][r] += p[(i * 8 + r) * 64 + lane];
+          gi[i][r] += p[(i * 8 + 4 + r) * 64 + lane];
+        }
+    };
+    if (wave >= 2) put(wave - 2);
+    if (!fresh) {          // the carried diagonal tiles
+      const int row = tid >> 4, col = tid & 15;
+      sG0[row * NC + col] = dg_p;
+      sG0[(JG + row) * NC + JG + col] = dg_q;
+    }
+    __syncthreads();
+    if (wave < 2) add(wave);
+    if (wave == 1) put(1);
+    __syncthreads();
+    if (wave == 0) {
+      add(1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = kq + 4 * r;
+        // tiles (0,0), (0,1), (1,1); the lower tile is the adjoint of (0,1); the diagonal is real
+        sG0[row * NC + JG + x] = make_double2(gr[1][r], gi[1][r]);
+        sG0[(JG + x) * NC + row] = make_double2(gr[1][r], -gi[1][r]);
+        if (fresh) {
+          sG0[row * NC + x] = make_double2(gr[0][r], row == x ? 0.0 : gi[0][r]);
+          sG0[(JG + row) * NC + JG + x] = make_double2(gr[2][r], row == x ? 0.0 : gi[2][r]);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 2. inner round robin on G
+    const double null2 = null2v[b], tol2 = B.tol * B.tol;
+    const bool full = step == 0;                        // (pairs inside a block: in the first launch of a sweep only)
+    const int nst = full ? NC - 1 : JG;
+    struct Rot {
+      double c, s, er, ei;
+      bool on;
+    };
+    auto pair_of = [&](int m, int st, int& p, int& q) {
+      if (full) {                                       // circle method on the 32 local columns
+        if (m == 0) {
+          p = st;                                       // (st < NC - 1)
+          q = NC - 1;
+        } else {
+          p = st + m;
+          if (p >= NC - 1) p -= NC - 1;
+          q = st - m + (NC - 1);
+          if (q >= NC - 1) q -= NC - 1;
+        }
+        if (p > q) {
+          const int t = p;
+          p = q;
+          q = t;
+        }
+      } else {                                          // cross pairs only
+        p = m;
+        q = JG + ((m + st) & (JG - 1));
+      }
+    };
+    // The rotation of the pair (p, q) from alpha = G_pp, beta = G_qq, g = G_pq - the one the column kernels form
+    // (tan 2 theta = 2 |g| / (beta - alpha), the smaller angle), arranged so that two long operations sit in series instead
+    // of four (every thread of the workgroup waits for this chain in every inner step): with d = beta - alpha,
+    // r = sqrt(d^2 + 4 |g|^2), w = |d| + r:  t = sign(d) 2 |g| / w,  c = w / sqrt(w^2 + 4 |g|^2),  s = c t;  the phase
+    // e = g / |g| comes from a reciprocal square root that runs beside the chain.  The three entries are scaled by a
+    // power of two first (squares of squared norms would leave the exponent range at column norms ~1e+-77).
+    // (Branch-free: the two rotations a thread forms are independent chains of ~30 dependent FP64 operations each and
+    // must overlap - behind a branch they ran one after the other, 4 900 cycles per inner step against 2 600 with every
+    // pair skipped.  Square root and reciprocal square root by the coupled iteration g -> sqrt, h -> 1 / (2 sqrt): two
+    // dependent levels per step instead of four.)
+    auto sqrt_pair = [](double xv, double& sq, double& rs) {
+      const double y = __builtin_amdgcn_rsq(xv);
+      double g = xv * y, h = 0.5 * y;
+      double e = __builtin_fma(-h, g, 0.5);
+      g = __builtin_fma(g, e, g);
+      h = __builtin_fma(h, e, h);
+      e = __builtin_fma(-h, g, 0.5);
+      sq = __builtin_fma(g, e, g);
+      rs = 2.0 * __builtin_fma(h, e, h);
+    };
+    auto rot_of = [&](const double2* G, int p, int q) {
+      const double alpha = G[p * NC + p].x, beta = G[q * NC + q].x;
+      const double2 g = G[p * NC + q];
+      const int ex = -__builtin_amdgcn_frexp_exp(alpha + beta);
+      const double as = __builtin_amdgcn_ldexp(alpha, ex), bs = __builtin_amdgcn_ldexp(beta, ex);
+      const double gx = __builtin_amdgcn_ldexp(g.x, ex), gy = __builtin_amdgcn_ldexp(g.y, ex);
+      const double g2 = gx * gx + gy * gy;
+      const bool on = alpha > null2 && beta > null2 && g2 != 0.0 && g2 > tol2 * as * bs;
+      const double g2s = on ? g2 : 1.0;                 // (a skipped pair runs the arithmetic on harmless numbers)
+      const double d = on ? bs - as : 0.0, f = __builtin_fma(d, d, 4.0 * g2s);
+      double absg, ig, r, ir;
+      sqrt_pair(g2s, absg, ig);
+      sqrt_pair(f, r, ir);
+      const double w = fabs(d) + r, f2 = __builtin_fma(w, w, 4.0 * g2s);
+      double r2, qn;
+      sqrt_pair(f2, r2, qn);
+      Rot rr;
+      rr.on = on;
+      rr.c = on ? w * qn : 1.0;
+      rr.s = on ? (d >= 0.0 ? 2.0 : -2.0) * absg * qn : 0.0;
+      rr.er = on ? gx * ig : 1.0;
+      rr.ei = on ? gy * ig : 0.0;
+      return rr;
+    };
+    // [a b] <- [a b] J,  J = [[c, s], [-s conj(e), c conj(e)]]  (the rotation of the column kernels: y = conj(e) b)
+    auto cols = [&](const Rot& r, double2& a, double2& bb) {
+      const double2 y = make_double2(bb.x * r.er + bb.y * r.ei, bb.y * r.er - bb.x * r.ei);
+      const double2 na = make_double2(r.c * a.x - r.s * y.x, r.c * a.y - r.s * y.y);
+      bb = make_double2(r.s * a.x + r.c * y.x, r.s * a.y + r.c * y.y);
+      a = na;
+    };
+    // [a; b] <- J^H [a; b]:  a' = c a - s e b,  b' = s a + c e b
+    auto rows = [&](const Rot& r, double2& a, double2& bb) {
+      const double2 y = make_double2(bb.x * r.er - bb.y * r.ei, bb.y * r.er + bb.x * r.ei);
+      const double2 na = make_double2(r.c * a.x - r.s * y.x, r.c * a.y - r.s * y.y);
+      bb = make_double2(r.s * a.x + r.c * y.x, r.s * a.y + r.c * y.y);
+      a = na;
+    };
+    const int k = tid >> 4, l = tid & 15;               // thread (k, l): the 2 x 2 block of pair k against pair l
+    // U <- U J_k (rows l, l + 16 of the column pair k) runs one step behind: it does not feed the next rotations, so its
+    // LDS round trips overlap the chain of the next step's rotation parameters instead of standing in front of the barrier
+    Rot ru{1.0, 0.0, 1.0, 0.0, false};
+    int pu = 0, qu = 0;
+    auto u_update = [&]() {
+      if (ru.on) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          double2 a = sU[pu * NCP + l + 16 * i], c = sU[qu * NCP + l + 16 * i];
+          cols(ru, a, c);
+          sU[pu * NCP + l + 16 * i] = a;
+          sU[qu * NCP + l + 16 * i] = c;
+        }
+      }
+    };
+    for (int st = 0; st < nst; ++st) {
+      const double2* Gc = (st & 1) ? sG1 : sG0;
+      double2* Gn = (st & 1) ? sG0 : sG1;
+      int pk, qk, pl, ql;
+      pair_of(k, st, pk, qk);
+      pair_of(l, st, pl, ql);
+      double2 b00 = Gc[pk * NC + pl], b01 = Gc[pk * NC + ql], b10 = Gc[qk * NC + pl], b11 = Gc[qk * NC + ql];
+      const Rot rk = rot_of(Gc, pk, qk), rl = rot_of(Gc, pl, ql);
+      u_update();                                       // (of the previous step)
+      cols(rl, b00, b01);
+      cols(rl, b10, b11);
+      rows(rk, b00, b10);
+      rows(rk, b01, b11);
+      if (k == l) {
+        b00.y = b11.y = 0.0;
+        if (rk.on) {
+          b01 = b10 = make_double2(0.0, 0.0);
+          ++rotated;
+        }
+      }
+      Gn[pk * NC + pl] = b00;
+      Gn[pk * NC + ql] = b01;
+      Gn[qk * NC + pl] = b10;
+      Gn[qk * NC + ql] = b11;
+      ru = rk;
+      pu = pk;
+      qu = qk;
+      __syncthreads();
+    }
+    u_update();
+    if (rotated) atomicAdd(&s_cnt, rotated);
+    if (slab == 0) {       // the diagonal tiles of the final G travel with the column blocks
+      const double2* Gf = ((nst - 1) & 1) ? sG0 : sG1;
+      const int row = tid >> 4, col = tid & 15;
+      dgp_out[tid] = Gf[row * NC + col];
+      dgq_out[tid] = Gf[(JG + row) * NC + JG + col];
+    }
+  } else if (slab == 0) {
+    dgp_out[tid] = dgp_in[tid];
+    dgq_out[tid] = dgq_in[tid];
+  }
+  __syncthreads();
+  const int cnt = s_cnt;
+  if (cnt && slab == 0 && tid == 0) atomicAdd(nrot + b, cnt);
+  // ---- 3. the rows of this workgroup: 16-row tiles slab, slab + R, .. of [X; V], dealt to the waves
+  const int nt = (nn + 15) >> 4;
+  double ur[2][8], ui[2][8];
+  if (cnt) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) {
+        const double2 w = sU[(JG * ct + x) * NCP + 4 * k4 + kq];
+        ur[ct][k4] = w.x;
+        ui[ct][k4] = w.y;
+      }
+  }
+  int gc[8];
+#pragma unroll
+  for (int k4 = 0; k4 < 8; ++k4) gc[k4] = gcol(4 * k4 + kq);
+  for (int ti = slab + R * wave; ti < 2 * nt; ti += 4 * R) {
+    const bool isx = ti < nt;
+    const double* src = isx ? X : V;
+    double* dst = isx ? Xo : Vo;
+    const int row = 16 * (isx ? ti : ti - nt) + x;
+    const bool okr = row < nn;
+    double2 y[8];
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      y[k4] = make_double2(0.0, 0.0);
+      if (okr && gc[k4] < nn) y[k4] = Cx<CPLX>::ld(src, (long long)gc[k4] * nn + row);
+    }
+    if (!cnt) {                                         // nothing rotated: the rows pass through
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4)
+        if (okr && gc[k4] < nn) Cx<CPLX>::st(dst, (long long)gc[k4] * nn + row, y[k4]);
+      continue;
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      // out^T[col][row] = sum_k U[k][col] Y[row][k]
+      jg_v4d ore = {0, 0, 0, 0}, oim = {0, 0, 0, 0};
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) {
+        ore = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[ct][k4], y[k4].x, ore, 0, 0, 0);
+        if constexpr (CPLX) {
+          ore = __builtin_amdgcn_mfma_f64_16x16x4f64(-ui[ct][k4], y[k4].y, ore, 0, 0, 0);
+          oim = __builtin_amdgcn_mfma_f64_16x16x4f64(ui[ct][k4], y[k4].x, oim, 0, 0, 0);
+          oim = __builtin_amdgcn_mfma_f64_16x16x4f64(ur[ct][k4], y[k4].y, oim, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int g = gcol(JG * ct + kq + 4 * r);
+        if (okr && g < nn) Cx<CPLX>::st(dst, (long long)g * nn + row, make_double2(ore[r], oim[r]));
+      }
+    }
+  }
+}
+
 template <bool CPLX>
 __global__ void k_normalise_perm_b(double* un_base, const double* __restrict__ ws, const SvdBlk* __restrict__ blks,
                                    const double* __restrict__ sig, const long long* __restrict__ perm,
@@ -1030,34 +1418,88 @@ int block_svd_batched(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t nco
                        PERM.as<const long long>(), dsq);
     MPSE_HIP(ctx, hipGetLastError());
   }
+  // Which block step runs the sweeps: the column kernel in LDS (k_jacobi_block) where the column blocks of X and V fit
+  // (nn <= 256 complex, 512 real), the Gram kernel (k_jacobi_gram) for wider blocks, where the alternative is a launch
+  // per rotation step.  MPSE_SVD_GRAM=2: the Gram kernel for every size, =0: never (read per call: tests switch it).
+  const int gram_mode = [] {
+    const char* e = getenv("MPSE_SVD_GRAM");
+    return e ? atoi(e) : 1;
+  }();
+  const int gram_r_env = [] {
+    const char* e = getenv("MPSE_SVD_GRAM_R");     // row slabs per column-block pair (default: a 16-row tile per wave)
+    return e ? atoi(e) : 0;
+  }();
+  TmpBuf X2(ctx), VM2(ctx), DG(ctx);
+  double2* dgbuf[2] = {nullptr, nullptr};
+  double* xbuf[2] = {xs, nullptr};
+  double* vbuf[2] = {vm, nullptr};
+  int cur = 0;                      // which copy of X, V holds the state (Gram kernel: every launch writes the other)
   if (maxN > 1) {
     std::vector<int> hdone(nblk, 0);
     bool all = false;
+    const size_t gram_lds = size_t(2) * 32 * 32 * 16 + size_t(32) * 33 * 16 + size_t(2) * 1536 * 8;
+    static const bool gram_attr = [&] {
+      const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_gram<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds);
+      const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_gram<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds);
+      (void)hipGetLastError();
+      return a == hipSuccess && b == hipSuccess;
+    }();
+    const size_t blk_lds = size_t(4) * JB_COLS * maxnn * es;      // X and V columns of a pair of column blocks
+    // beyond the default 64 KB of dynamic LDS (the CU has 160 KB): asked for once; a runtime that refuses keeps the
+    // column kernel to the problems that fit 64 KB
+    static const bool lds_attr = [] {
+      const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_block<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_block<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipGetLastError();
+      return a == hipSuccess && b == hipSuccess;
+    }();
+    const bool cols_fit = blk_lds <= (lds_attr ? size_t(150) : size_t(64)) * 1024;
+    const bool use_gram = gram_attr && (gram_mode >= 2 || (gram_mode == 1 && !cols_fit));
+    int gram_R = 1;
+    if (use_gram) {
+      MPSE_TRY(X2.alloc(size_t(x_tot) * es));
+      MPSE_TRY(VM2.alloc(size_t(x_tot) * es));
+      xbuf[1] = X2.as<double>();
+      vbuf[1] = VM2.as<double>();
+      // the diagonal Gram tiles that travel with the column blocks (two copies like X and V)
+      const size_t dg_elems = size_t(nblk) * size_t((((maxnn + JG - 1) / JG + 1) & ~1)) * 256;
+      MPSE_TRY(DG.alloc(2 * dg_elems * 16));
+      dgbuf[0] = DG.as<double2>();
+      dgbuf[1] = DG.as<double2>() + dg_elems;
+      const int tiles = 2 * ((maxnn + 15) / 16), pairs = (((maxnn + JG - 1) / JG + 1) & ~1) / 2;
+      gram_R = gram_r_env > 0 ? gram_r_env : (tiles + 3) / 4;      // (a 16-row tile per wave)
+      while (gram_R > 1 && (long long)gram_R * pairs * nblk > 1024) gram_R >>= 1;
+      if (gram_R < 1) gram_R = 1;
+      if (gram_R > 16) gram_R = 16;
+    }
     for (int sweep = 0; sweep < 60 && !all; ++sweep) {
-      const size_t blk_lds = size_t(4) * JB_COLS * maxnn * es;      // X and V columns of a pair of column blocks
-      // beyond the default 64 KB of dynamic LDS (the CU has 160 KB): asked for once; a runtime that refuses keeps the
-      // blocked kernel to the problems that fit 64 KB and sends the others through the column-pair kernels below
-      static const bool lds_attr = [] {
-        const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_block<true>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        const hipError_t b = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jacobi_block<false>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipGetLastError();
-        return a == hipSuccess && b == hipSuccess;
-      }();
-      if (blk_lds <= (lds_attr ? size_t(150) : size_t(64)) * 1024) {
+      if (use_gram) {
+        const int nbmax = ((maxnn + JG - 1) / JG + 1) & ~1;
+        for (int step = 0; step < nbmax - 1; ++step) {
+          hipLaunchKernelGGL((k_jacobi_gram<CPLX>), dim3(nbmax / 2 * gram_R, nblk), dim3(256), gram_lds, ctx->stream,
+                             (const double*)xbuf[cur], xbuf[cur ^ 1], (const double*)vbuf[cur], vbuf[cur ^ 1],
+                             (const double2*)dgbuf[cur], dgbuf[cur ^ 1], nbmax, dsq, step, gram_R, (const double*)null2, nrot,
+                             (const int*)done);
+          cur ^= 1;
+        }
+      } else if (cols_fit) {
         const int nbmax = ((maxnn + JB_COLS - 1) / JB_COLS + 1) & ~1;
         for (int step = 0; step < nbmax - 1; ++step)
           hipLaunchKernelGGL((k_jacobi_block<CPLX>), dim3(nbmax / 2, nblk), dim3(64 * JB_COLS), blk_lds, ctx->stream, xs,
                              vm, dsq, step, (const double*)null2, nrot, (const int*)done);
-      } else
-      for (int step = 0; step < maxN - 1; ++step) {
-        if (maxnn <= 2048)     // square problems: a wave per column pair
-          hipLaunchKernelGGL((k_jacobi_step_w<CPLX>), dim3((maxN / 2 + 3) / 4, nblk), dim3(256), 0, ctx->stream, xs, vm,
-                             dsq, step, (const double*)null2, nrot, (const int*)done);
-        else
-          hipLaunchKernelGGL((k_jacobi_step_b<CPLX>), dim3(maxN / 2, nblk), dim3(RED_THREADS), 0, ctx->stream, xs, vm,
-                             dsq, step, (const double*)null2, nrot, (const int*)done);
+      } else {
+        for (int step = 0; step < maxN - 1; ++step) {
+          if (maxnn <= 2048)     // square problems: a wave per column pair
+            hipLaunchKernelGGL((k_jacobi_step_w<CPLX>), dim3((maxN / 2 + 3) / 4, nblk), dim3(256), 0, ctx->stream, xs, vm,
+                               dsq, step, (const double*)null2, nrot, (const int*)done);
+          else
+            hipLaunchKernelGGL((k_jacobi_step_b<CPLX>), dim3(maxN / 2, nblk), dim3(RED_THREADS), 0, ctx->stream, xs, vm,
+                               dsq, step, (const double*)null2, nrot, (const int*)done);
+        }
       }
       hipLaunchKernelGGL(k_sweep_end, dim3((nblk + 255) / 256), dim3(256), 0, ctx->stream, nblk, nrot, done);
       MPSE_HIP(ctx, hipGetLastError());
@@ -1074,6 +1516,8 @@ int block_svd_batched(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t nco
     }
     if (!all) return mpse_fail(ctx, MPSE_ERR_NOCONV, "block_svd: Jacobi did not converge within 60 sweeps");
   }
+  xs = xbuf[cur];
+  vm = vbuf[cur];
   hipLaunchKernelGGL((k_col_norms_b<CPLX>), dim3(maxnn, nblk), dim3(RED_THREADS), 0, ctx->stream, (const double*)xs, dsq,
                      sigd);
   std::vector<double> sig((size_t)sig_tot), th((size_t)nblk);
@@ -1111,7 +1555,7 @@ int block_svd_batched(mpse_ctx* ctx, const void* coef, int64_t nrow, int64_t nco
     const SvdBlk& S = sq[b];
     const int dt = CPLX ? MPSE_C128 : MPSE_F64;
     MPSE_TRY(gemm_call(ctx, dt, dt, 0, 0, idx1(B.mm, 1), idx1(B.nn, B.mm), idx1(B.nn, 1), idx1(B.nn, B.nn), idx1(B.mm, 1),
-                       idx1(B.nn, B.mm), 1, 0, 0, 0, Q1.as<char>() + size_t(B.q1_off) * es, VM.as<char>() + size_t(S.v_off) * es,
+                       idx1(B.nn, B.mm), 1, 0, 0, 0, Q1.as<char>() + size_t(B.q1_off) * es, reinterpret_cast<char*>(vm) + size_t(S.v_off) * es,
                        WS.as<char>() + size_t(B.ws_off) * es));
   }
   hipLaunchKernelGGL((k_scatter_svd2_b<CPLX>), dim3(gt, nblk), dim3(256), 0, ctx->stream, (double*)U, (double*)Vt,

@@ -753,6 +753,61 @@ def test_block_svd_shapes_and_rank(eng, cplx):
         assert np.abs(vt @ vt.conj().T - np.eye(k)).max() < 1e-12
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_block_svd_wide_blocks_gram_step(eng, cplx, monkeypatch):
+    """Blocks wider than the column kernel's LDS holds (more than 256 complex / 512 real columns) run their sweeps through
+    the Gram-matrix block step (``k_jacobi_gram``: MFMA Gram tile, two-sided rotations on the 32 x 32 matrix, MFMA update
+    of the rows): values against LAPACK, both factors isometries, reconstruction - for a graded spectrum with a rank
+    deficit, two blocks of different width in one call (the narrower one idles through the extra steps), and
+    ``MPSE_SVD_GRAM=2`` sending EVERY size of ``test_block_svd_shapes_and_rank`` and the captured extreme-range input
+    through the same kernel (column counts that are no multiple of 16, single columns, a block narrower than one tile)."""
+    rng = np.random.default_rng(12)
+
+    def check(a, qnl, qnr, tol=1e-13, tol_o=1e-12):
+        # (tol: 1e-13 up to ~250 columns as in the other tests of the decomposition; the wide blocks - 300 / 530 columns,
+        # eleven sweeps of up to 530 rotations per column - are held to 1e-12: the column kernels give the same figures
+        # on these inputs, 3.4e-13 at 530 columns)
+        u, s, vt, blocks = dev_block_svd(eng, a, qnl, qnr, np.array([0]))
+        sref = np.concatenate([np.linalg.svd(a[np.ix_(ls, rs)], compute_uv=False) for _, _, ls, rs in blocks])
+        assert np.abs(np.sort(s)[::-1] - np.sort(sref)[::-1]).max() < tol * sref.max()
+        assert _relerr((u * s) @ vt, a) < tol
+        assert np.abs(u.conj().T @ u - np.eye(u.shape[1])).max() < tol_o
+        assert np.abs(vt @ vt.conj().T - np.eye(vt.shape[0])).max() < tol_o
+
+    n = 300 if cplx else 530
+    m = 2 * n + 7
+    uu, _ = np.linalg.qr(_rand(rng, (m, n), cplx))
+    vv, _ = np.linalg.qr(_rand(rng, (n, n), cplx))
+    sv = np.exp(-30.0 * np.arange(n) / n)
+    sv[-5:] = 0.0
+    a = (uu * sv) @ vv.conj().T
+    check(a, np.zeros((m, 1), dtype=int), np.zeros((n, 1), dtype=int), tol=1e-12)
+    # two blocks, the second one narrow: one call, shared launches
+    n2 = 70
+    b = np.zeros((m + 150, n + n2), dtype=a.dtype)
+    b[:m, :n] = a
+    b[m:, n:] = _rand(rng, (150, n2), cplx)
+    qnl = np.concatenate([np.zeros(m, dtype=int), np.ones(150, dtype=int)])[:, None]
+    qnr = -np.concatenate([np.zeros(n, dtype=int), np.ones(n2, dtype=int)])[:, None]
+    check(b, qnl, qnr, tol=1e-12)
+    # every size through the Gram kernel
+    monkeypatch.setenv("MPSE_SVD_GRAM", "2")
+    for (mm, nn) in [(120, 40), (40, 120), (64, 64), (1, 7), (7, 1), (33, 1), (257, 90), (200, 17), (90, 33)]:
+        c = _rand(rng, (mm, nn), cplx)
+        k = min(mm, nn)
+        if k > 6:
+            u0, s0, v0 = np.linalg.svd(c, full_matrices=False)
+            s0[-3:] = 0
+            s0[-4] *= 1e-12
+            c = (u0 * s0) @ v0
+        check(c, np.zeros((mm, 1), dtype=int), np.zeros((nn, 1), dtype=int))
+
+
+def test_block_svd_extreme_dynamic_range_gram_step(eng, golden_dir, monkeypatch):
+    monkeypatch.setenv("MPSE_SVD_GRAM", "2")
+    test_block_svd_extreme_dynamic_range(eng, golden_dir)
+
+
 def test_block_svd_extreme_dynamic_range(eng, golden_dir):
     """Regression input captured from expand_bond_dimension: column norms 0.7, 2e-21, 2e-119, 4e-142, 3e-152
     inside one block (products of squared norms underflow).  Jacobi must converge and still return isometries."""
