@@ -629,6 +629,7 @@ __global__ __launch_bounds__(256) void k_jacobi_step_w(double* ws, double* vbase
 // robin over the 2 JB_COLS columns); the other launches rotate the JB_COLS x JB_COLS cross pairs (JB_COLS inner
 // steps).  Needs 2 x 2 JB_COLS x nn elements of LDS: nn <= 256 (complex) / 512 (real).
 constexpr int JB_COLS = 8;
+constexpr int JB_KEEP = 4;          // x 64 rows of a column pair kept in registers through an inner step
 template <bool CPLX>
 __global__ __launch_bounds__(64 * JB_COLS) void k_jacobi_block(double* ws, double* vbase, const SvdBlk* __restrict__ blks,
                                                               int step, const double* __restrict__ null2v, int* nrot,
@@ -699,12 +700,41 @@ __global__ __launch_bounds__(64 * JB_COLS) void k_jacobi_block(double* ws, doubl
       double* ap = sx + (long long)p * nn * E;
       double* aq = sx + (long long)q * nn * E;
       double alpha = 0, beta = 0, gr = 0, gi = 0;
-      for (int r = lane; r < nn; r += 64) {
+      // (round 6: the first JB_KEEP x 64 rows of the two columns stay in registers between the Gram pass and the rotation,
+      // and the same rows of the two V columns are requested before the rotation parameters exist - the step is bound
+      // by its LDS traffic, 40 KB per wave, and by the round trips in front of and behind the scalar chain: 28.1 -> 25.8 us
+      // per launch at 256 columns.  Keeping the wave's own column resident over all the cross steps of a launch was
+      // built as well and measured slower, 28.2 us)
+      double2 xa[JB_KEEP], xy[JB_KEEP], va[JB_KEEP], vy[JB_KEEP];
+      double* vp = sv + (long long)p * nn * E;
+      double* vq = sv + (long long)q * nn * E;
+#pragma unroll
+      for (int i = 0; i < JB_KEEP; ++i) {
+        const int r = lane + 64 * i;
+        xa[i] = xy[i] = va[i] = vy[i] = make_double2(0.0, 0.0);
+        if (r < nn) {
+          xa[i] = Cx<CPLX>::ld(ap, r);
+          xy[i] = Cx<CPLX>::ld(aq, r);
+        }
+        alpha += xa[i].x * xa[i].x + xa[i].y * xa[i].y;
+        beta += xy[i].x * xy[i].x + xy[i].y * xy[i].y;
+        gr += xa[i].x * xy[i].x + xa[i].y * xy[i].y;
+        gi += xa[i].x * xy[i].y - xa[i].y * xy[i].x;
+      }
+      for (int r = lane + 64 * JB_KEEP; r < nn; r += 64) {
         const double2 a = Cx<CPLX>::ld(ap, r), y = Cx<CPLX>::ld(aq, r);
         alpha += a.x * a.x + a.y * a.y;
         beta += y.x * y.x + y.y * y.y;
         gr += a.x * y.x + a.y * y.y;
         gi += a.x * y.y - a.y * y.x;
+      }
+#pragma unroll
+      for (int i = 0; i < JB_KEEP; ++i) {
+        const int r = lane + 64 * i;
+        if (r < nn) {
+          va[i] = Cx<CPLX>::ld(vp, r);
+          vy[i] = Cx<CPLX>::ld(vq, r);
+        }
       }
       alpha = wave_sum(alpha);
       beta = wave_sum(beta);
@@ -715,14 +745,35 @@ __global__ __launch_bounds__(64 * JB_COLS) void k_jacobi_block(double* ws, doubl
       // their product at any realistic scale)
       const double g2 = gr * gr + gi * gi;
       if (g2 != 0.0 && alpha > null2 && beta > null2 && g2 > (tol * tol) * alpha * beta) {
-        const double ig = rsqrt(g2);
-        const double pr = gr * ig, pi = gi * ig;
-        const double zeta = 0.5 * (beta - alpha) * ig;
-        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double c = rsqrt(1.0 + t * t), sn = c * t;
-        double* vp = sv + (long long)p * nn * E;
-        double* vq = sv + (long long)q * nn * E;
-        for (int r = lane; r < nn; r += 64) {
+        // tan 2 theta = 2 |g| / (beta - alpha), the smaller angle, with two long operations in series instead of four
+        // (round 6; the form of k_jacobi_gram): d = beta - alpha, r = sqrt(d^2 + 4 |g|^2), w = |d| + r,
+        // c = w / sqrt(w^2 + 4 |g|^2), s = sign(d) 2 |g| / sqrt(w^2 + 4 |g|^2); the three Gram entries scaled by a power
+        // of two first (squares of squared norms)
+        const int ex = -__builtin_amdgcn_frexp_exp(alpha + beta);
+        const double gxs = __builtin_amdgcn_ldexp(gr, ex), gys = __builtin_amdgcn_ldexp(gi, ex);
+        const double d = __builtin_amdgcn_ldexp(beta, ex) - __builtin_amdgcn_ldexp(alpha, ex);
+        const double g2s = gxs * gxs + gys * gys;
+        const double ig = fast_rsqrt(g2s);
+        const double pr = gxs * ig, pi = gys * ig;
+        const double f = d * d + 4.0 * g2s;
+        const double w = fabs(d) + f * fast_rsqrt(f);
+        const double qn = fast_rsqrt(w * w + 4.0 * g2s);
+        const double c = w * qn, sn = (d >= 0.0 ? 2.0 : -2.0) * (g2s * ig) * qn;
+#pragma unroll
+        for (int i = 0; i < JB_KEEP; ++i) {
+          const int r = lane + 64 * i;
+          if (r < nn) {
+            const double2 a = xa[i], y0 = xy[i];
+            const double2 y = make_double2(y0.x * pr + y0.y * pi, y0.y * pr - y0.x * pi);
+            Cx<CPLX>::st(ap, r, make_double2(c * a.x - sn * y.x, c * a.y - sn * y.y));
+            Cx<CPLX>::st(aq, r, make_double2(sn * a.x + c * y.x, sn * a.y + c * y.y));
+            const double2 w2 = va[i], z0 = vy[i];
+            const double2 z = make_double2(z0.x * pr + z0.y * pi, z0.y * pr - z0.x * pi);
+            Cx<CPLX>::st(vp, r, make_double2(c * w2.x - sn * z.x, c * w2.y - sn * z.y));
+            Cx<CPLX>::st(vq, r, make_double2(sn * w2.x + c * z.x, sn * w2.y + c * z.y));
+          }
+        }
+        for (int r = lane + 64 * JB_KEEP; r < nn; r += 64) {
           const double2 a = Cx<CPLX>::ld(ap, r), y0 = Cx<CPLX>::ld(aq, r);
           const double2 y = make_double2(y0.x * pr + y0.y * pi, y0.y * pr - y0.x * pi);
           Cx<CPLX>::st(ap, r, make_double2(c * a.x - sn * y.x, c * a.y - sn * y.y));
