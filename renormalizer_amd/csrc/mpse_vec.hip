@@ -617,29 +617,51 @@ __global__ __launch_bounds__(64) void k_lz_coefs(double* __restrict__ scal, int 
   double g = lane < m ? fabs(a) + fabs(bup) + fabs(bdn) : 0.0;
   for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o, 64));
   const double rho = g * sqrt(dt_re * dt_re + dt_im * dt_im);
+  // x = |dt| * bound / 2^s <= 2 per repetition (round 6; 1 and 22 terms before): the series of exp(x) to 1e-17 of the
+  // result takes 16 / 19 / 26 terms for x <= 1/2, 1, 2 - half as many terms in all as 2^(s+1) repetitions of 22 at x <= 1 -
+  // and its largest term is e^2: the cancellation costs a digit at most.
   int sq = 0;
-  while (ldexp(rho, -sq) > 1.0 && sq < 40) ++sq;
+  while (ldexp(rho, -sq) > 2.0 && sq < 40) ++sq;
   if (sq > 8) {      // would need more than 256 repetitions: let the host do this one with its eigen-decomposition
     if (lane == 0) ctl->need_host = 1;
     return;
   }
+  const double xs = ldexp(rho, -sq);
+  const int nterm = xs <= 0.5 ? 16 : xs <= 1.0 ? 19 : 26;
   const double sr = ldexp(dt_re, -sq), si = ldexp(dt_im, -sq);
   double yr = lane == 0 ? sqrt(n2) : 0.0, yi = 0.0;
   const int reps = 1 << sq;
+  // neighbours by DPP wave shifts (lane 0 / lane 63 receive 0, which is what the tridiagonal matrix puts there): a
+  // ds_bpermute round trip per neighbour was most of a term's latency
+  auto from_below = [](double v) {   // value of lane - 1
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  };
+  auto from_above = [](double v) {   // value of lane + 1
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  };
+  // (dt / 2^s) T with the 1 / k of a term folded in at compile time
+  const double ar = sr * a, ai = si * a, dnr = sr * bdn, dni = si * bdn, upr = sr * bup, upi = si * bup;
   for (int rep = 0; rep < reps; ++rep) {
     double tr = yr, ti = yi;     // current Taylor term
-#pragma unroll 1
-    for (int k = 1; k <= 22; ++k) {
-      // t <- (dt / 2^s) T t / k
-      const double ur = __shfl_up(tr, 1, 64), ui = __shfl_up(ti, 1, 64);
-      const double dr = __shfl_down(tr, 1, 64), di = __shfl_down(ti, 1, 64);
-      const double wr = a * tr + bdn * ur + bup * dr, wi = a * ti + bdn * ui + bup * di;
-      const double ik = 1.0 / (double)k;
-      tr = (sr * wr - si * wi) * ik;
-      ti = (sr * wi + si * wr) * ik;
-      if (lane >= m) tr = ti = 0.0;
-      yr += tr;
-      yi += ti;
+#pragma unroll
+    for (int k = 1; k <= 26; ++k) {
+      if (k <= nterm) {
+        // t <- (dt / 2^s) T t / k
+        const double ur = from_below(tr), ui = from_below(ti);
+        const double dr = from_above(tr), di = from_above(ti);
+        const double wr = (ar * tr - ai * ti) + (dnr * ur - dni * ui) + (upr * dr - upi * di);
+        const double wi = (ar * ti + ai * tr) + (dnr * ui + dni * ur) + (upr * di + upi * dr);
+        const double ik = 1.0 / (double)k;
+        tr = wr * ik;
+        ti = wi * ik;
+        if (lane >= m) tr = ti = 0.0;
+        yr += tr;
+        yi += ti;
+      }
     }
   }
   if (lane < LZ_MAXM) {
